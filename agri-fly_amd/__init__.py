@@ -1,0 +1,31 @@
+"""agri-fly_amd -- MI355X-native batched quadrotor dynamics engine.
+
+This package is only the thin Python host over the C ABI of
+``include/agrifly_engine.h`` (ctypes, numpy); the product is the HIP library
+``lib/libagrifly_engine.so`` built from ``csrc/``.  There is no CPU fallback:
+importing works anywhere (the library loads without a GPU so its host-only
+entry points and symbol table can be checked), but creating an ``Ensemble``
+without a gfx950 device raises.
+
+The directory name carries a hyphen, so import it with
+``importlib.import_module("agri-fly_amd")``.
+"""
+from .engine import (  # noqa: F401
+    ABI_FUNCTIONS,
+    AFE_F32,
+    AFE_F64,
+    AFE_SEED_DECORRELATED,
+    AFE_SEED_REFERENCE,
+    AfeError,
+    DeviceView,
+    Ensemble,
+    VehicleParams,
+    build_library,
+    library,
+    library_path,
+    params_from_type,
+    plan_ticks,
+    type_from_id,
+)
+from . import scenarios  # noqa: F401
+from . import sharding  # noqa: F401

@@ -1,0 +1,71 @@
+// afe_device.h -- structures shared by the host engine and the HIP kernels.
+#pragma once
+#include <stdint.h>
+
+namespace afe {
+
+// Per-type constant record as the kernel wants it: the Quadcopter_T ctor
+// arguments (reference Components/Components/Simulation/Quadcopter_T.hpp:24-32)
+// expanded the way the ctor body does (Quadcopter_T.cpp:20,45-65,75-80), plus
+// the motor-lag factor exp(-dt/tau_m) of Motor.cpp:54-58, which depends only on
+// (type, dt) and is therefore evaluated once per dt on the host in double.
+// Staged into LDS at kernel start; all lanes of a homogeneous ensemble read
+// the same LDS words (broadcast, conflict-free).
+template <typename R>
+struct DevParams {
+  R mass;
+  R I[9];      // _inertiaMatrix, row major
+  R Iinv[9];   // _inertiaMatrixInv
+  R mpx[4];    // motor positions (FR, RR, RL, FL)
+  R mpy[4];
+  R mpz[4];
+  R kf;        // _thrustFromSpeedSqr
+  R ktau;      // _torqueFromSpeedSqr
+  R c_lag;     // exp(-dt/_timeConstant), or 0 when _timeConstant == 0
+  R Jm;        // Motor::_inertia
+  R wmin;
+  R wmax;
+  R drag[3];   // _linDragCoeffB
+  float Rimu[9];  // _R_inverse (float in the reference too)
+  float pad_[3];  // keep sizeof a multiple of 16 (208 B / 368 B)
+};
+static_assert(sizeof(DevParams<float>) % 16 == 0, "DevParams<float> size");
+static_assert(sizeof(DevParams<double>) % 16 == 0, "DevParams<double> size");
+
+// Motor i spins about s_i * z with s = (+1,-1,+1,-1) and pushes along +z
+// (Quadcopter_T.cpp:45-65 with Motor.cpp:32-36).
+#define AFE_MOTOR_SPIN(i) (((i) & 1) ? -1 : +1)
+
+template <typename R>
+struct StepView {
+  R *pos, *vel, *att, *ang_vel, *motor;  // planar SoA, `stride` between comps
+  const R *ext_force, *ext_torque;
+  const float *cmd;
+  float *gyro, *acc;
+  uint32_t *rng;
+  const uint8_t *type;
+  const DevParams<R> *table;
+  int n_types;
+  int64_t n;
+  int64_t stride;
+  R dt;
+  int n_steps;
+  unsigned long long tick_mask;  // bit s set: sub-step s fires the logic gate
+  float sigma_gyro, sigma_acc;
+};
+
+struct LaunchFlags {
+  bool ext_force, ext_torque, noise, renorm;
+};
+
+// kernel launchers (afe_kernels.hip); stream is a hipStream_t
+int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, void *stream);
+int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, void *stream);
+int launch_pack_positions_f32(const float *pos, int64_t stride, int64_t n, float *out, void *stream);
+int launch_pack_positions_f64(const double *pos, int64_t stride, int64_t n, float *out, void *stream);
+int launch_nearest_neighbour(const float *self_xyz, int64_t n_self, int64_t first_global,
+                             const float *all_xyz, int64_t n_all, float *dist2,
+                             int32_t *index, void *stream);
+int launch_seed_rng(uint32_t *rng, int64_t n, int64_t first_global, int policy, void *stream);
+
+}  // namespace afe

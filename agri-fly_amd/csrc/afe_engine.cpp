@@ -1,0 +1,568 @@
+// afe_engine.cpp -- host side of the C ABI (include/agrifly_engine.h): owns the
+// SoA slabs in HBM, the engine clock and the logic-gate plan, and launches the
+// kernels of afe_kernels.hip.  Compiled with hipcc; there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "afe_host.h"
+
+using namespace afe;
+
+struct afe_engine {
+  int64_t n = 0;
+  int64_t stride = 0;       // n rounded up to 256 elements
+  int precision = AFE_F32;
+  int device = 0;
+  int64_t first_global = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+
+  // device slabs
+  void *arena = nullptr;
+  size_t arena_bytes = 0;
+  void *pos = nullptr, *vel = nullptr, *att = nullptr, *ang_vel = nullptr, *motor = nullptr;
+  void *ext_force = nullptr, *ext_torque = nullptr;
+  float *cmd = nullptr, *gyro = nullptr, *acc = nullptr;
+  uint32_t *rng = nullptr;
+  uint8_t *type = nullptr;
+  void *dev_table = nullptr;  // n_types DevParams<R>
+  float *pack_scratch = nullptr;  // 3*n floats, lazily allocated
+
+  // configuration
+  std::vector<HostParams> table;
+  double table_dt = -1.0;   // dt the device table was built for
+  bool table_dirty = true;
+  double logic_period = 1.0 / 500.0;  // main.cpp:177
+  bool noise = true;
+  double sigma_gyro = 0.1, sigma_acc = 0.2;  // Quadcopter_T.cpp:5-6
+  int seed_policy = AFE_SEED_REFERENCE;
+  bool has_ext_force = false, has_ext_torque = false;
+  bool renorm = true;
+
+  // clock (ManualTimer + Timer semantics)
+  uint64_t now_us = 0;
+  uint64_t logic_elapsed_us = 0;
+  uint64_t n_ticks = 0;
+
+  std::string err;
+};
+
+namespace {
+
+inline size_t elem(const afe_engine *e) { return e->precision == AFE_F64 ? 8 : 4; }
+
+int fail(afe_engine *e, int status, const std::string &msg) {
+  if (e) e->err = msg;
+  return status;
+}
+
+#define AFE_HIP(e, call)                                                              \
+  do {                                                                                \
+    hipError_t err__ = (call);                                                        \
+    if (err__ != hipSuccess)                                                          \
+      return fail((e), AFE_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err__)); \
+  } while (0)
+
+int check_range(afe_engine *e, int64_t first, int64_t count) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  if (first < 0 || count < 0 || first + count > e->n)
+    return fail(e, AFE_ERR_OUT_OF_RANGE, "vehicle range [" + std::to_string(first) + ", " +
+                                             std::to_string(first + count) + ") outside [0, " +
+                                             std::to_string(e->n) + ")");
+  return AFE_OK;
+}
+
+// host planar [comps][count] <-> device planar [comps][stride] at offset first
+int copy_in(afe_engine *e, void *dev, size_t esz, int comps, int64_t first, int64_t count, const void *host) {
+  if (!host || count == 0) return AFE_OK;
+  AFE_HIP(e, hipMemcpy2DAsync((char *)dev + first * esz, e->stride * esz, host, count * esz,
+                              count * esz, comps, hipMemcpyHostToDevice, e->stream));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));  // host buffer may be reused by the caller
+  return AFE_OK;
+}
+int copy_out(afe_engine *e, const void *dev, size_t esz, int comps, int64_t first, int64_t count, void *host) {
+  if (!host || count == 0) return AFE_OK;
+  AFE_HIP(e, hipMemcpy2DAsync(host, count * esz, (const char *)dev + first * esz, e->stride * esz,
+                              count * esz, comps, hipMemcpyDeviceToHost, e->stream));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  return AFE_OK;
+}
+
+template <typename Dst, typename Src>
+int set_field(afe_engine *e, void *dev, int comps, int64_t first, int64_t count, const Src *host) {
+  if (!host) return AFE_OK;
+  if (sizeof(Dst) == sizeof(Src)) return copy_in(e, dev, sizeof(Dst), comps, first, count, host);
+  std::vector<Dst> tmp((size_t)comps * count);
+  for (size_t k = 0; k < tmp.size(); k++) tmp[k] = (Dst)host[k];
+  return copy_in(e, dev, sizeof(Dst), comps, first, count, tmp.data());
+}
+template <typename Src, typename Dst>
+int get_field(afe_engine *e, const void *dev, int comps, int64_t first, int64_t count, Dst *host) {
+  if (!host) return AFE_OK;
+  if (sizeof(Dst) == sizeof(Src)) return copy_out(e, dev, sizeof(Src), comps, first, count, host);
+  std::vector<Src> tmp((size_t)comps * count);
+  int rc = copy_out(e, dev, sizeof(Src), comps, first, count, tmp.data());
+  if (rc) return rc;
+  for (size_t k = 0; k < tmp.size(); k++) host[k] = (Dst)tmp[k];
+  return AFE_OK;
+}
+
+template <typename H>
+int set_state_any(afe_engine *e, int64_t first, int64_t count, const H *pos3, const H *vel3,
+                  const H *att4, const H *ang_vel3, const H *motor4) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  AFE_HIP(e, hipSetDevice(e->device));
+  if (e->precision == AFE_F64) {
+    if ((rc = set_field<double>(e, e->pos, 3, first, count, pos3))) return rc;
+    if ((rc = set_field<double>(e, e->vel, 3, first, count, vel3))) return rc;
+    if ((rc = set_field<double>(e, e->att, 4, first, count, att4))) return rc;
+    if ((rc = set_field<double>(e, e->ang_vel, 3, first, count, ang_vel3))) return rc;
+    if ((rc = set_field<double>(e, e->motor, 4, first, count, motor4))) return rc;
+  } else {
+    if ((rc = set_field<float>(e, e->pos, 3, first, count, pos3))) return rc;
+    if ((rc = set_field<float>(e, e->vel, 3, first, count, vel3))) return rc;
+    if ((rc = set_field<float>(e, e->att, 4, first, count, att4))) return rc;
+    if ((rc = set_field<float>(e, e->ang_vel, 3, first, count, ang_vel3))) return rc;
+    if ((rc = set_field<float>(e, e->motor, 4, first, count, motor4))) return rc;
+  }
+  return AFE_OK;
+}
+
+template <typename H>
+int get_state_any(afe_engine *e, int64_t first, int64_t count, H *pos3, H *vel3, H *att4,
+                  H *ang_vel3, H *motor4) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  AFE_HIP(e, hipSetDevice(e->device));
+  if (e->precision == AFE_F64) {
+    if ((rc = get_field<double>(e, e->pos, 3, first, count, pos3))) return rc;
+    if ((rc = get_field<double>(e, e->vel, 3, first, count, vel3))) return rc;
+    if ((rc = get_field<double>(e, e->att, 4, first, count, att4))) return rc;
+    if ((rc = get_field<double>(e, e->ang_vel, 3, first, count, ang_vel3))) return rc;
+    if ((rc = get_field<double>(e, e->motor, 4, first, count, motor4))) return rc;
+  } else {
+    if ((rc = get_field<float>(e, e->pos, 3, first, count, pos3))) return rc;
+    if ((rc = get_field<float>(e, e->vel, 3, first, count, vel3))) return rc;
+    if ((rc = get_field<float>(e, e->att, 4, first, count, att4))) return rc;
+    if ((rc = get_field<float>(e, e->ang_vel, 3, first, count, ang_vel3))) return rc;
+    if ((rc = get_field<float>(e, e->motor, 4, first, count, motor4))) return rc;
+  }
+  return AFE_OK;
+}
+
+int set_wrench(afe_engine *e, void *dev, bool &flag, int64_t first, int64_t count, const double *w3) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  AFE_HIP(e, hipSetDevice(e->device));
+  if (!w3) {
+    const size_t esz = elem(e);
+    AFE_HIP(e, hipMemset2DAsync((char *)dev + first * esz, e->stride * esz, 0, count * esz, 3, e->stream));
+    return AFE_OK;
+  }
+  flag = true;
+  if (e->precision == AFE_F64) return set_field<double>(e, dev, 3, first, count, w3);
+  return set_field<float>(e, dev, 3, first, count, w3);
+}
+
+// (re)build the device type table when the table or dt changed
+int refresh_table(afe_engine *e, double dt) {
+  if (!e->table_dirty && dt == e->table_dt) return AFE_OK;
+  const size_t n = e->table.size();
+  if (e->precision == AFE_F64) {
+    std::vector<DevParams<double>> t(n);
+    for (size_t k = 0; k < n; k++) to_device_params<double>(e->table[k], dt, t[k]);
+    AFE_HIP(e, hipMemcpyAsync(e->dev_table, t.data(), n * sizeof(t[0]), hipMemcpyHostToDevice, e->stream));
+    AFE_HIP(e, hipStreamSynchronize(e->stream));
+  } else {
+    std::vector<DevParams<float>> t(n);
+    for (size_t k = 0; k < n; k++) to_device_params<float>(e->table[k], dt, t[k]);
+    AFE_HIP(e, hipMemcpyAsync(e->dev_table, t.data(), n * sizeof(t[0]), hipMemcpyHostToDevice, e->stream));
+    AFE_HIP(e, hipStreamSynchronize(e->stream));
+  }
+  e->table_dt = dt;
+  e->table_dirty = false;
+  return AFE_OK;
+}
+
+template <typename R>
+void fill_view(const afe_engine *e, StepView<R> &v) {
+  v.pos = (R *)e->pos; v.vel = (R *)e->vel; v.att = (R *)e->att;
+  v.ang_vel = (R *)e->ang_vel; v.motor = (R *)e->motor;
+  v.ext_force = (const R *)e->ext_force; v.ext_torque = (const R *)e->ext_torque;
+  v.cmd = e->cmd; v.gyro = e->gyro; v.acc = e->acc; v.rng = e->rng; v.type = e->type;
+  v.table = (const DevParams<R> *)e->dev_table;
+  v.n_types = (int)e->table.size();
+  v.n = e->n; v.stride = e->stride;
+  v.sigma_gyro = (float)e->sigma_gyro;  // float(_stdDevRateGyroNoise), Quadcopter_T.cpp:170
+  v.sigma_acc = (float)e->sigma_acc;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+
+extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, int device,
+                          int64_t first_global_index) {
+  if (!out || n_vehicles <= 0 || (precision != AFE_F32 && precision != AFE_F64) || first_global_index < 0)
+    return AFE_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return AFE_ERR_NO_DEVICE;
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) return AFE_ERR_NO_DEVICE;
+  }
+  if (device >= n_dev) return AFE_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return AFE_ERR_NO_DEVICE;
+  // the code object carries gfx950 ISA only
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return AFE_ERR_NO_DEVICE;
+
+  afe_engine *e = new afe_engine();
+  e->n = n_vehicles;
+  e->stride = (n_vehicles + 255) / 256 * 256;
+  e->precision = precision;
+  e->device = device;
+  e->first_global = first_global_index;
+  e->renorm = (precision == AFE_F32);
+
+  auto bail = [&](const char *what, hipError_t err) {
+    std::fprintf(stderr, "agrifly_engine: %s failed: %s\n", what, hipGetErrorString(err));
+    afe_destroy(e);
+    return AFE_ERR_HIP;
+  };
+  hipError_t err;
+  if ((err = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", err);
+  if ((err = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking)) != hipSuccess)
+    return bail("hipStreamCreate", err);
+  e->stream = e->own_stream;
+
+  // one arena, 256-B aligned slabs:
+  //   state 17 comps + wrench 6 comps (elem size), cmd 4 + imu 6 floats, rng u32, type u8
+  const size_t S = (size_t)e->stride, es = elem(e);
+  const size_t bytes = S * (17 + 6) * es + S * (4 + 6) * 4 + S * 4 + S + 256 * sizeof(DevParams<double>);
+  if ((err = hipMalloc(&e->arena, bytes)) != hipSuccess) return bail("hipMalloc", err);
+  e->arena_bytes = bytes;
+  if ((err = hipMemsetAsync(e->arena, 0, bytes, e->stream)) != hipSuccess) return bail("hipMemset", err);
+  char *p = (char *)e->arena;
+  auto carve = [&](size_t nbytes) { void *r = p; p += nbytes; return r; };
+  e->pos = carve(3 * S * es);
+  e->vel = carve(3 * S * es);
+  e->att = carve(4 * S * es);
+  e->ang_vel = carve(3 * S * es);
+  e->motor = carve(4 * S * es);
+  e->ext_force = carve(3 * S * es);
+  e->ext_torque = carve(3 * S * es);
+  e->cmd = (float *)carve(4 * S * 4);
+  e->gyro = (float *)carve(3 * S * 4);
+  e->acc = (float *)carve(3 * S * 4);
+  e->rng = (uint32_t *)carve(S * 4);
+  e->type = (uint8_t *)carve(S);
+  e->dev_table = carve(256 * sizeof(DevParams<double>));
+
+  // identity attitude (SimulationObject6DOF.hpp:17): w component = 1
+  {
+    std::vector<char> ones(S * es);
+    for (size_t k = 0; k < S; k++) {
+      if (precision == AFE_F64) ((double *)ones.data())[k] = 1.0;
+      else ((float *)ones.data())[k] = 1.0f;
+    }
+    if ((err = hipMemcpyAsync(e->att, ones.data(), S * es, hipMemcpyHostToDevice, e->stream)) != hipSuccess)
+      return bail("hipMemcpy", err);
+    if ((err = hipStreamSynchronize(e->stream)) != hipSuccess) return bail("hipStreamSynchronize", err);
+  }
+  if (launch_seed_rng(e->rng, e->n, e->first_global, e->seed_policy, e->stream) != 0)
+    return bail("seed kernel launch (is the gfx950 code object present?)", hipGetLastError());
+  if ((err = hipStreamSynchronize(e->stream)) != hipSuccess) return bail("seed kernel", err);
+  *out = e;
+  return AFE_OK;
+}
+
+extern "C" int afe_destroy(afe_engine *e) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  (void)hipSetDevice(e->device);
+  if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+  if (e->pack_scratch) (void)hipFree(e->pack_scratch);
+  if (e->arena) (void)hipFree(e->arena);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+  return AFE_OK;
+}
+
+extern "C" const char *afe_last_error(const afe_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+extern "C" int afe_set_stream(afe_engine *e, void *hip_stream) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  AFE_HIP(e, hipSetDevice(e->device));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return AFE_OK;
+}
+
+extern "C" int afe_set_type_table(afe_engine *e, const afe_vehicle_params *table, int n_types) {
+  if (!e || !table || n_types < 1 || n_types > 256) return fail(e, AFE_ERR_INVALID_ARG, "type table must hold 1..256 records");
+  std::vector<HostParams> t((size_t)n_types);
+  for (int k = 0; k < n_types; k++) {
+    const char *why = "";
+    int rc = expand_params(table[k], t[(size_t)k], &why);
+    if (rc) return fail(e, rc, "type " + std::to_string(k) + ": " + why);
+  }
+  e->table.swap(t);
+  e->table_dirty = true;
+  return AFE_OK;
+}
+
+extern "C" int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count, const uint8_t *type_index) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  if (!type_index) return fail(e, AFE_ERR_INVALID_ARG, "type_index is NULL");
+  for (int64_t k = 0; k < count; k++)
+    if (type_index[k] >= e->table.size())
+      return fail(e, AFE_ERR_INVALID_ARG, "type index " + std::to_string(type_index[k]) + " of vehicle " +
+                                              std::to_string(first + k) + " is outside the type table");
+  AFE_HIP(e, hipSetDevice(e->device));
+  AFE_HIP(e, hipMemcpyAsync(e->type + first, type_index, (size_t)count, hipMemcpyHostToDevice, e->stream));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  return AFE_OK;
+}
+
+extern "C" int afe_set_logic_period(afe_engine *e, double seconds) {
+  if (!e || !(seconds > 0) || !std::isfinite(seconds)) return fail(e, AFE_ERR_INVALID_ARG, "logic period must be > 0");
+  e->logic_period = seconds;
+  return AFE_OK;
+}
+
+extern "C" int afe_set_imu_noise(afe_engine *e, int enabled, double sigma_gyro, double sigma_acc, int seed_policy) {
+  if (!e || !(sigma_gyro >= 0) || !(sigma_acc >= 0) ||
+      (seed_policy != AFE_SEED_REFERENCE && seed_policy != AFE_SEED_DECORRELATED))
+    return fail(e, AFE_ERR_INVALID_ARG, "bad noise configuration");
+  e->noise = enabled != 0;
+  e->sigma_gyro = sigma_gyro;
+  e->sigma_acc = sigma_acc;
+  if (seed_policy != e->seed_policy) {
+    e->seed_policy = seed_policy;
+    AFE_HIP(e, hipSetDevice(e->device));
+    if (launch_seed_rng(e->rng, e->n, e->first_global, seed_policy, e->stream) != 0)
+      return fail(e, AFE_ERR_HIP, "seed kernel launch failed");
+  }
+  return AFE_OK;
+}
+
+extern "C" int afe_set_state(afe_engine *e, int64_t first, int64_t count, const double *pos3,
+                             const double *vel3, const double *att4, const double *ang_vel3,
+                             const double *motor_speed4) {
+  return set_state_any<double>(e, first, count, pos3, vel3, att4, ang_vel3, motor_speed4);
+}
+extern "C" int afe_get_state(afe_engine *e, int64_t first, int64_t count, double *pos3, double *vel3,
+                             double *att4, double *ang_vel3, double *motor_speed4) {
+  return get_state_any<double>(e, first, count, pos3, vel3, att4, ang_vel3, motor_speed4);
+}
+extern "C" int afe_set_state_f32(afe_engine *e, int64_t first, int64_t count, const float *pos3,
+                                 const float *vel3, const float *att4, const float *ang_vel3,
+                                 const float *motor_speed4) {
+  return set_state_any<float>(e, first, count, pos3, vel3, att4, ang_vel3, motor_speed4);
+}
+extern "C" int afe_get_state_f32(afe_engine *e, int64_t first, int64_t count, float *pos3, float *vel3,
+                                 float *att4, float *ang_vel3, float *motor_speed4) {
+  return get_state_any<float>(e, first, count, pos3, vel3, att4, ang_vel3, motor_speed4);
+}
+
+extern "C" int afe_set_rng_state(afe_engine *e, int64_t first, int64_t count, const uint32_t *state) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  if (!state) return fail(e, AFE_ERR_INVALID_ARG, "state is NULL");
+  for (int64_t k = 0; k < count; k++)
+    if (state[k] == 0 || state[k] >= 2147483647u) return fail(e, AFE_ERR_INVALID_ARG, "minstd_rand0 state must be in [1, 2^31-2]");
+  AFE_HIP(e, hipSetDevice(e->device));
+  AFE_HIP(e, hipMemcpyAsync(e->rng + first, state, (size_t)count * 4, hipMemcpyHostToDevice, e->stream));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  return AFE_OK;
+}
+extern "C" int afe_get_rng_state(afe_engine *e, int64_t first, int64_t count, uint32_t *state) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  if (!state) return fail(e, AFE_ERR_INVALID_ARG, "state is NULL");
+  AFE_HIP(e, hipSetDevice(e->device));
+  AFE_HIP(e, hipMemcpyAsync(state, e->rng + first, (size_t)count * 4, hipMemcpyDeviceToHost, e->stream));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  return AFE_OK;
+}
+
+extern "C" int afe_set_motor_cmds(afe_engine *e, int64_t first, int64_t count, const float *cmd4) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  if (!cmd4) return fail(e, AFE_ERR_INVALID_ARG, "cmd4 is NULL");
+  AFE_HIP(e, hipSetDevice(e->device));
+  return copy_in(e, e->cmd, 4, 4, first, count, cmd4);
+}
+extern "C" int afe_set_external_force(afe_engine *e, int64_t first, int64_t count, const double *force3) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  return set_wrench(e, e->ext_force, e->has_ext_force, first, count, force3);
+}
+extern "C" int afe_set_external_torque(afe_engine *e, int64_t first, int64_t count, const double *torque3) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  return set_wrench(e, e->ext_torque, e->has_ext_torque, first, count, torque3);
+}
+
+extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
+  if (!e || n_steps < 0) return fail(e, AFE_ERR_INVALID_ARG, "n_steps must be >= 0");
+  if (e->table.empty()) return fail(e, AFE_ERR_NOT_CONFIGURED, "afe_set_type_table has not been called");
+  if (n_steps == 0) return AFE_OK;
+  const double dt = us_to_seconds(dt_us);  // Timer::GetSeconds<double>, Timer.hpp:36-38
+  if (dt < 1e-6) return AFE_OK;            // Quadcopter_T.cpp:88-90
+  AFE_HIP(e, hipSetDevice(e->device));
+  int rc = refresh_table(e, dt);
+  if (rc) return rc;
+  LaunchFlags f;
+  f.ext_force = e->has_ext_force;
+  f.ext_torque = e->has_ext_torque;
+  f.noise = e->noise;
+  f.renorm = e->renorm;
+  int done = 0;
+  while (done < n_steps) {
+    const int chunk = (n_steps - done) < 64 ? (n_steps - done) : 64;
+    unsigned long long mask = 0;
+    for (int s = 0; s < chunk; s++) {
+      e->now_us += dt_us;  // ManualTimer::AdvanceMicroSeconds, main.cpp:392
+      if (gate_step(e->logic_period, e->logic_elapsed_us, dt_us)) {
+        mask |= (1ull << s);
+        e->n_ticks++;
+      }
+    }
+    int lrc;
+    if (e->precision == AFE_F64) {
+      StepView<double> v;
+      fill_view(e, v);
+      v.dt = dt; v.n_steps = chunk; v.tick_mask = mask;
+      lrc = launch_step_f64(v, f, e->stream);
+    } else {
+      StepView<float> v;
+      fill_view(e, v);
+      v.dt = (float)dt; v.n_steps = chunk; v.tick_mask = mask;
+      lrc = launch_step_f32(v, f, e->stream);
+    }
+    if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+    done += chunk;
+  }
+  return AFE_OK;
+}
+
+extern "C" int afe_steps_until_tick(const afe_engine *e, uint64_t dt_us, int *n_steps) {
+  if (!e || !n_steps) return AFE_ERR_INVALID_ARG;
+  if (us_to_seconds(dt_us) < 1e-6) return AFE_ERR_INVALID_ARG;
+  uint64_t el = e->logic_elapsed_us;
+  int k = 0;
+  for (;;) {
+    k++;
+    if (gate_step(e->logic_period, el, dt_us)) break;
+    if (k >= (1 << 30)) return AFE_ERR_INVALID_ARG;
+  }
+  *n_steps = k;
+  return AFE_OK;
+}
+
+extern "C" int afe_sync(afe_engine *e) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  AFE_HIP(e, hipSetDevice(e->device));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  return AFE_OK;
+}
+
+extern "C" int afe_time_us(const afe_engine *e, uint64_t *now_us) {
+  if (!e || !now_us) return AFE_ERR_INVALID_ARG;
+  *now_us = e->now_us;
+  return AFE_OK;
+}
+extern "C" int afe_logic_ticks(const afe_engine *e, uint64_t *n_ticks) {
+  if (!e || !n_ticks) return AFE_ERR_INVALID_ARG;
+  *n_ticks = e->n_ticks;
+  return AFE_OK;
+}
+
+extern "C" int afe_get_imu(afe_engine *e, int64_t first, int64_t count, float *gyro3, float *acc3) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  AFE_HIP(e, hipSetDevice(e->device));
+  if ((rc = copy_out(e, e->gyro, 4, 3, first, count, gyro3))) return rc;
+  return copy_out(e, e->acc, 4, 3, first, count, acc3);
+}
+
+extern "C" int afe_get_device_view(afe_engine *e, afe_device_view *out) {
+  if (!e || !out) return AFE_ERR_INVALID_ARG;
+  out->n_vehicles = e->n;
+  out->stride = e->stride;
+  out->state_elem_size = (int)elem(e);
+  out->pos = e->pos; out->vel = e->vel; out->att = e->att; out->ang_vel = e->ang_vel;
+  out->motor_speed = e->motor;
+  out->ext_force = e->ext_force; out->ext_torque = e->ext_torque;
+  out->motor_cmd = e->cmd; out->gyro = e->gyro; out->acc = e->acc;
+  out->rng = e->rng; out->type_index = e->type;
+  return AFE_OK;
+}
+
+extern "C" int afe_algorithmic_bytes_per_step(const afe_engine *e, int imu_tick, double *bytes) {
+  if (!e || !bytes) return AFE_ERR_INVALID_ARG;
+  const double es = (double)elem(e);
+  double b = 17 * es * 2;      // state read + write (pos3 vel3 att4 angvel3 motor4)
+  b += 4 * 4;                  // motor commands (float)
+  b += 1;                      // type index
+  if (e->has_ext_force) b += 3 * es;
+  if (e->has_ext_torque) b += 3 * es;
+  if (imu_tick) {
+    b += 6 * 4;                // gyro + accelerometer sample
+    if (e->noise) b += 8;      // RNG word read + write
+  }
+  *bytes = b;
+  return AFE_OK;
+}
+
+extern "C" int afe_event_create(void **event) {
+  if (!event) return AFE_ERR_INVALID_ARG;
+  hipEvent_t ev;
+  if (hipEventCreate(&ev) != hipSuccess) return AFE_ERR_HIP;
+  *event = (void *)ev;
+  return AFE_OK;
+}
+extern "C" int afe_event_destroy(void *event) {
+  if (!event) return AFE_ERR_INVALID_ARG;
+  return hipEventDestroy((hipEvent_t)event) == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+}
+extern "C" int afe_event_record(afe_engine *e, void *event) {
+  if (!e || !event) return AFE_ERR_INVALID_ARG;
+  AFE_HIP(e, hipSetDevice(e->device));
+  AFE_HIP(e, hipEventRecord((hipEvent_t)event, e->stream));
+  return AFE_OK;
+}
+extern "C" int afe_event_elapsed_ms(void *start, void *stop, float *ms) {
+  if (!start || !stop || !ms) return AFE_ERR_INVALID_ARG;
+  if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return AFE_ERR_HIP;
+  return hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+}
+
+extern "C" int afe_pack_positions(afe_engine *e, float *device_xyz) {
+  if (!e || !device_xyz) return fail(e, AFE_ERR_INVALID_ARG, "device_xyz is NULL");
+  AFE_HIP(e, hipSetDevice(e->device));
+  int rc = (e->precision == AFE_F64)
+               ? launch_pack_positions_f64((const double *)e->pos, e->stride, e->n, device_xyz, e->stream)
+               : launch_pack_positions_f32((const float *)e->pos, e->stride, e->n, device_xyz, e->stream);
+  if (rc) return fail(e, AFE_ERR_HIP, "pack kernel launch failed");
+  return AFE_OK;
+}
+
+extern "C" int afe_nearest_neighbour(afe_engine *e, const float *all_xyz, int64_t n_all, float *dist2_out,
+                                     int32_t *index_out) {
+  if (!e || !all_xyz || n_all <= 0 || !dist2_out || !index_out)
+    return fail(e, AFE_ERR_INVALID_ARG, "bad nearest-neighbour arguments");
+  AFE_HIP(e, hipSetDevice(e->device));
+  if (!e->pack_scratch) AFE_HIP(e, hipMalloc((void **)&e->pack_scratch, (size_t)e->n * 3 * sizeof(float)));
+  int rc = afe_pack_positions(e, e->pack_scratch);
+  if (rc) return rc;
+  if (launch_nearest_neighbour(e->pack_scratch, e->n, e->first_global, all_xyz, n_all, dist2_out, index_out, e->stream))
+    return fail(e, AFE_ERR_HIP, "nearest-neighbour kernel launch failed");
+  return AFE_OK;
+}

@@ -1,0 +1,44 @@
+// afe_host.h -- host-only helpers of the engine (no HIP): parameter expansion,
+// vehicle-type table, clock / logic-gate planning.  Kept free of GPU calls so
+// the CPU test job can exercise them through the C ABI without a device.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/agrifly_engine.h"
+#include "afe_device.h"
+
+namespace afe {
+
+// Expanded constants in double (what the Quadcopter_T ctor computes once).
+struct HostParams {
+  double mass;
+  double I[9], Iinv[9];
+  double mp[4][3];
+  double kf, ktau, tau_m, Jm, wmin, wmax;
+  double drag[3];
+  float Rimu[9];
+};
+
+// Quadcopter_T ctor body, reference Quadcopter_T.cpp:20,45-65,75-80.
+// Returns AFE_OK or AFE_ERR_INVALID_ARG (the reference asserts instead:
+// Motor.cpp:27-30).
+int expand_params(const afe_vehicle_params &in, HostParams &out, const char **why);
+
+// Narrow to the kernel record for a given dt (c_lag = exp(-dt/tau_m)).
+template <typename R>
+void to_device_params(const HostParams &h, double dt, DevParams<R> &d);
+
+// Timer semantics, reference Common/Common/Time/Timer.hpp:27-54.
+inline double us_to_seconds(uint64_t us) { return (double)((double)us * 1e-6); }
+inline uint64_t period_to_us(double period_s) { return (uint64_t)((-period_s) * -1e6); }
+// one step of dt_us: returns true when the gate of Quadcopter_T.cpp:159 fires
+inline bool gate_step(double period_s, uint64_t &elapsed_us, uint64_t dt_us) {
+  elapsed_us += dt_us;
+  if (us_to_seconds(elapsed_us) > period_s) {
+    elapsed_us -= period_to_us(period_s);
+    return true;
+  }
+  return false;
+}
+
+}  // namespace afe

@@ -1,0 +1,377 @@
+"""ctypes binding of include/agrifly_engine.h (the C ABI of the HIP engine).
+
+Mirrors the C entry points one to one; see the header for which reference
+interface (agri-fly file:line) each call replaces.  Host arrays are numpy,
+planar ``[components, count]``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libagrifly_engine.so")
+
+AFE_F32, AFE_F64 = 0, 1
+AFE_SEED_REFERENCE, AFE_SEED_DECORRELATED = 0, 1
+
+# every symbol include/agrifly_engine.h declares (checked by tests/test_abi.py)
+ABI_FUNCTIONS = [
+    "afe_params_from_type", "afe_type_from_id", "afe_create", "afe_destroy",
+    "afe_last_error", "afe_status_string", "afe_abi_version", "afe_set_stream",
+    "afe_set_type_table", "afe_set_vehicle_types", "afe_set_logic_period",
+    "afe_set_imu_noise", "afe_set_state", "afe_get_state", "afe_set_state_f32",
+    "afe_get_state_f32", "afe_set_rng_state", "afe_get_rng_state",
+    "afe_set_motor_cmds", "afe_set_external_force", "afe_set_external_torque",
+    "afe_step", "afe_steps_until_tick", "afe_sync", "afe_time_us",
+    "afe_logic_ticks", "afe_get_imu", "afe_plan_ticks", "afe_get_device_view",
+    "afe_algorithmic_bytes_per_step", "afe_event_create", "afe_event_destroy",
+    "afe_event_record", "afe_event_elapsed_ms", "afe_pack_positions",
+    "afe_nearest_neighbour",
+]
+
+
+class AfeError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("agrifly_engine status %d: %s" % (status, message))
+        self.status = status
+
+
+class VehicleParams(C.Structure):
+    """afe_vehicle_params == the Quadcopter_T constructor arguments
+    (reference Components/Components/Simulation/Quadcopter_T.hpp:24-32)."""
+    _fields_ = [
+        ("mass", C.c_double),
+        ("inertia", C.c_double * 9),
+        ("arm_length", C.c_double),
+        ("com_error", C.c_double * 3),
+        ("motor_min_speed", C.c_double),
+        ("motor_max_speed", C.c_double),
+        ("prop_thrust_from_speed_sqr", C.c_double),
+        ("prop_torque_from_speed_sqr", C.c_double),
+        ("motor_time_const", C.c_double),
+        ("motor_inertia", C.c_double),
+        ("lin_drag_coeff_b", C.c_double * 3),
+        ("imu_yaw", C.c_float),
+        ("imu_pitch", C.c_float),
+        ("imu_roll", C.c_float),
+    ]
+
+    def copy(self):
+        other = VehicleParams()
+        C.memmove(C.byref(other), C.byref(self), C.sizeof(VehicleParams))
+        return other
+
+    @property
+    def hover_speed(self):
+        """per-motor speed at which 4 k_f w^2 = m g"""
+        return float(np.sqrt(self.mass * 9.81 / (4.0 * self.prop_thrust_from_speed_sqr)))
+
+
+class DeviceView(C.Structure):
+    _fields_ = [
+        ("n_vehicles", C.c_int64), ("stride", C.c_int64), ("state_elem_size", C.c_int),
+        ("pos", C.c_void_p), ("vel", C.c_void_p), ("att", C.c_void_p),
+        ("ang_vel", C.c_void_p), ("motor_speed", C.c_void_p),
+        ("ext_force", C.c_void_p), ("ext_torque", C.c_void_p),
+        ("motor_cmd", C.c_void_p), ("gyro", C.c_void_p), ("acc", C.c_void_p),
+        ("rng", C.c_void_p), ("type_index", C.c_void_p),
+    ]
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ into lib/ (in-tree)."""
+    src = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(_LIB):
+        os.remove(_LIB)
+    subprocess.check_call(["make", "-s", "-C", src])
+    if not os.path.exists(_LIB):
+        raise RuntimeError("engine build produced no " + _LIB)
+    return _LIB
+
+
+_lib = None
+
+
+def library():
+    """Load the engine library; fails loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise ImportError(
+            "HIP engine library %s is missing: run `python -c \"import __graft_entry__ as g; "
+            "g.build()\"` (hipcc, gfx950). There is no CPU fallback." % _LIB)
+    L = C.CDLL(_LIB)
+    i64, u64, vp, ci = C.c_int64, C.c_uint64, C.c_void_p, C.c_int
+    eng = vp
+    sig = {
+        "afe_params_from_type": [ci, C.POINTER(VehicleParams)],
+        "afe_type_from_id": [C.c_uint],
+        "afe_create": [C.POINTER(vp), i64, ci, ci, i64],
+        "afe_destroy": [eng],
+        "afe_abi_version": [],
+        "afe_set_stream": [eng, vp],
+        "afe_set_type_table": [eng, C.POINTER(VehicleParams), ci],
+        "afe_set_vehicle_types": [eng, i64, i64, vp],
+        "afe_set_logic_period": [eng, C.c_double],
+        "afe_set_imu_noise": [eng, ci, C.c_double, C.c_double, ci],
+        "afe_set_state": [eng, i64, i64, vp, vp, vp, vp, vp],
+        "afe_get_state": [eng, i64, i64, vp, vp, vp, vp, vp],
+        "afe_set_state_f32": [eng, i64, i64, vp, vp, vp, vp, vp],
+        "afe_get_state_f32": [eng, i64, i64, vp, vp, vp, vp, vp],
+        "afe_set_rng_state": [eng, i64, i64, vp],
+        "afe_get_rng_state": [eng, i64, i64, vp],
+        "afe_set_motor_cmds": [eng, i64, i64, vp],
+        "afe_set_external_force": [eng, i64, i64, vp],
+        "afe_set_external_torque": [eng, i64, i64, vp],
+        "afe_step": [eng, u64, ci],
+        "afe_steps_until_tick": [eng, u64, C.POINTER(ci)],
+        "afe_sync": [eng],
+        "afe_time_us": [eng, C.POINTER(u64)],
+        "afe_logic_ticks": [eng, C.POINTER(u64)],
+        "afe_get_imu": [eng, i64, i64, vp, vp],
+        "afe_plan_ticks": [C.c_double, C.POINTER(u64), u64, ci, vp],
+        "afe_get_device_view": [eng, C.POINTER(DeviceView)],
+        "afe_algorithmic_bytes_per_step": [eng, ci, C.POINTER(C.c_double)],
+        "afe_event_create": [C.POINTER(vp)],
+        "afe_event_destroy": [vp],
+        "afe_event_record": [eng, vp],
+        "afe_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
+        "afe_pack_positions": [eng, vp],
+        "afe_nearest_neighbour": [eng, vp, i64, vp, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = ci
+    L.afe_last_error.argtypes = [eng]
+    L.afe_last_error.restype = C.c_char_p
+    L.afe_status_string.argtypes = [ci]
+    L.afe_status_string.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def params_from_type(quadcopter_type):
+    p = VehicleParams()
+    rc = library().afe_params_from_type(int(quadcopter_type), C.byref(p))
+    if rc:
+        raise AfeError(rc, "invalid quadcopter type %r" % (quadcopter_type,))
+    return p
+
+
+def type_from_id(vehicle_id):
+    return library().afe_type_from_id(int(vehicle_id))
+
+
+def plan_ticks(logic_period, elapsed_us, dt_us, n_steps):
+    """(ticks[n_steps], new elapsed_us): pure host, no GPU needed."""
+    el = C.c_uint64(int(elapsed_us))
+    out = np.zeros(n_steps, np.uint8)
+    rc = library().afe_plan_ticks(float(logic_period), C.byref(el), int(dt_us), int(n_steps),
+                                  out.ctypes.data)
+    if rc:
+        raise AfeError(rc, "afe_plan_ticks")
+    return out, el.value
+
+
+def _planar(a, comps, count, dtype):
+    if a is None:
+        return None, None
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    if arr.shape != (comps, count):
+        raise ValueError("expected planar array of shape (%d, %d), got %r" % (comps, count, arr.shape))
+    return arr, arr.ctypes.data
+
+
+class Ensemble:
+    """One engine = one vehicle ensemble (or one rank's shard of it) on one GPU."""
+
+    def __init__(self, n_vehicles, precision=AFE_F32, device=-1, first_global_index=0):
+        self._L = library()
+        self._h = C.c_void_p()
+        rc = self._L.afe_create(C.byref(self._h), int(n_vehicles), int(precision), int(device),
+                                int(first_global_index))
+        if rc:
+            self._h = None
+            raise AfeError(rc, self._L.afe_status_string(rc).decode() +
+                           " (the HIP engine needs an MI355X / gfx950 device; there is no CPU fallback)")
+        self.n = int(n_vehicles)
+        self.precision = precision
+        self.first_global_index = int(first_global_index)
+
+    # -- plumbing ---------------------------------------------------------
+    def _ck(self, rc):
+        if rc:
+            raise AfeError(rc, self._L.afe_last_error(self._h).decode() or
+                           self._L.afe_status_string(rc).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.afe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _range(self, first, count):
+        first = int(first)
+        count = self.n - first if count is None else int(count)
+        return first, count
+
+    # -- configuration ----------------------------------------------------
+    def set_type_table(self, params_list):
+        arr = (VehicleParams * len(params_list))()
+        for i, p in enumerate(params_list):
+            C.memmove(C.byref(arr[i]), C.byref(p), C.sizeof(VehicleParams))
+        self._ck(self._L.afe_set_type_table(self._h, arr, len(params_list)))
+
+    def set_vehicle_types(self, type_index, first=0):
+        t = np.ascontiguousarray(type_index, dtype=np.uint8)
+        self._ck(self._L.afe_set_vehicle_types(self._h, int(first), t.size, t.ctypes.data))
+
+    def set_logic_period(self, seconds):
+        self._ck(self._L.afe_set_logic_period(self._h, float(seconds)))
+
+    def set_imu_noise(self, enabled=True, sigma_gyro=0.1, sigma_acc=0.2,
+                      seed_policy=AFE_SEED_REFERENCE):
+        self._ck(self._L.afe_set_imu_noise(self._h, int(bool(enabled)), float(sigma_gyro),
+                                           float(sigma_acc), int(seed_policy)))
+
+    def set_stream(self, hip_stream):
+        self._ck(self._L.afe_set_stream(self._h, C.c_void_p(hip_stream or None)))
+
+    # -- state ------------------------------------------------------------
+    def set_state(self, pos=None, vel=None, att=None, ang_vel=None, motor_speed=None,
+                  first=0, count=None, dtype=np.float64):
+        first, count = self._range(first, count)
+        fn = self._L.afe_set_state if dtype == np.float64 else self._L.afe_set_state_f32
+        keep = [_planar(a, c, count, dtype) for a, c in
+                ((pos, 3), (vel, 3), (att, 4), (ang_vel, 3), (motor_speed, 4))]
+        self._ck(fn(self._h, first, count, *[k[1] for k in keep]))
+
+    def get_state(self, first=0, count=None, dtype=np.float64):
+        first, count = self._range(first, count)
+        fn = self._L.afe_get_state if dtype == np.float64 else self._L.afe_get_state_f32
+        out = dict(pos=np.empty((3, count), dtype), vel=np.empty((3, count), dtype),
+                   att=np.empty((4, count), dtype), ang_vel=np.empty((3, count), dtype),
+                   motor_speed=np.empty((4, count), dtype))
+        self._ck(fn(self._h, first, count, out["pos"].ctypes.data, out["vel"].ctypes.data,
+                    out["att"].ctypes.data, out["ang_vel"].ctypes.data,
+                    out["motor_speed"].ctypes.data))
+        return out
+
+    def set_rng_state(self, state, first=0):
+        s = np.ascontiguousarray(state, dtype=np.uint32)
+        self._ck(self._L.afe_set_rng_state(self._h, int(first), s.size, s.ctypes.data))
+
+    def get_rng_state(self, first=0, count=None):
+        first, count = self._range(first, count)
+        s = np.empty(count, np.uint32)
+        self._ck(self._L.afe_get_rng_state(self._h, first, count, s.ctypes.data))
+        return s
+
+    # -- inputs -----------------------------------------------------------
+    def set_motor_cmds(self, cmd4, first=0, count=None):
+        first, count = self._range(first, count)
+        arr, ptr = _planar(cmd4, 4, count, np.float32)
+        self._ck(self._L.afe_set_motor_cmds(self._h, first, count, ptr))
+
+    def set_external_force(self, force3, first=0, count=None):
+        first, count = self._range(first, count)
+        arr, ptr = _planar(force3, 3, count, np.float64)
+        self._ck(self._L.afe_set_external_force(self._h, first, count, ptr))
+
+    def set_external_torque(self, torque3, first=0, count=None):
+        first, count = self._range(first, count)
+        arr, ptr = _planar(torque3, 3, count, np.float64)
+        self._ck(self._L.afe_set_external_torque(self._h, first, count, ptr))
+
+    # -- stepping ---------------------------------------------------------
+    def step(self, dt_us, n_steps=1):
+        self._ck(self._L.afe_step(self._h, int(dt_us), int(n_steps)))
+
+    def steps_until_tick(self, dt_us):
+        n = C.c_int(0)
+        self._ck(self._L.afe_steps_until_tick(self._h, int(dt_us), C.byref(n)))
+        return n.value
+
+    def sync(self):
+        self._ck(self._L.afe_sync(self._h))
+
+    @property
+    def time_us(self):
+        t = C.c_uint64(0)
+        self._ck(self._L.afe_time_us(self._h, C.byref(t)))
+        return t.value
+
+    @property
+    def logic_ticks(self):
+        t = C.c_uint64(0)
+        self._ck(self._L.afe_logic_ticks(self._h, C.byref(t)))
+        return t.value
+
+    def get_imu(self, first=0, count=None):
+        first, count = self._range(first, count)
+        gyro = np.empty((3, count), np.float32)
+        acc = np.empty((3, count), np.float32)
+        self._ck(self._L.afe_get_imu(self._h, first, count, gyro.ctypes.data, acc.ctypes.data))
+        return gyro, acc
+
+    def device_view(self):
+        v = DeviceView()
+        self._ck(self._L.afe_get_device_view(self._h, C.byref(v)))
+        return v
+
+    def algorithmic_bytes_per_step(self, imu_tick):
+        b = C.c_double(0)
+        self._ck(self._L.afe_algorithmic_bytes_per_step(self._h, int(bool(imu_tick)), C.byref(b)))
+        return b.value
+
+    # -- HIP events on the engine stream ------------------------------------
+    def event(self):
+        ev = C.c_void_p()
+        rc = self._L.afe_event_create(C.byref(ev))
+        if rc:
+            raise AfeError(rc, "afe_event_create")
+        return ev
+
+    def record(self, ev):
+        self._ck(self._L.afe_event_record(self._h, ev))
+
+    def elapsed_ms(self, start, stop):
+        ms = C.c_float(0)
+        rc = self._L.afe_event_elapsed_ms(start, stop, C.byref(ms))
+        if rc:
+            raise AfeError(rc, "afe_event_elapsed_ms")
+        return ms.value
+
+    def destroy_event(self, ev):
+        self._L.afe_event_destroy(ev)
+
+    # -- shared-world query -------------------------------------------------
+    def pack_positions(self, device_ptr):
+        self._ck(self._L.afe_pack_positions(self._h, C.c_void_p(int(device_ptr))))
+
+    def nearest_neighbour(self, all_xyz_ptr, n_all, dist2_ptr, index_ptr):
+        self._ck(self._L.afe_nearest_neighbour(self._h, C.c_void_p(int(all_xyz_ptr)), int(n_all),
+                                               C.c_void_p(int(dist2_ptr)), C.c_void_p(int(index_ptr))))

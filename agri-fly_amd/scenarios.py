@@ -1,0 +1,133 @@
+"""Seeded synthetic ensembles shaped like BASELINE.json's configs (numpy only).
+
+Value distributions follow SURVEY.md 8(d): positions U(-5,5)^2 x U(0,5) m,
+velocities N(0,2) m/s, attitude uniform with tilt <= 60 deg, body rates N(0,2)
+rad/s, motor speeds and commands U(0, w_max).  PRNG: numpy PCG64.
+"""
+import numpy as np
+
+
+class EnsembleData:
+    """Planar host arrays for n vehicles; `types` index into `type_ids`."""
+
+    def __init__(self, n):
+        self.n = n
+        self.type_ids = [5]                      # QuadcopterType values, table order
+        self.types = np.zeros(n, np.uint8)       # index into type_ids
+        self.pos = np.zeros((3, n))
+        self.vel = np.zeros((3, n))
+        self.att = np.zeros((4, n))
+        self.att[0] = 1.0
+        self.ang_vel = np.zeros((3, n))
+        self.motor_speed = np.zeros((4, n))
+        self.motor_cmd = np.zeros((4, n), np.float32)
+        self.ext_force = None
+        self.ext_torque = None
+
+    def slice(self, first, count):
+        out = EnsembleData(count)
+        out.type_ids = list(self.type_ids)
+        sl = slice(first, first + count)
+        for name in ("pos", "vel", "att", "ang_vel", "motor_speed", "motor_cmd"):
+            setattr(out, name, np.ascontiguousarray(getattr(self, name)[:, sl]))
+        out.types = np.ascontiguousarray(self.types[sl])
+        for name in ("ext_force", "ext_torque"):
+            a = getattr(self, name)
+            setattr(out, name, None if a is None else np.ascontiguousarray(a[:, sl]))
+        return out
+
+
+def _quat_mul(a, b):
+    """a * b, product convention of Rotation.hpp:124-131 (this = a, r1 = b)."""
+    return np.stack([
+        b[0] * a[0] - b[1] * a[1] - b[2] * a[2] - b[3] * a[3],
+        b[1] * a[0] + b[0] * a[1] + b[3] * a[2] - b[2] * a[3],
+        b[2] * a[0] - b[3] * a[1] + b[0] * a[2] + b[1] * a[3],
+        b[3] * a[0] + b[2] * a[1] - b[1] * a[2] + b[0] * a[3]])
+
+
+def random_attitudes(rng, n, max_tilt_deg=60.0):
+    yaw = rng.uniform(-np.pi, np.pi, n)
+    tilt = rng.uniform(0.0, np.deg2rad(max_tilt_deg), n)
+    az = rng.uniform(-np.pi, np.pi, n)
+    qyaw = np.stack([np.cos(yaw / 2), 0 * yaw, 0 * yaw, np.sin(yaw / 2)])
+    qtilt = np.stack([np.cos(tilt / 2), np.sin(tilt / 2) * np.cos(az),
+                      np.sin(tilt / 2) * np.sin(az), 0 * tilt])
+    q = _quat_mul(qyaw, qtilt)
+    return q / np.linalg.norm(q, axis=0)
+
+
+def hover_speed(params):
+    return float(np.sqrt(params.mass * 9.81 / (4.0 * params.prop_thrust_from_speed_sqr)))
+
+
+def random_ensemble(n, seed, type_ids=(5, 1, 2, 4), max_speeds=None, with_wrench=True,
+                    ground_fraction=0.05):
+    """G1-style random states over several vehicle types.
+    max_speeds: {type_id: w_max}; defaults to 3000 rad/s when not given."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    e = EnsembleData(n)
+    e.type_ids = list(type_ids)
+    e.types = rng.integers(0, len(type_ids), n).astype(np.uint8)
+    e.pos[0] = rng.uniform(-5, 5, n)
+    e.pos[1] = rng.uniform(-5, 5, n)
+    e.pos[2] = rng.uniform(0, 5, n)
+    e.vel = rng.normal(0, 2, (3, n))
+    e.att = random_attitudes(rng, n)
+    e.ang_vel = rng.normal(0, 2, (3, n))
+    wmax = np.array([(max_speeds or {}).get(t, 3000.0) for t in type_ids])[e.types]
+    e.motor_speed = rng.uniform(0, 1, (4, n)) * wmax
+    e.motor_cmd = (rng.uniform(0, 1, (4, n)) * wmax).astype(np.float32)
+    # a few vehicles touching / entering the ground (Quadcopter_T.cpp:146-151)
+    k = int(n * ground_fraction)
+    if k:
+        idx = rng.choice(n, k, replace=False)
+        e.pos[2, idx] = rng.uniform(0, 1e-4, k)
+        e.vel[2, idx] = -np.abs(e.vel[2, idx]) - 0.5
+    # a few with |w| dt below the one-arc-second identity threshold (Rotation.hpp:39,86)
+    k2 = max(1, n // 50)
+    idx2 = rng.choice(n, k2, replace=False)
+    e.ang_vel[:, idx2] *= 1e-6
+    # a few negative commands (Motor.cpp:48-50)
+    idx3 = rng.choice(n, max(1, n // 50), replace=False)
+    e.motor_cmd[0, idx3] = -100.0
+    if with_wrench:
+        e.ext_force = rng.normal(0, 0.2, (3, n))
+        e.ext_torque = rng.normal(0, 1e-3, (3, n))
+    return e
+
+
+def hover_ensemble(n, params, height=3.5):
+    """Config 2: every vehicle hovering at `height` m, motors at hover speed,
+    commands held at hover speed (open loop)."""
+    e = EnsembleData(n)
+    e.pos[2] = height
+    w = hover_speed(params)
+    e.motor_speed[:] = w
+    e.motor_cmd[:] = np.float32(w)
+    return e
+
+
+def gust_ensemble(n, params, seed=4, sigma_max=0.5, height=3.5, first_global=0, n_global=None):
+    """Config 4: hovering ensemble with a per-vehicle constant wind-gust force
+    F ~ N(0, sigma_i^2) per axis, sigma_i swept 0..sigma_max over the GLOBAL
+    ensemble (so a shard [first_global, first_global+n) of a bigger ensemble
+    reproduces exactly the rows an unsharded run would have)."""
+    n_global = n if n_global is None else n_global
+    e = hover_ensemble(n, params, height)
+    idx = np.arange(first_global, first_global + n)
+    sigma = sigma_max * idx / max(1, n_global - 1)
+    # counter-based: vehicle i's gust depends only on (seed, i)
+    f = np.empty((3, n))
+    for axis in range(3):
+        ss = np.random.SeedSequence([seed, axis])
+        # Philox is counter-based: jump to this shard's offset
+        bg = np.random.Philox(key=ss.generate_state(2, np.uint64))
+        bg = bg.advance(first_global)
+        # one normal per vehicle drawn from one uniform pair (Box-Muller) so the
+        # stream position is exactly one counter block per vehicle
+        gen = np.random.Generator(bg)
+        u = gen.random((n, 4))  # one 4x64-bit Philox block per vehicle
+        f[axis] = np.sqrt(-2.0 * np.log1p(-u[:, 0])) * np.cos(2 * np.pi * u[:, 1])
+    e.ext_force = f * sigma
+    return e

@@ -1,0 +1,236 @@
+/*
+ * agrifly_engine.h -- C ABI of the MI355X batched quadrotor dynamics engine.
+ *
+ * This is the drop-in boundary for agri-fly's vehicle-step hot path.  The
+ * reference has no FFI: its seams are a C++ abstract class and a template
+ * parameter compiled in-process.  The entry points below are
+ * what a binding of that path has to reach; each one names the reference
+ * interface it replaces (paths relative to the agri-fly tree).  The C++ facade
+ * in include/agrifly/ re-creates the reference's Vehicle / logicType classes
+ * on top of exactly these calls.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ or torch types.
+ *   - every call returns an afe_status (0 = ok); no exceptions cross the ABI;
+ *     afe_last_error() gives the message of the last failure on that engine.
+ *   - host arrays are caller-allocated and PLANAR: a 3-vector field of `count`
+ *     vehicles is x[0..count) y[0..count) z[0..count); quaternions are scalar
+ *     first (w x y z), as Common/Common/Math/Rotation.hpp:46-51.
+ *   - one engine = one ensemble on one GPU with one clock; one host thread at
+ *     a time per engine (the reference is single-threaded as well).
+ *   - stepping is asynchronous on the engine's HIP stream; getters synchronise.
+ *   - there is NO CPU fallback: without a usable gfx950 device afe_create
+ *     fails with AFE_ERR_NO_DEVICE.
+ */
+#ifndef AGRIFLY_ENGINE_H
+#define AGRIFLY_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFE_ABI_VERSION 1
+
+typedef struct afe_engine afe_engine; /* opaque */
+
+typedef enum afe_status {
+  AFE_OK = 0,
+  AFE_ERR_INVALID_ARG = 1,
+  AFE_ERR_NO_DEVICE = 2,   /* no HIP device / not gfx950 / kernels missing */
+  AFE_ERR_HIP = 3,         /* a HIP runtime call failed (see afe_last_error) */
+  AFE_ERR_OUT_OF_RANGE = 4,
+  AFE_ERR_NOT_CONFIGURED = 5, /* stepping before a type table was set */
+  AFE_ERR_COMM = 6
+} afe_status;
+
+typedef enum afe_precision {
+  AFE_F32 = 0, /* fp32 state + arithmetic: the production path (176 B/step) */
+  AFE_F64 = 1  /* fp64 state + arithmetic: the reference's own precision */
+} afe_precision;
+
+typedef enum afe_seed_policy {
+  /* every vehicle seeds std::default_random_engine with 1, exactly like the
+   * reference ensemble does (Quadcopter_T.cpp:27) */
+  AFE_SEED_REFERENCE = 0,
+  /* seed = 1 + global vehicle index: independent Monte-Carlo streams */
+  AFE_SEED_DECORRELATED = 1
+} afe_seed_policy;
+
+/* The per-vehicle constant record: the arguments of
+ *   Simulation::Quadcopter_T<logicType>::Quadcopter_T(...)
+ *   Components/Components/Simulation/Quadcopter_T.hpp:24-32
+ * (masterTimer, id and quadcopterType are engine / facade concerns).  The
+ * engine derives motor geometry, I^-1 and the IMU mount matrix from it the way
+ * the ctor body does (Quadcopter_T.cpp:20,45-65,75-80). */
+typedef struct afe_vehicle_params {
+  double mass;                       /* [kg] */
+  double inertia[9];                 /* row-major 3x3 [kg m^2] */
+  double arm_length;                 /* [m] */
+  double com_error[3];               /* centreOfMassError [m] */
+  double motor_min_speed;            /* [rad/s] */
+  double motor_max_speed;            /* [rad/s] */
+  double prop_thrust_from_speed_sqr; /* [N/(rad/s)^2] */
+  double prop_torque_from_speed_sqr; /* [N m/(rad/s)^2] */
+  double motor_time_const;           /* [s]; 0 = instantaneous */
+  double motor_inertia;              /* [kg m^2] */
+  double lin_drag_coeff_b[3];        /* [N s/m], body axes */
+  float imu_yaw, imu_pitch, imu_roll; /* QuadcopterConstants::IMU_* [rad] */
+} afe_vehicle_params;
+
+/* ---- vehicle-type table -------------------------------------------------
+ * Replaces Onboard::QuadcopterConstants(QuadcopterType) +
+ * GetVehicleTypeFromID (Components/Components/Logic/QuadcopterConstants.hpp:
+ * 31-274,297-332) as consumed by Simulator/Rappids_Simulator/main.cpp:147-218.
+ * type: 1 CF_STANDARD, 2 CF_BIGMOTORSPROPS, 4 CF_LARGEQUAD, 5 CF_MINIQUAD.
+ * Pure host functions: usable without a GPU. */
+int afe_params_from_type(int quadcopter_type, afe_vehicle_params *out);
+int afe_type_from_id(unsigned vehicle_id);
+
+/* ---- lifetime -----------------------------------------------------------
+ * Replaces `new Simulation::Quadcopter(...)` x n_vehicles (main.cpp:211-218;
+ * the multi-vehicle form is the std::vector<SimVehicle> of
+ * AIFS_ROS/hiperlab_rostools/src/Simulator/main.cpp:58-95).
+ * device < 0 selects the current HIP device.  first_global_index is this
+ * shard's offset in the whole ensemble (used by AFE_SEED_DECORRELATED and by
+ * afe_gather_positions); 0 for a single-GPU ensemble.  Initial state is the
+ * reference's: origin, at rest, identity attitude, motors stopped, engine
+ * clock 0 (SimulationObject6DOF.hpp:14-19, Motor.cpp:18). */
+int afe_create(afe_engine **out, int64_t n_vehicles, int precision, int device,
+               int64_t first_global_index);
+int afe_destroy(afe_engine *e);
+const char *afe_last_error(const afe_engine *e);
+const char *afe_status_string(int status);
+int afe_abi_version(void);
+
+/* Use a caller-owned HIP stream (hipStream_t) for all engine work, e.g.
+ * torch's current stream.  NULL restores the engine's own stream. */
+int afe_set_stream(afe_engine *e, void *hip_stream);
+
+/* ---- configuration ------------------------------------------------------ */
+/* Table of up to 256 parameter records, staged into LDS by the step kernel;
+ * vehicle i uses table[type_index[i]].  Replaces the per-object ctor args. */
+int afe_set_type_table(afe_engine *e, const afe_vehicle_params *table, int n_types);
+int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count,
+                          const uint8_t *type_index);
+/* onboardLogicPeriod ctor argument (Quadcopter_T.hpp:32, used at
+ * Quadcopter_T.cpp:159-160).  Default 1/500 s (main.cpp:177). */
+int afe_set_logic_period(afe_engine *e, double seconds);
+/* IMU noise (Quadcopter_T.cpp:5-6,165-180).  The reference hard-codes
+ * sigma_gyro = 0.1, sigma_acc = 0.2 and seed 1; these are the defaults.
+ * enabled = 0 switches the six draws off (the stream does not advance). */
+int afe_set_imu_noise(afe_engine *e, int enabled, double sigma_gyro,
+                      double sigma_acc, int seed_policy);
+
+/* ---- state in / out -----------------------------------------------------
+ * Replace SimulationObject6DOF::Set/Get{Position,Velocity,Attitude,
+ * AngularVelocity} (Components/Components/Simulation/SimulationObject6DOF.hpp:
+ * 26-56) and Motor::SetSpeed / the motor speed read behind GetMotorForce
+ * (Motor.hpp:30-32, Quadcopter_T.hpp:39).  NULL field pointers are skipped. */
+int afe_set_state(afe_engine *e, int64_t first, int64_t count,
+                  const double *pos3, const double *vel3, const double *att4,
+                  const double *ang_vel3, const double *motor_speed4);
+int afe_get_state(afe_engine *e, int64_t first, int64_t count, double *pos3,
+                  double *vel3, double *att4, double *ang_vel3,
+                  double *motor_speed4);
+int afe_set_state_f32(afe_engine *e, int64_t first, int64_t count,
+                      const float *pos3, const float *vel3, const float *att4,
+                      const float *ang_vel3, const float *motor_speed4);
+int afe_get_state_f32(afe_engine *e, int64_t first, int64_t count, float *pos3,
+                      float *vel3, float *att4, float *ang_vel3,
+                      float *motor_speed4);
+/* per-vehicle std::minstd_rand0 word (Quadcopter_T.hpp:122); checkpointing */
+int afe_set_rng_state(afe_engine *e, int64_t first, int64_t count, const uint32_t *state);
+int afe_get_rng_state(afe_engine *e, int64_t first, int64_t count, uint32_t *state);
+
+/* ---- per-tick inputs ----------------------------------------------------
+ * afe_set_motor_cmds replaces the read-back of logicType::GetMotorSpeedCmd(i)
+ * into _motorSpeedCommands (Quadcopter_T.cpp:187-189; float, Quadcopter_T.hpp:
+ * 100).  afe_set_external_force / _torque replace SetExternalForce /
+ * SetExternalTorque (Quadcopter_T.hpp:45-51; world frame, persist until
+ * replaced).  Passing NULL to the external setters zeroes the range; the
+ * kernel only reads the wrench arrays once one has been set non-NULL. */
+int afe_set_motor_cmds(afe_engine *e, int64_t first, int64_t count, const float *cmd4);
+int afe_set_external_force(afe_engine *e, int64_t first, int64_t count, const double *force3);
+int afe_set_external_torque(afe_engine *e, int64_t first, int64_t count, const double *torque3);
+
+/* ---- stepping -----------------------------------------------------------
+ * afe_step replaces the loop body
+ *     for (v : vehicles) v->Run();  simTimer.AdvanceMicroSeconds(dt_us);
+ * (Simulator/Rappids_Simulator/main.cpp:391-392; AIFS_ROS/.../Simulator/
+ * main.cpp:323-325) n_steps times: every vehicle takes n_steps physics steps
+ * of dt = dt_us * 1e-6 s (Quadcopter_T.cpp:85-156, Motor.cpp:39-84).  The
+ * engine clock advances by dt_us per step; whenever the onboard-logic gate of
+ * Quadcopter_T.cpp:159-160 fires (strict >, then minus one period) the step
+ * also synthesises the IMU sample of :165-180 into the IMU buffers and counts
+ * one logic tick.  dt_us == 0 is the reference's "dt < 1e-6: return".
+ * Within one call the motor commands and external wrench are held constant,
+ * as they are between two logicType::Run() calls in the reference.
+ * afe_steps_until_tick tells a host-side logicType driver how many steps of
+ * dt_us may be fused before its Run() is due (>= 1). */
+int afe_step(afe_engine *e, uint64_t dt_us, int n_steps);
+int afe_steps_until_tick(const afe_engine *e, uint64_t dt_us, int *n_steps);
+int afe_sync(afe_engine *e);
+int afe_time_us(const afe_engine *e, uint64_t *now_us);
+int afe_logic_ticks(const afe_engine *e, uint64_t *n_ticks);
+
+/* The IMU sample handed to logicType::SetIMUMeasurementRateGyro /
+ * SetIMUMeasurementAccelerometer at the most recent logic tick
+ * (Quadcopter_T.cpp:171,180); floats, like the reference's Vec3f. */
+int afe_get_imu(afe_engine *e, int64_t first, int64_t count, float *gyro3, float *acc3);
+
+/* Pure host helper (no GPU): the logic-gate pattern of n_steps steps of dt_us
+ * starting from *elapsed_us (time since the gate last fired), per Timer.hpp:
+ * 27-54.  tick_out[i] = 1 if step i fires.  Updates *elapsed_us. */
+int afe_plan_ticks(double logic_period_s, uint64_t *elapsed_us, uint64_t dt_us,
+                   int n_steps, uint8_t *tick_out);
+
+/* ---- zero-copy device view ---------------------------------------------
+ * Raw device pointers to the SoA slabs for HIP-side consumers (renderers,
+ * planners, torch via __cuda_array_interface__).  Each field is planar with
+ * `stride` elements between components.  state_elem_size is 4 or 8. */
+typedef struct afe_device_view {
+  int64_t n_vehicles;
+  int64_t stride;
+  int state_elem_size;
+  void *pos, *vel, *att, *ang_vel, *motor_speed; /* 3,3,4,3,4 components */
+  void *ext_force, *ext_torque;                  /* 3,3 components */
+  float *motor_cmd;                              /* 4 components */
+  float *gyro, *acc;                             /* 3,3 components */
+  uint32_t *rng;
+  uint8_t *type_index;
+} afe_device_view;
+int afe_get_device_view(afe_engine *e, afe_device_view *out);
+
+/* Algorithmic HBM bytes one vehicle-step of the current configuration moves
+ * (176 B for fp32 state + cmds + IMU, +12 per active wrench
+ * array, ...); what bench.py's roofline is computed from. */
+int afe_algorithmic_bytes_per_step(const afe_engine *e, int imu_tick, double *bytes);
+
+/* ---- HIP-event timing on the engine's stream (for bench.py) ------------- */
+int afe_event_create(void **event);
+int afe_event_destroy(void *event);
+int afe_event_record(afe_engine *e, void *event);
+int afe_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* ---- multi-GPU shared-world query ---------------------------------------
+ * The only inter-vehicle exchange of the path (the reference's analogue is
+ * UWBNetwork::Run reading other vehicles' positions, Components/Components/
+ * Simulation/UWBNetwork.cpp:54-84).  One process per GPU; the all-gather
+ * itself is done by the host's communicator (RCCL through torch.distributed
+ * in bench.py / the Python host).  afe_pack_positions
+ * writes this shard's positions as fp32 planar xyz into a caller-provided
+ * DEVICE buffer of 3*n_vehicles floats, on the engine's stream. */
+int afe_pack_positions(afe_engine *e, float *device_xyz);
+/* Shared-world consumer: for each local vehicle the squared distance to, and
+ * global index of, its nearest neighbour among all_xyz (device, fp32 planar,
+ * n_all vehicles, the gathered ensemble).  Outputs are device buffers. */
+int afe_nearest_neighbour(afe_engine *e, const float *all_xyz, int64_t n_all,
+                          float *dist2_out, int32_t *index_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGRIFLY_ENGINE_H */

@@ -1,0 +1,218 @@
+"""ctypes binding of oracle/libagrifly_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module, and only as the checker / the reported CPU baseline.  The product
+path (agri-fly_amd/) never imports anything from oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libagrifly_oracle.so")
+
+
+class OraParams(C.Structure):
+    _fields_ = [
+        ("mass", C.c_double),
+        ("inertia", C.c_double * 9),
+        ("inertia_inv", C.c_double * 9),
+        ("motor_pos", (C.c_double * 3) * 4),
+        ("motor_rot_axis", (C.c_double * 3) * 4),
+        ("motor_thrust_axis", (C.c_double * 3) * 4),
+        ("motor_min_speed", C.c_double),
+        ("motor_max_speed", C.c_double),
+        ("k_thrust", C.c_double),
+        ("k_torque", C.c_double),
+        ("motor_time_const", C.c_double),
+        ("motor_inertia", C.c_double),
+        ("lin_drag", C.c_double * 3),
+        ("R_imu_inv", C.c_float * 9),
+        ("sigma_acc", C.c_double),
+        ("sigma_gyro", C.c_double),
+    ]
+
+
+class OraState(C.Structure):
+    _fields_ = [
+        ("pos", C.c_double * 3),
+        ("vel", C.c_double * 3),
+        ("att", C.c_double * 4),
+        ("ang_vel", C.c_double * 3),
+        ("motor_speed", C.c_double * 4),
+        ("rng", C.c_uint32),
+    ]
+
+
+class OraClock(C.Structure):
+    _fields_ = [
+        ("now_us", C.c_uint64),
+        ("integ_reset_us", C.c_uint64),
+        ("logic_reset_us", C.c_uint64),
+        ("logic_period", C.c_double),
+    ]
+
+
+def build(force=False):
+    """Compile the checker (and the _ref probes when /root/reference exists)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "agrifly_oracle.c"))):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libagrifly_oracle.so"])
+    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        fp = C.POINTER(C.c_float)
+        L.ora_params_init.argtypes = [C.POINTER(OraParams), C.c_double, dp, C.c_double, dp,
+                                      C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, C.c_double, dp, C.c_float, C.c_float, C.c_float]
+        L.ora_params_init.restype = None
+        L.ora_params_from_type.argtypes = [C.POINTER(OraParams), C.c_int]
+        L.ora_params_from_type.restype = C.c_int
+        L.ora_type_from_id.argtypes = [C.c_uint]
+        L.ora_type_from_id.restype = C.c_int
+        L.ora_state_init.argtypes = [C.POINTER(OraState)]
+        L.ora_state_init.restype = None
+        L.ora_quad_step.argtypes = [C.POINTER(OraParams), C.POINTER(OraState), fp, dp, dp,
+                                    C.c_double, C.c_int, fp, fp, dp]
+        L.ora_quad_step.restype = None
+        L.ora_motor_run.argtypes = [C.POINTER(OraParams), C.c_int, C.c_double, C.c_double,
+                                    C.c_double, dp, dp, dp, dp]
+        L.ora_motor_run.restype = C.c_double
+        L.ora_minstd_next.argtypes = [C.POINTER(C.c_uint32)]
+        L.ora_minstd_next.restype = C.c_uint32
+        L.ora_canonical.argtypes = [C.POINTER(C.c_uint32)]
+        L.ora_canonical.restype = C.c_double
+        L.ora_normal_pair.argtypes = [C.POINTER(C.c_uint32), dp, dp]
+        L.ora_normal_pair.restype = None
+        for name, nin in (("ora_rot_matrix", 4), ("ora_rot_from_rotvec", 3), ("ora_rot_to_euler_ypr", 4)):
+            getattr(L, name).argtypes = [dp, dp]
+            getattr(L, name).restype = None
+        for name in ("ora_rot_mul", "ora_rotate", "ora_rotate_inv"):
+            getattr(L, name).argtypes = [dp, dp, dp]
+            getattr(L, name).restype = None
+        L.ora_rot_from_euler_ypr.argtypes = [C.c_double, C.c_double, C.c_double, dp]
+        L.ora_rot_from_euler_ypr.restype = None
+        L.ora_clock_init.argtypes = [C.POINTER(OraClock), C.c_double]
+        L.ora_clock_init.restype = None
+        L.ora_clock_run.argtypes = [C.POINTER(OraClock), C.POINTER(C.c_int)]
+        L.ora_clock_run.restype = C.c_double
+        L.ora_clock_advance.argtypes = [C.POINTER(OraClock), C.c_uint64]
+        L.ora_clock_advance.restype = None
+        L.ora_step_batch.argtypes = [C.c_int64, C.c_int, C.POINTER(OraParams), C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ora_step_batch.restype = None
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def params_from_type(t):
+    p = OraParams()
+    if lib().ora_params_from_type(C.byref(p), int(t)) != 0:
+        raise ValueError("invalid quadcopter type %r" % (t,))
+    return p
+
+
+def params_init(mass, inertia, arm_length, com_error, motor_min_speed, motor_max_speed,
+                k_thrust, k_torque, motor_time_const, motor_inertia, lin_drag,
+                imu_ypr=(0.0, 0.0, 0.0)):
+    p = OraParams()
+    I = np.ascontiguousarray(np.asarray(inertia, dtype=np.float64).reshape(9))
+    ce = np.ascontiguousarray(np.asarray(com_error, dtype=np.float64))
+    dr = np.ascontiguousarray(np.asarray(lin_drag, dtype=np.float64))
+    lib().ora_params_init(C.byref(p), mass, _dp(I), arm_length, _dp(ce), motor_min_speed,
+                          motor_max_speed, k_thrust, k_torque, motor_time_const,
+                          motor_inertia, _dp(dr), *[float(x) for x in imu_ypr])
+    return p
+
+
+def params_table(plist):
+    arr = (OraParams * len(plist))()
+    for i, p in enumerate(plist):
+        C.memmove(C.byref(arr[i]), C.byref(p), C.sizeof(OraParams))
+    return arr
+
+
+def params_to_dict(p):
+    """Plain-python view of a record (what the engine's afe_vehicle_params wants)."""
+    return dict(
+        mass=p.mass, inertia=list(p.inertia), inertia_inv=list(p.inertia_inv),
+        motor_pos=[list(r) for r in p.motor_pos],
+        motor_rot_axis=[list(r) for r in p.motor_rot_axis],
+        motor_thrust_axis=[list(r) for r in p.motor_thrust_axis],
+        motor_min_speed=p.motor_min_speed, motor_max_speed=p.motor_max_speed,
+        k_thrust=p.k_thrust, k_torque=p.k_torque, motor_time_const=p.motor_time_const,
+        motor_inertia=p.motor_inertia, lin_drag=list(p.lin_drag),
+        R_imu_inv=list(p.R_imu_inv), sigma_acc=p.sigma_acc, sigma_gyro=p.sigma_gyro)
+
+
+class Batch:
+    """Planar SoA ensemble stepped by the oracle (double precision)."""
+
+    def __init__(self, n, table, types=None):
+        self.n = int(n)
+        self.table = table if not isinstance(table, (list, tuple)) else params_table(table)
+        self.types = (np.zeros(n, np.uint8) if types is None
+                      else np.ascontiguousarray(types, dtype=np.uint8))
+        self.pos = np.zeros((3, n))
+        self.vel = np.zeros((3, n))
+        self.att = np.zeros((4, n))
+        self.att[0] = 1.0
+        self.ang_vel = np.zeros((3, n))
+        self.motor_speed = np.zeros((4, n))
+        self.rng = np.ones(n, np.uint32)
+        self.motor_cmd = np.zeros((4, n), np.float32)
+        self.ext_force = np.zeros((3, n))
+        self.ext_torque = np.zeros((3, n))
+        self.gyro = np.zeros((3, n), np.float32)
+        self.acc = np.zeros((3, n), np.float32)
+
+    def step(self, dt, n_steps=1, ticks=None):
+        ticks = (np.zeros(n_steps, np.uint8) if ticks is None
+                 else np.ascontiguousarray(ticks, dtype=np.uint8))
+        assert ticks.shape == (n_steps,)
+        for a in (self.pos, self.vel, self.att, self.ang_vel, self.motor_speed,
+                  self.motor_cmd, self.ext_force, self.ext_torque, self.gyro, self.acc):
+            assert a.flags.c_contiguous
+        lib().ora_step_batch(self.n, n_steps, self.table, self.types.ctypes.data,
+                             self.pos.ctypes.data, self.vel.ctypes.data, self.att.ctypes.data,
+                             self.ang_vel.ctypes.data, self.motor_speed.ctypes.data,
+                             self.rng.ctypes.data, self.motor_cmd.ctypes.data,
+                             self.ext_force.ctypes.data, self.ext_torque.ctypes.data,
+                             float(dt), ticks.ctypes.data, self.gyro.ctypes.data,
+                             self.acc.ctypes.data)
+
+
+def clock_ticks(loop_dt, period, n_runs):
+    """dt and logic-tick pattern of n_runs Run() calls in the reference loop."""
+    c = OraClock()
+    lib().ora_clock_init(C.byref(c), period)
+    adv = int(np.uint64(loop_dt * 1e6))  # main.cpp:392 uint64_t(dt*1e6)
+    dts, ticks = [], []
+    t = C.c_int(0)
+    for _ in range(n_runs):
+        dts.append(lib().ora_clock_run(C.byref(c), C.byref(t)))
+        ticks.append(t.value)
+        lib().ora_clock_advance(C.byref(c), adv)
+    return dts, ticks

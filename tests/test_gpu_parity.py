@@ -1,0 +1,325 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Needs an MI355X: run with -m gpu.
+
+Tolerance definition (BASELINE.json: <= 1e-5 relative state error):
+  rel = max |engine - oracle| / max(|oracle|, floor), floor = 1e-3 of the
+  field's natural scale (1 m, 1 m/s, 1 for quaternions, 1 rad/s, 1 rad/s for
+  rotor speeds ~1e3) -- teacher-forced single steps and <= 100-step open-loop
+  rollouts.  The fp64 instantiation runs the same code in the reference's own
+  precision and must agree to 1e-12.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.scenarios import afa, random_ensemble, rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5
+FLOORS = dict(pos=1.0, vel=1.0, att=1.0, ang_vel=1.0, motor_speed=1.0)
+
+
+def _cmp_state(st, b, tol, what=""):
+    pairs = dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, motor_speed=b.motor_speed)
+    for k, ref in pairs.items():
+        e = rel_err(st[k], ref, FLOORS[k])
+        assert e <= tol, "%s %s: rel err %.3g > %.1g" % (what, k, e, tol)
+
+
+def _ticks(afa_mod, period, dt_us, n):
+    return afa_mod.plan_ticks(period, 0, dt_us, n)[0]
+
+
+@pytest.mark.parametrize("precision,tol", [(afa.AFE_F64, 1e-12), (afa.AFE_F32, F32_TOL)])
+def test_single_step_teacher_forced(precision, tol):
+    """G1: 4096 random states x 4 vehicle types, wrench on, one dt = 1 ms step
+    with the logic gate firing (IMU + noise)."""
+    ens = random_ensemble(4096, seed=20261002)
+    b = ens.to_oracle_batch()
+    with ens.to_engine(precision) as e:
+        e.set_logic_period(0.0005)   # dt > period: the gate fires on the first step
+        e.step(1000, 1)
+        st = e.get_state()
+        gyro, acc = e.get_imu()
+        assert e.logic_ticks == 1 and e.time_us == 1000
+        rng = e.get_rng_state()
+    b.step(1000 * 1e-6, 1, ticks=[1])
+    _cmp_state(st, b, tol, "single step")
+    # IMU: noise-free part to tolerance, noise identical (same libstdc++ stream)
+    imu_tol = 1e-12 if precision == afa.AFE_F64 else F32_TOL
+    assert rel_err(gyro, b.gyro, 1.0) <= max(imu_tol, 2e-7)
+    assert rel_err(acc, b.acc, 10.0) <= max(imu_tol, 2e-7)
+    np.testing.assert_array_equal(rng, b.rng)
+
+
+def test_single_step_fp64_is_near_bit_exact():
+    """same algorithm, same precision: only libm-vs-device sin/cos and FMA
+    contraction may differ (a few ulp)"""
+    ens = random_ensemble(2048, seed=11, with_wrench=True)
+    b = ens.to_oracle_batch()
+    with ens.to_engine(afa.AFE_F64) as e:
+        e.set_imu_noise(False)
+        e.step(1000, 1)
+        st = e.get_state()
+    b.step(1000 * 1e-6, 1)
+    for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, motor_speed=b.motor_speed).items():
+        assert rel_err(st[k], ref, 1e-3) < 5e-15, k
+
+
+@pytest.mark.parametrize("precision,tol", [(afa.AFE_F64, 1e-11), (afa.AFE_F32, F32_TOL)])
+def test_rollout_100_steps_open_loop(precision, tol):
+    """G2: 100 steps of 1 ms, logic period 1/500 s (gate pattern from the
+    reference Timer semantics), constant commands."""
+    ens = random_ensemble(1024, seed=64, ground_fraction=0.0)
+    # keep rollouts away from the ground so a 1-ulp different contact time
+    # cannot flip the clamp branch
+    ens.data.pos[2] += 20.0
+    b = ens.to_oracle_batch()
+    ticks = _ticks(afa, 1 / 500, 1000, 100)
+    with ens.to_engine(precision) as e:
+        e.step(1000, 100)
+        st = e.get_state()
+        gyro, acc = e.get_imu()
+        assert e.logic_ticks == int(ticks.sum())
+        rng = e.get_rng_state()
+    b.step(1000 * 1e-6, 100, ticks=ticks)
+    _cmp_state(st, b, tol, "100-step rollout")
+    np.testing.assert_array_equal(rng, b.rng)
+    assert rel_err(gyro, b.gyro, 1.0) <= max(tol, 1e-6)
+    assert rel_err(acc, b.acc, 10.0) <= max(tol, 1e-6)
+
+
+def test_fused_steps_equal_single_steps_bitwise():
+    """K steps in one launch == K launches of one step (state lives in registers
+    between sub-steps; per-step renormalisation makes this exact)."""
+    ens = random_ensemble(3000, seed=5)
+    with ens.to_engine(afa.AFE_F32) as e1, ens.to_engine(afa.AFE_F32) as e2:
+        e1.step(1000, 37)
+        for _ in range(37):
+            e2.step(1000, 1)
+        s1, s2 = e1.get_state(dtype=np.float32), e2.get_state(dtype=np.float32)
+        for k in s1:
+            np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
+        g1, a1 = e1.get_imu()
+        g2, a2 = e2.get_imu()
+        np.testing.assert_array_equal(g1, g2)
+        np.testing.assert_array_equal(a1, a2)
+        assert e1.logic_ticks == e2.logic_ticks == 18
+        np.testing.assert_array_equal(e1.get_rng_state(), e2.get_rng_state())
+
+
+def test_more_than_64_fused_steps_and_clock():
+    ens = random_ensemble(512, seed=6)
+    ens.data.pos[2] += 50
+    b = ens.to_oracle_batch()
+    ticks = _ticks(afa, 1 / 500, 2000, 150)   # the reference's own dt = 2 ms
+    with ens.to_engine(afa.AFE_F64) as e:
+        e.step(2000, 150)
+        assert e.time_us == 300000
+        assert e.logic_ticks == int(ticks.sum())
+        st = e.get_state()
+    b.step(2000 * 1e-6, 150, ticks=ticks)
+    _cmp_state(st, b, 1e-10, "150 x 2 ms")
+
+
+def test_zero_dt_is_the_early_return():
+    ens = random_ensemble(256, seed=8)
+    with ens.to_engine(afa.AFE_F32) as e:
+        before = e.get_state(dtype=np.float32)
+        e.step(0, 5)      # Quadcopter_T.cpp:88-90: dt < 1e-6 -> nothing happens
+        after = e.get_state(dtype=np.float32)
+        assert e.time_us == 0 and e.logic_ticks == 0
+        for k in before:
+            np.testing.assert_array_equal(before[k], after[k])
+
+
+def test_ground_contact_and_small_angle_edge_cases():
+    ens = random_ensemble(4096, seed=99, ground_fraction=0.5)
+    b = ens.to_oracle_batch()
+    with ens.to_engine(afa.AFE_F64) as e:
+        e.set_imu_noise(False)
+        e.set_logic_period(0.0005)
+        e.step(1000, 1)
+        st = e.get_state()
+        gyro, acc = e.get_imu()
+    bb = ens.to_oracle_batch()
+    bb.step(1e-3, 1, ticks=[0])
+    hit = (bb.pos[2] == 0) & (bb.vel[2] == 0)
+    assert hit.sum() > 1000
+    np.testing.assert_array_equal(st["pos"][2][hit], 0.0)
+    np.testing.assert_array_equal(st["vel"][2][hit], 0.0)
+    np.testing.assert_array_equal(st["ang_vel"][:, hit], 0.0)
+    _cmp_state(st, bb, 1e-12, "ground")
+    # noise-free IMU of grounded vehicles: gyro exactly 0, acc = R^T (ax, ay, g)
+    np.testing.assert_array_equal(gyro[:, hit], 0.0)
+
+
+def test_reference_initial_state_and_first_steps():
+    """config 1 start: at rest on the ground, identity attitude, motors off
+    (main.cpp:234-236,279-280): the vehicle must stay put."""
+    n = 300
+    with afa.Ensemble(n, precision=afa.AFE_F32) as e:
+        e.set_type_table([afa.params_from_type(5)])
+        st = e.get_state()
+        np.testing.assert_array_equal(st["att"], np.array([[1.0], [0], [0], [0]]) * np.ones((1, n)))
+        e.step(1000, 10)
+        st = e.get_state()
+        for k in ("pos", "vel", "ang_vel", "motor_speed"):
+            np.testing.assert_array_equal(st[k], 0.0)
+        gyro, acc = e.get_imu()
+        # resting on the ground: specific force +g on body z, plus noise
+        assert abs(float(acc[2].mean()) - 9.81) < 0.2
+        assert np.all(gyro == gyro[:, :1])   # reference seeding: identical streams
+
+
+def test_seed_policies():
+    n = 2000
+    with afa.Ensemble(n, first_global_index=1000) as e:
+        e.set_type_table([afa.params_from_type(5)])
+        np.testing.assert_array_equal(e.get_rng_state(), 1)
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+        np.testing.assert_array_equal(e.get_rng_state(), 1001 + np.arange(n))
+        e.set_logic_period(0.0005)
+        e.step(1000, 1)
+        gyro, _ = e.get_imu()
+        assert len(np.unique(gyro[0])) > n * 0.99
+        # each lane must reproduce libstdc++ for ITS seed, rejection loops included
+        from oracle import oracle_py
+        b = oracle_py.Batch(n, [oracle_py.params_from_type(5)])
+        b.rng[:] = 1001 + np.arange(n)
+        b.step(1e-3, 1, ticks=[1])
+        np.testing.assert_array_equal(e.get_rng_state(), b.rng)
+        np.testing.assert_allclose(gyro, b.gyro, rtol=0, atol=1e-7)
+
+
+def test_partial_ranges_and_errors():
+    ens = random_ensemble(1000, seed=3)
+    with ens.to_engine(afa.AFE_F32) as e:
+        part = e.get_state(first=100, count=50)
+        np.testing.assert_allclose(part["pos"], ens.data.pos[:, 100:150], rtol=1e-7)
+        new = np.ones((3, 50))
+        e.set_state(pos=new, first=100, count=50)
+        np.testing.assert_array_equal(e.get_state(first=100, count=50)["pos"], 1.0)
+        np.testing.assert_allclose(e.get_state(first=150, count=10)["pos"], ens.data.pos[:, 150:160], rtol=1e-7)
+        with pytest.raises(afa.AfeError) as ei:
+            e.get_state(first=990, count=20)
+        assert ei.value.status == 4
+        with pytest.raises(afa.AfeError):
+            e.set_vehicle_types(np.full(10, 200, np.uint8))
+    with afa.Ensemble(8) as e:
+        with pytest.raises(afa.AfeError) as ei:
+            e.step(1000, 1)
+        assert ei.value.status == 5   # no type table
+        bad = afa.params_from_type(5)
+        bad.motor_max_speed = -1.0    # Motor.cpp:29 assert(maxSpeed > minSpeed)
+        with pytest.raises(afa.AfeError):
+            e.set_type_table([bad])
+
+
+def test_motor_lag_types():
+    """tau_m > 0, J_m > 0, CoM error, drag, tilted IMU mount: every parameter
+    the ctor takes, not just the shipped types."""
+    from oracle import oracle_py
+    rng = np.random.default_rng(5)
+    n = 2048
+    plist, olist = [], []
+    for k in range(7):
+        p = afa.params_from_type([1, 2, 4, 5][k % 4])
+        p.motor_time_const = float(rng.uniform(0.005, 0.05))
+        p.motor_inertia = float(rng.uniform(1e-7, 1e-5))
+        p.motor_min_speed = float(rng.uniform(0, 200))
+        for a in range(3):
+            p.com_error[a] = float(rng.uniform(-3e-3, 3e-3))
+            p.lin_drag_coeff_b[a] = float(rng.uniform(0, 0.3))
+        I = np.array(p.inertia).reshape(3, 3)
+        off = rng.uniform(-0.05, 0.05, (3, 3)) * I[0, 0]
+        I = I + off + off.T
+        for a in range(9):
+            p.inertia[a] = float(I.reshape(9)[a])
+        p.imu_yaw, p.imu_pitch, p.imu_roll = [float(x) for x in rng.uniform(-0.5, 0.5, 3)]
+        plist.append(p)
+        olist.append(oracle_py.params_init(p.mass, list(p.inertia), p.arm_length, list(p.com_error),
+                                           p.motor_min_speed, p.motor_max_speed,
+                                           p.prop_thrust_from_speed_sqr, p.prop_torque_from_speed_sqr,
+                                           p.motor_time_const, p.motor_inertia, list(p.lin_drag_coeff_b),
+                                           (p.imu_yaw, p.imu_pitch, p.imu_roll)))
+    ens = random_ensemble(n, seed=77, type_ids=(5,) * 7)
+    ens.data.pos[2] += 30
+    b = oracle_py.Batch(n, olist, ens.data.types)
+    d = ens.data
+    b.pos[:], b.vel[:], b.att[:], b.ang_vel[:] = d.pos, d.vel, d.att, d.ang_vel
+    b.motor_speed[:], b.motor_cmd[:] = d.motor_speed, d.motor_cmd
+    b.ext_force[:], b.ext_torque[:] = d.ext_force, d.ext_torque
+    ticks = _ticks(afa, 1 / 500, 1000, 20)
+    b.step(1e-3, 20, ticks=ticks)
+    for precision, tol in ((afa.AFE_F64, 1e-11), (afa.AFE_F32, F32_TOL)):
+        with afa.Ensemble(n, precision=precision) as e:
+            e.set_type_table(plist)
+            e.set_vehicle_types(d.types)
+            e.set_state(d.pos, d.vel, d.att, d.ang_vel, d.motor_speed)
+            e.set_motor_cmds(d.motor_cmd)
+            e.set_external_force(d.ext_force)
+            e.set_external_torque(d.ext_torque)
+            e.step(1000, 20)
+            st = e.get_state()
+            gyro, acc = e.get_imu()
+        _cmp_state(st, b, tol, "lag types p%d" % precision)
+        assert rel_err(gyro, b.gyro, 1.0) <= max(tol, 1e-6)
+        assert rel_err(acc, b.acc, 10.0) <= max(tol, 1e-6)
+
+
+def test_oracle_regression_fixture_on_gpu(golden_dir):
+    """the committed fixture (tests/golden/oracle_regression.npz) vs the HIP path"""
+    g = np.load(os.path.join(golden_dir, "oracle_regression.npz"))
+    ens = random_ensemble(n=256, seed=int(g["seed"]))
+    with ens.to_engine(afa.AFE_F32) as e:
+        e.set_logic_period(0.0005)
+        e.step(1000, 1)
+        st = e.get_state()
+        gyro, acc = e.get_imu()
+    for k, key in (("pos", "s1_pos"), ("vel", "s1_vel"), ("att", "s1_att"), ("ang_vel", "s1_ang_vel"),
+                   ("motor_speed", "s1_motor")):
+        assert rel_err(st[k], g[key], 1.0) <= F32_TOL, k
+    assert rel_err(gyro, g["s1_gyro"], 1.0) <= F32_TOL
+    assert rel_err(acc, g["s1_acc"], 10.0) <= F32_TOL
+
+
+def test_full_size_properties_1m_vehicles():
+    """BASELINE full size (1,048,576 vehicles): size-independent properties."""
+    n = 1 << 20
+    p = afa.params_from_type(5)
+    data = afa.scenarios.gust_ensemble(n, p, seed=4)
+    with afa.Ensemble(n) as e:
+        e.set_type_table([p])
+        e.set_state(data.pos, data.vel, data.att, data.ang_vel, data.motor_speed)
+        e.set_motor_cmds(data.motor_cmd)
+        e.set_external_force(data.ext_force)
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+        e.step(1000, 100)
+        st = e.get_state(dtype=np.float32)
+        gyro, acc = e.get_imu()
+    # unit quaternions, finite state
+    for k, a in st.items():
+        assert np.isfinite(a).all(), k
+    assert np.abs(np.linalg.norm(st["att"], axis=0) - 1).max() < 1e-6
+    # linearity in the gust force: hovering thrust cancels gravity, so after
+    # t = 0.1 s  v = F t / m and x = F t^2 / (2 m) (no drag on the MINIQUAD)
+    t = 0.1
+    np.testing.assert_allclose(st["vel"][:2], data.ext_force[:2] * t / p.mass, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(st["pos"][:2], data.ext_force[:2] * t * t / (2 * p.mass), rtol=2e-4, atol=2e-6)
+    # a subsample against the oracle
+    idx = np.arange(0, n, n // 512)
+    sub = afa.scenarios.EnsembleData(len(idx))
+    from tests.scenarios import TestEnsemble
+    for name in ("pos", "vel", "att", "ang_vel", "motor_speed", "motor_cmd", "ext_force"):
+        setattr(sub, name, np.ascontiguousarray(getattr(data, name)[:, idx]))
+    b = TestEnsemble(sub).to_oracle_batch()
+    b.rng[:] = 1 + idx
+    b.step(1e-3, 100, ticks=_ticks(afa, 1 / 500, 1000, 100))
+    for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel).items():
+        assert rel_err(st[k][:, idx], ref, 1.0) <= F32_TOL, k
+    assert rel_err(gyro[:, idx], b.gyro, 1.0) <= 1e-5
+    # noise statistics over the decorrelated ensemble
+    assert abs(float(gyro[2].std()) - 0.1) < 2e-3

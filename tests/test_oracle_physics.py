@@ -1,0 +1,255 @@
+"""Independent checks of the (reference-unpinned) rigid-body restatement:
+physical invariants and hand-derived values that do not come from the oracle's
+own code, plus agreement between the oracle's and the engine's separately
+written vehicle-type tables.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+G = 9.81
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _one(ora, type_id=5, **over):
+    p = ora.params_from_type(type_id)
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p, ora.Batch(1, [p])
+
+
+def test_type_tables_agree_between_oracle_and_engine(ora, afa):
+    """two separately written restatements of QuadcopterConstants.hpp"""
+    for t in (1, 2, 4, 5):
+        o = ora.params_from_type(t)
+        e = afa.params_from_type(t)
+        assert o.mass == e.mass
+        assert list(o.inertia) == list(e.inertia)
+        assert o.k_thrust == e.prop_thrust_from_speed_sqr
+        assert o.k_torque == e.prop_torque_from_speed_sqr
+        assert o.motor_max_speed == e.motor_max_speed
+        assert o.motor_min_speed == e.motor_min_speed
+        assert list(o.lin_drag) == list(e.lin_drag_coeff_b)
+        a = e.arm_length / np.sqrt(2)
+        assert [list(r) for r in o.motor_pos] == [[a, -a, 0], [-a, -a, 0], [-a, a, 0], [a, a, 0]]
+    for bad in (0, 3, 6, 99):
+        with pytest.raises(ValueError):
+            ora.params_from_type(bad)
+        with pytest.raises(afa.AfeError):
+            afa.params_from_type(bad)
+    for vid in range(0, 30):
+        assert ora.lib().ora_type_from_id(vid) == afa.type_from_id(vid)
+    assert afa.type_from_id(1) == 5  # the id every shipped main uses
+
+
+def test_survey_constants(ora):
+    # SURVEY.md App. C / 8d [probe]
+    p = ora.params_from_type(5)
+    assert p.motor_max_speed == pytest.approx(7150.0, rel=1e-6)
+    assert np.sqrt(p.mass * G / (4 * p.k_thrust)) == pytest.approx(2839.27, rel=1e-6)
+    assert ora.params_from_type(4).motor_max_speed == pytest.approx(1385.4, rel=1e-4)
+    assert list(p.R_imu_inv) == [1, 0, 0, 0, 1, 0, 0, 0, 1]  # zero mount angles: exact identity
+
+
+def test_free_fall(ora):
+    p, b = _one(ora)
+    b.pos[2] = 100.0
+    b.vel[:, 0] = [1.0, -2.0, 0.5]
+    dt, n = 1e-3, 1000
+    b.step(dt, n)
+    t = n * dt
+    # explicit Euler in v with the 0.5 a dt^2 term: exact for constant acceleration
+    np.testing.assert_allclose(b.vel[:, 0], [1.0, -2.0, 0.5 - G * t], rtol=1e-12)
+    np.testing.assert_allclose(b.pos[:, 0], [t, -2 * t, 100 + 0.5 * t - 0.5 * G * t * t], rtol=1e-12)
+    np.testing.assert_array_equal(b.att[:, 0], [1, 0, 0, 0])
+
+
+def test_hover_equilibrium_and_thrust_direction(ora):
+    p, b = _one(ora)
+    wh = np.sqrt(p.mass * G / (4 * p.k_thrust))
+    b.pos[2] = 3.5
+    b.motor_speed[:] = wh
+    b.motor_cmd[:] = np.float32(wh)
+    b.step(1e-3, 1)
+    # residual comes only from float32(wh)
+    assert abs(b.vel[2, 0]) < 1e-8
+    assert np.abs(b.ang_vel).max() < 1e-9   # balanced reaction torques, symmetric arms
+    # 90 deg roll about +x: body z (thrust) points along world -y
+    q = np.zeros(4)
+    ora.lib().ora_rot_from_euler_ypr(0.0, 0.0, np.pi / 2, _dp(q))
+    p, b = _one(ora)
+    b.att[:, 0] = q
+    b.pos[2] = 10
+    b.motor_speed[:] = wh
+    b.motor_cmd[:] = np.float32(wh)
+    acc = np.zeros(3)
+    s = ora.OraState()
+    ora.lib().ora_state_init(C.byref(s))
+    s.pos[2] = 10.0
+    for k in range(4):
+        s.att[k] = q[k]
+        s.motor_speed[k] = wh
+    cmd = (C.c_float * 4)(*[wh] * 4)
+    ora.lib().ora_quad_step(C.byref(p), C.byref(s), cmd, None, None, 1e-3, 0, None, None, _dp(acc))
+    np.testing.assert_allclose(acc, [0, -G, -G], atol=1e-6)
+
+
+def test_motor_torque_signs_and_arms(ora):
+    """motor 0 (front right, +x -y) spins +z: speeding it up alone must roll
+    the vehicle toward +y... check against a hand computation of
+    tau = sum p_i x (0,0,T_i) - k_tau w_i^2 s_i z."""
+    p, b = _one(ora)
+    w = np.array([3000.0, 2800.0, 2900.0, 2700.0])
+    b.pos[2] = 10
+    b.motor_speed[:, 0] = w
+    b.motor_cmd[:, 0] = w.astype(np.float32)
+    dt = 1e-3
+    b.step(dt, 1)
+    T = p.k_thrust * w * w
+    a = np.array([r[:] for r in p.motor_pos])
+    spin = np.array([1, -1, 1, -1])
+    tau = np.array([np.sum(a[:, 1] * T), np.sum(-a[:, 0] * T), np.sum(-p.k_torque * w * w * spin)])
+    I = np.array(p.inertia).reshape(3, 3)
+    np.testing.assert_allclose(b.ang_vel[:, 0], np.linalg.solve(I, tau) * dt, rtol=1e-12)
+    np.testing.assert_allclose(b.vel[2, 0], (T.sum() / p.mass - G) * dt, rtol=1e-10)
+
+
+def test_torque_free_precession_conserves_world_angular_momentum(ora):
+    p, b = _one(ora)
+    b.pos[2] = 1e6          # never reaches the ground
+    b.ang_vel[:, 0] = [3.0, -2.0, 5.0]
+    I = np.array(p.inertia).reshape(3, 3)
+    R0 = np.zeros(9)
+    ora.lib().ora_rot_matrix(_dp(np.ascontiguousarray(b.att[:, 0])), _dp(R0))
+    L0 = R0.reshape(3, 3) @ (I @ b.ang_vel[:, 0])
+    E0 = 0.5 * b.ang_vel[:, 0] @ I @ b.ang_vel[:, 0]
+    dt = 1e-4
+    b.step(dt, 10000)
+    R1 = np.zeros(9)
+    ora.lib().ora_rot_matrix(_dp(np.ascontiguousarray(b.att[:, 0])), _dp(R1))
+    L1 = R1.reshape(3, 3) @ (I @ b.ang_vel[:, 0])
+    E1 = 0.5 * b.ang_vel[:, 0] @ I @ b.ang_vel[:, 0]
+    # first-order integrator: drift O(dt) over 1 s of tumbling
+    np.testing.assert_allclose(L1, L0, rtol=0, atol=2e-3 * np.linalg.norm(L0))
+    assert abs(E1 - E0) / E0 < 2e-3
+    assert abs(np.linalg.norm(b.att[:, 0]) - 1) < 1e-12  # never normalised, barely drifts
+
+
+def test_quaternion_increment_is_exact_exponential(ora):
+    """constant body rate about z: q(t) = (cos(wt/2), 0, 0, sin(wt/2)) exactly"""
+    p, b = _one(ora)
+    b.pos[2] = 1e6
+    b.ang_vel[2, 0] = 2.0
+    # zero z-torque: no motors, I diagonal => w stays constant
+    b.step(1e-3, 500)
+    np.testing.assert_allclose(b.att[:, 0], [np.cos(0.5), 0, 0, np.sin(0.5)], atol=1e-13)
+
+
+def test_small_angle_identity_threshold(ora):
+    """Rotation.hpp:39,86: |w dt| < 4.84813681e-6 => identity increment"""
+    q = np.zeros(4)
+    L = ora.lib()
+    L.ora_rot_from_rotvec(_dp(np.array([4.8e-6, 0, 0])), _dp(q))
+    np.testing.assert_array_equal(q, [1, 0, 0, 0])
+    L.ora_rot_from_rotvec(_dp(np.array([4.9e-6, 0, 0])), _dp(q))
+    assert q[1] == pytest.approx(2.45e-6, rel=1e-9) and q[0] < 1.0 + 1e-16
+
+
+def test_ground_contact(ora):
+    """Quadcopter_T.cpp:146-151: z clamps, w zeroes, x/y velocity kept"""
+    p, b = _one(ora)
+    b.pos[:, 0] = [1.0, 2.0, 1e-5]
+    b.vel[:, 0] = [0.3, -0.4, -1.0]
+    b.ang_vel[:, 0] = [1, 2, 3]
+    b.step(1e-3, 1, ticks=[1])
+    assert b.pos[2, 0] == 0 and b.vel[2, 0] == 0
+    np.testing.assert_array_equal(b.ang_vel[:, 0], [0, 0, 0])
+    np.testing.assert_allclose(b.vel[:2, 0], [0.3, -0.4])
+    # acc.z was zeroed before the IMU: the accelerometer reads +g along body z
+    # (attitude moved by one step of w dt, so compare loosely; noise sigma .2)
+    assert abs(float(b.acc[2, 0]) - G) < 1.5
+    # resting on the ground with zero velocity is NOT a contact (strict <): falls through z<=0
+    p, b = _one(ora)
+    b.step(1e-3, 1)
+    assert b.pos[2, 0] == 0 and b.vel[2, 0] == 0  # vz = -g dt < 0 -> clamped
+
+
+def test_negative_command_and_clamps(ora):
+    p, b = _one(ora)
+    b.pos[2] = 10
+    b.motor_speed[:, 0] = [100, 100, 100, 100]
+    b.motor_cmd[:, 0] = [-50, 1e9, 200, 0]
+    b.step(1e-3, 1)
+    np.testing.assert_array_equal(b.motor_speed[:, 0], [0, p.motor_max_speed, 200, 0])
+
+
+def test_motor_lag_and_spinup_torque(ora):
+    base = ora.params_from_type(5)
+    tau_m, J = 0.02, 1e-6
+    p = ora.params_init(base.mass, list(base.inertia), 0.058, [0, 0, 0], 0, base.motor_max_speed,
+                        base.k_thrust, base.k_torque, tau_m, J, [0, 0, 0])
+    b = ora.Batch(1, [p])
+    b.pos[2] = 10
+    b.motor_cmd[:, 0] = [1000, 0, 0, 0]
+    dt = 1e-3
+    b.step(dt, 1)
+    c = np.exp(-dt / tau_m)
+    w0 = (1 - c) * 1000
+    assert b.motor_speed[0, 0] == pytest.approx(w0, rel=1e-14)
+    # z torque = -k_tau w^2 - J (w - 0)/dt on a +z rotor; gyroscopic term vanishes (w_body = 0)
+    tz = -base.k_torque * w0 * w0 - J * w0 / dt
+    assert b.ang_vel[2, 0] == pytest.approx(tz / base.inertia[8] * dt, rel=1e-12)
+
+
+def test_drag_and_external_wrench(ora):
+    p = ora.params_from_type(4)  # LARGEQUAD: isotropic drag 0.1286181
+    b = ora.Batch(1, [p])
+    b.pos[2] = 100
+    b.vel[:, 0] = [2.0, 0, 0]
+    b.ext_force[:, 0] = [0.0, 0.5, 0.0]
+    b.ext_torque[:, 0] = [0.0, 0.0, 1e-3]
+    dt = 1e-3
+    b.step(dt, 1)
+    k = p.lin_drag[0]
+    assert b.vel[0, 0] == pytest.approx(2.0 - k * 2.0 / p.mass * dt, rel=1e-13)
+    assert b.vel[1, 0] == pytest.approx(0.5 / p.mass * dt, rel=1e-13)
+    assert b.ang_vel[2, 0] == pytest.approx(1e-3 / p.inertia[8] * dt, rel=1e-13)
+
+
+def test_imu_noise_free_part(ora):
+    """gyro = w' and acc = R(q')^T (a + g) up to the N(0, sigma) draws"""
+    p, b = _one(ora)
+    wh = np.sqrt(p.mass * G / (4 * p.k_thrust))
+    b.pos[2] = 5
+    b.motor_speed[:] = wh
+    b.motor_cmd[:] = np.float32(wh)
+    n = 4000
+    g = np.zeros((n, 3))
+    a = np.zeros((n, 3))
+    for k in range(n):
+        b.step(1e-3, 1, ticks=[1])
+        g[k] = b.gyro[:, 0] - b.ang_vel[:, 0]
+        a[k] = b.acc[:, 0]
+    assert np.all(np.abs(g.mean(0)) < 0.01) and np.all(np.abs(g.std(0) - 0.1) < 0.01)
+    assert np.all(np.abs(a.std(0) - 0.2) < 0.02)
+    assert abs(a[:, 2].mean() - G) < 0.05   # hovering: specific force = +g along body z
+
+
+def test_euler_roundtrip(ora):
+    L = ora.lib()
+    q = np.zeros(4)
+    ypr = np.zeros(3)
+    L.ora_rot_from_euler_ypr(0.3, 0.1, -0.2, _dp(q))
+    L.ora_rot_to_euler_ypr(_dp(q), _dp(ypr))
+    np.testing.assert_allclose(ypr, [0.3, 0.1, -0.2], atol=1e-15)
+    # composition: R(a*b) = R(a) R(b)  (Rotation.hpp:123 "r2*r1")
+    q2 = np.zeros(4)
+    L.ora_rot_from_euler_ypr(-1.0, 0.4, 0.7, _dp(q2))
+    q12 = np.zeros(4)
+    L.ora_rot_mul(_dp(q), _dp(q2), _dp(q12))
+    R1, R2, R12 = np.zeros(9), np.zeros(9), np.zeros(9)
+    L.ora_rot_matrix(_dp(q), _dp(R1)); L.ora_rot_matrix(_dp(q2), _dp(R2)); L.ora_rot_matrix(_dp(q12), _dp(R12))
+    np.testing.assert_allclose(R12.reshape(3, 3), R1.reshape(3, 3) @ R2.reshape(3, 3), atol=1e-15)
