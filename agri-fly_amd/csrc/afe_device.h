@@ -12,8 +12,9 @@ namespace afe {
 // Staged into LDS at kernel start; all lanes of a homogeneous ensemble read
 // the same LDS words (broadcast, conflict-free).
 template <typename R>
-struct DevParams {
+struct alignas(16) DevParams {
   R mass;
+  R inv_mass;  // 1/mass (fp32 kernel multiplies; the fp64 kernel divides like the reference)
   R I[9];      // _inertiaMatrix, row major
   R Iinv[9];   // _inertiaMatrixInv
   R mpx[4];    // motor positions (FR, RR, RL, FL)
@@ -27,7 +28,6 @@ struct DevParams {
   R wmax;
   R drag[3];   // _linDragCoeffB
   float Rimu[9];  // _R_inverse (float in the reference too)
-  float pad_[3];  // keep sizeof a multiple of 16 (208 B / 368 B)
 };
 static_assert(sizeof(DevParams<float>) % 16 == 0, "DevParams<float> size");
 static_assert(sizeof(DevParams<double>) % 16 == 0, "DevParams<double> size");
@@ -49,6 +49,7 @@ struct StepView {
   int64_t n;
   int64_t stride;
   R dt;
+  R inv_dt;  // 1/dt evaluated in double on the host
   int n_steps;
   unsigned long long tick_mask;  // bit s set: sub-step s fires the logic gate
   float sigma_gyro, sigma_acc;
@@ -59,8 +60,11 @@ struct LaunchFlags {
 };
 
 // kernel launchers (afe_kernels.hip); stream is a hipStream_t
-int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, void *stream);
-int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, void *stream);
+// `uniform` != nullptr: every vehicle uses this one record, passed by value in
+// the kernel-argument segment (scalar registers); otherwise v.table is staged
+// into LDS and indexed per lane by v.type.
+int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, const DevParams<float> *uniform, void *stream);
+int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> *uniform, void *stream);
 int launch_pack_positions_f32(const float *pos, int64_t stride, int64_t n, float *out, void *stream);
 int launch_pack_positions_f64(const double *pos, int64_t stride, int64_t n, float *out, void *stream);
 int launch_nearest_neighbour(const float *self_xyz, int64_t n_self, int64_t first_global,

@@ -31,6 +31,9 @@ struct afe_engine {
   uint32_t *rng = nullptr;
   uint8_t *type = nullptr;
   void *dev_table = nullptr;  // n_types DevParams<R>
+  std::vector<DevParams<float>> table_f32;   // host copies of the device table
+  std::vector<DevParams<double>> table_f64;
+  bool types_uniform = true;  // every vehicle uses record 0 (kernel-argument fast path)
   float *pack_scratch = nullptr;  // 3*n floats, lazily allocated
 
   // configuration
@@ -175,12 +178,14 @@ int refresh_table(afe_engine *e, double dt) {
   if (!e->table_dirty && dt == e->table_dt) return AFE_OK;
   const size_t n = e->table.size();
   if (e->precision == AFE_F64) {
-    std::vector<DevParams<double>> t(n);
+    std::vector<DevParams<double>> &t = e->table_f64;
+    t.resize(n);
     for (size_t k = 0; k < n; k++) to_device_params<double>(e->table[k], dt, t[k]);
     AFE_HIP(e, hipMemcpyAsync(e->dev_table, t.data(), n * sizeof(t[0]), hipMemcpyHostToDevice, e->stream));
     AFE_HIP(e, hipStreamSynchronize(e->stream));
   } else {
-    std::vector<DevParams<float>> t(n);
+    std::vector<DevParams<float>> &t = e->table_f32;
+    t.resize(n);
     for (size_t k = 0; k < n; k++) to_device_params<float>(e->table[k], dt, t[k]);
     AFE_HIP(e, hipMemcpyAsync(e->dev_table, t.data(), n * sizeof(t[0]), hipMemcpyHostToDevice, e->stream));
     AFE_HIP(e, hipStreamSynchronize(e->stream));
@@ -211,6 +216,8 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
                           int64_t first_global_index) {
   if (!out || n_vehicles <= 0 || (precision != AFE_F32 && precision != AFE_F64) || first_global_index < 0)
     return AFE_ERR_INVALID_ARG;
+  // the kernels address a slab component as base + 32-bit byte offset
+  if (n_vehicles > (precision == AFE_F64 ? (int64_t(1) << 29) : (int64_t(1) << 30)) - 256) return AFE_ERR_INVALID_ARG;
   *out = nullptr;
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return AFE_ERR_NO_DEVICE;
@@ -328,6 +335,11 @@ extern "C" int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count
   AFE_HIP(e, hipSetDevice(e->device));
   AFE_HIP(e, hipMemcpyAsync(e->type + first, type_index, (size_t)count, hipMemcpyHostToDevice, e->stream));
   AFE_HIP(e, hipStreamSynchronize(e->stream));
+  // the kernel-argument fast path needs every vehicle on record 0
+  bool all_zero = true;
+  for (int64_t k = 0; k < count; k++) all_zero = all_zero && (type_index[k] == 0);
+  if (!all_zero) e->types_uniform = false;
+  else if (first == 0 && count == e->n) e->types_uniform = true;
   return AFE_OK;
 }
 
@@ -434,17 +446,19 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
         e->n_ticks++;
       }
     }
+    // launches without a logic tick draw no noise: use the lean instantiation
+    f.noise = e->noise && mask != 0;
     int lrc;
     if (e->precision == AFE_F64) {
       StepView<double> v;
       fill_view(e, v);
-      v.dt = dt; v.n_steps = chunk; v.tick_mask = mask;
-      lrc = launch_step_f64(v, f, e->stream);
+      v.dt = dt; v.inv_dt = 1.0 / dt; v.n_steps = chunk; v.tick_mask = mask;
+      lrc = launch_step_f64(v, f, e->types_uniform ? &e->table_f64[0] : nullptr, e->stream);
     } else {
       StepView<float> v;
       fill_view(e, v);
-      v.dt = (float)dt; v.n_steps = chunk; v.tick_mask = mask;
-      lrc = launch_step_f32(v, f, e->stream);
+      v.dt = (float)dt; v.inv_dt = (float)(1.0 / dt); v.n_steps = chunk; v.tick_mask = mask;
+      lrc = launch_step_f32(v, f, e->types_uniform ? &e->table_f32[0] : nullptr, e->stream);
     }
     if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
     done += chunk;

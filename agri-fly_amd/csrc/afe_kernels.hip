@@ -8,11 +8,13 @@
 // per workgroup.  There is no dense contraction on this path (largest matrix
 // is 3x3), hence no MFMA; the bound is HBM bandwidth.
 //
-// The arithmetic follows the reference statement by statement, in the same
-// order (citations: Components/Components/Simulation/Quadcopter_T.cpp,
-// Motor.cpp, Common/Common/Math/Rotation.hpp, Vec3.hpp of agri-fly), so the
-// fp64 instantiation tracks the CPU oracle to rounding error and the fp32
-// instantiation differs from it only by fp32 rounding.
+// The arithmetic follows the reference statement by statement (citations:
+// Components/Components/Simulation/Quadcopter_T.cpp, Motor.cpp,
+// Common/Common/Math/Rotation.hpp, Vec3.hpp of agri-fly).  Sums of products are
+// written as explicit FMA chains (one rounding fewer than the reference's
+// mul+add, never one more) and implicit contraction is disabled, so every
+// instantiation rounds identically: the fp64 build tracks the CPU oracle to
+// ~1e-15 and the fp32 build differs from it only by fp32 rounding.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -22,34 +24,37 @@ namespace afe {
 
 // ---------------------------------------------------------------------------
 // scalar math, float / double
-__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
-__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+// explicit fused multiply-add: where the source says fm() the product is not
+// rounded; everywhere else contraction is off (see run_vehicle)
+__device__ __forceinline__ float fm(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fm(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
-__device__ __forceinline__ void m_sincos(float x, float *s, float *c) { sincosf(x, s, c); }
-__device__ __forceinline__ void m_sincos(double x, double *s, double *c) { sincos(x, s, c); }
 
-// Rotation<Real>::GetRotationMatrix, Rotation.hpp:196-220 (literal)
+// Rotation<Real>::GetRotationMatrix, Rotation.hpp:196-220; off-diagonals fused
 template <typename R>
 __device__ __forceinline__ void rot_matrix(R v0, R v1, R v2, R v3, R M[9]) {
+#pragma clang fp contract(off)
   const R r0 = v0 * v0, r1 = v1 * v1, r2 = v2 * v2, r3 = v3 * v3;
+  const R a = 2 * v0, b = 2 * v1, c = 2 * v2;
   M[0] = r0 + r1 - r2 - r3;
-  M[1] = 2 * v1 * v2 - 2 * v0 * v3;
-  M[2] = 2 * v1 * v3 + 2 * v0 * v2;
-  M[3] = 2 * v1 * v2 + 2 * v0 * v3;
+  M[1] = fm(b, v2, -(a * v3));
+  M[2] = fm(b, v3, a * v2);
+  M[3] = fm(b, v2, a * v3);
   M[4] = r0 - r1 + r2 - r3;
-  M[5] = 2 * v2 * v3 - 2 * v0 * v1;
-  M[6] = 2 * v1 * v3 - 2 * v0 * v2;
-  M[7] = 2 * v2 * v3 + 2 * v0 * v1;
+  M[5] = fm(c, v3, -(a * v1));
+  M[6] = fm(b, v3, -(a * v2));
+  M[7] = fm(c, v3, a * v1);
   M[8] = r0 - r1 - r2 + r3;
 }
 
-// Matrix<Real,3,3> * Vec3<Real>, Vec3.hpp:201-210 (accumulates from 0)
+// Matrix<Real,3,3> * Vec3<Real>, Vec3.hpp:201-210, as a chain of two FMAs
 template <typename R, typename M>
 __device__ __forceinline__ void mat_vec(const M *A, R x, R y, R z, R &ox, R &oy, R &oz) {
-  ox = ((R(0) + R(A[0]) * x) + R(A[1]) * y) + R(A[2]) * z;
-  oy = ((R(0) + R(A[3]) * x) + R(A[4]) * y) + R(A[5]) * z;
-  oz = ((R(0) + R(A[6]) * x) + R(A[7]) * y) + R(A[8]) * z;
+#pragma clang fp contract(off)
+  ox = fm(R(A[2]), z, fm(R(A[1]), y, R(A[0]) * x));
+  oy = fm(R(A[5]), z, fm(R(A[4]), y, R(A[3]) * x));
+  oz = fm(R(A[8]), z, fm(R(A[7]), y, R(A[6]) * x));
 }
 
 // ---------------------------------------------------------------------------
@@ -66,60 +71,146 @@ __device__ __forceinline__ uint32_t minstd_next(uint32_t &s) {
 
 __device__ __forceinline__ double canonical53(uint32_t &s) {
 #pragma clang fp contract(off)
-  // generate_canonical<double,53>: two engine calls, R = 2147483646
+  // generate_canonical<double,53>: two engine calls, R = 2147483646; the
+  // product and the sum round separately, as in libstdc++.
   double sum = (double)(minstd_next(s) - 1u);
   sum = sum + (double)(minstd_next(s) - 1u) * 2147483646.0;
-  double ret = sum / 4611686009837453312.0;  // (double)(R*R as long double)
+  // sum / (double)(R*R): correctly rounded quotient by a constant divisor in
+  // three FMAs (q0 = a*y; r = a - q0*b exactly; q = q0 + r*y, y = RN(1/b))
+  // instead of the ~11-instruction generic IEEE division sequence.
+  const double b = 4611686009837453312.0;
+  const double y = 1.0 / 4611686009837453312.0;
+  const double q0 = sum * y;
+  const double r = __builtin_fma(-q0, b, sum);
+  double ret = __builtin_fma(r, y, q0);
   if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;  // nextafter(1, 0)
   return ret;
 }
 
-// one Marsaglia polar pair; `first` is what the first operator() call returns
-__device__ __forceinline__ void normal_pair(uint32_t &s, double &first, double &second) {
+// Six N(0,1) draws = three Marsaglia polar pairs, in libstdc++'s order: pair k
+// yields d[2k] = y*mult (returned by the first operator() call) and d[2k+1] =
+// x*mult (the cached value returned by the second call).  Lanes with different
+// engine words reject different candidates; one merged acceptance loop (each
+// lane keeps drawing until it holds three accepted candidates) costs
+// max-over-lanes of the SUM of three geometric counts instead of three times
+// the max of one, and keeps log/sqrt/divide out of the divergent loop.
+__device__ __forceinline__ void six_normals(uint32_t &s, double d[6]) {
 #pragma clang fp contract(off)
-  double x, y, r2;
-  do {
-    x = 2.0 * canonical53(s) - 1.0;
-    y = 2.0 * canonical53(s) - 1.0;
-    r2 = x * x + y * y;
-  } while (r2 > 1.0 || r2 == 0.0);
-  const double mult = sqrt(-2 * log(r2) / r2);
-  first = y * mult;
-  second = x * mult;
+  double ax0 = 0, ay0 = 0, ar0 = 1, ax1 = 0, ay1 = 0, ar1 = 1, ax2 = 0, ay2 = 0, ar2 = 1;
+  int got = 0;
+  while (got < 3) {
+    const double x = 2.0 * canonical53(s) - 1.0;
+    const double y = 2.0 * canonical53(s) - 1.0;
+    const double r2 = x * x + y * y;
+    if (!(r2 > 1.0 || r2 == 0.0)) {
+      if (got == 0) { ax0 = x; ay0 = y; ar0 = r2; }
+      else if (got == 1) { ax1 = x; ay1 = y; ar1 = r2; }
+      else { ax2 = x; ay2 = y; ar2 = r2; }
+      got++;
+    }
+  }
+  const double m0 = sqrt(-2 * log(ar0) / ar0);
+  const double m1 = sqrt(-2 * log(ar1) / ar1);
+  const double m2 = sqrt(-2 * log(ar2) / ar2);
+  d[0] = ay0 * m0; d[1] = ax0 * m0;
+  d[2] = ay1 * m1; d[3] = ax1 * m1;
+  d[4] = ay2 * m2; d[5] = ax2 * m2;
 }
 
 // ---------------------------------------------------------------------------
-// The vehicle step.
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool RENORM>
-__global__ void __launch_bounds__(256)
-afe_step_kernel(const StepView<R> v) {
-  extern __shared__ __align__(16) unsigned char lds_raw[];
-  {
-    // stage the type table: n_types * sizeof(DevParams) bytes as dwords
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(v.table);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw);
-    const int nwords = v.n_types * (int)(sizeof(DevParams<R>) / 4);
-    for (int k = threadIdx.x; k < nwords; k += 256) dst[k] = src[k];
+// Quaternion increment FromRotationVector(angVel*dt), Rotation.hpp:84-97.
+// fp64: the reference's formula (sqrt, sin, cos, three divisions).
+__device__ __forceinline__ void rotvec_to_quat(double rx, double ry, double rz,
+                                               double &d0, double &d1, double &d2, double &d3) {
+#pragma clang fp contract(off)
+  const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+  d0 = 1; d1 = 0; d2 = 0; d3 = 0;
+  if (theta >= 4.84813681e-6) {
+    double sn, cs;
+    sincos(theta * 0.5, &sn, &cs);
+    d0 = cs;
+    d1 = sn * (rx / theta);
+    d2 = sn * (ry / theta);
+    d3 = sn * (rz / theta);
   }
-  __syncthreads();
+}
+// fp32: cos(theta/2) and sin(theta/2)/theta are even power series in theta, so
+// for theta < 0.5 rad per step (|w| < 500 rad/s at 1 ms) neither the square
+// root, the reciprocal nor sin/cos is needed; truncation error < 4e-10, below
+// fp32 rounding and smaller than the error of the reference-order evaluation in
+// fp32 (it scales the vector by 1/theta and multiplies back).  The reference's one-arc-second identity threshold is kept (it compares
+// theta, here theta^2 against the squared constant).
+__device__ __forceinline__ void rotvec_to_quat(float rx, float ry, float rz,
+                                               float &d0, float &d1, float &d2, float &d3) {
+#pragma clang fp contract(off)
+  float t = fm(rz, rz, fm(ry, ry, rx * rx));  // theta^2
+  const float kMin2 = 4.84813681e-6f * 4.84813681e-6f;
+  d0 = 1; d1 = 0; d2 = 0; d3 = 0;
+  if (t >= kMin2) {
+    // larger angles: evaluate the series for r / 2^k and square the unit
+    // quaternion k times, (c, s r') -> (c^2 - s^2 |r'|^2, (c s) 2r').  Rare
+    // (needs |w| dt >= 0.5 rad), so the lane-divergent loops cost nothing in
+    // normal flight; no library sin/cos/sqrt and no division anywhere.
+    int k = 0;
+    while (t >= 0.25f) { t *= 0.25f; k++; }
+    const float h2 = 0.25f * t;  // (theta/2)^2 of the scaled vector
+    float cs = fm(h2, fm(h2, fm(h2, fm(h2, 2.4801587e-5f, -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
+    float sc = 0.5f * fm(h2, fm(h2, fm(h2, fm(h2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.0f);
+    for (; k > 0; k--) {
+      const float c2 = fm(cs, cs, -((sc * sc) * t));
+      sc = cs * sc;
+      cs = c2;
+      t *= 4.0f;
+    }
+    d0 = cs;
+    d1 = sc * rx;
+    d2 = sc * ry;
+    d3 = sc * rz;
+  }
+}
 
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= v.n) return;
+__device__ __forceinline__ float quat_inv_norm(float n2) { return __builtin_amdgcn_rsqf(n2); }
+__device__ __forceinline__ double quat_inv_norm(double n2) { return 1.0 / sqrt(n2); }
+
+// (w - old)/dt and x/mass: the fp32 kernel multiplies by host-computed
+// reciprocals (<= 1 ulp from the quotient); the fp64 kernel divides.
+__device__ __forceinline__ float div_dt(float x, float, float inv_dt) { return x * inv_dt; }
+__device__ __forceinline__ double div_dt(double x, double dt, double) { return x / dt; }
+__device__ __forceinline__ float div_mass(float x, float, float inv_mass) { return x * inv_mass; }
+__device__ __forceinline__ double div_mass(double x, double mass, double) { return x / mass; }
+
+// ---------------------------------------------------------------------------
+// The vehicle step.  P is either the kernel-argument copy of the single
+// parameter record of a homogeneous ensemble (scalar registers: costs no
+// VGPRs) or this lane's record in the LDS-staged type table.
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool RENORM>
+__device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParams<R> &P, const int64_t i) {
+  // No implicit FMA contraction: every rounding is the one the source spells
+  // out, so all instantiations (noise on/off, wrench on/off, table/uniform,
+  // fused or single-step) produce bit-identical physics, and the operation
+  // order is the reference's (which is built without FMA on x86-64).
+#pragma clang fp contract(off)
+  // Addressing: every slab component is a wave-uniform base (scalar registers)
+  // plus ONE 32-bit per-lane byte offset, i.e. the saddr + voffset form of
+  // global_load/store; no 64-bit per-lane address is ever formed or kept live.
   const int64_t S = v.stride;
+  const uint32_t off = (uint32_t)i * (uint32_t)sizeof(R);  // engine caps n so this cannot wrap
+  const uint32_t off4 = (uint32_t)i * 4u;
+#define AFE_LD(T, base, comp, o) (*reinterpret_cast<const T *>(reinterpret_cast<const char *>((base) + (comp) * S) + (o)))
+#define AFE_ST(T, base, comp, o, val) (*reinterpret_cast<T *>(reinterpret_cast<char *>((base) + (comp) * S) + (o)) = (val))
 
   // ---- issue every load up front (independent, coalesced) ----
-  R px = v.pos[i], py = v.pos[S + i], pz = v.pos[2 * S + i];
-  R vx = v.vel[i], vy = v.vel[S + i], vz = v.vel[2 * S + i];
-  R q0 = v.att[i], q1 = v.att[S + i], q2 = v.att[2 * S + i], q3 = v.att[3 * S + i];
-  R wx = v.ang_vel[i], wy = v.ang_vel[S + i], wz = v.ang_vel[2 * S + i];
-  R ms[4] = {v.motor[i], v.motor[S + i], v.motor[2 * S + i], v.motor[3 * S + i]};
-  const float cmd_f[4] = {v.cmd[i], v.cmd[S + i], v.cmd[2 * S + i], v.cmd[3 * S + i]};
+  R px = AFE_LD(R, v.pos, 0, off), py = AFE_LD(R, v.pos, 1, off), pz = AFE_LD(R, v.pos, 2, off);
+  R vx = AFE_LD(R, v.vel, 0, off), vy = AFE_LD(R, v.vel, 1, off), vz = AFE_LD(R, v.vel, 2, off);
+  R q0 = AFE_LD(R, v.att, 0, off), q1 = AFE_LD(R, v.att, 1, off), q2 = AFE_LD(R, v.att, 2, off), q3 = AFE_LD(R, v.att, 3, off);
+  R wx = AFE_LD(R, v.ang_vel, 0, off), wy = AFE_LD(R, v.ang_vel, 1, off), wz = AFE_LD(R, v.ang_vel, 2, off);
+  R ms[4] = {AFE_LD(R, v.motor, 0, off), AFE_LD(R, v.motor, 1, off), AFE_LD(R, v.motor, 2, off), AFE_LD(R, v.motor, 3, off)};
+  const float cmd_f[4] = {AFE_LD(float, v.cmd, 0, off4), AFE_LD(float, v.cmd, 1, off4), AFE_LD(float, v.cmd, 2, off4), AFE_LD(float, v.cmd, 3, off4)};
   R fex = 0, fey = 0, fez = 0, tex = 0, tey = 0, tez = 0;
-  if (FEXT) { fex = v.ext_force[i]; fey = v.ext_force[S + i]; fez = v.ext_force[2 * S + i]; }
-  if (TEXT) { tex = v.ext_torque[i]; tey = v.ext_torque[S + i]; tez = v.ext_torque[2 * S + i]; }
+  if (FEXT) { fex = AFE_LD(R, v.ext_force, 0, off); fey = AFE_LD(R, v.ext_force, 1, off); fez = AFE_LD(R, v.ext_force, 2, off); }
+  if (TEXT) { tex = AFE_LD(R, v.ext_torque, 0, off); tey = AFE_LD(R, v.ext_torque, 1, off); tez = AFE_LD(R, v.ext_torque, 2, off); }
   uint32_t rng = 0;
-  if (NOISE && v.tick_mask) rng = v.rng[i];
-  const DevParams<R> &P = reinterpret_cast<const DevParams<R> *>(lds_raw)[v.type[i]];
+  if (NOISE && v.tick_mask) rng = AFE_LD(uint32_t, v.rng, 0, off4);
 
   const R dt = v.dt;
   float gx = 0, gy = 0, gz = 0, ax_m = 0, ay_m = 0, az_m = 0;
@@ -141,17 +232,17 @@ afe_step_kernel(const StepView<R> v) {
     for (int m = 0; m < 4; m++) {
       const R spin = (R)AFE_MOTOR_SPIN(m);
       const R old = ms[m];
-      R w = c * old + (1 - c) * cmd[m];                      // :60
+      R w = fm(c, old, (1 - c) * cmd[m]);                    // :60
       if (w > P.wmax) w = P.wmax; else if (w < P.wmin) w = P.wmin;  // :62-66
       ms[m] = w;
       const R thrust = P.kf * w * m_abs(w);                  // :70 (along +z)
       const R aero = -P.ktau * w * m_abs(w);                 // :73 (along spin*z)
-      const R ang_acc = (w - old) / dt;                      // :78
+      const R ang_acc = div_dt(w - old, dt, v.inv_dt);       // :78
       // torque = aero*axis + p x (0,0,thrust) - ang_acc*J*axis   :71-79
       const R tz_m = (aero * spin) - (ang_acc * P.Jm) * spin;
       Fz = Fz + thrust;                                      // Quadcopter_T.cpp:102
-      Tx = Tx + (P.mpy[m] * thrust);                         // Vec3.hpp:106-109
-      Ty = Ty + (-(P.mpx[m] * thrust));                      // z*rx - x*rz, rx = 0
+      Tx = fm(P.mpy[m], thrust, Tx);                         // Vec3.hpp:106-109
+      Ty = fm(-P.mpx[m], thrust, Ty);                        // z*rx - x*rz, rx = 0
       Tz = Tz + tz_m;
       Lm[m] = (w * P.Jm) * spin;                             // Motor.cpp:68
     }
@@ -160,62 +251,54 @@ afe_step_kernel(const StepView<R> v) {
     rot_matrix<R>(q0, q1, q2, q3, Rm);   // R(att); R(att.Inverse()) == Rm^T bitwise
 
     if (TEXT) {                          // Quadcopter_T.cpp:106
-      Tx = Tx + (Rm[0] * tex + Rm[3] * tey + Rm[6] * tez);
-      Ty = Ty + (Rm[1] * tex + Rm[4] * tey + Rm[7] * tez);
-      Tz = Tz + (Rm[2] * tex + Rm[5] * tey + Rm[8] * tez);
+      Tx = Tx + fm(Rm[6], tez, fm(Rm[3], tey, Rm[0] * tex));
+      Ty = Ty + fm(Rm[7], tez, fm(Rm[4], tey, Rm[1] * tex));
+      Tz = Tz + fm(Rm[8], tez, fm(Rm[5], tey, Rm[2] * tex));
     }
 
     // angular momentum and acceleration, Quadcopter_T.cpp:113-120
     R Lx, Ly, Lzz;
     mat_vec<R>(P.I, wx, wy, wz, Lx, Ly, Lzz);
     Lzz = (((Lzz + Lm[0]) + Lm[1]) + Lm[2]) + Lm[3];
-    const R cx = wy * Lzz - wz * Ly;     // _angVel.Cross(angMomentum)
-    const R cy = wz * Lx - wx * Lzz;
-    const R cz = wx * Ly - wy * Lx;
+    const R cx = fm(wy, Lzz, -(wz * Ly));   // _angVel.Cross(angMomentum)
+    const R cy = fm(wz, Lx, -(wx * Lzz));
+    const R cz = fm(wx, Ly, -(wy * Lx));
     R aax, aay, aaz;
     mat_vec<R>(P.Iinv, Tx - cx, Ty - cy, Tz - cz, aax, aay, aaz);
 
     // body drag, Quadcopter_T.cpp:123-128
-    const R vbx = Rm[0] * vx + Rm[3] * vy + Rm[6] * vz;
-    const R vby = Rm[1] * vx + Rm[4] * vy + Rm[7] * vz;
-    const R vbz = Rm[2] * vx + Rm[5] * vy + Rm[8] * vz;
+    const R vbx = fm(Rm[6], vz, fm(Rm[3], vy, Rm[0] * vx));
+    const R vby = fm(Rm[7], vz, fm(Rm[4], vy, Rm[1] * vx));
+    const R vbz = fm(Rm[8], vz, fm(Rm[5], vy, Rm[2] * vx));
     const R Fbx = P.drag[0] * (-vbx);
     const R Fby = P.drag[1] * (-vby);
-    const R Fbz = Fz + P.drag[2] * (-vbz);
+    const R Fbz = fm(P.drag[2], -vbz, Fz);
 
     // acceleration, Quadcopter_T.cpp:131-132
-    R accx = R(0) + ((Rm[0] * Fbx + Rm[1] * Fby + Rm[2] * Fbz) + fex) / P.mass;
-    R accy = R(0) + ((Rm[3] * Fbx + Rm[4] * Fby + Rm[5] * Fbz) + fey) / P.mass;
-    R accz = R(-9.81) + ((Rm[6] * Fbx + Rm[7] * Fby + Rm[8] * Fbz) + fez) / P.mass;
+    R accx = div_mass(fm(Rm[2], Fbz, fm(Rm[1], Fby, Rm[0] * Fbx)) + fex, P.mass, P.inv_mass);
+    R accy = div_mass(fm(Rm[5], Fbz, fm(Rm[4], Fby, Rm[3] * Fbx)) + fey, P.mass, P.inv_mass);
+    R accz = R(-9.81) + div_mass(fm(Rm[8], Fbz, fm(Rm[7], Fby, Rm[6] * Fbx)) + fez, P.mass, P.inv_mass);
 
     // integration, Quadcopter_T.cpp:140-143 (old vel / old angVel / old att)
-    R npx = (px + dt * vx) + dt * (dt * (R(0.5) * accx));
-    R npy = (py + dt * vy) + dt * (dt * (R(0.5) * accy));
-    R npz = (pz + dt * vz) + dt * (dt * (R(0.5) * accz));
-    R nvx = vx + dt * accx, nvy = vy + dt * accy, nvz = vz + dt * accz;
-    // FromRotationVector(angVel*dt), Rotation.hpp:84-97
-    const R rx = dt * wx, ry = dt * wy, rz = dt * wz;
-    const R theta = m_sqrt(rx * rx + ry * ry + rz * rz);
-    R d0 = 1, d1 = 0, d2 = 0, d3 = 0;
-    if (theta >= R(4.84813681e-6)) {
-      R sn, cs;
-      m_sincos(theta * R(0.5), &sn, &cs);
-      d0 = cs;
-      d1 = sn * (rx / theta);
-      d2 = sn * (ry / theta);
-      d3 = sn * (rz / theta);
-    }
+    // p + v dt + 0.5 a dt^2 = p + dt (v + (0.5 dt) a): two FMAs per axis
+    const R hdt = R(0.5) * dt;
+    R npx = fm(dt, fm(hdt, accx, vx), px);
+    R npy = fm(dt, fm(hdt, accy, vy), py);
+    R npz = fm(dt, fm(hdt, accz, vz), pz);
+    R nvx = fm(dt, accx, vx), nvy = fm(dt, accy, vy), nvz = fm(dt, accz, vz);
+    R d0, d1, d2, d3;
+    rotvec_to_quat(dt * wx, dt * wy, dt * wz, d0, d1, d2, d3);
     // att * dq, Rotation.hpp:124-131 (this = att, r1 = dq)
-    R n0 = d0 * q0 - d1 * q1 - d2 * q2 - d3 * q3;
-    R n1 = d1 * q0 + d0 * q1 + d3 * q2 - d2 * q3;
-    R n2 = d2 * q0 - d3 * q1 + d0 * q2 + d1 * q3;
-    R n3 = d3 * q0 + d2 * q1 - d1 * q2 + d0 * q3;
-    R nwx = wx + dt * aax, nwy = wy + dt * aay, nwz = wz + dt * aaz;
+    R n0 = fm(-d3, q3, fm(-d2, q2, fm(-d1, q1, d0 * q0)));
+    R n1 = fm(-d2, q3, fm(d3, q2, fm(d0, q1, d1 * q0)));
+    R n2 = fm(d1, q3, fm(d0, q2, fm(-d3, q1, d2 * q0)));
+    R n3 = fm(d0, q3, fm(-d1, q2, fm(d2, q1, d3 * q0)));
+    R nwx = fm(dt, aax, wx), nwy = fm(dt, aay, wy), nwz = fm(dt, aaz, wz);
 
     if (RENORM) {
       // fp32 storage only: the reference keeps |q| = 1 to 5e-14 over 1e4 steps
       // without ever normalising; fp32 needs this to stay inside tolerance.
-      const R inv = R(1) / m_sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+      const R inv = quat_inv_norm(fm(n3, n3, fm(n2, n2, fm(n1, n1, n0 * n0))));
       n0 *= inv; n1 *= inv; n2 *= inv; n3 *= inv;
     }
 
@@ -236,9 +319,7 @@ afe_step_kernel(const StepView<R> v) {
         // g++ evaluates the ctor arguments right to left (Quadcopter_T.cpp:
         // 167-169,176-178): z <- draw 1, y <- 2, x <- 3
         double d[6];
-        normal_pair(rng, d[0], d[1]);
-        normal_pair(rng, d[2], d[3]);
-        normal_pair(rng, d[4], d[5]);
+        six_normals(rng, d);
         ng[0] = v.sigma_gyro * (float)d[2];
         ng[1] = v.sigma_gyro * (float)d[1];
         ng[2] = v.sigma_gyro * (float)d[0];
@@ -253,9 +334,9 @@ afe_step_kernel(const StepView<R> v) {
       R Rn[9];
       rot_matrix<R>(q0, q1, q2, q3, Rn);
       const R sx = accx + R(0), sy = accy + R(0), sz = accz + R(9.81);
-      const R bx = Rn[0] * sx + Rn[3] * sy + Rn[6] * sz;
-      const R by = Rn[1] * sx + Rn[4] * sy + Rn[7] * sz;
-      const R bz = Rn[2] * sx + Rn[5] * sy + Rn[8] * sz;
+      const R bx = fm(Rn[6], sz, fm(Rn[3], sy, Rn[0] * sx));
+      const R by = fm(Rn[7], sz, fm(Rn[4], sy, Rn[1] * sx));
+      const R bz = fm(Rn[8], sz, fm(Rn[5], sy, Rn[2] * sx));
       mat_vec<float>(P.Rimu, (float)bx, (float)by, (float)bz, tx_, ty_, tz_);  // :175
       ax_m = tx_ + na[0]; ay_m = ty_ + na[1]; az_m = tz_ + na[2];              // :176-179
       have_imu = true;
@@ -263,25 +344,63 @@ afe_step_kernel(const StepView<R> v) {
   }
 
   // ---- write back (in place: same lines this lane just read) ----
-  v.pos[i] = px; v.pos[S + i] = py; v.pos[2 * S + i] = pz;
-  v.vel[i] = vx; v.vel[S + i] = vy; v.vel[2 * S + i] = vz;
-  v.att[i] = q0; v.att[S + i] = q1; v.att[2 * S + i] = q2; v.att[3 * S + i] = q3;
-  v.ang_vel[i] = wx; v.ang_vel[S + i] = wy; v.ang_vel[2 * S + i] = wz;
-  v.motor[i] = ms[0]; v.motor[S + i] = ms[1]; v.motor[2 * S + i] = ms[2]; v.motor[3 * S + i] = ms[3];
+  AFE_ST(R, v.pos, 0, off, px); AFE_ST(R, v.pos, 1, off, py); AFE_ST(R, v.pos, 2, off, pz);
+  AFE_ST(R, v.vel, 0, off, vx); AFE_ST(R, v.vel, 1, off, vy); AFE_ST(R, v.vel, 2, off, vz);
+  AFE_ST(R, v.att, 0, off, q0); AFE_ST(R, v.att, 1, off, q1); AFE_ST(R, v.att, 2, off, q2); AFE_ST(R, v.att, 3, off, q3);
+  AFE_ST(R, v.ang_vel, 0, off, wx); AFE_ST(R, v.ang_vel, 1, off, wy); AFE_ST(R, v.ang_vel, 2, off, wz);
+  AFE_ST(R, v.motor, 0, off, ms[0]); AFE_ST(R, v.motor, 1, off, ms[1]); AFE_ST(R, v.motor, 2, off, ms[2]); AFE_ST(R, v.motor, 3, off, ms[3]);
   if (have_imu) {
-    v.gyro[i] = gx; v.gyro[S + i] = gy; v.gyro[2 * S + i] = gz;
-    v.acc[i] = ax_m; v.acc[S + i] = ay_m; v.acc[2 * S + i] = az_m;
-    if (NOISE) v.rng[i] = rng;
+    AFE_ST(float, v.gyro, 0, off4, gx); AFE_ST(float, v.gyro, 1, off4, gy); AFE_ST(float, v.gyro, 2, off4, gz);
+    AFE_ST(float, v.acc, 0, off4, ax_m); AFE_ST(float, v.acc, 1, off4, ay_m); AFE_ST(float, v.acc, 2, off4, az_m);
+    if (NOISE) AFE_ST(uint32_t, v.rng, 0, off4, rng);
   }
+#undef AFE_LD
+#undef AFE_ST
+}
+
+#ifndef AFE_LB_WAVES
+#define AFE_LB_WAVES 1
+#endif
+
+// homogeneous ensemble: the one parameter record rides in the kernel arguments
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool RENORM>
+__global__ void __launch_bounds__(256, AFE_LB_WAVES)
+afe_step_kernel(const StepView<R> v, const DevParams<R> P) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= v.n) return;
+  run_vehicle<R, FEXT, TEXT, NOISE, RENORM>(v, P, i);
+}
+
+// heterogeneous ensemble: type table staged into LDS, one record per lane
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool RENORM>
+__global__ void __launch_bounds__(256)
+afe_step_kernel_table(const StepView<R> v) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(v.table);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw);
+    const int nwords = v.n_types * (int)(sizeof(DevParams<R>) / 4);
+    for (int k = threadIdx.x; k < nwords; k += 256) dst[k] = src[k];
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= v.n) return;
+  const DevParams<R> &P = reinterpret_cast<const DevParams<R> *>(lds_raw)[v.type[(uint32_t)i]];
+  run_vehicle<R, FEXT, TEXT, NOISE, RENORM>(v, P, i);
 }
 
 template <typename R>
-static int launch_step(const StepView<R> &v, const LaunchFlags &f, hipStream_t st) {
+static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevParams<R> *uniform, hipStream_t st) {
   if (v.n <= 0) return 0;
   const unsigned grid = (unsigned)((v.n + 255) / 256);
   const size_t lds = (size_t)v.n_types * sizeof(DevParams<R>);
-#define AFE_LAUNCH(FE, TE, NO, RE) \
-  hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, RE>), dim3(grid), dim3(256), lds, st, v)
+#define AFE_LAUNCH(FE, TE, NO, RE)                                                                      \
+  do {                                                                                                  \
+    if (uniform)                                                                                        \
+      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, RE>), dim3(grid), dim3(256), 0, st, v, *uniform); \
+    else                                                                                                \
+      hipLaunchKernelGGL((afe_step_kernel_table<R, FE, TE, NO, RE>), dim3(grid), dim3(256), lds, st, v);   \
+  } while (0)
 #define AFE_SEL_RE(FE, TE, NO) do { if (f.renorm) AFE_LAUNCH(FE, TE, NO, true); else AFE_LAUNCH(FE, TE, NO, false); } while (0)
 #define AFE_SEL_NO(FE, TE) do { if (f.noise) AFE_SEL_RE(FE, TE, true); else AFE_SEL_RE(FE, TE, false); } while (0)
 #define AFE_SEL_TE(FE) do { if (f.ext_torque) AFE_SEL_NO(FE, true); else AFE_SEL_NO(FE, false); } while (0)
@@ -293,11 +412,11 @@ static int launch_step(const StepView<R> &v, const LaunchFlags &f, hipStream_t s
   return (int)hipGetLastError();
 }
 
-int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, void *stream) {
-  return launch_step<float>(v, f, (hipStream_t)stream);
+int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, const DevParams<float> *uniform, void *stream) {
+  return launch_step<float>(v, f, uniform, (hipStream_t)stream);
 }
-int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, void *stream) {
-  return launch_step<double>(v, f, (hipStream_t)stream);
+int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> *uniform, void *stream) {
+  return launch_step<double>(v, f, uniform, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -90,6 +90,7 @@ template <typename R>
 void to_device_params(const HostParams &h, double dt, DevParams<R> &d) {
   std::memset(&d, 0, sizeof(d));
   d.mass = (R)h.mass;
+  d.inv_mass = (R)(1.0 / h.mass);
   for (int k = 0; k < 9; k++) { d.I[k] = (R)h.I[k]; d.Iinv[k] = (R)h.Iinv[k]; d.Rimu[k] = h.Rimu[k]; }
   for (int m = 0; m < 4; m++) { d.mpx[m] = (R)h.mp[m][0]; d.mpy[m] = (R)h.mp[m][1]; d.mpz[m] = (R)h.mp[m][2]; }
   d.kf = (R)h.kf;

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "lib", "libagrifly_engine.so")
+# AGRIFLY_ENGINE_LIB selects another build of the same library (kernel A/B runs)
+_LIB = os.environ.get("AGRIFLY_ENGINE_LIB") or os.path.join(_HERE, "lib", "libagrifly_engine.so")
 
 AFE_F32, AFE_F64 = 0, 1
 AFE_SEED_REFERENCE, AFE_SEED_DECORRELATED = 0, 1
