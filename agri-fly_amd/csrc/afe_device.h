@@ -70,6 +70,7 @@ int launch_pack_positions_f64(const double *pos, int64_t stride, int64_t n, floa
 int launch_nearest_neighbour(const float *self_xyz, int64_t n_self, int64_t first_global,
                              const float *all_xyz, int64_t n_all, float *dist2,
                              int32_t *index, void *stream);
+int launch_normals_selftest(const uint32_t *seeds, int64_t n, double *out, uint32_t *state_out, void *stream);
 int launch_seed_rng(uint32_t *rng, int64_t n, int64_t first_global, int policy, void *stream);
 
 }  // namespace afe

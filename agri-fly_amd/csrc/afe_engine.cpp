@@ -558,6 +558,27 @@ extern "C" int afe_event_elapsed_ms(void *start, void *stop, float *ms) {
   return hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? AFE_OK : AFE_ERR_HIP;
 }
 
+extern "C" int afe_selftest_normals(afe_engine *e, const uint32_t *seeds, int64_t n, double *normals6, uint32_t *state_after) {
+  if (!e || !seeds || n <= 0 || !normals6 || !state_after) return fail(e, AFE_ERR_INVALID_ARG, "bad selftest arguments");
+  for (int64_t k = 0; k < n; k++)
+    if (seeds[k] == 0 || seeds[k] >= 2147483647u) return fail(e, AFE_ERR_INVALID_ARG, "minstd_rand0 state must be in [1, 2^31-2]");
+  AFE_HIP(e, hipSetDevice(e->device));
+  uint32_t *d_seed = nullptr, *d_state = nullptr;
+  double *d_out = nullptr;
+  AFE_HIP(e, hipMalloc((void **)&d_seed, (size_t)n * 4));
+  AFE_HIP(e, hipMalloc((void **)&d_state, (size_t)n * 4));
+  AFE_HIP(e, hipMalloc((void **)&d_out, (size_t)n * 48));
+  int rc = AFE_OK;
+  if (hipMemcpy(d_seed, seeds, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      launch_normals_selftest(d_seed, n, d_out, d_state, e->stream) != 0 ||
+      hipStreamSynchronize(e->stream) != hipSuccess ||
+      hipMemcpy(normals6, d_out, (size_t)n * 48, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(state_after, d_state, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    rc = fail(e, AFE_ERR_HIP, "normals selftest failed");
+  (void)hipFree(d_seed); (void)hipFree(d_state); (void)hipFree(d_out);
+  return rc;
+}
+
 extern "C" int afe_pack_positions(afe_engine *e, float *device_xyz) {
   if (!e || !device_xyz) return fail(e, AFE_ERR_INVALID_ARG, "device_xyz is NULL");
   AFE_HIP(e, hipSetDevice(e->device));

@@ -29,7 +29,7 @@ ABI_FUNCTIONS = [
     "afe_logic_ticks", "afe_get_imu", "afe_plan_ticks", "afe_get_device_view",
     "afe_algorithmic_bytes_per_step", "afe_event_create", "afe_event_destroy",
     "afe_event_record", "afe_event_elapsed_ms", "afe_pack_positions",
-    "afe_nearest_neighbour",
+    "afe_nearest_neighbour", "afe_selftest_normals",
 ]
 
 
@@ -146,6 +146,7 @@ def library():
         "afe_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
         "afe_pack_positions": [eng, vp],
         "afe_nearest_neighbour": [eng, vp, i64, vp, vp],
+        "afe_selftest_normals": [eng, vp, i64, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -368,6 +369,14 @@ class Ensemble:
 
     def destroy_event(self, ev):
         self._L.afe_event_destroy(ev)
+
+    def selftest_normals(self, seeds):
+        """(normals[n, 6] float64, state_after[n] uint32) from the device generator"""
+        s = np.ascontiguousarray(seeds, dtype=np.uint32)
+        out = np.empty((s.size, 6), np.float64)
+        st = np.empty(s.size, np.uint32)
+        self._ck(self._L.afe_selftest_normals(self._h, s.ctypes.data, s.size, out.ctypes.data, st.ctypes.data))
+        return out, st
 
     # -- shared-world query -------------------------------------------------
     def pack_positions(self, device_ptr):

@@ -209,6 +209,15 @@ int afe_get_device_view(afe_engine *e, afe_device_view *out);
  * array, ...); what bench.py's roofline is computed from. */
 int afe_algorithmic_bytes_per_step(const afe_engine *e, int imu_tick, double *bytes);
 
+/* Self-test hook for the IMU noise generator: for each of n minstd_rand0 words
+ * the first six std::normal_distribution<double>(0,1) draws the engine's
+ * device code produces from it (normals6[6*i .. 6*i+5], libstdc++ order) and
+ * the engine word afterwards.  Lets a host check the device generator against
+ * libstdc++ known answers (tests/golden/rng_kat.json) without going through a
+ * physics step.  Replaces nothing in the reference. */
+int afe_selftest_normals(afe_engine *e, const uint32_t *seeds, int64_t n,
+                         double *normals6, uint32_t *state_after);
+
 /* ---- HIP-event timing on the engine's stream (for bench.py) ------------- */
 int afe_event_create(void **event);
 int afe_event_destroy(void *event);

@@ -4,6 +4,12 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime (same SONAME as /opt/rocm's).  Whichever
+# libamdhip64 is loaded first serves the whole process, so a process that uses
+# both torch.cuda and the engine must import torch BEFORE the engine library is
+# loaded (otherwise torch finds "No HIP GPUs").  See INTEGRATION.md.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -323,3 +323,37 @@ def test_full_size_properties_1m_vehicles():
     assert rel_err(gyro[:, idx], b.gyro, 1.0) <= 1e-5
     # noise statistics over the decorrelated ensemble
     assert abs(float(gyro[2].std()) - 0.1) < 2e-3
+
+
+def test_device_normals_match_libstdcxx_known_answers(golden_dir):
+    """the DEVICE generator against the committed libstdc++ fixture directly
+    (not through the oracle): raw engine words bit-exact, normals to a few ulp"""
+    import json
+    kat = json.load(open(os.path.join(golden_dir, "rng_kat.json")))["streams"]
+    seeds = [s["seed"] % 2147483647 or 1 for s in kat]
+    with afa.Ensemble(8) as e:
+        got, state = e.selftest_normals(seeds)
+        for k, s in enumerate(kat):
+            np.testing.assert_allclose(got[k], s["normals"][:6], rtol=4e-15, atol=0)
+        # and against the oracle for many seeds (rejection paths, r2 near 0 and 1)
+        from oracle import oracle_py
+        import ctypes as C
+        rng = np.random.default_rng(3)
+        many = rng.integers(1, 2147483646, 200000).astype(np.uint32)
+        got, state = e.selftest_normals(many)
+        L = oracle_py.lib()
+        ref = np.empty((2000, 6))
+        ref_state = np.empty(2000, np.uint32)
+        a, b = C.c_double(), C.c_double()
+        for i in range(2000):
+            st = C.c_uint32(int(many[i]))
+            for p in range(3):
+                L.ora_normal_pair(C.byref(st), C.byref(a), C.byref(b))
+                ref[i, 2 * p], ref[i, 2 * p + 1] = a.value, b.value
+            ref_state[i] = st.value
+        np.testing.assert_array_equal(state[:2000], ref_state)
+        np.testing.assert_allclose(got[:2000], ref, rtol=4e-15, atol=0)
+        # float narrowing is what the IMU sees: identical in (nearly) all draws
+        same = (got[:2000].astype(np.float32) == ref.astype(np.float32)).mean()
+        assert same == 1.0
+        assert np.isfinite(got).all() and abs(got.mean()) < 5e-3 and abs(got.std() - 1) < 5e-3
