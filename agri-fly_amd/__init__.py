@@ -19,12 +19,14 @@ from .engine import (  # noqa: F401
     AfeError,
     DeviceView,
     Ensemble,
+    RatesLogicParams,
     VehicleParams,
     build_library,
     library,
     library_path,
     params_from_type,
     plan_ticks,
+    rates_logic_params_from_type,
     type_from_id,
 )
 from . import scenarios  # noqa: F401

@@ -32,6 +32,18 @@ struct alignas(16) DevParams {
 static_assert(sizeof(DevParams<float>) % 16 == 0, "DevParams<float> size");
 static_assert(sizeof(DevParams<double>) % 16 == 0, "DevParams<double> size");
 
+// On-device onboard rates logic (optional): constants of the rates-control slice
+// of Onboard::QuadcopterLogic, all float like the reference's onboard code.
+struct alignas(16) DevLogic {
+  float mass;
+  float I[9];        // QuadcopterConstants::inertiaMatrix
+  float tc_xy, tc_z; // angular-velocity controller time constants
+  float d, kt, kf;   // QuadcopterMixer::_d, _kt, _kf
+  float max_thrust, min_thrust, max_cmd_total;
+  float R[9];        // QuadcopterLogic::_R (IMU mount, NOT inverted)
+  float a1, a2, b0, b1, b2;  // LowPassFilterSecondOrder coefficients (gyro)
+};
+
 // Motor i spins about s_i * z with s = (+1,-1,+1,-1) and pushes along +z
 // (Quadcopter_T.cpp:45-65 with Motor.cpp:32-36).
 #define AFE_MOTOR_SPIN(i) (((i) & 1) ? -1 : +1)
@@ -53,18 +65,27 @@ struct StepView {
   int n_steps;
   unsigned long long tick_mask;  // bit s set: sub-step s fires the logic gate
   float sigma_gyro, sigma_acc;
+  // on-device rates logic (null when disabled)
+  float *lpf;               // 12 comps: xm0[3] xm1[3] ym0[3] ym1[3]
+  const float *rates_cmd;   // 4 comps: thrust_norm, wx, wy, wz
+  const uint8_t *have_cmd;  // 1: EXTERNAL_RATES_CONTROL, 0: IDLE
+  uint8_t *imu_init;        // KalmanFilter6DOF::_IMUInitialized
+  float *cmd_out;           // == cmd (written by the logic)
+  const DevLogic *logic_table;
 };
 
 struct LaunchFlags {
-  bool ext_force, ext_torque, noise, renorm;
+  bool ext_force, ext_torque, noise, logic;
 };
 
 // kernel launchers (afe_kernels.hip); stream is a hipStream_t
 // `uniform` != nullptr: every vehicle uses this one record, passed by value in
 // the kernel-argument segment (scalar registers); otherwise v.table is staged
 // into LDS and indexed per lane by v.type.
-int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, const DevParams<float> *uniform, void *stream);
-int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> *uniform, void *stream);
+int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, const DevParams<float> *uniform,
+                    const DevLogic *uniform_logic, void *stream);
+int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> *uniform,
+                    const DevLogic *uniform_logic, void *stream);
 int launch_pack_positions_f32(const float *pos, int64_t stride, int64_t n, float *out, void *stream);
 int launch_pack_positions_f64(const double *pos, int64_t stride, int64_t n, float *out, void *stream);
 int launch_nearest_neighbour(const float *self_xyz, int64_t n_self, int64_t first_global,

@@ -35,6 +35,15 @@ struct afe_engine {
   std::vector<DevParams<double>> table_f64;
   bool types_uniform = true;  // every vehicle uses record 0 (kernel-argument fast path)
   float *pack_scratch = nullptr;  // 3*n floats, lazily allocated
+  // on-device rates logic (allocated by afe_set_rates_logic)
+  bool logic_on = false;
+  void *logic_arena = nullptr;
+  float *lpf = nullptr, *rates_cmd = nullptr;
+  uint8_t *have_cmd = nullptr, *imu_init = nullptr;
+  DevLogic *dev_logic_table = nullptr;
+  std::vector<afe_rates_logic_params> logic_params;
+  std::vector<DevLogic> logic_table;
+  float logic_table_period = -1.0f;
 
   // configuration
   std::vector<HostParams> table;
@@ -195,8 +204,27 @@ int refresh_table(afe_engine *e, double dt) {
   return AFE_OK;
 }
 
+// (re)build the logic constants when the table or the logic period changed
+int refresh_logic(afe_engine *e) {
+  const float period = (float)e->logic_period;  // float(onboardLogicPeriod), Quadcopter_T.cpp:18
+  if (period == e->logic_table_period) return AFE_OK;
+  const size_t n = e->logic_params.size();
+  e->logic_table.resize(n);
+  for (size_t k = 0; k < n; k++) {
+    const char *why = "";
+    int rc = expand_logic(e->logic_params[k], period, e->logic_table[k], &why);
+    if (rc) return fail(e, rc, "logic type " + std::to_string(k) + ": " + why);
+  }
+  AFE_HIP(e, hipMemcpyAsync(e->dev_logic_table, e->logic_table.data(), n * sizeof(DevLogic), hipMemcpyHostToDevice, e->stream));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  e->logic_table_period = period;
+  return AFE_OK;
+}
+
 template <typename R>
 void fill_view(const afe_engine *e, StepView<R> &v) {
+  v.lpf = e->lpf; v.rates_cmd = e->rates_cmd; v.have_cmd = e->have_cmd; v.imu_init = e->imu_init;
+  v.cmd_out = e->cmd; v.logic_table = e->dev_logic_table;
   v.pos = (R *)e->pos; v.vel = (R *)e->vel; v.att = (R *)e->att;
   v.ang_vel = (R *)e->ang_vel; v.motor = (R *)e->motor;
   v.ext_force = (const R *)e->ext_force; v.ext_torque = (const R *)e->ext_torque;
@@ -295,6 +323,7 @@ extern "C" int afe_destroy(afe_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
   if (e->pack_scratch) (void)hipFree(e->pack_scratch);
+  if (e->logic_arena) (void)hipFree(e->logic_arena);
   if (e->arena) (void)hipFree(e->arena);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -412,6 +441,65 @@ extern "C" int afe_set_motor_cmds(afe_engine *e, int64_t first, int64_t count, c
   AFE_HIP(e, hipSetDevice(e->device));
   return copy_in(e, e->cmd, 4, 4, first, count, cmd4);
 }
+extern "C" int afe_get_motor_cmds(afe_engine *e, int64_t first, int64_t count, float *cmd4) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  if (!cmd4) return fail(e, AFE_ERR_INVALID_ARG, "cmd4 is NULL");
+  AFE_HIP(e, hipSetDevice(e->device));
+  return copy_out(e, e->cmd, 4, 4, first, count, cmd4);
+}
+
+extern "C" int afe_set_rates_logic(afe_engine *e, const afe_rates_logic_params *table, int n_types) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  AFE_HIP(e, hipSetDevice(e->device));
+  if (!table) {
+    AFE_HIP(e, hipStreamSynchronize(e->stream));
+    e->logic_on = false;
+    return AFE_OK;
+  }
+  if (e->table.empty() || n_types != (int)e->table.size())
+    return fail(e, AFE_ERR_INVALID_ARG, "the logic table must have one record per vehicle type record");
+  std::vector<DevLogic> probe((size_t)n_types);
+  for (int k = 0; k < n_types; k++) {
+    const char *why = "";
+    int rc = expand_logic(table[k], (float)e->logic_period, probe[(size_t)k], &why);
+    if (rc) return fail(e, rc, "logic type " + std::to_string(k) + ": " + why);
+  }
+  const size_t S = (size_t)e->stride;
+  if (!e->logic_arena) {
+    const size_t bytes = S * 12 * 4 + S * 4 * 4 + S * 2 + 256 * sizeof(DevLogic);
+    AFE_HIP(e, hipMalloc(&e->logic_arena, bytes));
+    char *p = (char *)e->logic_arena;
+    e->lpf = (float *)p; p += S * 12 * 4;
+    e->rates_cmd = (float *)p; p += S * 4 * 4;
+    e->dev_logic_table = (DevLogic *)p; p += 256 * sizeof(DevLogic);
+    e->have_cmd = (uint8_t *)p; p += S;
+    e->imu_init = (uint8_t *)p;
+  }
+  // QuadcopterLogic::Initialise: filters at 0 (QuadcopterLogic.cpp:38,133), _kf.Reset(), FS_IDLE
+  AFE_HIP(e, hipMemsetAsync(e->lpf, 0, S * 12 * 4, e->stream));
+  AFE_HIP(e, hipMemsetAsync(e->rates_cmd, 0, S * 4 * 4, e->stream));
+  AFE_HIP(e, hipMemsetAsync(e->have_cmd, 0, S * 2, e->stream));
+  AFE_HIP(e, hipMemsetAsync(e->cmd, 0, S * 4 * 4, e->stream));
+  e->logic_params.assign(table, table + n_types);
+  e->logic_table_period = -1.0f;
+  e->logic_on = true;
+  return refresh_logic(e);
+}
+
+extern "C" int afe_set_rates_commands(afe_engine *e, int64_t first, int64_t count, const float *thrust_norm,
+                                      const float *ang_vel3) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  if (!e->logic_on) return fail(e, AFE_ERR_NOT_CONFIGURED, "afe_set_rates_logic has not been called");
+  if (!thrust_norm || !ang_vel3) return fail(e, AFE_ERR_INVALID_ARG, "command arrays are NULL");
+  AFE_HIP(e, hipSetDevice(e->device));
+  if ((rc = copy_in(e, e->rates_cmd, 4, 1, first, count, thrust_norm))) return rc;
+  if ((rc = copy_in(e, e->rates_cmd + e->stride, 4, 3, first, count, ang_vel3))) return rc;
+  AFE_HIP(e, hipMemsetAsync(e->have_cmd + first, 1, (size_t)count, e->stream));
+  return AFE_OK;
+}
+
 extern "C" int afe_set_external_force(afe_engine *e, int64_t first, int64_t count, const double *force3) {
   if (!e) return AFE_ERR_INVALID_ARG;
   return set_wrench(e, e->ext_force, e->has_ext_force, first, count, force3);
@@ -430,11 +518,12 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   AFE_HIP(e, hipSetDevice(e->device));
   int rc = refresh_table(e, dt);
   if (rc) return rc;
+  if (e->logic_on && (rc = refresh_logic(e))) return rc;
   LaunchFlags f;
   f.ext_force = e->has_ext_force;
   f.ext_torque = e->has_ext_torque;
   f.noise = e->noise;
-  f.renorm = e->renorm;
+  f.logic = e->logic_on;
   int done = 0;
   while (done < n_steps) {
     const int chunk = (n_steps - done) < 64 ? (n_steps - done) : 64;
@@ -448,17 +537,19 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     }
     // launches without a logic tick draw no noise: use the lean instantiation
     f.noise = e->noise && mask != 0;
+    f.logic = e->logic_on && mask != 0;
+    const DevLogic *ulogic = (e->logic_on && e->types_uniform) ? &e->logic_table[0] : nullptr;
     int lrc;
     if (e->precision == AFE_F64) {
       StepView<double> v;
       fill_view(e, v);
       v.dt = dt; v.inv_dt = 1.0 / dt; v.n_steps = chunk; v.tick_mask = mask;
-      lrc = launch_step_f64(v, f, e->types_uniform ? &e->table_f64[0] : nullptr, e->stream);
+      lrc = launch_step_f64(v, f, e->types_uniform ? &e->table_f64[0] : nullptr, ulogic, e->stream);
     } else {
       StepView<float> v;
       fill_view(e, v);
       v.dt = (float)dt; v.inv_dt = (float)(1.0 / dt); v.n_steps = chunk; v.tick_mask = mask;
-      lrc = launch_step_f32(v, f, e->types_uniform ? &e->table_f32[0] : nullptr, e->stream);
+      lrc = launch_step_f32(v, f, e->types_uniform ? &e->table_f32[0] : nullptr, ulogic, e->stream);
     }
     if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
     done += chunk;
@@ -530,6 +621,7 @@ extern "C" int afe_algorithmic_bytes_per_step(const afe_engine *e, int imu_tick,
   if (imu_tick) {
     b += 6 * 4;                // gyro + accelerometer sample
     if (e->noise) b += 8;      // RNG word read + write
+    if (e->logic_on) b += 12 * 4 * 2 + 4 * 4 + 4 * 4 + 3;  // LPF state r/w, rates cmd, motor cmd write, flags
   }
   *bytes = b;
   return AFE_OK;

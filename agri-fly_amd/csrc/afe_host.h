@@ -28,6 +28,10 @@ int expand_params(const afe_vehicle_params &in, HostParams &out, const char **wh
 template <typename R>
 void to_device_params(const HostParams &h, double dt, DevParams<R> &d);
 
+// QuadcopterLogic::Initialise (QuadcopterLogic.cpp:97-150) for the rates slice:
+// mixer constants, IMU mount matrix, gyro low-pass coefficients, all in float.
+int expand_logic(const afe_rates_logic_params &in, float onboard_period, DevLogic &out, const char **why);
+
 // Timer semantics, reference Common/Common/Time/Timer.hpp:27-54.
 inline double us_to_seconds(uint64_t us) { return (double)((double)us * 1e-6); }
 inline uint64_t period_to_us(double period_s) { return (uint64_t)((-period_s) * -1e6); }

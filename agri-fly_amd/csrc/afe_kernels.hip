@@ -227,16 +227,87 @@ __device__ __forceinline__ float div_mass(float x, float, float inv_mass) { retu
 __device__ __forceinline__ double div_mass(double x, double mass, double) { return x / mass; }
 
 // ---------------------------------------------------------------------------
+// On-device onboard rates logic, one tick.  Literal float
+// arithmetic in the reference's operation order with contraction off and IEEE
+// division / sqrt, so that for a bit-identical IMU sample the motor commands
+// are bit-identical to the reference's onboard code.
+struct LogicRegs {
+  float xm0[3], xm1[3], ym0[3], ym1[3];
+  uint8_t imu_init, have_cmd;
+  float thrust_norm, wdes[3];
+};
+
+__device__ __forceinline__ void rates_logic_tick(const DevLogic &G, LogicRegs &s, float gx, float gy, float gz,
+                                                 float cmd_out[4]) {
+#pragma clang fp contract(off)
+  // SetIMUMeasurementRateGyro: rawMeas = _R * gyro (QuadcopterLogic.hpp:43; Vec3.hpp:201-210)
+  const float g[3] = {gx, gy, gz};
+  float raw[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) raw[i] = ((0.0f + G.R[3 * i] * g[0]) + G.R[3 * i + 1] * g[1]) + G.R[3 * i + 2] * g[2];
+  // lowPass.Apply(rawMeas - bias), LowPassFilterSecondOrder.hpp:51-64 (bias = 0)
+  float filt[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float in = raw[k] - 0.0f;
+    float out = G.b2 * in;
+    out = out + (+G.b0 * s.xm0[k] + G.b1 * s.xm1[k]);
+    out = out + (-G.a1 * s.ym0[k] - G.a2 * s.ym1[k]);
+    s.xm0[k] = s.xm1[k]; s.xm1[k] = in;
+    s.ym0[k] = s.ym1[k]; s.ym1[k] = out;
+    filt[k] = out;
+  }
+  // KalmanFilter6DOF::Predict, no UWB: first call initialises only
+  // (KalmanFilter6DOF.cpp:71-108), later calls set _angVel = measGyro (:115).
+  float w[3] = {0.0f, 0.0f, 0.0f};
+  if (s.imu_init) { w[0] = filt[0]; w[1] = filt[1]; w[2] = filt[2]; }
+  else s.imu_init = 1;
+  if (!s.have_cmd) {  // FS_IDLE: QuadcopterLogic.cpp:213-217
+    cmd_out[0] = cmd_out[1] = cmd_out[2] = cmd_out[3] = 0.0f;
+    return;
+  }
+  // GetDesiredTorques, QuadcopterAngularVelocityController.hpp:25-38
+  const float ex = s.wdes[0] - w[0], ey = s.wdes[1] - w[1], ez = s.wdes[2] - w[2];
+  const float aa[3] = {ex / G.tc_xy, ey / G.tc_xy, ez / G.tc_z};
+  float Iw[3], Ia[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    Iw[i] = ((0.0f + G.I[3 * i] * w[0]) + G.I[3 * i + 1] * w[1]) + G.I[3 * i + 2] * w[2];
+    Ia[i] = ((0.0f + G.I[3 * i] * aa[0]) + G.I[3 * i + 1] * aa[1]) + G.I[3 * i + 2] * aa[2];
+  }
+  const float tx = Ia[0] + (w[1] * Iw[2] - w[2] * Iw[1]);
+  const float ty = Ia[1] + (w[2] * Iw[0] - w[0] * Iw[2]);
+  const float tz = Ia[2] + (w[0] * Iw[1] - w[1] * Iw[0]);
+  // QuadcopterMixer::GetMotorForces, QuadcopterMixer.hpp:63-86
+  const float totF = s.thrust_norm * G.mass;            // QuadcopterLogic.cpp:538
+  const float desF = totF > G.max_cmd_total ? G.max_cmd_total : totF;
+  float F[4];
+  F[0] = (-tx / G.d - ty / G.d - tz / G.kt + desF) / 4.0f;
+  F[1] = (-tx / G.d + ty / G.d + tz / G.kt + desF) / 4.0f;
+  F[2] = (+tx / G.d + ty / G.d - tz / G.kt + desF) / 4.0f;
+  F[3] = (+tx / G.d - ty / G.d + tz / G.kt + desF) / 4.0f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (F[i] < G.min_thrust) F[i] = G.min_thrust;
+    else if (F[i] > G.max_thrust) F[i] = G.max_thrust;
+    // PropellerSpeedsFromThrust, QuadcopterMixer.hpp:88-99 (correction factor 1)
+    cmd_out[i] = (F[i] <= 0) ? 0.0f : sqrtf(F[i] / (1.0f * G.kf));
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The vehicle step.  P is either the kernel-argument copy of the single
 // parameter record of a homogeneous ensemble (scalar registers: costs no
 // VGPRs) or this lane's record in the LDS-staged type table.
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool RENORM>
-__device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParams<R> &P, const int64_t i) {
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC>
+__device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParams<R> &P, const DevLogic &G,
+                                            const int64_t i) {
   // No implicit FMA contraction: every rounding is the one the source spells
   // out, so all instantiations (noise on/off, wrench on/off, table/uniform,
   // fused or single-step) produce bit-identical physics, and the operation
   // order is the reference's (which is built without FMA on x86-64).
 #pragma clang fp contract(off)
+  constexpr bool RENORM = (sizeof(R) == 4);  // fp32 storage renormalises the quaternion
   // Addressing: every slab component is a wave-uniform base (scalar registers)
   // plus ONE 32-bit per-lane byte offset, i.e. the saddr + voffset form of
   // global_load/store; no 64-bit per-lane address is ever formed or kept live.
@@ -258,6 +329,21 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   if (TEXT) { tex = AFE_LD(R, v.ext_torque, 0, off); tey = AFE_LD(R, v.ext_torque, 1, off); tez = AFE_LD(R, v.ext_torque, 2, off); }
   uint32_t rng = 0;
   if (NOISE && v.tick_mask) rng = AFE_LD(uint32_t, v.rng, 0, off4);
+  LogicRegs lg;
+  if (LOGIC && v.tick_mask) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      lg.xm0[k] = AFE_LD(float, v.lpf, k, off4);
+      lg.xm1[k] = AFE_LD(float, v.lpf, 3 + k, off4);
+      lg.ym0[k] = AFE_LD(float, v.lpf, 6 + k, off4);
+      lg.ym1[k] = AFE_LD(float, v.lpf, 9 + k, off4);
+      lg.wdes[k] = AFE_LD(float, v.rates_cmd, 1 + k, off4);
+    }
+    lg.thrust_norm = AFE_LD(float, v.rates_cmd, 0, off4);
+    lg.imu_init = v.imu_init[(uint32_t)i];
+    lg.have_cmd = v.have_cmd[(uint32_t)i];
+  }
+  float cmd_new[4] = {0, 0, 0, 0};
 
   const R dt = v.dt;
   float gx = 0, gy = 0, gz = 0, ax_m = 0, ay_m = 0, az_m = 0;
@@ -387,6 +473,13 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
       mat_vec<float>(P.Rimu, (float)bx, (float)by, (float)bz, tx_, ty_, tz_);  // :175
       ax_m = tx_ + na[0]; ay_m = ty_ + na[1]; az_m = tz_ + na[2];              // :176-179
       have_imu = true;
+      if (LOGIC) {
+        // logic.Run() and the command read-back of Quadcopter_T.cpp:185-189;
+        // the new commands act from the next sub-step on
+        rates_logic_tick(G, lg, gx, gy, gz, cmd_new);
+#pragma unroll
+        for (int m = 0; m < 4; m++) { cmd[m] = (R)cmd_new[m]; if (cmd[m] < 0) cmd[m] = 0; }
+      }
     }
   }
 
@@ -400,6 +493,18 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     AFE_ST(float, v.gyro, 0, off4, gx); AFE_ST(float, v.gyro, 1, off4, gy); AFE_ST(float, v.gyro, 2, off4, gz);
     AFE_ST(float, v.acc, 0, off4, ax_m); AFE_ST(float, v.acc, 1, off4, ay_m); AFE_ST(float, v.acc, 2, off4, az_m);
     if (NOISE) AFE_ST(uint32_t, v.rng, 0, off4, rng);
+    if (LOGIC) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        AFE_ST(float, v.lpf, k, off4, lg.xm0[k]);
+        AFE_ST(float, v.lpf, 3 + k, off4, lg.xm1[k]);
+        AFE_ST(float, v.lpf, 6 + k, off4, lg.ym0[k]);
+        AFE_ST(float, v.lpf, 9 + k, off4, lg.ym1[k]);
+      }
+      v.imu_init[(uint32_t)i] = lg.imu_init;
+#pragma unroll
+      for (int m = 0; m < 4; m++) AFE_ST(float, v.cmd_out, m, off4, cmd_new[m]);
+    }
   }
 #undef AFE_LD
 #undef AFE_ST
@@ -410,60 +515,72 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #endif
 
 // homogeneous ensemble: the one parameter record rides in the kernel arguments
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool RENORM>
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC>
 __global__ void __launch_bounds__(256, AFE_LB_WAVES)
-afe_step_kernel(const StepView<R> v, const DevParams<R> P) {
+afe_step_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= v.n) return;
-  run_vehicle<R, FEXT, TEXT, NOISE, RENORM>(v, P, i);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC>(v, P, G, i);
 }
 
-// heterogeneous ensemble: type table staged into LDS, one record per lane
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool RENORM>
+// heterogeneous ensemble: type tables staged into LDS, one record per lane
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC>
 __global__ void __launch_bounds__(256)
 afe_step_kernel_table(const StepView<R> v) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
+  const int words_p = v.n_types * (int)(sizeof(DevParams<R>) / 4);
+  const int words_g = LOGIC ? v.n_types * (int)(sizeof(DevLogic) / 4) : 0;
   {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(v.table);
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw);
-    const int nwords = v.n_types * (int)(sizeof(DevParams<R>) / 4);
-    for (int k = threadIdx.x; k < nwords; k += 256) dst[k] = src[k];
+    for (int k = threadIdx.x; k < words_p; k += 256) dst[k] = src[k];
+    if (LOGIC) {
+      const uint32_t *srcg = reinterpret_cast<const uint32_t *>(v.logic_table);
+      for (int k = threadIdx.x; k < words_g; k += 256) dst[words_p + k] = srcg[k];
+    }
   }
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= v.n) return;
-  const DevParams<R> &P = reinterpret_cast<const DevParams<R> *>(lds_raw)[v.type[(uint32_t)i]];
-  run_vehicle<R, FEXT, TEXT, NOISE, RENORM>(v, P, i);
+  const unsigned t = v.type[(uint32_t)i];
+  const DevParams<R> &P = reinterpret_cast<const DevParams<R> *>(lds_raw)[t];
+  const DevLogic &G = reinterpret_cast<const DevLogic *>(lds_raw + (size_t)words_p * 4)[LOGIC ? t : 0];
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC>(v, P, G, i);
 }
 
 template <typename R>
-static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevParams<R> *uniform, hipStream_t st) {
+static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevParams<R> *uniform,
+                       const DevLogic *uniform_logic, hipStream_t st) {
   if (v.n <= 0) return 0;
   const unsigned grid = (unsigned)((v.n + 255) / 256);
-  const size_t lds = (size_t)v.n_types * sizeof(DevParams<R>);
-#define AFE_LAUNCH(FE, TE, NO, RE)                                                                      \
-  do {                                                                                                  \
-    if (uniform)                                                                                        \
-      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, RE>), dim3(grid), dim3(256), 0, st, v, *uniform); \
-    else                                                                                                \
-      hipLaunchKernelGGL((afe_step_kernel_table<R, FE, TE, NO, RE>), dim3(grid), dim3(256), lds, st, v);   \
+  const size_t lds = (size_t)v.n_types * (sizeof(DevParams<R>) + (f.logic ? sizeof(DevLogic) : 0));
+  DevLogic no_logic = {};
+  const DevLogic &G = uniform_logic ? *uniform_logic : no_logic;
+#define AFE_LAUNCH(FE, TE, NO, LO)                                                                         \
+  do {                                                                                                     \
+    if (uniform)                                                                                           \
+      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO>), dim3(grid), dim3(256), 0, st, v, *uniform, G); \
+    else                                                                                                   \
+      hipLaunchKernelGGL((afe_step_kernel_table<R, FE, TE, NO, LO>), dim3(grid), dim3(256), lds, st, v);      \
   } while (0)
-#define AFE_SEL_RE(FE, TE, NO) do { if (f.renorm) AFE_LAUNCH(FE, TE, NO, true); else AFE_LAUNCH(FE, TE, NO, false); } while (0)
-#define AFE_SEL_NO(FE, TE) do { if (f.noise) AFE_SEL_RE(FE, TE, true); else AFE_SEL_RE(FE, TE, false); } while (0)
+#define AFE_SEL_LO(FE, TE, NO) do { if (f.logic) AFE_LAUNCH(FE, TE, NO, true); else AFE_LAUNCH(FE, TE, NO, false); } while (0)
+#define AFE_SEL_NO(FE, TE) do { if (f.noise) AFE_SEL_LO(FE, TE, true); else AFE_SEL_LO(FE, TE, false); } while (0)
 #define AFE_SEL_TE(FE) do { if (f.ext_torque) AFE_SEL_NO(FE, true); else AFE_SEL_NO(FE, false); } while (0)
   if (f.ext_force) AFE_SEL_TE(true); else AFE_SEL_TE(false);
 #undef AFE_SEL_TE
 #undef AFE_SEL_NO
-#undef AFE_SEL_RE
+#undef AFE_SEL_LO
 #undef AFE_LAUNCH
   return (int)hipGetLastError();
 }
 
-int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, const DevParams<float> *uniform, void *stream) {
-  return launch_step<float>(v, f, uniform, (hipStream_t)stream);
+int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, const DevParams<float> *uniform,
+                    const DevLogic *uniform_logic, void *stream) {
+  return launch_step<float>(v, f, uniform, uniform_logic, (hipStream_t)stream);
 }
-int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> *uniform, void *stream) {
-  return launch_step<double>(v, f, uniform, (hipStream_t)stream);
+int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> *uniform,
+                    const DevLogic *uniform_logic, void *stream) {
+  return launch_step<double>(v, f, uniform, uniform_logic, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

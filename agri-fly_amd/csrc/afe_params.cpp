@@ -86,6 +86,42 @@ int expand_params(const afe_vehicle_params &in, HostParams &out, const char **wh
   return AFE_OK;
 }
 
+int expand_logic(const afe_rates_logic_params &in, float onboard_period, DevLogic &g, const char **why) {
+  if (!(in.mass > 0) || !(in.ang_vel_time_const_xy > 0) || !(in.ang_vel_time_const_z > 0) ||
+      !(in.arm_length > 0) || !(in.prop_thrust_from_speed_sqr > 0) || !(in.prop_torque_from_thrust != 0) ||
+      (in.prop0_spin_dir != 1 && in.prop0_spin_dir != -1) || !(in.gyro_lowpass_cutoff > 0)) {
+    *why = "rates logic parameters out of range";
+    return AFE_ERR_INVALID_ARG;
+  }
+  std::memset(&g, 0, sizeof(g));
+  g.mass = in.mass;
+  for (int k = 0; k < 9; k++) g.I[k] = in.inertia[k];
+  g.tc_xy = in.ang_vel_time_const_xy;
+  g.tc_z = in.ang_vel_time_const_z;
+  // QuadcopterMixer::SetParameters, reference QuadcopterMixer.hpp:36-52
+  g.d = in.arm_length / sqrtf(2.0f);
+  g.kt = in.prop0_spin_dir * in.prop_torque_from_thrust;
+  g.kf = in.prop_thrust_from_speed_sqr;
+  g.max_thrust = in.max_thrust_per_propeller;
+  g.min_thrust = in.min_thrust_per_propeller;
+  g.max_cmd_total = in.max_cmd_total_thrust < 0 ? 4 * in.max_thrust_per_propeller * 0.8f : in.max_cmd_total_thrust;
+  // _R = Rotationf::FromEulerYPR(yaw, pitch, roll).GetRotationMatrix(), QuadcopterLogic.cpp:116-117:
+  // the transpose of the (bitwise transposable) inverse-mount matrix
+  float Rinv[9];
+  imu_mount_matrix(in.imu_yaw, in.imu_pitch, in.imu_roll, Rinv);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) g.R[3 * i + j] = Rinv[3 * j + i];
+  // LowPassFilterSecondOrder<float,...>::Initialise, LowPassFilterSecondOrder.hpp:22-49
+  const float dt = onboard_period, wc = in.gyro_lowpass_cutoff;
+  const float sqrt2 = float(std::sqrt(2.0));
+  g.a1 = (dt * dt * wc * wc - 2 * sqrt2 * dt * wc + 4) / (dt * dt * wc * wc + 2 * sqrt2 * dt * wc + 4);
+  g.a2 = 2 * (dt * dt * wc * wc - 4) / (dt * dt * wc * wc + 2 * sqrt2 * dt * wc + 4);
+  g.b0 = dt * dt * wc * wc / (dt * dt * wc * wc + 2 * sqrt2 * dt * wc + 4);
+  g.b1 = dt * dt * wc * wc / (dt * dt * wc * wc + 2 * sqrt2 * dt * wc + 4);
+  g.b2 = 2 * dt * dt * wc * wc / (dt * dt * wc * wc + 2 * sqrt2 * dt * wc + 4);
+  return AFE_OK;
+}
+
 template <typename R>
 void to_device_params(const HostParams &h, double dt, DevParams<R> &d) {
   std::memset(&d, 0, sizeof(d));
@@ -130,6 +166,19 @@ float esc_max_speed(float offset, float slope) {
 struct TypeRow {  // the float members the simulator loops read
   float mass, ixx, izz, arm, kf, torque_per_thrust, max_speed, drag[3];
 };
+
+struct LogicRow {  // controller / mixer members, QuadcopterConstants.hpp:34-47 and per type
+  float tc_xy, tc_z, min_thrust, max_cmd_frac;  // max_cmd_frac < 0: mixer default
+};
+bool logic_row(int type, LogicRow &r) {
+  switch (type) {
+    case 1: r = {0.04f, 0.5f, 0.0f, 0.9f}; return true;     // :78-82
+    case 2: r = {0.03f, 0.5f, 0.0f, 0.8f}; return true;     // :36-39,113
+    case 4: r = {0.0457f, 0.2545f, 0.0f, -1.0f}; return true;  // :183-186
+    case 5: r = {0.04f, 0.04f * 5, 0.03f, 0.7f}; return true;  // :214-224
+    default: return false;
+  }
+}
 
 bool type_row(int type, TypeRow &r) {
   switch (type) {
@@ -180,6 +229,30 @@ extern "C" int afe_params_from_type(int quadcopter_type, afe_vehicle_params *out
   out->motor_inertia = 0.0f;
   for (int k = 0; k < 3; k++) out->lin_drag_coeff_b[k] = r.drag[k];
   out->imu_yaw = out->imu_pitch = out->imu_roll = 0.0f;
+  return AFE_OK;
+}
+
+extern "C" int afe_rates_logic_params_from_type(int quadcopter_type, afe_rates_logic_params *out) {
+  if (!out) return AFE_ERR_INVALID_ARG;
+  TypeRow r;
+  LogicRow l;
+  if (!type_row(quadcopter_type, r) || !logic_row(quadcopter_type, l)) return AFE_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  out->mass = r.mass;
+  out->inertia[0] = r.ixx; out->inertia[4] = r.ixx; out->inertia[8] = r.izz;  // QuadcopterConstants.hpp:269-271
+  out->ang_vel_time_const_xy = l.tc_xy;
+  out->ang_vel_time_const_z = l.tc_z;
+  out->arm_length = r.arm;
+  out->prop_thrust_from_speed_sqr = r.kf;
+  out->prop_torque_from_thrust = r.torque_per_thrust;
+  out->prop0_spin_dir = 1;
+  out->max_thrust_per_propeller = r.kf * powf(r.max_speed, 2);
+  out->min_thrust_per_propeller = l.min_thrust;
+  out->max_cmd_total_thrust = l.max_cmd_frac < 0 ? -1.0f
+      : (quadcopter_type == 5 ? l.max_cmd_frac * (out->max_thrust_per_propeller * 4)   // :221
+                              : l.max_cmd_frac * out->max_thrust_per_propeller * 4);   // :80,113
+  out->imu_yaw = out->imu_pitch = out->imu_roll = 0.0f;
+  out->gyro_lowpass_cutoff = 200.0f;  // QuadcopterLogic.cpp:103
   return AFE_OK;
 }
 

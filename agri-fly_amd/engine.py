@@ -30,6 +30,8 @@ ABI_FUNCTIONS = [
     "afe_algorithmic_bytes_per_step", "afe_event_create", "afe_event_destroy",
     "afe_event_record", "afe_event_elapsed_ms", "afe_pack_positions",
     "afe_nearest_neighbour", "afe_selftest_normals",
+    "afe_rates_logic_params_from_type", "afe_set_rates_logic", "afe_set_rates_commands",
+    "afe_get_motor_cmds",
 ]
 
 
@@ -68,6 +70,20 @@ class VehicleParams(C.Structure):
     def hover_speed(self):
         """per-motor speed at which 4 k_f w^2 = m g"""
         return float(np.sqrt(self.mass * 9.81 / (4.0 * self.prop_thrust_from_speed_sqr)))
+
+
+class RatesLogicParams(C.Structure):
+    """afe_rates_logic_params: the rates-control slice of Onboard::QuadcopterLogic."""
+    _fields_ = [
+        ("mass", C.c_float), ("inertia", C.c_float * 9),
+        ("ang_vel_time_const_xy", C.c_float), ("ang_vel_time_const_z", C.c_float),
+        ("arm_length", C.c_float), ("prop_thrust_from_speed_sqr", C.c_float),
+        ("prop_torque_from_thrust", C.c_float), ("prop0_spin_dir", C.c_int),
+        ("max_thrust_per_propeller", C.c_float), ("min_thrust_per_propeller", C.c_float),
+        ("max_cmd_total_thrust", C.c_float),
+        ("imu_yaw", C.c_float), ("imu_pitch", C.c_float), ("imu_roll", C.c_float),
+        ("gyro_lowpass_cutoff", C.c_float),
+    ]
 
 
 class DeviceView(C.Structure):
@@ -147,6 +163,10 @@ def library():
         "afe_pack_positions": [eng, vp],
         "afe_nearest_neighbour": [eng, vp, i64, vp, vp],
         "afe_selftest_normals": [eng, vp, i64, vp, vp],
+        "afe_rates_logic_params_from_type": [ci, C.POINTER(RatesLogicParams)],
+        "afe_set_rates_logic": [eng, C.POINTER(RatesLogicParams), ci],
+        "afe_set_rates_commands": [eng, i64, i64, vp, vp],
+        "afe_get_motor_cmds": [eng, i64, i64, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -163,6 +183,14 @@ def library():
 def params_from_type(quadcopter_type):
     p = VehicleParams()
     rc = library().afe_params_from_type(int(quadcopter_type), C.byref(p))
+    if rc:
+        raise AfeError(rc, "invalid quadcopter type %r" % (quadcopter_type,))
+    return p
+
+
+def rates_logic_params_from_type(quadcopter_type):
+    p = RatesLogicParams()
+    rc = library().afe_rates_logic_params_from_type(int(quadcopter_type), C.byref(p))
     if rc:
         raise AfeError(rc, "invalid quadcopter type %r" % (quadcopter_type,))
     return p
@@ -307,6 +335,31 @@ class Ensemble:
         first, count = self._range(first, count)
         arr, ptr = _planar(torque3, 3, count, np.float64)
         self._ck(self._L.afe_set_external_torque(self._h, first, count, ptr))
+
+    # -- on-device onboard rates logic (f1) ---------------------------------
+    def set_rates_logic(self, params_list):
+        """enable (list of RatesLogicParams, one per vehicle type) or disable (None)"""
+        if params_list is None:
+            self._ck(self._L.afe_set_rates_logic(self._h, None, 0))
+            return
+        arr = (RatesLogicParams * len(params_list))()
+        for i, p in enumerate(params_list):
+            C.memmove(C.byref(arr[i]), C.byref(p), C.sizeof(RatesLogicParams))
+        self._ck(self._L.afe_set_rates_logic(self._h, arr, len(params_list)))
+
+    def set_rates_commands(self, thrust_norm, ang_vel3, first=0, count=None):
+        first, count = self._range(first, count)
+        t = np.ascontiguousarray(thrust_norm, dtype=np.float32)
+        if t.shape != (count,):
+            raise ValueError("thrust_norm must have shape (%d,)" % count)
+        w, wp = _planar(ang_vel3, 3, count, np.float32)
+        self._ck(self._L.afe_set_rates_commands(self._h, first, count, t.ctypes.data, wp))
+
+    def get_motor_cmds(self, first=0, count=None):
+        first, count = self._range(first, count)
+        out = np.empty((4, count), np.float32)
+        self._ck(self._L.afe_get_motor_cmds(self._h, first, count, out.ctypes.data))
+        return out
 
     # -- stepping ---------------------------------------------------------
     def step(self, dt_us, n_steps=1):

@@ -156,6 +156,57 @@ int afe_set_motor_cmds(afe_engine *e, int64_t first, int64_t count, const float 
 int afe_set_external_force(afe_engine *e, int64_t first, int64_t count, const double *force3);
 int afe_set_external_torque(afe_engine *e, int64_t first, int64_t count, const double *torque3);
 
+/* ---- on-device onboard rates logic (optional) -------
+ * Instead of handing each IMU sample to a host-side logicType, the step kernel
+ * can run the rates-control slice of Onboard::QuadcopterLogic itself at every
+ * logic tick, closing the loop on the GPU:
+ *   SetIMUMeasurementRateGyro: _R * gyro -> 2nd-order low-pass
+ *       (Components/Components/Logic/QuadcopterLogic.hpp:40-45,
+ *        Common/Common/Math/LowPassFilterSecondOrder.hpp:22-64)
+ *   KalmanFilter6DOF::Predict without UWB: angular-velocity estimate = filtered
+ *       gyro; the first call only initialises (KalmanFilter6DOF.cpp:70-116)
+ *   RunControllerExternalRatesControl (QuadcopterLogic.cpp:528-541):
+ *       QuadcopterAngularVelocityController::GetDesiredTorques
+ *       (QuadcopterAngularVelocityController.hpp:25-38),
+ *       QuadcopterMixer::GetMotorForces / PropellerSpeedsFromThrust
+ *       (QuadcopterMixer.hpp:63-99)
+ * and write the four motor-speed commands, which act from the next step on as
+ * in Quadcopter_T.cpp:187-189.  Not included: the flight-state machine beyond
+ * IDLE -> EXTERNAL_RATES_CONTROL, panic checks, attitude estimate, telemetry,
+ * motor calibration (host-side logic).  All logic arithmetic is float, as in
+ * the reference.  Record i of the logic table pairs with record i of the
+ * vehicle type table. */
+typedef struct afe_rates_logic_params {
+  float mass;                       /* QuadcopterLogic::_mass */
+  float inertia[9];                 /* QuadcopterConstants::inertiaMatrix */
+  float ang_vel_time_const_xy;      /* angVelControl_timeConst_xy [s] */
+  float ang_vel_time_const_z;       /* angVelControl_timeConst_z [s] */
+  float arm_length;                 /* [m] */
+  float prop_thrust_from_speed_sqr; /* [N/(rad/s)^2] */
+  float prop_torque_from_thrust;    /* [N m/N] */
+  int prop0_spin_dir;               /* +1 / -1 */
+  float max_thrust_per_propeller;   /* [N] */
+  float min_thrust_per_propeller;   /* [N] */
+  float max_cmd_total_thrust;       /* [N]; < 0: mixer default 4*max*0.8 */
+  float imu_yaw, imu_pitch, imu_roll; /* [rad] */
+  float gyro_lowpass_cutoff;        /* [rad/s]; the reference uses 200 */
+} afe_rates_logic_params;
+/* QuadcopterConstants(type) narrowed to the fields above. Pure host. */
+int afe_rates_logic_params_from_type(int quadcopter_type, afe_rates_logic_params *out);
+/* Enable (table != NULL) or disable (table == NULL) the on-device logic.
+ * Enabling resets the logic state: filters at 0, estimator uninitialised,
+ * flight state IDLE (motor commands 0) until afe_set_rates_commands.  The
+ * filter sampling period is float(logic period), as Quadcopter_T.cpp:18. */
+int afe_set_rates_logic(afe_engine *e, const afe_rates_logic_params *table, int n_types);
+/* The decoded externalRatesCmd radio message (RadioTypes.hpp:218-226):
+ * floats[0] = total thrust normalised by mass [m/s^2], floats[1..3] = desired
+ * body rates [rad/s].  Persists until replaced; puts the vehicles of the range
+ * into EXTERNAL_RATES_CONTROL. */
+int afe_set_rates_commands(afe_engine *e, int64_t first, int64_t count,
+                           const float *thrust_norm, const float *ang_vel3);
+/* The motor-speed commands currently in force (host- or logic-written). */
+int afe_get_motor_cmds(afe_engine *e, int64_t first, int64_t count, float *cmd4);
+
 /* ---- stepping -----------------------------------------------------------
  * afe_step replaces the loop body
  *     for (v : vehicles) v->Run();  simTimer.AdvanceMicroSeconds(dt_us);

@@ -216,3 +216,85 @@ def clock_ticks(loop_dt, period, n_runs):
         ticks.append(t.value)
         lib().ora_clock_advance(C.byref(c), adv)
     return dts, ticks
+
+
+# ---------------------------------------------------------------------------
+# onboard rates-control path (oracle/agrifly_oracle_logic.c), SURVEY 8f row f1
+
+class OraLpf2(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("a1", "a2", "b0", "b1", "b2", "xm0", "xm1", "ym0", "ym1")]
+
+
+class OraLogicParams(C.Structure):
+    _fields_ = [("mass", C.c_float), ("inertia", C.c_float * 9), ("tc_xy", C.c_float), ("tc_z", C.c_float),
+                ("d", C.c_float), ("kt", C.c_float), ("kf", C.c_float), ("max_thrust", C.c_float),
+                ("min_thrust", C.c_float), ("max_cmd_total_thrust", C.c_float), ("R", C.c_float * 9),
+                ("onboard_period", C.c_float), ("gyro_cutoff", C.c_float)]
+
+
+class OraLogicState(C.Structure):
+    _fields_ = [("gyro_lpf", OraLpf2 * 3), ("ang_vel_est", C.c_float * 3), ("imu_initialized", C.c_int),
+                ("have_rates_cmd", C.c_int), ("thrust_norm", C.c_float), ("des_ang_vel", C.c_float * 3),
+                ("motor_speed_cmd", C.c_float * 4), ("motor_force_cmd", C.c_float * 4)]
+
+
+_logic_bound = False
+
+
+def logic_lib():
+    global _logic_bound
+    L = lib()
+    if not _logic_bound:
+        L.ora_lpf2_init.argtypes = [C.POINTER(OraLpf2), C.c_float, C.c_float, C.c_float]
+        L.ora_lpf2_init.restype = None
+        L.ora_lpf2_apply.argtypes = [C.POINTER(OraLpf2), C.c_float]
+        L.ora_lpf2_apply.restype = C.c_float
+        L.ora_logic_params_from_type.argtypes = [C.POINTER(OraLogicParams), C.c_int, C.c_float]
+        L.ora_logic_params_from_type.restype = C.c_int
+        L.ora_logic_init.argtypes = [C.POINTER(OraLogicParams), C.POINTER(OraLogicState)]
+        L.ora_logic_init.restype = None
+        L.ora_logic_set_rates_cmd.argtypes = [C.POINTER(OraLogicState), C.c_float, C.POINTER(C.c_float)]
+        L.ora_logic_set_rates_cmd.restype = None
+        L.ora_logic_tick.argtypes = [C.POINTER(OraLogicParams), C.POINTER(OraLogicState), C.POINTER(C.c_float)]
+        L.ora_logic_tick.restype = None
+        _logic_bound = True
+    return L
+
+
+def logic_params_from_type(t, onboard_period):
+    p = OraLogicParams()
+    if logic_lib().ora_logic_params_from_type(C.byref(p), int(t), float(np.float32(onboard_period))) != 0:
+        raise ValueError("invalid quadcopter type %r" % (t,))
+    return p
+
+
+class ClosedLoopBatch:
+    """n vehicles stepped by the oracle with the restated onboard rates logic in
+    the loop: the sequence of Quadcopter_T::Run (physics, gate, IMU, logic.Run,
+    motor commands taking effect on the next step)."""
+
+    def __init__(self, batch, logic_params_list, onboard_period):
+        self.b = batch
+        self.L = logic_lib()
+        self.lp = logic_params_list
+        self.states = []
+        for i in range(batch.n):
+            s = OraLogicState()
+            self.L.ora_logic_init(C.byref(self.lp[int(batch.types[i])]), C.byref(s))
+            self.states.append(s)
+
+    def set_rates_cmd(self, thrust_norm, des_ang_vel):
+        """thrust_norm[n], des_ang_vel[3, n]"""
+        for i, s in enumerate(self.states):
+            w = (C.c_float * 3)(*[float(des_ang_vel[k][i]) for k in range(3)])
+            self.L.ora_logic_set_rates_cmd(C.byref(s), float(thrust_norm[i]), w)
+
+    def step(self, dt, ticks):
+        for tick in ticks:
+            self.b.step(dt, 1, ticks=[int(tick)])
+            if tick:
+                for i, s in enumerate(self.states):
+                    g = (C.c_float * 3)(*[float(self.b.gyro[k, i]) for k in range(3)])
+                    self.L.ora_logic_tick(C.byref(self.lp[int(self.b.types[i])]), C.byref(s), g)
+                    for m in range(4):
+                        self.b.motor_cmd[m, i] = s.motor_speed_cmd[m]

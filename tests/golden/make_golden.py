@@ -12,6 +12,9 @@ Run in the build container (needs /root/reference for the timer probe):
 * rng_kat.json        <- oracle/_ref/rng_probe: libstdc++'s
   std::default_random_engine + std::normal_distribution<double>, the library
   code the reference's IMU noise comes from, compiled with g++.
+* lpf_kat.json        <- oracle/_ref/lpf_probe: the REFERENCE's own
+  LowPassFilterSecondOrder.hpp (stand-alone header) with the onboard logic's
+  gyro / accelerometer settings.
 * oracle_regression.npz <- the oracle itself (NOT the reference): seeded
   single-step / rollout vectors that freeze the restatement so later edits of
   oracle/agrifly_oracle.c cannot drift silently.  It pins nothing against the
@@ -69,6 +72,14 @@ def main():
         json.dump({"generator": "oracle/_ref/rng_probe (libstdc++ <random>, g++)",
                    "gxx": subprocess.check_output(["g++", "--version"]).decode().splitlines()[0],
                    "streams": kats}, f, indent=0)
+
+    lpf = os.path.join(ref, "lpf_probe")
+    lpfs = []
+    for per, cut, n in ((1 / 500.0, 200.0, 200), (1 / 500.0, 100.0, 200), (1 / 1000.0, 200.0, 200)):
+        lpfs.append(json.loads(subprocess.check_output([lpf, repr(per), repr(cut), str(n)])))
+    with open(os.path.join(HERE, "lpf_kat.json"), "w") as f:
+        json.dump({"generator": "oracle/_ref/lpf_probe (reference LowPassFilterSecondOrder.hpp compiled in place, "
+                                "LowPassFilterSecondOrder<float,float>)", "cases": lpfs}, f, indent=0)
 
     # --- oracle regression vectors (oracle-generated; not a reference pin) ---
     from tests.scenarios import random_ensemble
