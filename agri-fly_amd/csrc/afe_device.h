@@ -65,6 +65,10 @@ struct StepView {
   int n_steps;
   unsigned long long tick_mask;  // bit s set: sub-step s fires the logic gate
   float sigma_gyro, sigma_acc;
+  // every type has tau_m == 0 and J_m == 0 (all shipped vehicle types): the rotor
+  // speed is then a pure function of the command, Motor.cpp:54-66, and is not
+  // read back (it is still written, for GetMotorForce / afe_get_state)
+  int motor_stateless;
   // on-device rates logic (null when disabled)
   float *lpf;               // 12 comps: xm0[3] xm1[3] ym0[3] ym1[3]
   const float *rates_cmd;   // 4 comps: thrust_norm, wx, wy, wz

@@ -232,6 +232,8 @@ void fill_view(const afe_engine *e, StepView<R> &v) {
   v.table = (const DevParams<R> *)e->dev_table;
   v.n_types = (int)e->table.size();
   v.n = e->n; v.stride = e->stride;
+  v.motor_stateless = 1;
+  for (const HostParams &h : e->table) if (h.tau_m != 0 || h.Jm != 0) v.motor_stateless = 0;
   v.sigma_gyro = (float)e->sigma_gyro;  // float(_stdDevRateGyroNoise), Quadcopter_T.cpp:170
   v.sigma_acc = (float)e->sigma_acc;
 }
@@ -614,8 +616,11 @@ extern "C" int afe_algorithmic_bytes_per_step(const afe_engine *e, int imu_tick,
   if (!e || !bytes) return AFE_ERR_INVALID_ARG;
   const double es = (double)elem(e);
   double b = 17 * es * 2;      // state read + write (pos3 vel3 att4 angvel3 motor4)
+  bool stateless = !e->table.empty();
+  for (const HostParams &h : e->table) if (h.tau_m != 0 || h.Jm != 0) stateless = false;
+  if (stateless) b -= 4 * es;  // tau_m == 0, J_m == 0: rotor speeds are written but never read
   b += 4 * 4;                  // motor commands (float)
-  b += 1;                      // type index
+  if (!e->types_uniform) b += 1;  // type index (heterogeneous ensembles only)
   if (e->has_ext_force) b += 3 * es;
   if (e->has_ext_torque) b += 3 * es;
   if (imu_tick) {

@@ -322,7 +322,11 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   R vx = AFE_LD(R, v.vel, 0, off), vy = AFE_LD(R, v.vel, 1, off), vz = AFE_LD(R, v.vel, 2, off);
   R q0 = AFE_LD(R, v.att, 0, off), q1 = AFE_LD(R, v.att, 1, off), q2 = AFE_LD(R, v.att, 2, off), q3 = AFE_LD(R, v.att, 3, off);
   R wx = AFE_LD(R, v.ang_vel, 0, off), wy = AFE_LD(R, v.ang_vel, 1, off), wz = AFE_LD(R, v.ang_vel, 2, off);
-  R ms[4] = {AFE_LD(R, v.motor, 0, off), AFE_LD(R, v.motor, 1, off), AFE_LD(R, v.motor, 2, off), AFE_LD(R, v.motor, 3, off)};
+  R ms[4] = {0, 0, 0, 0};
+  if (!v.motor_stateless) {  // wave-uniform: with c_lag == 0 and J_m == 0 the old speed only ever meets a zero factor
+    ms[0] = AFE_LD(R, v.motor, 0, off); ms[1] = AFE_LD(R, v.motor, 1, off);
+    ms[2] = AFE_LD(R, v.motor, 2, off); ms[3] = AFE_LD(R, v.motor, 3, off);
+  }
   const float cmd_f[4] = {AFE_LD(float, v.cmd, 0, off4), AFE_LD(float, v.cmd, 1, off4), AFE_LD(float, v.cmd, 2, off4), AFE_LD(float, v.cmd, 3, off4)};
   R fex = 0, fey = 0, fez = 0, tex = 0, tey = 0, tez = 0;
   if (FEXT) { fex = AFE_LD(R, v.ext_force, 0, off); fey = AFE_LD(R, v.ext_force, 1, off); fez = AFE_LD(R, v.ext_force, 2, off); }
