@@ -299,7 +299,7 @@ __device__ __forceinline__ void rates_logic_tick(const DevLogic &G, LogicRegs &s
 // The vehicle step.  P is either the kernel-argument copy of the single
 // parameter record of a homogeneous ensemble (scalar registers: costs no
 // VGPRs) or this lane's record in the LDS-staged type table.
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC>
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE>
 __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParams<R> &P, const DevLogic &G,
                                             const int64_t i) {
   // No implicit FMA contraction: every rounding is the one the source spells
@@ -318,6 +318,11 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #define AFE_ST(T, base, comp, o, val) (*reinterpret_cast<T *>(reinterpret_cast<char *>((base) + (comp) * S) + (o)) = (val))
 
   // ---- issue every load up front (independent, coalesced) ----
+  // The engine word goes first: loads return in order, so the Gaussian draws of
+  // this launch's first logic tick (which need nothing else) run while the ~24
+  // state loads behind it are still in flight.
+  uint32_t rng = 0;
+  if (NOISE && v.tick_mask) rng = AFE_LD(uint32_t, v.rng, 0, off4);
   R px = AFE_LD(R, v.pos, 0, off), py = AFE_LD(R, v.pos, 1, off), pz = AFE_LD(R, v.pos, 2, off);
   R vx = AFE_LD(R, v.vel, 0, off), vy = AFE_LD(R, v.vel, 1, off), vz = AFE_LD(R, v.vel, 2, off);
   R q0 = AFE_LD(R, v.att, 0, off), q1 = AFE_LD(R, v.att, 1, off), q2 = AFE_LD(R, v.att, 2, off), q3 = AFE_LD(R, v.att, 3, off);
@@ -331,8 +336,6 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   R fex = 0, fey = 0, fez = 0, tex = 0, tey = 0, tez = 0;
   if (FEXT) { fex = AFE_LD(R, v.ext_force, 0, off); fey = AFE_LD(R, v.ext_force, 1, off); fez = AFE_LD(R, v.ext_force, 2, off); }
   if (TEXT) { tex = AFE_LD(R, v.ext_torque, 0, off); tey = AFE_LD(R, v.ext_torque, 1, off); tez = AFE_LD(R, v.ext_torque, 2, off); }
-  uint32_t rng = 0;
-  if (NOISE && v.tick_mask) rng = AFE_LD(uint32_t, v.rng, 0, off4);
   LogicRegs lg;
   if (LOGIC && v.tick_mask) {
 #pragma unroll
@@ -353,13 +356,29 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   float gx = 0, gy = 0, gz = 0, ax_m = 0, ay_m = 0, az_m = 0;
   bool have_imu = false;
 
+  // noise of the first tick of this launch, drawn under the load latency
+  // (g++ evaluates the ctor arguments right to left, Quadcopter_T.cpp:167-169,
+  // 176-178: z <- draw 1, y <- 2, x <- 3)
+  float ng[3] = {0, 0, 0}, na[3] = {0, 0, 0};
+  bool noise_ready = false;
+  if (NOISE && v.tick_mask) {
+    double d[6];
+    six_normals(rng, d);
+    ng[0] = v.sigma_gyro * (float)d[2]; ng[1] = v.sigma_gyro * (float)d[1]; ng[2] = v.sigma_gyro * (float)d[0];
+    na[0] = v.sigma_acc * (float)d[5]; na[1] = v.sigma_acc * (float)d[4]; na[2] = v.sigma_acc * (float)d[3];
+    noise_ready = true;
+  }
+
   // Motor.cpp:48-50: negative commands clamp to zero (the command is a float,
   // Quadcopter_T.hpp:100, widened at Quadcopter_T.cpp:98)
   R cmd[4];
 #pragma unroll
   for (int m = 0; m < 4; m++) { cmd[m] = (R)cmd_f[m]; if (cmd[m] < 0) cmd[m] = 0; }
 
-  for (int step = 0; step < v.n_steps; step++) {
+  // SINGLE: one sub-step per launch (the per-step-observable mode): no loop, and
+  // the only Gaussian draws are the ones made above under the load latency
+  const int n_steps = SINGLE ? 1 : v.n_steps;
+  for (int step = 0; step < n_steps; step++) {
     // ---- 4 motors: Motor::Run, Motor.cpp:39-84 ----
     R Fz = 0;                       // totalForce_b (thrust axes are all +z)
     R Tx = 0, Ty = 0, Tz = 0;       // totalTorque_b
@@ -451,18 +470,14 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 
     // ---- onboard-logic gate fired on this sub-step: IMU synthesis ----
     if ((v.tick_mask >> step) & 1ull) {                      // Quadcopter_T.cpp:159
-      float ng[3] = {0, 0, 0}, na[3] = {0, 0, 0};
       if (NOISE) {
-        // g++ evaluates the ctor arguments right to left (Quadcopter_T.cpp:
-        // 167-169,176-178): z <- draw 1, y <- 2, x <- 3
-        double d[6];
-        six_normals(rng, d);
-        ng[0] = v.sigma_gyro * (float)d[2];
-        ng[1] = v.sigma_gyro * (float)d[1];
-        ng[2] = v.sigma_gyro * (float)d[0];
-        na[0] = v.sigma_acc * (float)d[5];
-        na[1] = v.sigma_acc * (float)d[4];
-        na[2] = v.sigma_acc * (float)d[3];
+        if (!SINGLE && !noise_ready) {  // second and later ticks of a fused launch
+          double d[6];
+          six_normals(rng, d);
+          ng[0] = v.sigma_gyro * (float)d[2]; ng[1] = v.sigma_gyro * (float)d[1]; ng[2] = v.sigma_gyro * (float)d[0];
+          na[0] = v.sigma_acc * (float)d[5]; na[1] = v.sigma_acc * (float)d[4]; na[2] = v.sigma_acc * (float)d[3];
+        }
+        noise_ready = false;
       }
       float tx_, ty_, tz_;
       mat_vec<float>(P.Rimu, (float)wx, (float)wy, (float)wz, tx_, ty_, tz_);  // :165-166
@@ -519,12 +534,12 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #endif
 
 // homogeneous ensemble: the one parameter record rides in the kernel arguments
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC>
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE>
 __global__ void __launch_bounds__(256, AFE_LB_WAVES)
 afe_step_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= v.n) return;
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC>(v, P, G, i);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE>(v, P, G, i);
 }
 
 // heterogeneous ensemble: type tables staged into LDS, one record per lane
@@ -549,7 +564,7 @@ afe_step_kernel_table(const StepView<R> v) {
   const unsigned t = v.type[(uint32_t)i];
   const DevParams<R> &P = reinterpret_cast<const DevParams<R> *>(lds_raw)[t];
   const DevLogic &G = reinterpret_cast<const DevLogic *>(lds_raw + (size_t)words_p * 4)[LOGIC ? t : 0];
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC>(v, P, G, i);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false>(v, P, G, i);
 }
 
 template <typename R>
@@ -562,8 +577,10 @@ static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevPara
   const DevLogic &G = uniform_logic ? *uniform_logic : no_logic;
 #define AFE_LAUNCH(FE, TE, NO, LO)                                                                         \
   do {                                                                                                     \
-    if (uniform)                                                                                           \
-      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO>), dim3(grid), dim3(256), 0, st, v, *uniform, G); \
+    if (uniform && v.n_steps == 1)                                                                         \
+      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true>), dim3(grid), dim3(256), 0, st, v, *uniform, G); \
+    else if (uniform)                                                                                      \
+      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, false>), dim3(grid), dim3(256), 0, st, v, *uniform, G); \
     else                                                                                                   \
       hipLaunchKernelGGL((afe_step_kernel_table<R, FE, TE, NO, LO>), dim3(grid), dim3(256), lds, st, v);      \
   } while (0)

@@ -90,7 +90,7 @@ def test_device_view_matches_host_getters():
     ens = random_ensemble(n, seed=24)
     with ens.to_engine(afa.AFE_F32) as e:
         v = e.device_view()
-        assert v.n_vehicles == n and v.stride == 1024 and v.state_elem_size == 4
+        assert v.n_vehicles == n and v.stride == 1280 and v.state_elem_size == 4   # 256 x odd
 
         class _Wrap:
             def __init__(self, ptr, shape):

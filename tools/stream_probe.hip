@@ -1,0 +1,89 @@
+// tools/stream_probe.hip -- development micro-benchmark (not part of the product):
+// does the step kernel's access pattern (24 dword read streams + 17 write
+// streams, planar SoA) stream slower than the same bytes laid out as 64-vehicle
+// tiles (one contiguous block per wave), or than dwordx2 / dwordx4 per lane?
+//   hipcc --offload-arch=gfx950 -O3 tools/stream_probe.hip -o /tmp/stream_probe && /tmp/stream_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define NR 24
+#define NW 17
+
+// planar: comp k of vehicle i at base[k*S + i]
+template <int VPL>
+__global__ void __launch_bounds__(256) planar(const float *__restrict__ in, float *__restrict__ out, long S, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * VPL;
+  if (i >= n) return;
+  float acc[VPL];
+  float v[NR][VPL];
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    if (VPL == 1) v[k][0] = in[k * S + i];
+    if (VPL == 2) { float2 t = *(const float2 *)&in[k * S + i]; v[k][0] = t.x; v[k][1] = t.y; }
+    if (VPL == 4) { float4 t = *(const float4 *)&in[k * S + i]; v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w; }
+  }
+#pragma unroll
+  for (int j = 0; j < VPL; j++) { acc[j] = 0; for (int k = NW; k < NR; k++) acc[j] += v[k][j]; }
+#pragma unroll
+  for (int k = 0; k < NW; k++) {
+    if (VPL == 1) out[k * S + i] = v[k][0] * 1.0001f + acc[0];
+    if (VPL == 2) *(float2 *)&out[k * S + i] = make_float2(v[k][0] * 1.0001f + acc[0], v[k][1] * 1.0001f + acc[1]);
+    if (VPL == 4) *(float4 *)&out[k * S + i] = make_float4(v[k][0] * 1.0001f + acc[0], v[k][1] * 1.0001f + acc[1], v[k][2] * 1.0001f + acc[2], v[k][3] * 1.0001f + acc[3]);
+  }
+}
+
+// tiled: 64-vehicle tile = NR rows of 64 floats; comp k of vehicle i at base[(i/64)*NR*64 + k*64 + i%64]
+__global__ void __launch_bounds__(256) tiled(const float *__restrict__ in, float *__restrict__ out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long base = (i >> 6) * (NR * 64) + (i & 63);
+  float v[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) v[k] = in[base + k * 64];
+  float acc = 0;
+  for (int k = NW; k < NR; k++) acc += v[k];
+#pragma unroll
+  for (int k = 0; k < NW; k++) out[base + k * 64] = v[k] * 1.0001f + acc;
+}
+
+int main() {
+  const long n = 1 << 20;
+  long S = n;
+  float *a, *b;
+  const long SMAX = n + (1 << 16);
+  hipMalloc(&a, sizeof(float) * NR * SMAX);
+  hipMalloc(&b, sizeof(float) * NR * SMAX);
+  hipMemset(a, 0, sizeof(float) * NR * SMAX);
+  hipMemset(b, 0, sizeof(float) * NR * SMAX);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const double bytes = (double)n * 4 * (NR + NW);
+  const long pads[] = {0, 0, 0, 0, 0, 256, 1024 + 256, 4096 + 256, 16384 + 1024 + 64, 64, 32768 + 2048 + 128};
+  for (int variant = 0; variant < 11; variant++) {
+    S = n + pads[variant];
+    float best = 1e9;
+    for (int rep = 0; rep < 5; rep++) {
+      hipEventRecord(e0);
+      for (int it = 0; it < 100; it++) {
+        // in-place like the engine: read and write the same buffer
+        switch (variant) {
+          case 0: planar<1><<<(n + 255) / 256, 256>>>(a, a, S, n); break;
+          case 1: planar<2><<<(n / 2 + 255) / 256, 256>>>(a, a, S, n); break;
+          case 2: planar<4><<<(n / 4 + 255) / 256, 256>>>(a, a, S, n); break;
+          case 3: tiled<<<(n + 255) / 256, 256>>>(a, a, n); break;
+          case 4: planar<1><<<(n + 255) / 256, 256>>>(a, b, S, n); break;  // out of place
+          default: planar<1><<<(n + 255) / 256, 256>>>(a, a, S, n); break;  // padded stride
+        }
+      }
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best) best = ms;
+    }
+    const char *names[] = {"planar dword in-place", "planar dwordx2 in-place", "planar dwordx4 in-place", "tiled-64 dword in-place", "planar dword out-of-place"};
+    if (variant < 5) printf("%-28s %.2f us/launch  %.0f GB/s\n", names[variant], best * 10, bytes / (best * 1e-5) / 1e9);
+    else printf("planar dword pad %-10ld  %.2f us/launch  %.0f GB/s\n", pads[variant], best * 10, bytes / (best * 1e-5) / 1e9);
+  }
+  return 0;
+}
