@@ -356,18 +356,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   float gx = 0, gy = 0, gz = 0, ax_m = 0, ay_m = 0, az_m = 0;
   bool have_imu = false;
 
-  // noise of the first tick of this launch, drawn under the load latency
-  // (g++ evaluates the ctor arguments right to left, Quadcopter_T.cpp:167-169,
-  // 176-178: z <- draw 1, y <- 2, x <- 3)
-  float ng[3] = {0, 0, 0}, na[3] = {0, 0, 0};
-  bool noise_ready = false;
-  if (NOISE && v.tick_mask) {
-    double d[6];
-    six_normals(rng, d);
-    ng[0] = v.sigma_gyro * (float)d[2]; ng[1] = v.sigma_gyro * (float)d[1]; ng[2] = v.sigma_gyro * (float)d[0];
-    na[0] = v.sigma_acc * (float)d[5]; na[1] = v.sigma_acc * (float)d[4]; na[2] = v.sigma_acc * (float)d[3];
-    noise_ready = true;
-  }
+  float ng[3] = {0, 0, 0}, na[3] = {0, 0, 0};  // IMU noise of the current logic tick
 
   // Motor.cpp:48-50: negative commands clamp to zero (the command is a float,
   // Quadcopter_T.hpp:100, widened at Quadcopter_T.cpp:98)
@@ -375,10 +364,21 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #pragma unroll
   for (int m = 0; m < 4; m++) { cmd[m] = (R)cmd_f[m]; if (cmd[m] < 0) cmd[m] = 0; }
 
-  // SINGLE: one sub-step per launch (the per-step-observable mode): no loop, and
-  // the only Gaussian draws are the ones made above under the load latency
+  // SINGLE: one sub-step per launch (the per-step-observable mode): no loop
   const int n_steps = SINGLE ? 1 : v.n_steps;
   for (int step = 0; step < n_steps; step++) {
+    const bool tick = (v.tick_mask >> step) & 1ull;        // Quadcopter_T.cpp:159 (wave-uniform)
+    if (NOISE && tick) {
+      // The six Gaussian draws of this sub-step's logic tick need only the engine
+      // word, so they are made FIRST: on the first sub-step they run while the
+      // state loads issued above are still in flight.  g++ evaluates the ctor
+      // arguments right to left (Quadcopter_T.cpp:167-169,176-178): z <- draw 1,
+      // y <- 2, x <- 3.
+      double d[6];
+      six_normals(rng, d);
+      ng[0] = v.sigma_gyro * (float)d[2]; ng[1] = v.sigma_gyro * (float)d[1]; ng[2] = v.sigma_gyro * (float)d[0];
+      na[0] = v.sigma_acc * (float)d[5]; na[1] = v.sigma_acc * (float)d[4]; na[2] = v.sigma_acc * (float)d[3];
+    }
     // ---- 4 motors: Motor::Run, Motor.cpp:39-84 ----
     R Fz = 0;                       // totalForce_b (thrust axes are all +z)
     R Tx = 0, Ty = 0, Tz = 0;       // totalTorque_b
@@ -469,16 +469,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     wx = nwx; wy = nwy; wz = nwz;
 
     // ---- onboard-logic gate fired on this sub-step: IMU synthesis ----
-    if ((v.tick_mask >> step) & 1ull) {                      // Quadcopter_T.cpp:159
-      if (NOISE) {
-        if (!SINGLE && !noise_ready) {  // second and later ticks of a fused launch
-          double d[6];
-          six_normals(rng, d);
-          ng[0] = v.sigma_gyro * (float)d[2]; ng[1] = v.sigma_gyro * (float)d[1]; ng[2] = v.sigma_gyro * (float)d[0];
-          na[0] = v.sigma_acc * (float)d[5]; na[1] = v.sigma_acc * (float)d[4]; na[2] = v.sigma_acc * (float)d[3];
-        }
-        noise_ready = false;
-      }
+    if (tick) {
       float tx_, ty_, tz_;
       mat_vec<float>(P.Rimu, (float)wx, (float)wy, (float)wz, tx_, ty_, tz_);  // :165-166
       gx = tx_ + ng[0]; gy = ty_ + ng[1]; gz = tz_ + ng[2];                    // :167-170
@@ -532,12 +523,15 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #ifndef AFE_LB_WAVES
 #define AFE_LB_WAVES 1
 #endif
+#ifndef AFE_BLOCK
+#define AFE_BLOCK 256   // threads per workgroup of the homogeneous-ensemble step kernel
+#endif
 
 // homogeneous ensemble: the one parameter record rides in the kernel arguments
 template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE>
-__global__ void __launch_bounds__(256, AFE_LB_WAVES)
+__global__ void __launch_bounds__(AFE_BLOCK, AFE_LB_WAVES)
 afe_step_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;
   if (i >= v.n) return;
   run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE>(v, P, G, i);
 }
@@ -572,15 +566,16 @@ static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevPara
                        const DevLogic *uniform_logic, hipStream_t st) {
   if (v.n <= 0) return 0;
   const unsigned grid = (unsigned)((v.n + 255) / 256);
+  const unsigned grid_u = (unsigned)((v.n + AFE_BLOCK - 1) / AFE_BLOCK);
   const size_t lds = (size_t)v.n_types * (sizeof(DevParams<R>) + (f.logic ? sizeof(DevLogic) : 0));
   DevLogic no_logic = {};
   const DevLogic &G = uniform_logic ? *uniform_logic : no_logic;
 #define AFE_LAUNCH(FE, TE, NO, LO)                                                                         \
   do {                                                                                                     \
     if (uniform && v.n_steps == 1)                                                                         \
-      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true>), dim3(grid), dim3(256), 0, st, v, *uniform, G); \
+      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
     else if (uniform)                                                                                      \
-      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, false>), dim3(grid), dim3(256), 0, st, v, *uniform, G); \
+      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, false>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
     else                                                                                                   \
       hipLaunchKernelGGL((afe_step_kernel_table<R, FE, TE, NO, LO>), dim3(grid), dim3(256), lds, st, v);      \
   } while (0)
