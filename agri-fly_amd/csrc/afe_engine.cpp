@@ -54,7 +54,6 @@ struct afe_engine {
   double sigma_gyro = 0.1, sigma_acc = 0.2;  // Quadcopter_T.cpp:5-6
   int seed_policy = AFE_SEED_REFERENCE;
   bool has_ext_force = false, has_ext_torque = false;
-  bool renorm = true;
 
   // clock (ManualTimer + Timer semantics)
   uint64_t now_us = 0;
@@ -271,7 +270,6 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
   e->precision = precision;
   e->device = device;
   e->first_global = first_global_index;
-  e->renorm = (precision == AFE_F32);
 
   auto bail = [&](const char *what, hipError_t err) {
     std::fprintf(stderr, "agrifly_engine: %s failed: %s\n", what, hipGetErrorString(err));
@@ -658,6 +656,70 @@ extern "C" int afe_event_elapsed_ms(void *start, void *stop, float *ms) {
   if (!start || !stop || !ms) return AFE_ERR_INVALID_ARG;
   if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return AFE_ERR_HIP;
   return hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+}
+
+namespace {
+struct CheckpointHeader {
+  uint64_t magic, n, stride, precision, arena_bytes, logic_bytes;
+  uint64_t now_us, logic_elapsed_us, n_ticks;
+  uint64_t has_ext_force, has_ext_torque, logic_on;
+};
+const uint64_t kCheckpointMagic = 0x4146452d434b5031ull;  // "AFE-CKP1"
+size_t logic_arena_bytes(const afe_engine *e) {
+  const size_t S = (size_t)e->stride;
+  return e->logic_arena ? S * 12 * 4 + S * 4 * 4 + S * 2 + 256 * sizeof(DevLogic) : 0;
+}
+}  // namespace
+
+extern "C" int afe_checkpoint_size(const afe_engine *e, uint64_t *bytes) {
+  if (!e || !bytes) return AFE_ERR_INVALID_ARG;
+  *bytes = sizeof(CheckpointHeader) + e->arena_bytes + (e->logic_on ? logic_arena_bytes(e) : 0);
+  return AFE_OK;
+}
+
+extern "C" int afe_save_checkpoint(afe_engine *e, void *host_buffer, uint64_t bytes) {
+  uint64_t need = 0;
+  if (!e || !host_buffer || afe_checkpoint_size(e, &need) != AFE_OK) return AFE_ERR_INVALID_ARG;
+  if (bytes < need) return fail(e, AFE_ERR_INVALID_ARG, "checkpoint buffer too small");
+  AFE_HIP(e, hipSetDevice(e->device));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  CheckpointHeader h = {kCheckpointMagic, (uint64_t)e->n, (uint64_t)e->stride, (uint64_t)e->precision,
+                        (uint64_t)e->arena_bytes, e->logic_on ? (uint64_t)logic_arena_bytes(e) : 0,
+                        e->now_us, e->logic_elapsed_us, e->n_ticks,
+                        e->has_ext_force, e->has_ext_torque, e->logic_on};
+  char *p = (char *)host_buffer;
+  std::memcpy(p, &h, sizeof(h));
+  p += sizeof(h);
+  AFE_HIP(e, hipMemcpy(p, e->arena, e->arena_bytes, hipMemcpyDeviceToHost));
+  p += e->arena_bytes;
+  if (h.logic_bytes) AFE_HIP(e, hipMemcpy(p, e->logic_arena, h.logic_bytes, hipMemcpyDeviceToHost));
+  return AFE_OK;
+}
+
+extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint64_t bytes) {
+  if (!e || !host_buffer || bytes < sizeof(CheckpointHeader)) return AFE_ERR_INVALID_ARG;
+  CheckpointHeader h;
+  std::memcpy(&h, host_buffer, sizeof(h));
+  if (h.magic != kCheckpointMagic || h.n != (uint64_t)e->n || h.stride != (uint64_t)e->stride ||
+      h.precision != (uint64_t)e->precision || h.arena_bytes != e->arena_bytes ||
+      h.logic_on != (uint64_t)e->logic_on || (h.logic_on && h.logic_bytes != logic_arena_bytes(e)) ||
+      bytes < sizeof(h) + h.arena_bytes + h.logic_bytes)
+    return fail(e, AFE_ERR_INVALID_ARG, "checkpoint does not match this engine's size / precision / logic configuration");
+  AFE_HIP(e, hipSetDevice(e->device));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  const char *p = (const char *)host_buffer + sizeof(h);
+  AFE_HIP(e, hipMemcpy(e->arena, p, e->arena_bytes, hipMemcpyHostToDevice));
+  p += e->arena_bytes;
+  if (h.logic_bytes) AFE_HIP(e, hipMemcpy(e->logic_arena, p, h.logic_bytes, hipMemcpyHostToDevice));
+  e->now_us = h.now_us;
+  e->logic_elapsed_us = h.logic_elapsed_us;
+  e->n_ticks = h.n_ticks;
+  e->has_ext_force = h.has_ext_force != 0;
+  e->has_ext_torque = h.has_ext_torque != 0;
+  // the arena also holds the device copy of the type table for the checkpoint's dt: rebuild on next step
+  e->table_dirty = true;
+  e->logic_table_period = -1.0f;
+  return AFE_OK;
 }
 
 extern "C" int afe_selftest_normals(afe_engine *e, const uint32_t *seeds, int64_t n, double *normals6, uint32_t *state_after) {

@@ -31,7 +31,7 @@ ABI_FUNCTIONS = [
     "afe_event_record", "afe_event_elapsed_ms", "afe_pack_positions",
     "afe_nearest_neighbour", "afe_selftest_normals",
     "afe_rates_logic_params_from_type", "afe_set_rates_logic", "afe_set_rates_commands",
-    "afe_get_motor_cmds",
+    "afe_get_motor_cmds", "afe_checkpoint_size", "afe_save_checkpoint", "afe_load_checkpoint",
 ]
 
 
@@ -167,6 +167,9 @@ def library():
         "afe_set_rates_logic": [eng, C.POINTER(RatesLogicParams), ci],
         "afe_set_rates_commands": [eng, i64, i64, vp, vp],
         "afe_get_motor_cmds": [eng, i64, i64, vp],
+        "afe_checkpoint_size": [eng, C.POINTER(u64)],
+        "afe_save_checkpoint": [eng, vp, u64],
+        "afe_load_checkpoint": [eng, vp, u64],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -401,6 +404,18 @@ class Ensemble:
         b = C.c_double(0)
         self._ck(self._L.afe_algorithmic_bytes_per_step(self._h, int(bool(imu_tick)), C.byref(b)))
         return b.value
+
+    # -- checkpoint / resume --------------------------------------------------
+    def save_checkpoint(self):
+        n = C.c_uint64(0)
+        self._ck(self._L.afe_checkpoint_size(self._h, C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        self._ck(self._L.afe_save_checkpoint(self._h, buf.ctypes.data, n.value))
+        return buf
+
+    def load_checkpoint(self, buf):
+        b = np.ascontiguousarray(buf, dtype=np.uint8)
+        self._ck(self._L.afe_load_checkpoint(self._h, b.ctypes.data, b.size))
 
     # -- HIP events on the engine stream ------------------------------------
     def event(self):

@@ -95,7 +95,7 @@ int afe_type_from_id(unsigned vehicle_id);
  * AIFS_ROS/hiperlab_rostools/src/Simulator/main.cpp:58-95).
  * device < 0 selects the current HIP device.  first_global_index is this
  * shard's offset in the whole ensemble (used by AFE_SEED_DECORRELATED and by
- * afe_gather_positions); 0 for a single-GPU ensemble.  Initial state is the
+ * afe_nearest_neighbour's self-exclusion); 0 for a single-GPU ensemble.  Initial state is the
  * reference's: origin, at rest, identity attitude, motors stopped, engine
  * clock 0 (SimulationObject6DOF.hpp:14-19, Motor.cpp:18). */
 int afe_create(afe_engine **out, int64_t n_vehicles, int precision, int device,
@@ -231,6 +231,18 @@ int afe_logic_ticks(const afe_engine *e, uint64_t *n_ticks);
  * SetIMUMeasurementAccelerometer at the most recent logic tick
  * (Quadcopter_T.cpp:171,180); floats, like the reference's Vec3f. */
 int afe_get_imu(afe_engine *e, int64_t first, int64_t count, float *gyro3, float *acc3);
+
+/* ---- checkpoint / resume -------------------------------------------------
+ * The reference has none (its motor speeds, timers, RNG and logic state have no
+ * accessor).  Here the SoA slabs ARE the checkpoint: state,
+ * motor speeds and commands, wrench, last IMU sample, RNG words, on-device logic
+ * state and the engine clock.  afe_checkpoint_size gives the byte count for the
+ * current configuration; a checkpoint can only be loaded into an engine created
+ * with the same n_vehicles / precision and configured the same way (type table,
+ * logic on/off). */
+int afe_checkpoint_size(const afe_engine *e, uint64_t *bytes);
+int afe_save_checkpoint(afe_engine *e, void *host_buffer, uint64_t bytes);
+int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint64_t bytes);
 
 /* Pure host helper (no GPU): the logic-gate pattern of n_steps steps of dt_us
  * starting from *elapsed_us (time since the gate last fired), per Timer.hpp:

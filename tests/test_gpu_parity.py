@@ -357,3 +357,49 @@ def test_device_normals_match_libstdcxx_known_answers(golden_dir):
         same = (got[:2000].astype(np.float32) == ref.astype(np.float32)).mean()
         assert same == 1.0
         assert np.isfinite(got).all() and abs(got.mean()) < 5e-3 and abs(got.std() - 1) < 5e-3
+
+
+def test_checkpoint_resume_is_bitwise():
+    """the SoA slabs + clock + RNG (+ logic state) are the checkpoint"""
+    ens = random_ensemble(1500, seed=41)
+    with ens.to_engine(afa.AFE_F32) as e:
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+        e.set_rates_logic([afa.rates_logic_params_from_type(t) for t in ens.data.type_ids])
+        e.set_rates_commands(np.full(1500, 9.81, np.float32), np.zeros((3, 1500), np.float32))
+        e.step(1000, 37)
+        ck = e.save_checkpoint()
+        t0, k0 = e.time_us, e.logic_ticks
+        e.step(1000, 45)
+        a = e.get_state(dtype=np.float32)
+        a_rng, a_cmd, a_imu = e.get_rng_state(), e.get_motor_cmds(), e.get_imu()
+        e.load_checkpoint(ck)
+        assert e.time_us == t0 and e.logic_ticks == k0
+        e.step(1000, 45)
+        b = e.get_state(dtype=np.float32)
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        np.testing.assert_array_equal(a_rng, e.get_rng_state())
+        np.testing.assert_array_equal(a_cmd, e.get_motor_cmds())
+        np.testing.assert_array_equal(a_imu[0], e.get_imu()[0])
+        with afa.Ensemble(1501) as other:
+            other.set_type_table([afa.params_from_type(5)])
+            with pytest.raises(afa.AfeError):
+                other.load_checkpoint(ck)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 257, 1000])
+def test_ragged_sizes(n):
+    """ensemble sizes that are not a multiple of the wave / workgroup / slab granule"""
+    ens = random_ensemble(n, seed=50 + n)
+    b = ens.to_oracle_batch()
+    with ens.to_engine(afa.AFE_F64) as e:
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+        e.step(1000, 6)
+        st = e.get_state()
+        g, a = e.get_imu()
+        assert e.get_state(first=n, count=0)["pos"].shape == (3, 0)   # empty range at the end
+        assert e.device_view().stride % 512 == 256                    # 256 x odd
+    b.rng[:] = 1 + np.arange(n)
+    b.step(1e-3, 6, ticks=_ticks(afa, 1 / 500, 1000, 6))
+    _cmp_state(st, b, 1e-11, "n=%d" % n)
+    assert rel_err(g, b.gyro, 1.0) < 1e-6
