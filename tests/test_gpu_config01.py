@@ -1,0 +1,69 @@
+"""BASELINE.json configs 0 and 1 flown closed loop on the HIP engine and on the
+oracle with the same caller (tests/closed_loop.py): take-off from the ground to
+a 3.5 m hover, dt = 1 ms, 500 Hz onboard rates logic (on the device / restated),
+100 Hz offboard controller, 16-bit radio quantisation, 30 ms radio delay, IMU
+noise from the reference's stream.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from tests.closed_loop import fly_engine, fly_oracle
+from tests.scenarios import afa
+
+pytestmark = pytest.mark.gpu
+
+
+def _worst(log_e, log_o):
+    d = np.abs(log_e - log_o) / np.maximum(np.abs(log_o), 1.0)
+    return float(d.max())
+
+
+# fp32 engine vs double oracle over a whole noisy closed-loop flight.  The loop
+# contains discontinuities (16-bit radio quantisation, float clamps): a 1e-7
+# difference ahead of a quantiser occasionally flips one code (1e-3 rad/s), so
+# the two runs are different realisations at the 1e-3 level in body rates while
+# staying together in position.  Measured on MI355X (tools/probe_closed_loop.py):
+# pos 6e-5, vel 2e-4, att 1.3e-4, ang_vel 3.7e-3 over 10 s; fp64 engine 1.4e-12.
+F32_FLIGHT_TOL = np.array([3e-4] * 3 + [1e-3] * 3 + [5e-4] * 4 + [2e-2] * 3).reshape(1, 13, 1)
+
+
+def _within(log_e, log_o, tol):
+    d = np.abs(log_e - log_o) / np.maximum(np.abs(log_o), 1.0)
+    return bool(np.all(d <= tol))
+
+
+@pytest.mark.parametrize("precision", [afa.AFE_F64, afa.AFE_F32])
+def test_config0_single_vehicle_hover_10s(ora, precision):
+    """10 s = 1e4 steps.  The fp64 engine must track the oracle through the
+    whole flight to 1e-10 (same algorithm, same precision: proves the kernel,
+    the clock, the noise stream and the on-device logic are the oracle's); the
+    fp32 engine to the per-field flight tolerances above."""
+    b, log_o = fly_oracle(ora, 1, 10.0)
+    e, log_e = fly_engine(afa, 1, 10.0, precision)
+    with e:
+        st = e.get_state()
+        assert e.time_us == 9999 * 1000 and e.logic_ticks == 4999
+        np.testing.assert_array_equal(e.get_rng_state(), b.rng)     # same noise stream position
+    assert log_e.shape == log_o.shape == (1000, 13, 1)
+    if precision == afa.AFE_F64:
+        assert _worst(log_e, log_o) <= 1e-10
+    else:
+        assert _within(log_e, log_o, F32_FLIGHT_TOL)
+    assert abs(st["pos"][2, 0] - 3.5) < 0.02 and np.abs(st["pos"][:2, 0]).max() < 0.02
+    # SURVEY App. B [probe drv]: the reference's own loop hovers at z = 3.49997 after 10 s
+    assert abs(b.pos[2, 0] - 3.5) < 0.02
+
+
+def test_config1_4096_vehicle_hover_ensemble(ora):
+    """4096 vehicles, decorrelated noise; the first 24 are checked against the
+    oracle flown with the same seeds, the rest for being a sane hover."""
+    n, m = 4096, 24
+    b, log_o = fly_oracle(ora, m, 3.0, seeds=1 + np.arange(m))
+    e, log_e = fly_engine(afa, n, 3.0, afa.AFE_F32, decorrelated=True)
+    with e:
+        st = e.get_state(dtype=np.float32)
+        np.testing.assert_array_equal(e.get_rng_state()[:m], b.rng)
+    assert _within(log_e[:, :, :m], log_o, F32_FLIGHT_TOL)
+    assert np.isfinite(st["pos"]).all()
+    assert np.all(np.abs(st["pos"][2] - 3.5) < 0.6)       # 3 s in: still closing in on 3.5 m
+    assert np.all(st["att"][0] > 0.99)
+    assert len(np.unique(st["ang_vel"][0])) > n * 0.99     # decorrelated noise: distinct trajectories
