@@ -249,6 +249,19 @@ def main():
                 sweep.append({"vehicles": n, "vsteps_per_s": n * k / t1,
                               "vsteps_per_s_fused2": n * k / tf, "vsteps_per_s_fused50": n * k / t50})
                 es.close()
+            # config 2 closed on the GPU: on-device onboard rates logic, hover command
+            closed = []
+            for n in (4096, 1 << 20):
+                es = build_shard(afa, n, 0, n, local_rank)
+                es.set_rates_logic([afa.rates_logic_params_from_type(5)])
+                es.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
+                k = 400
+                time_steps(es, 50, 1, sync, barrier)
+                t1 = time_steps(es, k, 1, sync, barrier)
+                t10 = time_steps(es, k, 10, sync, barrier)
+                closed.append({"vehicles": n, "vsteps_per_s": n * k / t1, "vsteps_per_s_fused10": n * k / t10})
+                es.close()
+            out["closed_loop_on_device"] = closed
             out["sweep"] = sweep
             out["sweep_note"] = ("fused2 = two 1 ms steps per launch (nothing is observable between 500 Hz logic "
                                  "ticks); fused50 = 50 steps per launch, state in registers (open-loop commands)")
