@@ -19,13 +19,19 @@ from .engine import (  # noqa: F401
     AfeError,
     DeviceView,
     Ensemble,
+    RADIO_PACKET_SIZE,
+    RadioMessage,
     RatesLogicParams,
+    TELEMETRY_PACKET_SIZE,
+    TelemetryPacket,
     VehicleParams,
     build_library,
     library,
     library_path,
     params_from_type,
     plan_ticks,
+    radio_create_rates_command,
+    radio_decode,
     rates_logic_params_from_type,
     type_from_id,
 )

@@ -505,6 +505,34 @@ extern "C" int afe_set_rates_commands(afe_engine *e, int64_t first, int64_t coun
   return AFE_OK;
 }
 
+extern "C" int afe_set_commands_from_radio(afe_engine *e, int64_t first, int64_t count, const uint8_t *raw_packets) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  if (!e->logic_on) return fail(e, AFE_ERR_NOT_CONFIGURED, "afe_set_rates_logic has not been called");
+  if (!raw_packets) return fail(e, AFE_ERR_INVALID_ARG, "raw_packets is NULL");
+  std::vector<float> cmd((size_t)(4 * count));
+  std::vector<uint8_t> have((size_t)count);
+  for (int64_t k = 0; k < count; k++) {
+    afe_radio_message m;
+    afe_radio_decode(raw_packets + k * AFE_RADIO_PACKET_SIZE, &m);
+    if (m.type == 5) {  // externalRatesCmd -> FS_EXTERNAL_RATES_CONTROL (QuadcopterLogic.cpp:293-295)
+      have[(size_t)k] = 1;
+      for (int c = 0; c < 4; c++) cmd[(size_t)(c * count + k)] = m.floats[c];
+    } else if (m.type == 6 || m.type == 2) {  // idle / kill: motors off
+      have[(size_t)k] = 0;
+      for (int c = 0; c < 4; c++) cmd[(size_t)(c * count + k)] = 0.0f;
+    } else {
+      return fail(e, AFE_ERR_INVALID_ARG, "radio message type " + std::to_string(m.type) + " for vehicle " +
+                                              std::to_string(first + k) + " needs the host-side logic");
+    }
+  }
+  AFE_HIP(e, hipSetDevice(e->device));
+  if ((rc = copy_in(e, e->rates_cmd, 4, 4, first, count, cmd.data()))) return rc;
+  AFE_HIP(e, hipMemcpyAsync(e->have_cmd + first, have.data(), (size_t)count, hipMemcpyHostToDevice, e->stream));
+  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  return AFE_OK;
+}
+
 extern "C" int afe_set_external_force(afe_engine *e, int64_t first, int64_t count, const double *force3) {
   if (!e) return AFE_ERR_INVALID_ARG;
   return set_wrench(e, e->ext_force, e->has_ext_force, first, count, force3);

@@ -32,6 +32,9 @@ ABI_FUNCTIONS = [
     "afe_nearest_neighbour", "afe_selftest_normals",
     "afe_rates_logic_params_from_type", "afe_set_rates_logic", "afe_set_rates_commands",
     "afe_get_motor_cmds", "afe_checkpoint_size", "afe_save_checkpoint", "afe_load_checkpoint",
+    "afe_radio_create_rates_command", "afe_radio_create_position_command",
+    "afe_radio_create_acceleration_command", "afe_radio_create_simple_command", "afe_radio_decode",
+    "afe_telemetry_encode", "afe_telemetry_decode", "afe_set_commands_from_radio",
 ]
 
 
@@ -84,6 +87,20 @@ class RatesLogicParams(C.Structure):
         ("imu_yaw", C.c_float), ("imu_pitch", C.c_float), ("imu_roll", C.c_float),
         ("gyro_lowpass_cutoff", C.c_float),
     ]
+
+
+class RadioMessage(C.Structure):
+    _fields_ = [("type", C.c_uint8), ("flags", C.c_uint8), ("floats", C.c_float * 10)]
+
+
+class TelemetryPacket(C.Structure):
+    _fields_ = [("type", C.c_uint8), ("packet_number", C.c_uint8), ("accel", C.c_float * 3),
+                ("gyro", C.c_float * 3), ("motor_forces", C.c_float * 4), ("position", C.c_float * 3),
+                ("batt_voltage", C.c_float), ("velocity", C.c_float * 3), ("attitude", C.c_float * 3),
+                ("debug_vals", C.c_float * 6), ("panic_reason", C.c_uint8), ("warnings", C.c_uint8)]
+
+
+RADIO_PACKET_SIZE, TELEMETRY_PACKET_SIZE = 23, 30
 
 
 class DeviceView(C.Structure):
@@ -167,6 +184,14 @@ def library():
         "afe_set_rates_logic": [eng, C.POINTER(RatesLogicParams), ci],
         "afe_set_rates_commands": [eng, i64, i64, vp, vp],
         "afe_get_motor_cmds": [eng, i64, i64, vp],
+        "afe_radio_create_rates_command": [C.c_uint8, C.c_float, vp, vp],
+        "afe_radio_create_position_command": [C.c_uint8, vp, vp, vp, vp],
+        "afe_radio_create_acceleration_command": [C.c_uint8, vp, C.c_float, vp],
+        "afe_radio_create_simple_command": [ci, C.c_uint8, vp],
+        "afe_radio_decode": [vp, C.POINTER(RadioMessage)],
+        "afe_telemetry_encode": [C.POINTER(TelemetryPacket), vp],
+        "afe_telemetry_decode": [vp, C.POINTER(TelemetryPacket)],
+        "afe_set_commands_from_radio": [eng, i64, i64, vp],
         "afe_checkpoint_size": [eng, C.POINTER(u64)],
         "afe_save_checkpoint": [eng, vp, u64],
         "afe_load_checkpoint": [eng, vp, u64],
@@ -197,6 +222,24 @@ def rates_logic_params_from_type(quadcopter_type):
     if rc:
         raise AfeError(rc, "invalid quadcopter type %r" % (quadcopter_type,))
     return p
+
+
+def radio_create_rates_command(flags, thrust, ang_vel):
+    raw = np.zeros(RADIO_PACKET_SIZE, np.uint8)
+    w = np.ascontiguousarray(ang_vel, dtype=np.float32)
+    rc = library().afe_radio_create_rates_command(int(flags), float(thrust), w.ctypes.data, raw.ctypes.data)
+    if rc:
+        raise AfeError(rc, "afe_radio_create_rates_command")
+    return raw
+
+
+def radio_decode(raw):
+    r = np.ascontiguousarray(raw, dtype=np.uint8)
+    m = RadioMessage()
+    rc = library().afe_radio_decode(r.ctypes.data, C.byref(m))
+    if rc:
+        raise AfeError(rc, "afe_radio_decode")
+    return m
 
 
 def type_from_id(vehicle_id):
@@ -357,6 +400,13 @@ class Ensemble:
             raise ValueError("thrust_norm must have shape (%d,)" % count)
         w, wp = _planar(ang_vel3, 3, count, np.float32)
         self._ck(self._L.afe_set_rates_commands(self._h, first, count, t.ctypes.data, wp))
+
+    def set_commands_from_radio(self, raw_packets, first=0):
+        """raw_packets: uint8 [count, 23]"""
+        r = np.ascontiguousarray(raw_packets, dtype=np.uint8)
+        if r.ndim != 2 or r.shape[1] != RADIO_PACKET_SIZE:
+            raise ValueError("raw_packets must have shape (count, 23)")
+        self._ck(self._L.afe_set_commands_from_radio(self._h, int(first), r.shape[0], r.ctypes.data))
 
     def get_motor_cmds(self, first=0, count=None):
         first, count = self._range(first, count)

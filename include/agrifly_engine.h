@@ -207,6 +207,44 @@ int afe_set_rates_commands(afe_engine *e, int64_t first, int64_t count,
 /* The motor-speed commands currently in force (host- or logic-written). */
 int afe_get_motor_cmds(afe_engine *e, int64_t first, int64_t count, float *cmd4);
 
+/* ---- wire formats either side of the step (host-only) --
+ * Byte-exact equivalents of RadioTypes::RadioMessageDecoded (Common/Common/
+ * DataTypes/RadioTypes.hpp:39-246: 23-byte uplink, type@0 reserved@1 flags@2,
+ * ten big-endian 16-bit fixed-point fields) and of TelemetryPacket::
+ * Encode/DecodeTelemetryPacket (TelemetryPacket.hpp:32-207: packed
+ * {u8 type; u8 packetNumber; u16 data[14]} = 30 bytes).  Usable without a GPU. */
+#define AFE_RADIO_PACKET_SIZE 23
+#define AFE_TELEMETRY_PACKET_SIZE 30
+typedef struct afe_radio_message {  /* RadioMessageDecoded: type, flags, floats[10] */
+  uint8_t type;   /* 2 kill, 3 position, 4 acceleration, 5 rates, 6 idle (RadioTypes.hpp:17-25) */
+  uint8_t flags;
+  float floats[10];
+} afe_radio_message;
+int afe_radio_create_rates_command(uint8_t flags, float des_total_thrust, const float des_ang_vel[3],
+                                   uint8_t raw_out[AFE_RADIO_PACKET_SIZE]);          /* :158-171 */
+int afe_radio_create_position_command(uint8_t flags, const float pos[3], const float vel[3],
+                                      const float acc[3], uint8_t raw_out[AFE_RADIO_PACKET_SIZE]); /* :137-156 */
+int afe_radio_create_acceleration_command(uint8_t flags, const float acc[3], float yaw_rate,
+                                          uint8_t raw_out[AFE_RADIO_PACKET_SIZE]);   /* :173-187 */
+int afe_radio_create_simple_command(int type /* 2 kill | 6 idle */, uint8_t flags,
+                                    uint8_t raw_out[AFE_RADIO_PACKET_SIZE]);         /* :123-135 */
+int afe_radio_decode(const uint8_t raw[AFE_RADIO_PACKET_SIZE], afe_radio_message *out); /* :189-240 */
+typedef struct afe_telemetry_packet {  /* TelemetryPacket::TelemetryPacket, TelemetryPacket.hpp:102-120 */
+  uint8_t type;            /* 0 = part 1 (accel gyro motorForces position battVoltage), 1 = part 2 */
+  uint8_t packet_number;
+  float accel[3], gyro[3], motor_forces[4], position[3], batt_voltage;
+  float velocity[3], attitude[3], debug_vals[6];
+  uint8_t panic_reason, warnings;
+} afe_telemetry_packet;
+int afe_telemetry_encode(const afe_telemetry_packet *src, uint8_t out[AFE_TELEMETRY_PACKET_SIZE]);
+int afe_telemetry_decode(const uint8_t in[AFE_TELEMETRY_PACKET_SIZE], afe_telemetry_packet *out);
+/* SetCommandRadioMsg (Quadcopter_T.hpp:62-67) for the on-device logic: decode
+ * `count` consecutive 23-byte packets and apply them to vehicles first..: rates
+ * commands enter EXTERNAL_RATES_CONTROL, idle / kill return to zero motor
+ * commands; other types are refused with AFE_ERR_INVALID_ARG (those flight
+ * modes live in the host-side logic). */
+int afe_set_commands_from_radio(afe_engine *e, int64_t first, int64_t count, const uint8_t *raw_packets);
+
 /* ---- stepping -----------------------------------------------------------
  * afe_step replaces the loop body
  *     for (v : vehicles) v->Run();  simTimer.AdvanceMicroSeconds(dt_us);

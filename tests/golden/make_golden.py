@@ -15,6 +15,8 @@ Run in the build container (needs /root/reference for the timer probe):
 * lpf_kat.json        <- oracle/_ref/lpf_probe: the REFERENCE's own
   LowPassFilterSecondOrder.hpp (stand-alone header) with the onboard logic's
   gyro / accelerometer settings.
+* telemetry_kat.json  <- oracle/_ref/telemetry_probe: the REFERENCE's own
+  TelemetryPacket.hpp (stand-alone header): packets -> 30-byte wire form -> back.
 * oracle_regression.npz <- the oracle itself (NOT the reference): seeded
   single-step / rollout vectors that freeze the restatement so later edits of
   oracle/agrifly_oracle.c cannot drift silently.  It pins nothing against the
@@ -80,6 +82,12 @@ def main():
     with open(os.path.join(HERE, "lpf_kat.json"), "w") as f:
         json.dump({"generator": "oracle/_ref/lpf_probe (reference LowPassFilterSecondOrder.hpp compiled in place, "
                                 "LowPassFilterSecondOrder<float,float>)", "cases": lpfs}, f, indent=0)
+
+    tel = json.loads(subprocess.check_output([os.path.join(ref, "telemetry_probe"), "48", "20261002"]))
+    tel["generator"] = ("oracle/_ref/telemetry_probe (reference TelemetryPacket.hpp compiled in place; "
+                        "EncodeTelemetryPacket / DecodeTelemetryPacket)")
+    with open(os.path.join(HERE, "telemetry_kat.json"), "w") as f:
+        json.dump(tel, f, indent=0)
 
     # --- oracle regression vectors (oracle-generated; not a reference pin) ---
     from tests.scenarios import random_ensemble

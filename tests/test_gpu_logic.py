@@ -127,3 +127,30 @@ def test_disable_logic_restores_host_commands():
         np.testing.assert_array_equal(e.get_motor_cmds(), ens.data.motor_cmd)
         with pytest.raises(afa.AfeError):
             e.set_rates_logic([afa.rates_logic_params_from_type(5)])   # 4 vehicle types need 4 records
+
+
+def test_radio_packets_drive_the_device_logic():
+    """SetCommandRadioMsg for the on-device logic: 23-byte packets in, same
+    behaviour as decoded float commands; idle returns the motors to zero"""
+    n = 500
+    ens, b, cl, e1, thrust, wdes = _closed_loop_pair(n, 35, afa.AFE_F32, type_ids=(5,))
+    _, _, _, e2, _, _ = _closed_loop_pair(n, 35, afa.AFE_F32, type_ids=(5,))
+    raw = np.stack([afa.radio_create_rates_command(0, thrust[i], wdes[:, i]) for i in range(n)])
+    with e1, e2:
+        e1.set_commands_from_radio(raw)
+        dec = np.array([list(afa.radio_decode(raw[i]).floats)[:4] for i in range(n)], np.float32)
+        e2.set_rates_commands(dec[:, 0], dec[:, 1:4].T)
+        for e in (e1, e2):
+            e.step(1000, 20)
+        np.testing.assert_array_equal(e1.get_motor_cmds(), e2.get_motor_cmds())
+        s1, s2 = e1.get_state(dtype=np.float32), e2.get_state(dtype=np.float32)
+        np.testing.assert_array_equal(s1["ang_vel"], s2["ang_vel"])
+        idle = np.zeros((n, 23), np.uint8)
+        idle[:, 0] = 6
+        e1.set_commands_from_radio(idle)
+        e1.step(1000, 4)
+        np.testing.assert_array_equal(e1.get_motor_cmds(), 0.0)
+        bad = idle.copy()
+        bad[3, 0] = 3     # positionCommand needs the host-side logic
+        with pytest.raises(afa.AfeError):
+            e1.set_commands_from_radio(bad)
