@@ -59,6 +59,7 @@ struct afe_engine {
   uint64_t now_us = 0;
   uint64_t logic_elapsed_us = 0;
   uint64_t n_ticks = 0;
+  int max_fused = 64;
 
   std::string err;
 };
@@ -559,7 +560,7 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   f.logic = e->logic_on;
   int done = 0;
   while (done < n_steps) {
-    const int chunk = (n_steps - done) < 64 ? (n_steps - done) : 64;
+    const int chunk = (n_steps - done) < e->max_fused ? (n_steps - done) : e->max_fused;
     unsigned long long mask = 0;
     for (int s = 0; s < chunk; s++) {
       e->now_us += dt_us;  // ManualTimer::AdvanceMicroSeconds, main.cpp:392
@@ -587,6 +588,12 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
     done += chunk;
   }
+  return AFE_OK;
+}
+
+extern "C" int afe_set_max_fused_steps(afe_engine *e, int k) {
+  if (!e || k < 1 || k > 64) return fail(e, AFE_ERR_INVALID_ARG, "max fused steps must be in 1..64");
+  e->max_fused = k;
   return AFE_OK;
 }
 

@@ -35,6 +35,7 @@ ABI_FUNCTIONS = [
     "afe_radio_create_rates_command", "afe_radio_create_position_command",
     "afe_radio_create_acceleration_command", "afe_radio_create_simple_command", "afe_radio_decode",
     "afe_telemetry_encode", "afe_telemetry_decode", "afe_set_commands_from_radio",
+    "afe_set_max_fused_steps",
 ]
 
 
@@ -192,6 +193,7 @@ def library():
         "afe_telemetry_encode": [C.POINTER(TelemetryPacket), vp],
         "afe_telemetry_decode": [vp, C.POINTER(TelemetryPacket)],
         "afe_set_commands_from_radio": [eng, i64, i64, vp],
+        "afe_set_max_fused_steps": [eng, ci],
         "afe_checkpoint_size": [eng, C.POINTER(u64)],
         "afe_save_checkpoint": [eng, vp, u64],
         "afe_load_checkpoint": [eng, vp, u64],
@@ -417,6 +419,9 @@ class Ensemble:
     # -- stepping ---------------------------------------------------------
     def step(self, dt_us, n_steps=1):
         self._ck(self._L.afe_step(self._h, int(dt_us), int(n_steps)))
+
+    def set_max_fused_steps(self, k):
+        self._ck(self._L.afe_set_max_fused_steps(self._h, int(k)))
 
     def steps_until_tick(self, dt_us):
         n = C.c_int(0)

@@ -246,7 +246,10 @@ def main():
                 t1 = time_steps(es, k, 1, sync, barrier)
                 tf = time_steps(es, k, 2, sync, barrier)
                 t50 = time_steps(es, k, 50, sync, barrier)
-                sweep.append({"vehicles": n, "vsteps_per_s": n * k / t1,
+                es.set_max_fused_steps(1)       # still one launch per step, issued by the engine's C++ loop
+                tc = time_steps(es, k, k, sync, barrier)
+                es.set_max_fused_steps(64)
+                sweep.append({"vehicles": n, "vsteps_per_s": n * k / t1, "vsteps_per_s_native_loop": n * k / tc,
                               "vsteps_per_s_fused2": n * k / tf, "vsteps_per_s_fused50": n * k / t50})
                 es.close()
             # config 2 closed on the GPU: on-device onboard rates logic, hover command
@@ -263,7 +266,8 @@ def main():
                 es.close()
             out["closed_loop_on_device"] = closed
             out["sweep"] = sweep
-            out["sweep_note"] = ("fused2 = two 1 ms steps per launch (nothing is observable between 500 Hz logic "
+            out["sweep_note"] = ("vsteps_per_s = one launch per step issued from Python; native_loop = the same "
+                                 "launches issued by afe_step's C++ loop (afe_set_max_fused_steps(1)); fused2 = two 1 ms steps per launch (nothing is observable between 500 Hz logic "
                                  "ticks); fused50 = 50 steps per launch, state in registers (open-loop commands)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(afa)

@@ -260,6 +260,11 @@ int afe_set_commands_from_radio(afe_engine *e, int64_t first, int64_t count, con
  * afe_steps_until_tick tells a host-side logicType driver how many steps of
  * dt_us may be fused before its Run() is due (>= 1). */
 int afe_step(afe_engine *e, uint64_t dt_us, int n_steps);
+/* How many sub-steps afe_step may fuse into one kernel launch (1..64, default
+ * 64).  1 = one launch per step (state goes through HBM every step: the
+ * per-step-observable mode bench.py reports); results are bitwise identical
+ * for every setting. */
+int afe_set_max_fused_steps(afe_engine *e, int max_steps_per_launch);
 int afe_steps_until_tick(const afe_engine *e, uint64_t dt_us, int *n_steps);
 int afe_sync(afe_engine *e);
 int afe_time_us(const afe_engine *e, uint64_t *now_us);

@@ -102,3 +102,16 @@ def test_radio_other_message_types(afa):
         m = afa.radio_decode(raw)
         assert m.type == t and m.flags == 0x80
     assert L.afe_radio_create_simple_command(5, 0, raw.ctypes.data) == 1
+
+
+def test_cpp_delay_line_matches_reference_communications_delay(golden_dir):
+    """include/agrifly/Wire.hpp DelayLine vs the reference CommunicationsDelay.hpp
+    behaviour recorded in tests/golden/timer_cadence.json (reference header compiled in place)"""
+    import subprocess
+    cpp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    subprocess.check_call(["make", "-s", "-C", cpp, "test_wire"])
+    for c in json.load(open(os.path.join(golden_dir, "timer_cadence.json")))["cases"]:
+        out = json.loads(subprocess.check_output([os.path.join(cpp, "test_wire"), str(c["advance_us"]),
+                                                  str(len(c["radio_delivered"]))]))
+        assert out["radio_delivered"] == c["radio_delivered"], c["loop_dt_expr"]
+    assert out["type"] == 5 and abs(out["thrust"] - 9.81) < 35 / 32768 and out["bytes"][0] == 5

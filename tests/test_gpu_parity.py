@@ -403,3 +403,20 @@ def test_ragged_sizes(n):
     b.step(1e-3, 6, ticks=_ticks(afa, 1 / 500, 1000, 6))
     _cmp_state(st, b, 1e-11, "n=%d" % n)
     assert rel_err(g, b.gyro, 1.0) < 1e-6
+
+
+def test_max_fused_steps_setting_is_bitwise_neutral():
+    ens = random_ensemble(700, seed=61)
+    outs = []
+    for k in (1, 7, 64):
+        with ens.to_engine(afa.AFE_F32) as e:
+            e.set_max_fused_steps(k)
+            e.step(1000, 90)
+            outs.append((e.get_state(dtype=np.float32), e.get_rng_state(), e.logic_ticks))
+            with pytest.raises(afa.AfeError):
+                e.set_max_fused_steps(65)
+    for st, rng, ticks in outs[1:]:
+        for key in st:
+            np.testing.assert_array_equal(st[key], outs[0][0][key])
+        np.testing.assert_array_equal(rng, outs[0][1])
+        assert ticks == outs[0][2]
