@@ -19,6 +19,8 @@ from .engine import (  # noqa: F401
     AfeError,
     DeviceView,
     Ensemble,
+    PlanOutput,
+    PlannerConfig,
     RADIO_PACKET_SIZE,
     RadioMessage,
     RatesLogicParams,
@@ -30,6 +32,9 @@ from .engine import (  # noqa: F401
     library_path,
     params_from_type,
     plan_ticks,
+    planner_default_config,
+    planner_samples,
+    rappids_plan,
     radio_create_rates_command,
     radio_decode,
     rates_logic_params_from_type,

@@ -1,0 +1,35 @@
+// afe_planner.h -- structures shared by the planner kernel and its host entry point.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/agrifly_engine.h"
+
+namespace afe {
+
+typedef afe_planner_config PlannerConfig;   // same layout as the public C struct
+typedef afe_plan_output PlanOutput;
+
+struct PlannerPyramid {   // RectangularPyramidPlanner::Pyramid (Pyramid.hpp:24-81)
+  double depth;
+  int right, top, left, bottom;
+  double normal[4][3];
+};
+
+struct PlannerBatch {
+  int64_t n;
+  const uint16_t *images;        // [n_images][height][width]
+  const int32_t *image_index;    // [n] or null (image i for planner i)
+  const double *vel0, *acc0, *grav;  // planar [3][n], camera-fixed frame
+  const double *cost_vec;        // planar [3][n] or null (cfg.cost_vec for all)
+  const double *samples;         // [n_tables][n_candidates][4] = pixelX, pixelY, depth, time
+  const int32_t *sample_table;   // [n] or null (table 0 for all)
+  int n_candidates;
+  PlannerPyramid *pyramids;      // [n][max_pyramids] scratch
+  int max_pyramids;
+  PlanOutput *out;               // [n]
+  uint8_t *flags;                // [n][n_candidates] or null
+};
+
+int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream);
+
+}  // namespace afe

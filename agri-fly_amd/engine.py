@@ -35,7 +35,7 @@ ABI_FUNCTIONS = [
     "afe_radio_create_rates_command", "afe_radio_create_position_command",
     "afe_radio_create_acceleration_command", "afe_radio_create_simple_command", "afe_radio_decode",
     "afe_telemetry_encode", "afe_telemetry_decode", "afe_set_commands_from_radio",
-    "afe_set_max_fused_steps",
+    "afe_set_max_fused_steps", "afe_planner_default_config", "afe_planner_samples", "afe_rappids_plan",
 ]
 
 
@@ -102,6 +102,23 @@ class TelemetryPacket(C.Structure):
 
 
 RADIO_PACKET_SIZE, TELEMETRY_PACKET_SIZE = 23, 30
+
+
+class PlannerConfig(C.Structure):
+    """afe_planner_config (RAPPIDS depth-image planner)"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("depth_scale", C.c_double), ("focal_length", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("true_vehicle_radius", C.c_double),
+                ("planning_vehicle_radius", C.c_double), ("min_checking_dist", C.c_double),
+                ("min_thrust", C.c_double), ("max_thrust", C.c_double), ("max_ang_vel", C.c_double),
+                ("max_velocity", C.c_double), ("min_section_time", C.c_double), ("max_pyramids", C.c_int),
+                ("pixel_buffer", C.c_int), ("cost_type", C.c_int), ("cost_vec", C.c_double * 3)]
+
+
+class PlanOutput(C.Structure):
+    _fields_ = [("found", C.c_int), ("best_index", C.c_int), ("best_cost", C.c_double),
+                ("coeffs", (C.c_double * 3) * 6), ("tf", C.c_double), ("n_generated", C.c_int),
+                ("n_cost_checks", C.c_int), ("n_collision_checks", C.c_int), ("n_velocity_checks", C.c_int),
+                ("n_collision_free", C.c_int), ("n_pyramids", C.c_int)]
 
 
 class DeviceView(C.Structure):
@@ -194,6 +211,10 @@ def library():
         "afe_telemetry_decode": [vp, C.POINTER(TelemetryPacket)],
         "afe_set_commands_from_radio": [eng, i64, i64, vp],
         "afe_set_max_fused_steps": [eng, ci],
+        "afe_planner_default_config": [C.POINTER(PlannerConfig), ci, ci] + [C.c_double] * 5,
+        "afe_planner_samples": [C.c_uint32, ci, ci, ci, vp],
+        "afe_rappids_plan": [ci, C.POINTER(PlannerConfig), i64, vp, i64, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp,
+                             C.POINTER(C.c_float)],
         "afe_checkpoint_size": [eng, C.POINTER(u64)],
         "afe_save_checkpoint": [eng, vp, u64],
         "afe_load_checkpoint": [eng, vp, u64],
@@ -242,6 +263,55 @@ def radio_decode(raw):
     if rc:
         raise AfeError(rc, "afe_radio_decode")
     return m
+
+
+def planner_default_config(width, height, depth_scale, focal_length, true_radius, planning_radius,
+                           min_checking_dist):
+    c = PlannerConfig()
+    rc = library().afe_planner_default_config(C.byref(c), width, height, depth_scale, focal_length, true_radius,
+                                              planning_radius, min_checking_dist)
+    if rc:
+        raise AfeError(rc, "afe_planner_default_config")
+    return c
+
+
+def planner_samples(seed, width, height, n_candidates):
+    s = np.empty((n_candidates, 4))
+    rc = library().afe_planner_samples(int(seed), width, height, n_candidates, s.ctypes.data)
+    if rc:
+        raise AfeError(rc, "afe_planner_samples")
+    return s
+
+
+def rappids_plan(cfg, depth_images, vel0, acc0, grav, samples, image_index=None, cost_vec=None,
+                 sample_table=None, want_flags=False, device=-1):
+    """Batched RAPPIDS plan.  depth_images uint16 [n_images, H, W]; vel0/acc0/grav [3, n];
+    samples [n_tables, M, 4] (or [M, 4]).  Returns (PlanOutput array, flags or None, kernel_ms)."""
+    img = np.ascontiguousarray(depth_images, dtype=np.uint16)
+    if img.ndim == 2:
+        img = img[None]
+    v = np.ascontiguousarray(vel0, dtype=np.float64)
+    n = v.shape[1]
+    a = np.ascontiguousarray(acc0, dtype=np.float64)
+    g = np.ascontiguousarray(grav, dtype=np.float64)
+    s = np.ascontiguousarray(samples, dtype=np.float64)
+    if s.ndim == 2:
+        s = s[None]
+    assert img.shape[1:] == (cfg.height, cfg.width) and v.shape == a.shape == g.shape == (3, n) and s.shape[2] == 4
+    idx = None if image_index is None else np.ascontiguousarray(image_index, dtype=np.int32)
+    cv = None if cost_vec is None else np.ascontiguousarray(cost_vec, dtype=np.float64)
+    st = None if sample_table is None else np.ascontiguousarray(sample_table, dtype=np.int32)
+    out = (PlanOutput * n)()
+    flags = np.zeros((n, s.shape[1]), np.uint8) if want_flags else None
+    ms = C.c_float(0)
+    rc = library().afe_rappids_plan(int(device), C.byref(cfg), n, img.ctypes.data, img.shape[0],
+                                    None if idx is None else idx.ctypes.data, v.ctypes.data, a.ctypes.data,
+                                    g.ctypes.data, None if cv is None else cv.ctypes.data, s.ctypes.data, s.shape[0],
+                                    None if st is None else st.ctypes.data, s.shape[1], out,
+                                    None if flags is None else flags.ctypes.data, C.byref(ms))
+    if rc:
+        raise AfeError(rc, library().afe_status_string(rc).decode())
+    return out, flags, ms.value
 
 
 def type_from_id(vehicle_id):

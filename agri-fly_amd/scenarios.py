@@ -131,3 +131,38 @@ def gust_ensemble(n, params, seed=4, sigma_max=0.5, height=3.5, first_global=0, 
         f[axis] = np.sqrt(-2.0 * np.log1p(-u[:, 0])) * np.cos(2 * np.pi * u[:, 1])
     e.ext_force = f * sigma
     return e
+
+
+def synthetic_depth_image(width=320, height=240, seed=0, n_trunks=6, far_m=10.0, depth_scale=10.0 / 256.0,
+                          focal_length=None, trunk_radius_m=(0.10, 0.25), trunk_range_m=(2.0, 9.0),
+                          ground_height_m=1.5):
+    """Config-3 stand-in for the AirSim DepthVis image (the Helios orchard is not in the
+    reference tree): vertical cylinders ("trunks") in front of a
+    pinhole camera (x right, y down, z forward, focal = width/2, principal point = centre;
+    main.cpp:360,484-488) plus a ground plane `ground_height_m` below the camera, quantised
+    like the reference's pipeline: counts = floor(z / depth_scale) clipped to 255 (8-bit
+    DepthVis widened to uint16, main.cpp:121-122,352-354).  Seeded (numpy PCG64)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    f = width / 2.0 if focal_length is None else focal_length
+    cx, cy = width / 2.0, height / 2.0
+    u = (np.arange(width) - cx) / f            # ray direction x/z per column
+    v = (np.arange(height) - cy) / f           # y/z per row
+    depth = np.full((height, width), far_m)
+    # ground plane y = ground_height_m (y points down): z = h / (y/z) for rows looking down
+    with np.errstate(divide="ignore"):
+        zg = np.where(v > 1e-9, ground_height_m / np.maximum(v, 1e-9), np.inf)
+    depth = np.minimum(depth, zg[:, None])
+    for _ in range(n_trunks):
+        r = rng.uniform(*trunk_radius_m)
+        zc = rng.uniform(*trunk_range_m)
+        xc = rng.uniform(-0.6, 0.6) * zc       # inside the horizontal field of view
+        # ray (u, ., 1) z hits the cylinder (x - xc)^2 + (z - zc)^2 = r^2: per column
+        a = u * u + 1.0
+        b = -2.0 * (u * xc + zc)
+        c = xc * xc + zc * zc - r * r
+        disc = b * b - 4 * a * c
+        z_hit = np.where(disc >= 0, (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a), np.inf)
+        z_hit = np.where(z_hit > 0.2, z_hit, np.inf)
+        depth = np.minimum(depth, z_hit[None, :])
+    counts = np.floor(depth / depth_scale)
+    return np.clip(counts, 0, 255).astype(np.uint16)

@@ -245,6 +245,65 @@ int afe_telemetry_decode(const uint8_t in[AFE_TELEMETRY_PACKET_SIZE], afe_teleme
  * modes live in the host-side logic). */
 int afe_set_commands_from_radio(afe_engine *e, int64_t first, int64_t count, const uint8_t *raw_packets);
 
+/* ---- batched RAPPIDS depth-image planner --------------
+ * The caller on the other side of the step: per vehicle, search random minimum-
+ * jerk motion primitives for the lowest-cost one that is input-feasible,
+ * velocity-admissible and collision-free against a depth image, exactly as
+ * RectangularPyramidPlanner::DepthImagePlanner::FindLowestCostTrajectory
+ * (Components/Components/DepthImagePlanner/DepthImagePlanner.cpp:91-212) with
+ * RandomTrajectoryGenerator (DepthImagePlanner.hpp:335-432), IsCollisionFree
+ * (:214-301), InflatePyramid (:456-970) and RapidTrajectoryGenerator
+ * (Components/Components/TrajectoryGenerator/RapidTrajectoryGenerator.cpp:
+ * 75-208), with ONE deliberate change: the reference stops after a wall-clock
+ * budget (main.cpp:498: 50 ms), which makes the number of candidates
+ * nondeterministic; here it is an explicit count.  Everything is double, in the
+ * camera-fixed frame (initial position 0; x right, y down, z into the image). */
+typedef struct afe_planner_config {
+  int width, height;                 /* depth image size [pixels] */
+  double depth_scale;                /* metres per count (main.cpp:121-122: 10/256) */
+  double focal_length, cx, cy;       /* pinhole intrinsics [pixels] (main.cpp:360,484-488) */
+  double true_vehicle_radius;        /* physicalVehicleRadius [m] */
+  double planning_vehicle_radius;    /* vehicleRadiusForPlanning [m] */
+  double min_checking_dist;          /* minimumCollisionDistance [m] */
+  double min_thrust, max_thrust;     /* [m/s^2]; reference defaults 5, 30 (DepthImagePlanner.cpp:43-44) */
+  double max_ang_vel;                /* [rad/s]; default 20 */
+  double max_velocity;               /* [m/s]; default 5 */
+  double min_section_time;           /* [s]; default 0.02 */
+  int max_pyramids;                  /* per plan (SetMaxNumberOfPyramids); also sizes the scratch */
+  int pixel_buffer;                  /* _pyramidSearchPixelBuffer = 2 */
+  int cost_type;                     /* 0: ExplorationCost, -dir.pos(T)/T (DepthImagePlanner.hpp:476-506)
+                                        1: Rappids_Simulator's goal cost, -(|G|-|G-pos(T)|)/T (main.cpp:86-107) */
+  double cost_vec[3];                /* direction or goal (camera frame) when no per-vehicle array is given */
+} afe_planner_config;
+int afe_planner_default_config(afe_planner_config *out, int width, int height, double depth_scale,
+                               double focal_length, double true_vehicle_radius,
+                               double planning_vehicle_radius, double min_checking_dist);
+typedef struct afe_plan_output {
+  int found;            /* FindLowestCostTrajectory's return value */
+  int best_index;       /* winning candidate, -1 if none */
+  double best_cost;
+  double coeffs[6][3];  /* CommonMath::Trajectory of the winner: t^5 .. t^0 (Trajectory.hpp:31-36) */
+  double tf;            /* its duration [s] */
+  int n_generated, n_cost_checks, n_collision_checks, n_velocity_checks, n_collision_free, n_pyramids;
+} afe_plan_output;
+/* Candidate end states exactly as RandomTrajectoryGenerator's default constructor
+ * draws them from std::mt19937(seed) (DepthImagePlanner.hpp:349-366,393-404, with
+ * GCC's right-to-left evaluation of the three arguments): samples[k] = {pixelX,
+ * pixelY, depth [m], duration [s]}.  The reference re-seeds with 0 at every call.
+ * Pure host. */
+int afe_planner_samples(uint32_t seed, int width, int height, int n_candidates, double *samples4);
+/* Plan for n vehicles on GPU `device` (< 0: current).  Host arrays:
+ *   depth_images [n_images][height][width] uint16; image_index[n] or NULL (image i)
+ *   vel0, acc0, grav: planar [3][n]; cost_vec planar [3][n] or NULL (cfg->cost_vec)
+ *   samples [n_tables][n_candidates][4]; sample_table[n] or NULL (table 0)
+ *   out[n]; flags [n][n_candidates] or NULL: TrajectoryTestResult bits per candidate
+ *   (1 LowCost, 2 DynamicsFeasible, 4 VelocityAdmissible, 8 CollisionFree). */
+int afe_rappids_plan(int device, const afe_planner_config *cfg, int64_t n, const uint16_t *depth_images,
+                     int64_t n_images, const int32_t *image_index, const double *vel0, const double *acc0,
+                     const double *grav, const double *cost_vec, const double *samples, int n_tables,
+                     const int32_t *sample_table, int n_candidates, afe_plan_output *out, uint8_t *flags,
+                     float *kernel_ms);
+
 /* ---- stepping -----------------------------------------------------------
  * afe_step replaces the loop body
  *     for (v : vehicles) v->Run();  simTimer.AdvanceMicroSeconds(dt_us);

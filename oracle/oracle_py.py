@@ -298,3 +298,86 @@ class ClosedLoopBatch:
                     self.L.ora_logic_tick(C.byref(self.lp[int(self.b.types[i])]), C.byref(s), g)
                     for m in range(4):
                         self.b.motor_cmd[m, i] = s.motor_speed_cmd[m]
+
+
+# ---------------------------------------------------------------------------
+# RAPPIDS depth-image planner (oracle/agrifly_oracle_planner.c), SURVEY 8f row f3
+
+class OraAxis(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("p0", "v0", "a0", "pf", "vf", "af", "a", "b", "g", "cost")] + \
+               [("peak_t", C.c_double * 2), ("peak_init", C.c_int)]
+
+
+class OraPlannerConfig(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("depth_scale", C.c_double), ("focal_length", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("true_vehicle_radius", C.c_double),
+                ("planning_vehicle_radius", C.c_double), ("min_checking_dist", C.c_double),
+                ("min_thrust", C.c_double), ("max_thrust", C.c_double), ("max_ang_vel", C.c_double),
+                ("max_velocity", C.c_double), ("min_section_time", C.c_double), ("max_pyramids", C.c_int),
+                ("pixel_buffer", C.c_int), ("cost_type", C.c_int), ("cost_vec", C.c_double * 3)]
+
+
+class OraPlanResult(C.Structure):
+    _fields_ = [("found", C.c_int), ("best_index", C.c_int), ("best_cost", C.c_double),
+                ("coeffs", (C.c_double * 3) * 6), ("tf", C.c_double), ("n_generated", C.c_int),
+                ("n_cost_checks", C.c_int), ("n_collision_checks", C.c_int), ("n_velocity_checks", C.c_int),
+                ("n_collision_free", C.c_int), ("n_pyramids", C.c_int)]
+
+
+_planner_bound = False
+
+
+def planner_lib():
+    global _planner_bound
+    L = lib()
+    if not _planner_bound:
+        dp = C.POINTER(C.c_double)
+        L.ora_solve_cubic.argtypes = [C.c_double, C.c_double, C.c_double, dp]
+        L.ora_solve_cubic.restype = C.c_uint
+        L.ora_solve_quartic.argtypes = [C.c_double] * 4 + [dp]
+        L.ora_solve_quartic.restype = C.c_uint
+        L.ora_axis_generate.argtypes = [C.POINTER(OraAxis), C.c_double]
+        L.ora_axis_generate.restype = None
+        L.ora_axis_minmax_acc.argtypes = [C.POINTER(OraAxis), dp, dp, C.c_double, C.c_double]
+        L.ora_axis_minmax_acc.restype = None
+        L.ora_axis_max_jerk_sq.argtypes = [C.POINTER(OraAxis), C.c_double, C.c_double]
+        L.ora_axis_max_jerk_sq.restype = C.c_double
+        for n in ("ora_axis_pos", "ora_axis_vel", "ora_axis_acc"):
+            getattr(L, n).argtypes = [C.POINTER(OraAxis), C.c_double]
+            getattr(L, n).restype = C.c_double
+        L.ora_planner_default_config.argtypes = [C.POINTER(OraPlannerConfig), C.c_int, C.c_int] + [C.c_double] * 5
+        L.ora_planner_default_config.restype = None
+        L.ora_planner_run.argtypes = [C.POINTER(OraPlannerConfig), C.c_void_p, dp, dp, dp, C.c_void_p, C.c_int,
+                                      C.POINTER(OraPlanResult), C.c_void_p]
+        L.ora_planner_run.restype = None
+        L.ora_planner_samples.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ora_planner_samples.restype = None
+        L.ora_planner_sampled_collision.argtypes = [C.POINTER(OraPlannerConfig), C.c_void_p, C.c_void_p, C.c_double, C.c_int]
+        L.ora_planner_sampled_collision.restype = C.c_int
+        _planner_bound = True
+    return L
+
+
+def planner_config(width, height, depth_scale, focal_length, true_radius, planning_radius, min_checking_dist):
+    c = OraPlannerConfig()
+    planner_lib().ora_planner_default_config(C.byref(c), width, height, depth_scale, focal_length, true_radius,
+                                             planning_radius, min_checking_dist)
+    return c
+
+
+def planner_samples(seed, width, height, n):
+    s = np.empty((n, 4))
+    planner_lib().ora_planner_samples(int(seed), width, height, n, s.ctypes.data)
+    return s
+
+
+def planner_run(cfg, depth, vel0, acc0, grav, samples):
+    d = np.ascontiguousarray(depth, dtype=np.uint16)
+    assert d.shape == (cfg.height, cfg.width)
+    s = np.ascontiguousarray(samples, dtype=np.float64)
+    flags = np.zeros(len(s), np.uint8)
+    res = OraPlanResult()
+    v, a, g = [np.ascontiguousarray(x, dtype=np.float64) for x in (vel0, acc0, grav)]
+    planner_lib().ora_planner_run(C.byref(cfg), d.ctypes.data, _dp(v), _dp(a), _dp(g), s.ctypes.data, len(s),
+                                  C.byref(res), flags.ctypes.data)
+    return res, flags

@@ -17,6 +17,8 @@ Run in the build container (needs /root/reference for the timer probe):
   gyro / accelerometer settings.
 * telemetry_kat.json  <- oracle/_ref/telemetry_probe: the REFERENCE's own
   TelemetryPacket.hpp (stand-alone header): packets -> 30-byte wire form -> back.
+* planner_math_kat.json <- oracle/_ref/traj_probe: the REFERENCE's own RootFinder.hpp
+  and SingleAxisTrajectory.{hpp,cpp} (stand-alone sources) + libstdc++ mt19937.
 * oracle_regression.npz <- the oracle itself (NOT the reference): seeded
   single-step / rollout vectors that freeze the restatement so later edits of
   oracle/agrifly_oracle.c cannot drift silently.  It pins nothing against the
@@ -88,6 +90,12 @@ def main():
                         "EncodeTelemetryPacket / DecodeTelemetryPacket)")
     with open(os.path.join(HERE, "telemetry_kat.json"), "w") as f:
         json.dump(tel, f, indent=0)
+
+    pm = json.loads(subprocess.check_output([os.path.join(ref, "traj_probe"), "64", "20261002"]))
+    pm["generator"] = ("oracle/_ref/traj_probe (reference RootFinder.hpp and SingleAxisTrajectory.{hpp,cpp} compiled in "
+                       "place; libstdc++ mt19937 + uniform_real_distribution in the planner's call shape)")
+    with open(os.path.join(HERE, "planner_math_kat.json"), "w") as f:
+        json.dump(pm, f, indent=0)
 
     # --- oracle regression vectors (oracle-generated; not a reference pin) ---
     from tests.scenarios import random_ensemble

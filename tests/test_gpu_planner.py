@@ -1,0 +1,133 @@
+"""Batched RAPPIDS planner on the GPU (BASELINE config 3 shape) against
+the oracle: the chosen candidate, every candidate's TrajectoryTestResult bits, the counters and
+the pyramid count must be IDENTICAL (integer / index work); coefficients to 1e-12.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from tests.scenarios import afa
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(ora_cfg):
+    c = afa.planner_default_config(ora_cfg.width, ora_cfg.height, ora_cfg.depth_scale, ora_cfg.focal_length,
+                                   ora_cfg.true_vehicle_radius, ora_cfg.planning_vehicle_radius,
+                                   ora_cfg.min_checking_dist)
+    c.max_pyramids = 64
+    c.cost_type = ora_cfg.cost_type
+    for k in range(3):
+        c.cost_vec[k] = ora_cfg.cost_vec[k]
+    return c
+
+
+def _compare(out, flags, refs):
+    for i, (res, rflags) in enumerate(refs):
+        o = out[i]
+        assert (o.found, o.best_index) == (res.found, res.best_index), i
+        np.testing.assert_array_equal(flags[i], rflags, err_msg="vehicle %d" % i)
+        assert (o.n_generated, o.n_cost_checks, o.n_collision_checks, o.n_velocity_checks, o.n_collision_free,
+                o.n_pyramids) == (res.n_generated, res.n_cost_checks, res.n_collision_checks,
+                                  res.n_velocity_checks, res.n_collision_free, res.n_pyramids), i
+        if res.found:
+            assert o.best_cost == pytest.approx(res.best_cost, rel=1e-14)
+            assert o.tf == res.tf
+            got = np.array([[o.coeffs[q][a] for a in range(3)] for q in range(6)])
+            want = np.array([[res.coeffs[q][a] for a in range(3)] for q in range(6)])
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14)
+
+
+def test_planner_matches_oracle_varied_states_and_images(ora):
+    rng = np.random.default_rng(7)
+    n, m, n_img = 96, 256, 6
+    images = np.stack([afa.scenarios.synthetic_depth_image(seed=200 + k, n_trunks=4 + k) for k in range(n_img)])
+    ocfg = ora.planner_config(320, 240, 10.0 / 256.0, 160.0, 0.116, 0.174, 0.5)
+    ocfg.max_pyramids = 64
+    ocfg.cost_type = 1
+    ocfg.cost_vec[0], ocfg.cost_vec[1], ocfg.cost_vec[2] = 0.0, 0.0, 120.0
+    image_index = rng.integers(0, n_img, n).astype(np.int32)
+    vel0 = np.stack([rng.normal(0, 0.5, n), rng.normal(0, 0.3, n), rng.uniform(0, 2.5, n)])
+    acc0 = rng.normal(0, 0.5, (3, n))
+    grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n))       # camera y points down
+    tables = np.stack([ora.planner_samples(seed, 320, 240, m) for seed in (0, 1, 2)])
+    table = rng.integers(0, 3, n).astype(np.int32)
+    refs = [ora.planner_run(ocfg, images[image_index[i]], vel0[:, i], acc0[:, i], grav[:, i], tables[table[i]])
+            for i in range(n)]
+    out, flags, ms = afa.rappids_plan(_cfg(ocfg), images, vel0, acc0, grav, tables, image_index=image_index,
+                                      sample_table=table, want_flags=True)
+    _compare(out, flags, refs)
+    assert sum(r[0].found for r in refs) > n // 2
+    assert max(r[0].n_pyramids for r in refs) >= 3
+
+
+def test_planner_exploration_cost_and_per_vehicle_directions(ora):
+    rng = np.random.default_rng(8)
+    n, m = 40, 200
+    img = afa.scenarios.synthetic_depth_image(seed=31, n_trunks=5)
+    ocfg = ora.planner_config(320, 240, 10.0 / 256.0, 160.0, 0.116, 0.174, 0.5)
+    ocfg.max_pyramids = 64
+    dirs = rng.normal(0, 1, (3, n))
+    dirs[2] = np.abs(dirs[2]) + 1.0
+    vel0 = np.stack([np.zeros(n), np.zeros(n), rng.uniform(0.2, 2.0, n)])
+    acc0 = np.zeros((3, n))
+    grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n))
+    samples = ora.planner_samples(0, 320, 240, m)
+    refs = []
+    for i in range(n):
+        for k in range(3):
+            ocfg.cost_vec[k] = dirs[k, i]
+        refs.append(ora.planner_run(ocfg, img, vel0[:, i], acc0[:, i], grav[:, i], samples))
+    out, flags, _ = afa.rappids_plan(_cfg(ocfg), img, vel0, acc0, grav, samples,
+                                     image_index=np.zeros(n, np.int32), cost_vec=dirs, want_flags=True)
+    _compare(out, flags, refs)
+
+
+def test_planner_blocked_and_pyramid_limit(ora):
+    n, m = 8, 128
+    wall = np.full((240, 320), 30, np.uint16)
+    ocfg = ora.planner_config(320, 240, 10.0 / 256.0, 160.0, 0.116, 0.174, 0.5)
+    ocfg.max_pyramids = 2
+    vel0 = np.tile(np.array([[0.0], [0.0], [1.0]]), (1, n))
+    acc0 = np.zeros((3, n))
+    grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n))
+    samples = ora.planner_samples(0, 320, 240, m)
+    cfg = _cfg(ocfg)
+    cfg.max_pyramids = 2
+    out, flags, _ = afa.rappids_plan(cfg, wall, vel0, acc0, grav, samples, image_index=np.zeros(n, np.int32),
+                                     want_flags=True)
+    assert all(o.found == 0 and o.best_index == -1 for o in out)
+    img = afa.scenarios.synthetic_depth_image(seed=3)
+    refs = [ora.planner_run(ocfg, img, vel0[:, i], acc0[:, i], grav[:, i], samples) for i in range(n)]
+    out, flags, _ = afa.rappids_plan(cfg, img, vel0, acc0, grav, samples, image_index=np.zeros(n, np.int32),
+                                     want_flags=True)
+    _compare(out, flags, refs)
+    assert all(o.n_pyramids <= 2 for o in out)
+
+
+def test_config3_shape_65536_planners():
+    """BASELINE config 3 shape: 65536 vehicles, one synthetic depth image each from a pool of 16,
+    256 candidates; size-independent properties + a subsample against the oracle."""
+    from oracle import oracle_py as ora
+    rng = np.random.default_rng(9)
+    n, m, n_img = 65536, 256, 16
+    images = np.stack([afa.scenarios.synthetic_depth_image(seed=300 + k, n_trunks=3 + k % 6) for k in range(n_img)])
+    ocfg = ora.planner_config(320, 240, 10.0 / 256.0, 160.0, 0.116, 0.174, 0.5)
+    ocfg.max_pyramids = 64
+    ocfg.cost_type = 1
+    ocfg.cost_vec[2] = 120.0
+    image_index = (np.arange(n) % n_img).astype(np.int32)
+    vel0 = np.stack([rng.normal(0, 0.4, n), rng.normal(0, 0.2, n), rng.uniform(0, 2.0, n)])
+    acc0 = rng.normal(0, 0.3, (3, n))
+    grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n))
+    samples = ora.planner_samples(0, 320, 240, m)
+    out, flags, ms = afa.rappids_plan(_cfg(ocfg), images, vel0, acc0, grav, samples, image_index=image_index,
+                                      want_flags=True)
+    found = np.array([o.found for o in out])
+    best = np.array([o.best_index for o in out])
+    assert found.mean() > 0.5
+    assert np.all((best >= 0) == (found == 1))
+    assert np.all(np.isin(flags, (0, 1, 3, 7, 15)))
+    assert np.all(flags[np.arange(n)[found == 1], best[found == 1]] == 15)
+    idx = rng.choice(n, 48, replace=False)
+    refs = [ora.planner_run(ocfg, images[image_index[i]], vel0[:, i], acc0[:, i], grav[:, i], samples) for i in idx]
+    _compare([out[i] for i in idx], flags[idx], refs)
+    print("config-3 shape: %d planners x %d candidates in %.1f ms (%.3g plans/s)" % (n, m, ms, n / (ms * 1e-3)))
