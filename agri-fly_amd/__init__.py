@@ -17,6 +17,8 @@ from .engine import (  # noqa: F401
     AFE_SEED_DECORRELATED,
     AFE_SEED_REFERENCE,
     AfeError,
+    Camera,
+    DeviceBuffer,
     DeviceView,
     Ensemble,
     PlanOutput,
@@ -24,10 +26,13 @@ from .engine import (  # noqa: F401
     RADIO_PACKET_SIZE,
     RadioMessage,
     RatesLogicParams,
+    Scene,
     TELEMETRY_PACKET_SIZE,
     TelemetryPacket,
     VehicleParams,
     build_library,
+    camera_default,
+    camera_default_mount,
     library,
     library_path,
     params_from_type,

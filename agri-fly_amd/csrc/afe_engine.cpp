@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "afe_host.h"
+#include "afe_render.h"
 
 using namespace afe;
 
@@ -636,6 +637,14 @@ extern "C" int afe_get_imu(afe_engine *e, int64_t first, int64_t count, float *g
   if ((rc = copy_out(e, e->gyro, 4, 3, first, count, gyro3))) return rc;
   return copy_out(e, e->acc, 4, 3, first, count, acc3);
 }
+
+namespace afe {
+// for the other translation units of the library (afe_render.hip)
+void engine_stream_device(afe_engine *e, void **stream, int *device) {
+  *stream = (void *)e->stream;
+  *device = e->device;
+}
+}  // namespace afe
 
 extern "C" int afe_get_device_view(afe_engine *e, afe_device_view *out) {
   if (!e || !out) return AFE_ERR_INVALID_ARG;

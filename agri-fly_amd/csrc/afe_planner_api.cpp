@@ -58,11 +58,11 @@ struct DevBuf {
 };
 }  // namespace
 
-extern "C" int afe_rappids_plan(int device, const afe_planner_config *cfg, int64_t n, const uint16_t *depth_images,
-                                int64_t n_images, const int32_t *image_index, const double *vel0,
-                                const double *acc0, const double *grav, const double *cost_vec,
-                                const double *samples, int n_tables, const int32_t *sample_table,
-                                int n_candidates, afe_plan_output *out, uint8_t *flags, float *kernel_ms) {
+static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const uint16_t *depth_images,
+                     bool depth_on_device, int64_t n_images, const int32_t *image_index, const double *vel0,
+                     const double *acc0, const double *grav, const double *cost_vec, const double *samples,
+                     int n_tables, const int32_t *sample_table, int n_candidates, afe_plan_output *out,
+                     uint8_t *flags, float *kernel_ms) {
   if (!cfg || n <= 0 || !depth_images || n_images <= 0 || !vel0 || !acc0 || !grav || !samples || n_tables <= 0 ||
       n_candidates <= 0 || !out || cfg->max_pyramids <= 0 || cfg->width <= 0 || cfg->height <= 0)
     return AFE_ERR_INVALID_ARG;
@@ -82,7 +82,7 @@ extern "C" int afe_rappids_plan(int device, const afe_planner_config *cfg, int64
 
   const size_t px = (size_t)cfg->width * cfg->height;
   DevBuf d_img, d_idx, d_v, d_a, d_g, d_c, d_s, d_t, d_pyr, d_out, d_flags;
-  if (!d_img.upload(depth_images, (size_t)n_images * px * 2) || !d_v.upload(vel0, (size_t)n * 24) ||
+  if ((!depth_on_device && !d_img.upload(depth_images, (size_t)n_images * px * 2)) || !d_v.upload(vel0, (size_t)n * 24) ||
       !d_a.upload(acc0, (size_t)n * 24) || !d_g.upload(grav, (size_t)n * 24) ||
       !d_s.upload(samples, (size_t)n_tables * n_candidates * 32))
     return AFE_ERR_HIP;
@@ -95,7 +95,7 @@ extern "C" int afe_rappids_plan(int device, const afe_planner_config *cfg, int64
 
   PlannerBatch b;
   b.n = n;
-  b.images = (const uint16_t *)d_img.p;
+  b.images = depth_on_device ? depth_images : (const uint16_t *)d_img.p;
   b.image_index = image_index ? (const int32_t *)d_idx.p : nullptr;
   b.vel0 = (const double *)d_v.p; b.acc0 = (const double *)d_a.p; b.grav = (const double *)d_g.p;
   b.cost_vec = cost_vec ? (const double *)d_c.p : nullptr;
@@ -122,4 +122,23 @@ extern "C" int afe_rappids_plan(int device, const afe_planner_config *cfg, int64
   if (hipMemcpy(out, d_out.p, (size_t)n * sizeof(PlanOutput), hipMemcpyDeviceToHost) != hipSuccess) return AFE_ERR_HIP;
   if (flags && hipMemcpy(flags, d_flags.p, (size_t)n * n_candidates, hipMemcpyDeviceToHost) != hipSuccess) return AFE_ERR_HIP;
   return AFE_OK;
+}
+
+extern "C" int afe_rappids_plan(int device, const afe_planner_config *cfg, int64_t n, const uint16_t *depth_images,
+                                int64_t n_images, const int32_t *image_index, const double *vel0,
+                                const double *acc0, const double *grav, const double *cost_vec,
+                                const double *samples, int n_tables, const int32_t *sample_table,
+                                int n_candidates, afe_plan_output *out, uint8_t *flags, float *kernel_ms) {
+  return plan_impl(device, cfg, n, depth_images, false, n_images, image_index, vel0, acc0, grav, cost_vec, samples,
+                   n_tables, sample_table, n_candidates, out, flags, kernel_ms);
+}
+
+extern "C" int afe_rappids_plan_device(int device, const afe_planner_config *cfg, int64_t n,
+                                       const void *dev_depth_images, int64_t n_images, const int32_t *image_index,
+                                       const double *vel0, const double *acc0, const double *grav,
+                                       const double *cost_vec, const double *samples, int n_tables,
+                                       const int32_t *sample_table, int n_candidates, afe_plan_output *out,
+                                       uint8_t *flags, float *kernel_ms) {
+  return plan_impl(device, cfg, n, (const uint16_t *)dev_depth_images, true, n_images, image_index, vel0, acc0, grav,
+                   cost_vec, samples, n_tables, sample_table, n_candidates, out, flags, kernel_ms);
 }

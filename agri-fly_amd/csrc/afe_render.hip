@@ -1,0 +1,588 @@
+// afe_render.hip -- depth camera for the whole ensemble.
+//
+// Replaces the AirSim DepthVis RPC of Simulator/Rappids_Simulator/main.cpp:332-354 (and
+// its image contract, :120-125,360): one ray per pixel, closest hit over a static
+// triangle mesh, z-depth quantised to counts.  The reference has no renderer of its own;
+// the test suite's CPU checker is a brute-force statement of the same contract and the
+// kernel below performs the same fp64 operations per ray / triangle pair in the same order
+// (no FMA contraction), so images are compared bit for bit.
+//
+// MI355X mapping
+//   * one wave (64 lanes) per 16x4 pixel tile of one view: neighbouring rays walk the
+//     same part of the tree, so node / triangle loads coalesce into a few lines;
+//   * the BVH (32-byte nodes, sibling pairs adjacent = one 64-byte line per inner-node
+//     visit) and the 48-byte padded triangles stay in HBM and are served from L2 /
+//     Infinity Cache; the block index is remapped so that each XCD (own L2) renders a
+//     contiguous range of views;
+//   * per-lane traversal stack in LDS, [depth][lane] layout (conflict-free), 32 entries:
+//     the host builder guarantees the tree depth fits;
+//   * poses are prepared by a small kernel straight from the engine's state slabs, so a
+//     closed loop never leaves the device: step -> render -> plan.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "afe_render.h"
+
+namespace afe {
+
+// ---------------------------------------------------------------------------------------
+// host: BVH construction (binned SAH, median fallback)
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct Box {
+  float lo[3], hi[3];
+  void reset() {
+    for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -lo[k]; }
+  }
+  void grow(const float *p) {
+    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+  }
+  void grow(const Box &b) {
+    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+  }
+  float half_area() const {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct Builder {
+  const float *tri;              // n x 9
+  std::vector<Box> tri_box;
+  std::vector<float> centroid;   // n x 3
+  std::vector<int32_t> order;    // permutation being partitioned
+  std::vector<BvhNode> nodes;
+  int max_depth = 0;
+  bool median_only = false;
+
+  static constexpr int kBins = 16;
+  static constexpr int kLeaf = 4;
+
+  Box range_box(int64_t first, int64_t count) const {
+    Box b; b.reset();
+    for (int64_t i = first; i < first + count; i++) b.grow(tri_box[order[i]]);
+    return b;
+  }
+
+  void set_bounds(BvhNode &n, const Box &b) const {
+    // inflate outward: the traversal's slab test may then round either way without ever
+    // rejecting a box whose triangles the ray touches
+    for (int k = 0; k < 3; k++) {
+      const float eps = 1e-4f + 1e-6f * std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
+      n.lo[k] = std::nextafterf(b.lo[k] - eps, -std::numeric_limits<float>::infinity());
+      n.hi[k] = std::nextafterf(b.hi[k] + eps, std::numeric_limits<float>::infinity());
+    }
+  }
+
+  // returns the split position (first index of the right part) or -1 for "make a leaf"
+  int64_t split(int64_t first, int64_t count) {
+    Box cb; cb.reset();
+    for (int64_t i = first; i < first + count; i++) cb.grow(&centroid[3 * (size_t)order[i]]);
+    int axis = 0;
+    float ext = -1;
+    for (int k = 0; k < 3; k++) if (cb.hi[k] - cb.lo[k] > ext) { ext = cb.hi[k] - cb.lo[k]; axis = k; }
+    auto median = [&]() -> int64_t {
+      const int64_t mid = first + count / 2;
+      std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                       [&](int32_t a, int32_t b) {
+                         const float ca = centroid[3 * (size_t)a + axis], cb2 = centroid[3 * (size_t)b + axis];
+                         return ca < cb2 || (ca == cb2 && a < b);
+                       });
+      return mid;
+    };
+    if (count <= kLeaf) return -1;
+    if (median_only || !(ext > 0)) return median();
+
+    float best_cost = std::numeric_limits<float>::infinity();
+    int best_axis = -1, best_bin = -1;
+    for (int k = 0; k < 3; k++) {
+      const float e = cb.hi[k] - cb.lo[k];
+      if (!(e > 0)) continue;
+      Box bin_box[kBins];
+      int64_t bin_n[kBins];
+      for (int b = 0; b < kBins; b++) { bin_box[b].reset(); bin_n[b] = 0; }
+      const float scale = kBins / e;
+      for (int64_t i = first; i < first + count; i++) {
+        const int32_t t = order[i];
+        int b = (int)((centroid[3 * (size_t)t + k] - cb.lo[k]) * scale);
+        b = std::min(std::max(b, 0), kBins - 1);
+        bin_box[b].grow(tri_box[t]);
+        bin_n[b]++;
+      }
+      float right_area[kBins];
+      Box acc; acc.reset();
+      for (int b = kBins - 1; b > 0; b--) { acc.grow(bin_box[b]); right_area[b] = acc.half_area(); }
+      acc.reset();
+      int64_t nl = 0;
+      for (int b = 0; b < kBins - 1; b++) {
+        acc.grow(bin_box[b]);
+        nl += bin_n[b];
+        const int64_t nr = count - nl;
+        if (nl == 0 || nr == 0) continue;
+        const float cost = acc.half_area() * (float)nl + right_area[b + 1] * (float)nr;
+        if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = b; }
+      }
+    }
+    if (best_axis < 0) return median();
+    const float e = cb.hi[best_axis] - cb.lo[best_axis];
+    const float scale = kBins / e;
+    const float lo = cb.lo[best_axis];
+    auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int32_t t) {
+      int b = (int)((centroid[3 * (size_t)t + best_axis] - lo) * scale);
+      b = std::min(std::max(b, 0), kBins - 1);
+      return b <= best_bin;
+    });
+    const int64_t mid = it - order.begin();
+    if (mid == first || mid == first + count) return median();
+    return mid;
+  }
+
+  void build(int64_t n) {
+    tri_box.resize((size_t)n);
+    centroid.resize(3 * (size_t)n);
+    order.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+      Box b; b.reset();
+      for (int v = 0; v < 3; v++) b.grow(tri + 9 * i + 3 * v);
+      tri_box[(size_t)i] = b;
+      for (int k = 0; k < 3; k++) centroid[3 * (size_t)i + k] = 0.5f * (b.lo[k] + b.hi[k]);
+      order[(size_t)i] = (int32_t)i;
+    }
+    nodes.clear();
+    nodes.reserve((size_t)(2 * n + 2));
+    nodes.push_back(BvhNode());
+    struct Work { int32_t node; int64_t first, count; int depth; };
+    std::vector<Work> todo;
+    todo.push_back({0, 0, n, 1});
+    max_depth = 1;
+    while (!todo.empty()) {
+      const Work w = todo.back();
+      todo.pop_back();
+      max_depth = std::max(max_depth, w.depth);
+      const Box b = range_box(w.first, w.count);
+      set_bounds(nodes[(size_t)w.node], b);
+      const int64_t mid = w.count > 1 ? split(w.first, w.count) : -1;
+      if (mid < 0) {
+        nodes[(size_t)w.node].a = (int32_t)w.first;
+        nodes[(size_t)w.node].b = (int32_t)w.count;
+        continue;
+      }
+      const int32_t left = (int32_t)nodes.size();
+      nodes.push_back(BvhNode());
+      nodes.push_back(BvhNode());
+      nodes[(size_t)w.node].a = left;
+      nodes[(size_t)w.node].b = 0;
+      todo.push_back({left, w.first, mid - w.first, w.depth + 1});
+      todo.push_back({left + 1, mid, w.first + w.count - mid, w.depth + 1});
+    }
+  }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------
+constexpr int kTileW = 16, kTileH = 4, kStack = 32;
+
+struct PoseArgs {
+  const void *pos, *att;      // planar, `stride` elements between components
+  int64_t stride, first, count;
+  int elem_size;              // 4 or 8
+  double mount[4];
+  double *poses;              // [count][12] = origin, row-major camera-to-world matrix
+};
+
+__global__ void afe_camera_pose_kernel(PoseArgs a) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.count) return;
+  const int64_t v = a.first + i;
+  double p[3], q[4];
+  if (a.elem_size == 8) {
+    const double *P = (const double *)a.pos, *Q = (const double *)a.att;
+    for (int k = 0; k < 3; k++) p[k] = P[k * a.stride + v];
+    for (int k = 0; k < 4; k++) q[k] = Q[k * a.stride + v];
+  } else {
+    const float *P = (const float *)a.pos, *Q = (const float *)a.att;
+    for (int k = 0; k < 3; k++) p[k] = (double)P[k * a.stride + v];
+    for (int k = 0; k < 4; k++) q[k] = (double)Q[k * a.stride + v];
+  }
+  const double *m = a.mount;
+  // att * mount, Rotation.hpp:124-131
+  const double c0 = m[0] * q[0] - m[1] * q[1] - m[2] * q[2] - m[3] * q[3];
+  const double c1 = m[1] * q[0] + m[0] * q[1] + m[3] * q[2] - m[2] * q[3];
+  const double c2 = m[2] * q[0] - m[3] * q[1] + m[0] * q[2] + m[1] * q[3];
+  const double c3 = m[3] * q[0] + m[2] * q[1] - m[1] * q[2] + m[0] * q[3];
+  const double r0 = c0 * c0, r1 = c1 * c1, r2 = c2 * c2, r3 = c3 * c3;
+  double *o = a.poses + 12 * i;
+  o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+  // Rotation.hpp:196-220
+  o[3] = r0 + r1 - r2 - r3;
+  o[4] = 2 * c1 * c2 - 2 * c0 * c3;
+  o[5] = 2 * c1 * c3 + 2 * c0 * c2;
+  o[6] = 2 * c1 * c2 + 2 * c0 * c3;
+  o[7] = r0 - r1 + r2 - r3;
+  o[8] = 2 * c2 * c3 - 2 * c0 * c1;
+  o[9] = 2 * c1 * c3 - 2 * c0 * c2;
+  o[10] = 2 * c2 * c3 + 2 * c0 * c1;
+  o[11] = r0 - r1 - r2 + r3;
+}
+
+struct RenderArgs {
+  const BvhNode *nodes;
+  const float4 *tris;       // 3 float4 per triangle: v0, v1, v2 (w unused)
+  const double *poses;
+  uint16_t *out;
+  int64_t n_views, n_blocks, blocks_per_xcd;
+  int width, height, tiles_x, tiles_per_view;
+  double focal, cx, cy, depth_scale;
+  int max_count;
+};
+
+// slab test against one node's (inflated) box; returns the entry distance or +inf
+__device__ __forceinline__ double box_entry(const BvhNode &n, const double o[3], const double inv[3], double best) {
+  double tmin = 0.0, tmax = best;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double t0 = ((double)n.lo[k] - o[k]) * inv[k];
+    const double t1 = ((double)n.hi[k] - o[k]) * inv[k];
+    tmin = fmax(tmin, fmin(t0, t1));
+    tmax = fmin(tmax, fmax(t0, t1));
+  }
+  return tmin <= tmax ? tmin : INFINITY;
+}
+
+__device__ __forceinline__ double ray_triangle(const double o[3], const double d[3], const float4 a, const float4 b,
+                                               const float4 c) {
+#pragma clang fp contract(off)
+  // Moeller-Trumbore, two-sided; operation order is part of the contract (see file header)
+  const double v0[3] = {(double)a.x, (double)a.y, (double)a.z};
+  const double e1[3] = {(double)b.x - v0[0], (double)b.y - v0[1], (double)b.z - v0[2]};
+  const double e2[3] = {(double)c.x - v0[0], (double)c.y - v0[1], (double)c.z - v0[2]};
+  const double p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+  const double det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+  if (fabs(det) < 1e-12) return INFINITY;
+  const double inv = 1.0 / det;
+  const double tv[3] = {o[0] - v0[0], o[1] - v0[1], o[2] - v0[2]};
+  const double u = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) * inv;
+  if (u < 0.0 || u > 1.0) return INFINITY;
+  const double q[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+  const double v = (d[0] * q[0] + d[1] * q[1] + d[2] * q[2]) * inv;
+  if (v < 0.0 || u + v > 1.0) return INFINITY;
+  const double t = (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]) * inv;
+  return t > 0.0 ? t : INFINITY;
+}
+
+__global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(RenderArgs a) {
+#pragma clang fp contract(off)
+  __shared__ int32_t stack_node[kStack][kTileW * kTileH];
+  __shared__ float stack_t[kStack][kTileW * kTileH];
+
+  // XCD-aware order: hardware block b runs on XCD b % 8; give each XCD a contiguous run
+  // of logical blocks (= consecutive tiles of consecutive views) so that its L2 keeps the
+  // part of the tree those views look at
+  const int64_t hw = blockIdx.x;
+  const int64_t logical = (hw % 8) * a.blocks_per_xcd + hw / 8;
+  if (logical >= a.n_blocks) return;
+  const int64_t view = logical / a.tiles_per_view;
+  const int tile = (int)(logical - view * a.tiles_per_view);
+  const int lane = threadIdx.x;
+  const int px = (tile % a.tiles_x) * kTileW + (lane % kTileW);
+  const int py = (tile / a.tiles_x) * kTileH + (lane / kTileW);
+  if (px >= a.width || py >= a.height) return;
+
+  const double *pose = a.poses + 12 * view;
+  const double o[3] = {pose[0], pose[1], pose[2]};
+  const double u = (px - a.cx) / a.focal;
+  const double v = (py - a.cy) / a.focal;
+  const double d[3] = {pose[3] * u + pose[4] * v + pose[5], pose[6] * u + pose[7] * v + pose[8],
+                       pose[9] * u + pose[10] * v + pose[11]};
+  const double inv[3] = {1.0 / d[0], 1.0 / d[1], 1.0 / d[2]};
+
+  double best = INFINITY;
+  int sp = 0;
+  int32_t node = 0;
+  bool live = box_entry(a.nodes[0], o, inv, best) < INFINITY;
+  while (live) {
+    const BvhNode n = a.nodes[node];
+    bool descended = false;
+    if (n.b > 0) {
+      for (int k = 0; k < n.b; k++) {
+        const float4 *t = a.tris + 3 * (int64_t)(n.a + k);
+        const double th = ray_triangle(o, d, t[0], t[1], t[2]);
+        if (th < best) best = th;
+      }
+    } else {
+      const BvhNode l = a.nodes[n.a], r = a.nodes[n.a + 1];
+      const double tl = box_entry(l, o, inv, best), tr = box_entry(r, o, inv, best);
+      const bool hl = tl < INFINITY, hr = tr < INFINITY;
+      if (hl && hr) {
+        const bool left_first = tl <= tr;
+        stack_node[sp][lane] = left_first ? n.a + 1 : n.a;
+        stack_t[sp][lane] = __double2float_rd(left_first ? tr : tl);
+        sp++;
+        node = left_first ? n.a : n.a + 1;
+        descended = true;
+      } else if (hl || hr) {
+        node = hl ? n.a : n.a + 1;
+        descended = true;
+      }
+    }
+    if (descended) continue;
+    live = false;
+    while (sp > 0) {
+      sp--;
+      if ((double)stack_t[sp][lane] < best) { node = stack_node[sp][lane]; live = true; break; }
+    }
+  }
+
+  uint16_t count = (uint16_t)a.max_count;
+  if (best < INFINITY) {
+    const double c = floor(best / a.depth_scale);
+    if (c < (double)a.max_count) count = (uint16_t)c;
+  }
+  a.out[(view * a.height + py) * (int64_t)a.width + px] = count;
+}
+
+}  // namespace afe
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+using namespace afe;
+
+struct afe_scene {
+  int device = 0;
+  int64_t n_tri = 0, n_nodes = 0;
+  int depth = 0;
+  double bounds[6] = {0, 0, 0, 0, 0, 0};
+  BvhNode *nodes = nullptr;
+  float4 *tris = nullptr;
+};
+
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess; }
+  bool upload(const void *src, size_t bytes) {
+    return alloc(bytes) && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  }
+};
+
+int pick_device(int device, int *out) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return AFE_ERR_NO_DEVICE;
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return AFE_ERR_NO_DEVICE;
+  if (device >= n_dev) return AFE_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return AFE_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return AFE_ERR_HIP;
+  *out = device;
+  return AFE_OK;
+}
+
+bool camera_ok(const afe_camera *c) {
+  return c && c->width > 0 && c->height > 0 && c->focal_length > 0 && c->depth_scale > 0 && c->max_count > 0 &&
+         c->max_count <= 65535;
+}
+
+// poses (device, [count][12]) -> images; out_dev: device buffer of count*h*w uint16
+int launch_render(const afe_scene *s, const afe_camera *cam, int64_t count, const double *poses, uint16_t *out_dev,
+                  hipStream_t stream, float *kernel_ms) {
+  RenderArgs r;
+  r.nodes = s->nodes; r.tris = s->tris; r.poses = poses; r.out = out_dev;
+  r.n_views = count;
+  r.width = cam->width; r.height = cam->height;
+  r.tiles_x = (cam->width + kTileW - 1) / kTileW;
+  r.tiles_per_view = r.tiles_x * ((cam->height + kTileH - 1) / kTileH);
+  r.n_blocks = count * r.tiles_per_view;
+  r.blocks_per_xcd = (r.n_blocks + 7) / 8;
+  r.focal = cam->focal_length; r.cx = cam->cx; r.cy = cam->cy; r.depth_scale = cam->depth_scale;
+  r.max_count = cam->max_count;
+  const int64_t grid = r.blocks_per_xcd * 8;
+  if (grid <= 0 || grid > 0x7fffffffLL) return AFE_ERR_OUT_OF_RANGE;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (kernel_ms && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return AFE_ERR_HIP;
+  if (kernel_ms) (void)hipEventRecord(e0, stream);
+  hipLaunchKernelGGL(afe_render_depth_kernel, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
+  int rc = hipGetLastError() == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+  if (kernel_ms) {
+    (void)hipEventRecord(e1, stream);
+    if (rc == AFE_OK && hipEventSynchronize(e1) != hipSuccess) rc = AFE_ERR_HIP;
+    if (rc == AFE_OK) (void)hipEventElapsedTime(kernel_ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  return rc;
+}
+
+int launch_poses(const void *pos, const void *att, int64_t stride, int64_t first, int64_t count, int elem_size,
+                 const double mount[4], double *poses, hipStream_t stream) {
+  PoseArgs p;
+  p.pos = pos; p.att = att; p.stride = stride; p.first = first; p.count = count; p.elem_size = elem_size;
+  static const double identity[4] = {1, 0, 0, 0};
+  const double *m = mount ? mount : identity;
+  for (int k = 0; k < 4; k++) p.mount[k] = m[k];
+  p.poses = poses;
+  hipLaunchKernelGGL(afe_camera_pose_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+}
+}  // namespace
+
+extern "C" int afe_camera_default(afe_camera *cam, int width, int height) {
+  if (!cam || width <= 0 || height <= 0) return AFE_ERR_INVALID_ARG;
+  std::memset(cam, 0, sizeof(*cam));
+  cam->width = width; cam->height = height;
+  cam->focal_length = width / 2.0;               // main.cpp:360
+  cam->cx = width / 2.0; cam->cy = height / 2.0; // main.cpp:485-486
+  cam->depth_scale = 10.0 / 256.0;               // main.cpp:121-122
+  cam->max_count = 255;                          // 8-bit DepthVis
+  return AFE_OK;
+}
+
+extern "C" int afe_camera_default_mount(double mount[4]) {
+  if (!mount) return AFE_ERR_INVALID_ARG;
+  // Rotationd::FromEulerYPR(-90 deg, 0, -90 deg), main.cpp:123-125 with Rotation.hpp:99-110
+  const double y = -90.0 * M_PI / 180.0, p = 0.0, r = -90.0 * M_PI / 180.0;
+  const double cy = std::cos(0.5 * y), sy = std::sin(0.5 * y), cp = std::cos(0.5 * p), sp = std::sin(0.5 * p);
+  const double cr = std::cos(0.5 * r), sr = std::sin(0.5 * r);
+  mount[0] = cy * cp * cr + sy * sp * sr;
+  mount[1] = cy * cp * sr - sy * sp * cr;
+  mount[2] = cy * sp * cr + sy * cp * sr;
+  mount[3] = sy * cp * cr - cy * sp * sr;
+  return AFE_OK;
+}
+
+extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tri, afe_scene **out) {
+  if (!triangles || n_tri <= 0 || n_tri > 0x3fffffff || !out) return AFE_ERR_INVALID_ARG;
+  for (int64_t i = 0; i < 9 * n_tri; i++) if (!std::isfinite(triangles[i])) return AFE_ERR_INVALID_ARG;
+  int dev = 0;
+  const int rc = pick_device(device, &dev);
+  if (rc != AFE_OK) return rc;
+
+  Builder b;
+  b.tri = triangles;
+  b.build(n_tri);
+  if (b.max_depth > kStack) {   // degenerate input (e.g. many coincident centroids): balanced tree instead
+    b.median_only = true;
+    b.build(n_tri);
+    if (b.max_depth > kStack) return AFE_ERR_OUT_OF_RANGE;
+  }
+  // triangles in leaf order, padded to three float4
+  std::vector<float> packed(12 * (size_t)n_tri, 0.0f);
+  for (int64_t i = 0; i < n_tri; i++) {
+    const float *src = triangles + 9 * (int64_t)b.order[(size_t)i];
+    for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) packed[12 * (size_t)i + 4 * v + k] = src[3 * v + k];
+  }
+  afe_scene *s = new afe_scene();
+  s->device = dev;
+  s->n_tri = n_tri;
+  s->n_nodes = (int64_t)b.nodes.size();
+  s->depth = b.max_depth;
+  Box all = b.range_box(0, n_tri);
+  for (int k = 0; k < 3; k++) { s->bounds[k] = all.lo[k]; s->bounds[3 + k] = all.hi[k]; }
+  if (hipMalloc((void **)&s->nodes, b.nodes.size() * sizeof(BvhNode)) != hipSuccess ||
+      hipMalloc((void **)&s->tris, packed.size() * sizeof(float)) != hipSuccess ||
+      hipMemcpy(s->nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(s->tris, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    afe_scene_destroy(s);
+    return AFE_ERR_HIP;
+  }
+  *out = s;
+  return AFE_OK;
+}
+
+extern "C" void afe_scene_destroy(afe_scene *s) {
+  if (!s) return;
+  if (s->nodes) (void)hipFree(s->nodes);
+  if (s->tris) (void)hipFree(s->tris);
+  delete s;
+}
+
+extern "C" int afe_scene_info(const afe_scene *s, int64_t *n_tri, int64_t *n_nodes, int *depth, double bounds[6]) {
+  if (!s) return AFE_ERR_INVALID_ARG;
+  if (n_tri) *n_tri = s->n_tri;
+  if (n_nodes) *n_nodes = s->n_nodes;
+  if (depth) *depth = s->depth;
+  if (bounds) for (int k = 0; k < 6; k++) bounds[k] = s->bounds[k];
+  return AFE_OK;
+}
+
+extern "C" int afe_render_depth(afe_scene *s, const afe_camera *cam, int64_t n_views, const double *pos,
+                                const double *att, const double mount[4], uint16_t *depth_out, float *kernel_ms) {
+  if (!s || !camera_ok(cam) || n_views <= 0 || !pos || !att || !depth_out) return AFE_ERR_INVALID_ARG;
+  if (hipSetDevice(s->device) != hipSuccess) return AFE_ERR_HIP;
+  const size_t px = (size_t)cam->width * cam->height;
+  DevBuf d_pos, d_att, d_pose, d_out;
+  if (!d_pos.upload(pos, (size_t)n_views * 24) || !d_att.upload(att, (size_t)n_views * 32) ||
+      !d_pose.alloc((size_t)n_views * 96) || !d_out.alloc((size_t)n_views * px * 2))
+    return AFE_ERR_HIP;
+  int rc = launch_poses(d_pos.p, d_att.p, n_views, 0, n_views, 8, mount, (double *)d_pose.p, nullptr);
+  if (rc != AFE_OK) return rc;
+  float ms = 0;
+  rc = launch_render(s, cam, n_views, (const double *)d_pose.p, (uint16_t *)d_out.p, nullptr, &ms);
+  if (rc != AFE_OK) return rc;
+  if (kernel_ms) *kernel_ms = ms;
+  if (hipMemcpy(depth_out, d_out.p, (size_t)n_views * px * 2, hipMemcpyDeviceToHost) != hipSuccess) return AFE_ERR_HIP;
+  return AFE_OK;
+}
+
+extern "C" int afe_render_depth_engine(afe_engine *e, afe_scene *s, const afe_camera *cam, int64_t first,
+                                       int64_t count, const double mount[4], void *depth_out, int out_is_device,
+                                       float *kernel_ms) {
+  if (!e || !s || !camera_ok(cam) || count <= 0 || first < 0 || !depth_out) return AFE_ERR_INVALID_ARG;
+  afe_device_view view;
+  int rc = afe_get_device_view(e, &view);
+  if (rc != AFE_OK) return rc;
+  if (first + count > view.n_vehicles) return AFE_ERR_OUT_OF_RANGE;
+  hipStream_t stream = nullptr;
+  int device = 0;
+  engine_stream_device(e, (void **)&stream, &device);
+  if (device != s->device) return AFE_ERR_INVALID_ARG;
+  if (hipSetDevice(device) != hipSuccess) return AFE_ERR_HIP;
+  const size_t px = (size_t)cam->width * cam->height;
+  DevBuf d_pose, d_out;
+  if (!d_pose.alloc((size_t)count * 96)) return AFE_ERR_HIP;
+  uint16_t *out_dev = (uint16_t *)depth_out;
+  if (!out_is_device) {
+    if (!d_out.alloc((size_t)count * px * 2)) return AFE_ERR_HIP;
+    out_dev = (uint16_t *)d_out.p;
+  }
+  rc = launch_poses(view.pos, view.att, view.stride, first, count, view.state_elem_size, mount, (double *)d_pose.p,
+                    stream);
+  if (rc != AFE_OK) return rc;
+  float ms = 0;
+  rc = launch_render(s, cam, count, (const double *)d_pose.p, out_dev, stream, &ms);  // synchronises (timing)
+  if (rc != AFE_OK) return rc;
+  if (kernel_ms) *kernel_ms = ms;
+  if (!out_is_device && hipMemcpy(depth_out, out_dev, (size_t)count * px * 2, hipMemcpyDeviceToHost) != hipSuccess)
+    return AFE_ERR_HIP;
+  return AFE_OK;
+}
+
+extern "C" int afe_device_alloc(int device, uint64_t bytes, void **out) {
+  if (!out || bytes == 0) return AFE_ERR_INVALID_ARG;
+  int dev = 0;
+  const int rc = pick_device(device, &dev);
+  if (rc != AFE_OK) return rc;
+  return hipMalloc(out, bytes) == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+}
+
+extern "C" int afe_device_free(void *p) {
+  if (!p) return AFE_OK;
+  return hipFree(p) == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+}
+
+extern "C" int afe_device_download(void *host_dst, const void *dev_src, uint64_t bytes) {
+  if (!host_dst || !dev_src) return AFE_ERR_INVALID_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return AFE_ERR_HIP;
+  return hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+}

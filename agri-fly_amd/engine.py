@@ -36,6 +36,9 @@ ABI_FUNCTIONS = [
     "afe_radio_create_acceleration_command", "afe_radio_create_simple_command", "afe_radio_decode",
     "afe_telemetry_encode", "afe_telemetry_decode", "afe_set_commands_from_radio",
     "afe_set_max_fused_steps", "afe_planner_default_config", "afe_planner_samples", "afe_rappids_plan",
+    "afe_rappids_plan_device", "afe_camera_default", "afe_camera_default_mount", "afe_scene_create",
+    "afe_scene_destroy", "afe_scene_info", "afe_render_depth", "afe_render_depth_engine",
+    "afe_device_alloc", "afe_device_free", "afe_device_download",
 ]
 
 
@@ -147,6 +150,16 @@ def build_library(force=False):
     return _LIB
 
 
+class Camera(C.Structure):
+    """afe_camera: the pinhole depth camera of Rappids_Simulator/main.cpp:120-122,360."""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("focal_length", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("depth_scale", C.c_double),
+        ("max_count", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 _lib = None
 
 
@@ -215,6 +228,17 @@ def library():
         "afe_planner_samples": [C.c_uint32, ci, ci, ci, vp],
         "afe_rappids_plan": [ci, C.POINTER(PlannerConfig), i64, vp, i64, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp,
                              C.POINTER(C.c_float)],
+        "afe_rappids_plan_device": [ci, C.POINTER(PlannerConfig), i64, vp, i64, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp,
+                                    vp, C.POINTER(C.c_float)],
+        "afe_camera_default": [C.POINTER(Camera), ci, ci],
+        "afe_camera_default_mount": [vp],
+        "afe_scene_create": [ci, vp, i64, C.POINTER(vp)],
+        "afe_scene_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(ci), vp],
+        "afe_render_depth": [vp, C.POINTER(Camera), i64, vp, vp, vp, vp, C.POINTER(C.c_float)],
+        "afe_render_depth_engine": [eng, vp, C.POINTER(Camera), i64, i64, vp, vp, ci, C.POINTER(C.c_float)],
+        "afe_device_alloc": [ci, u64, C.POINTER(vp)],
+        "afe_device_free": [vp],
+        "afe_device_download": [vp, vp, u64],
         "afe_checkpoint_size": [eng, C.POINTER(u64)],
         "afe_save_checkpoint": [eng, vp, u64],
         "afe_load_checkpoint": [eng, vp, u64],
@@ -223,6 +247,8 @@ def library():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = ci
+    L.afe_scene_destroy.argtypes = [vp]
+    L.afe_scene_destroy.restype = None
     L.afe_last_error.argtypes = [eng]
     L.afe_last_error.restype = C.c_char_p
     L.afe_status_string.argtypes = [ci]
@@ -285,11 +311,14 @@ def planner_samples(seed, width, height, n_candidates):
 
 def rappids_plan(cfg, depth_images, vel0, acc0, grav, samples, image_index=None, cost_vec=None,
                  sample_table=None, want_flags=False, device=-1):
-    """Batched RAPPIDS plan.  depth_images uint16 [n_images, H, W]; vel0/acc0/grav [3, n];
+    """Batched RAPPIDS plan.  depth_images uint16 [n_images, H, W] (or a DeviceBuffer holding them,
+    e.g. filled by Scene.render_engine); vel0/acc0/grav [3, n];
     samples [n_tables, M, 4] (or [M, 4]).  Returns (PlanOutput array, flags or None, kernel_ms)."""
-    img = np.ascontiguousarray(depth_images, dtype=np.uint16)
-    if img.ndim == 2:
-        img = img[None]
+    on_device = isinstance(depth_images, DeviceBuffer)
+    if not on_device:
+        img = np.ascontiguousarray(depth_images, dtype=np.uint16)
+        if img.ndim == 2:
+            img = img[None]
     v = np.ascontiguousarray(vel0, dtype=np.float64)
     n = v.shape[1]
     a = np.ascontiguousarray(acc0, dtype=np.float64)
@@ -297,21 +326,138 @@ def rappids_plan(cfg, depth_images, vel0, acc0, grav, samples, image_index=None,
     s = np.ascontiguousarray(samples, dtype=np.float64)
     if s.ndim == 2:
         s = s[None]
-    assert img.shape[1:] == (cfg.height, cfg.width) and v.shape == a.shape == g.shape == (3, n) and s.shape[2] == 4
+    assert v.shape == a.shape == g.shape == (3, n) and s.shape[2] == 4
+    if on_device:
+        n_images = depth_images.nbytes // (2 * cfg.height * cfg.width)
+        img_ptr, fn = depth_images.ptr, library().afe_rappids_plan_device
+    else:
+        assert img.shape[1:] == (cfg.height, cfg.width)
+        n_images, img_ptr, fn = img.shape[0], img.ctypes.data, library().afe_rappids_plan
     idx = None if image_index is None else np.ascontiguousarray(image_index, dtype=np.int32)
     cv = None if cost_vec is None else np.ascontiguousarray(cost_vec, dtype=np.float64)
     st = None if sample_table is None else np.ascontiguousarray(sample_table, dtype=np.int32)
     out = (PlanOutput * n)()
     flags = np.zeros((n, s.shape[1]), np.uint8) if want_flags else None
     ms = C.c_float(0)
-    rc = library().afe_rappids_plan(int(device), C.byref(cfg), n, img.ctypes.data, img.shape[0],
-                                    None if idx is None else idx.ctypes.data, v.ctypes.data, a.ctypes.data,
-                                    g.ctypes.data, None if cv is None else cv.ctypes.data, s.ctypes.data, s.shape[0],
-                                    None if st is None else st.ctypes.data, s.shape[1], out,
-                                    None if flags is None else flags.ctypes.data, C.byref(ms))
+    rc = fn(int(device), C.byref(cfg), n, img_ptr, n_images,
+            None if idx is None else idx.ctypes.data, v.ctypes.data, a.ctypes.data,
+            g.ctypes.data, None if cv is None else cv.ctypes.data, s.ctypes.data, s.shape[0],
+            None if st is None else st.ctypes.data, s.shape[1], out,
+            None if flags is None else flags.ctypes.data, C.byref(ms))
     if rc:
         raise AfeError(rc, library().afe_status_string(rc).decode())
     return out, flags, ms.value
+
+
+def camera_default(width, height):
+    cam = Camera()
+    rc = library().afe_camera_default(C.byref(cam), int(width), int(height))
+    if rc:
+        raise AfeError(rc, "afe_camera_default")
+    return cam
+
+
+def camera_default_mount():
+    """depthCamAtt (main.cpp:123-125) as (w, x, y, z)."""
+    q = np.empty(4)
+    rc = library().afe_camera_default_mount(q.ctypes.data)
+    if rc:
+        raise AfeError(rc, "afe_camera_default_mount")
+    return q
+
+
+class DeviceBuffer:
+    """A raw HBM allocation (afe_device_alloc) for chaining render -> plan on the device."""
+
+    def __init__(self, nbytes, device=-1):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes)
+        rc = library().afe_device_alloc(int(device), self.nbytes, C.byref(self.ptr))
+        if rc:
+            raise AfeError(rc, library().afe_status_string(rc).decode())
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        rc = library().afe_device_download(out.ctypes.data, self.ptr, out.nbytes)
+        if rc:
+            raise AfeError(rc, library().afe_status_string(rc).decode())
+        return out
+
+    def close(self):
+        if self.ptr:
+            library().afe_device_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene:
+    """afe_scene: a static triangle mesh (world frame, metres) + its BVH in HBM."""
+
+    def __init__(self, triangles, device=-1):
+        t = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
+        self._h = C.c_void_p()
+        rc = library().afe_scene_create(int(device), t.ctypes.data, t.shape[0], C.byref(self._h))
+        if rc:
+            raise AfeError(rc, library().afe_status_string(rc).decode())
+
+    def close(self):
+        if self._h:
+            library().afe_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        nt, nn, d = C.c_int64(), C.c_int64(), C.c_int()
+        b = np.empty(6)
+        rc = library().afe_scene_info(self._h, C.byref(nt), C.byref(nn), C.byref(d), b.ctypes.data)
+        if rc:
+            raise AfeError(rc, "afe_scene_info")
+        return {"n_tri": nt.value, "n_nodes": nn.value, "depth": d.value, "bounds": b}
+
+    def render(self, cam, pos, att, mount=None):
+        """pos [3, n], att [4, n] -> (uint16 [n, H, W], kernel_ms)."""
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        q = np.ascontiguousarray(att, dtype=np.float64)
+        n = p.shape[1]
+        assert p.shape == (3, n) and q.shape == (4, n)
+        m = None if mount is None else np.ascontiguousarray(mount, dtype=np.float64)
+        out = np.empty((n, cam.height, cam.width), np.uint16)
+        ms = C.c_float(0)
+        rc = library().afe_render_depth(self._h, C.byref(cam), n, p.ctypes.data, q.ctypes.data,
+                                        None if m is None else m.ctypes.data, out.ctypes.data, C.byref(ms))
+        if rc:
+            raise AfeError(rc, library().afe_status_string(rc).decode())
+        return out, ms.value
+
+    def render_engine(self, ensemble, cam, mount=None, first=0, count=None, out=None):
+        """Depth images of vehicles [first, first+count) from the engine's device state.
+        out: a DeviceBuffer to keep the images in HBM (returns kernel_ms only), or None to
+        get (uint16 [count, H, W], kernel_ms) on the host."""
+        count = ensemble.n - first if count is None else count
+        m = None if mount is None else np.ascontiguousarray(mount, dtype=np.float64)
+        ms = C.c_float(0)
+        if out is None:
+            img = np.empty((count, cam.height, cam.width), np.uint16)
+            dst, is_dev = img.ctypes.data, 0
+        else:
+            assert out.nbytes >= count * cam.height * cam.width * 2
+            img, dst, is_dev = None, out.ptr, 1
+        rc = library().afe_render_depth_engine(ensemble.handle, self._h, C.byref(cam), first, count,
+                                               None if m is None else m.ctypes.data, dst, is_dev, C.byref(ms))
+        if rc:
+            raise AfeError(rc, library().afe_status_string(rc).decode())
+        return (img, ms.value) if out is None else ms.value
 
 
 def type_from_id(vehicle_id):

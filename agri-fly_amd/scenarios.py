@@ -166,3 +166,62 @@ def synthetic_depth_image(width=320, height=240, seed=0, n_trunks=6, far_m=10.0,
         depth = np.minimum(depth, z_hit[None, :])
     counts = np.floor(depth / depth_scale)
     return np.clip(counts, 0, 255).astype(np.uint16)
+
+
+def _icosphere(subdiv):
+    t = (1.0 + np.sqrt(5.0)) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    verts = [np.array(p, float) / np.linalg.norm(p) for p in v]
+    faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2),
+             (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11),
+             (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(subdiv):
+        cache = {}
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = verts[a] + verts[b]
+                verts.append(m / np.linalg.norm(m))
+                cache[key] = len(verts) - 1
+            return cache[key]
+
+        nf = []
+        for a, b, c in faces:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        faces = nf
+    return np.array(verts), np.array(faces)
+
+
+def orchard_mesh(rows=8, cols=8, row_spacing=4.0, tree_spacing=3.0, seed=0, trunk_sides=8, canopy_subdiv=1,
+                 margin=10.0, jitter=0.3):
+    """Stand-in for the Helios orchard scene the reference renders through AirSim/Unity (not in
+    the reference tree): a ground plane at z = 0 and rows x cols
+    trees (a prism trunk and an ellipsoidal canopy each) on a jittered lattice, rows along +x.
+    World frame z up, metres.  Returns float32 [n_tri, 9] (v0 v1 v2).  Seeded (numpy PCG64)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tris = []
+    x1, y1 = (cols - 1) * tree_spacing + margin, (rows - 1) * row_spacing + margin
+    g = np.array([[-margin, -margin, 0], [x1, -margin, 0], [x1, y1, 0], [-margin, y1, 0]], float)
+    tris += [np.concatenate([g[0], g[1], g[2]]), np.concatenate([g[0], g[2], g[3]])]
+    sv, sf = _icosphere(canopy_subdiv)
+    ang = 2 * np.pi * np.arange(trunk_sides) / trunk_sides
+    for r in range(rows):
+        for c in range(cols):
+            cx = c * tree_spacing + rng.uniform(-jitter, jitter)
+            cy = r * row_spacing + rng.uniform(-jitter, jitter)
+            tr = rng.uniform(0.08, 0.18)
+            th = rng.uniform(1.2, 2.0)
+            ring = np.stack([cx + tr * np.cos(ang), cy + tr * np.sin(ang)], 1)
+            for k in range(trunk_sides):
+                a, b = ring[k], ring[(k + 1) % trunk_sides]
+                tris.append(np.array([a[0], a[1], 0, b[0], b[1], 0, b[0], b[1], th]))
+                tris.append(np.array([a[0], a[1], 0, b[0], b[1], th, a[0], a[1], th]))
+            rad = np.array([rng.uniform(0.8, 1.3), rng.uniform(0.8, 1.3), rng.uniform(0.9, 1.5)])
+            centre = np.array([cx, cy, th + 0.7 * rad[2]])
+            pv = sv * rad + centre
+            for f in sf:
+                tris.append(pv[f].reshape(9))
+    return np.asarray(tris, dtype=np.float32)

@@ -304,6 +304,71 @@ int afe_rappids_plan(int device, const afe_planner_config *cfg, int64_t n, const
                      const int32_t *sample_table, int n_candidates, afe_plan_output *out, uint8_t *flags,
                      float *kernel_ms);
 
+/* ---- depth camera --------------------------------------
+ * The reference gets its depth image from AirSim/Unity over RPC
+ * (Simulator/Rappids_Simulator/main.cpp:332-354: ImageType::DepthVis, 8-bit,
+ * widened to uint16; far = 10 m, depthScale = far/256, focal = width/2,
+ * :120-122,360) with the camera mounted at depthCamAtt = FromEulerYPR(-90 deg,
+ * 0, -90 deg) on the body (:123-125; camera-to-world = att * depthCamAtt,
+ * :520).  Neither the renderer nor the orchard scene is in the reference tree,
+ * so what is replaced here is that RPC and its image contract: one ray per
+ * pixel through ((x - cx)/f, (y - cy)/f, 1) in the camera frame (x right,
+ * y down, z forward), closest hit over a triangle mesh, count =
+ * min(max_count, floor(z / depth_scale)), max_count for a miss.
+ *
+ * A scene is a static triangle mesh (world frame, metres) with a bounding-
+ * volume hierarchy built on the host and kept in HBM. */
+typedef struct afe_scene afe_scene;
+
+typedef struct afe_camera {
+  int32_t width, height;
+  double focal_length, cx, cy;
+  double depth_scale;   /* metres per count */
+  int32_t max_count;    /* 255: 8-bit DepthVis */
+  int32_t reserved;
+} afe_camera;
+
+/* main.cpp's camera: focal = width/2, principal point = centre, 10 m / 256. */
+int afe_camera_default(afe_camera *cam, int width, int height);
+/* depthCamAtt of main.cpp:123-125 as a quaternion (w, x, y, z). */
+int afe_camera_default_mount(double mount[4]);
+
+/* triangles: n_tri x 9 floats (v0, v1, v2).  device < 0: current device. */
+int afe_scene_create(int device, const float *triangles, int64_t n_tri, afe_scene **out);
+void afe_scene_destroy(afe_scene *s);
+/* n_tri, number of BVH nodes, tree depth, world bounds {min xyz, max xyz} */
+int afe_scene_info(const afe_scene *s, int64_t *n_tri, int64_t *n_nodes, int *depth, double bounds[6]);
+
+/* n_views depth images from explicit poses.  pos: planar [3][n_views]
+ * doubles, att: planar [4][n_views] (w,x,y,z) body attitudes, mount: body-to-
+ * camera mount quaternion applied to every view (NULL = identity, att is then
+ * the camera attitude itself).  depth_out: host buffer of n_views * height *
+ * width uint16.  kernel_ms (optional): HIP-event time of the render launch. */
+int afe_render_depth(afe_scene *s, const afe_camera *cam, int64_t n_views, const double *pos, const double *att,
+                     const double mount[4], uint16_t *depth_out, float *kernel_ms);
+
+/* The same, with the poses read on the device from the engine's state slabs
+ * (vehicles [first, first+count)), replacing client.simGetImages() for every
+ * vehicle at once.  depth_out is a DEVICE pointer when out_is_device != 0
+ * (count * height * width uint16, e.g. the buffer handed to
+ * afe_rappids_plan_device), else a host buffer.  Engine and scene must live on
+ * the same device; the launch is ordered on the engine's stream. */
+int afe_render_depth_engine(afe_engine *e, afe_scene *s, const afe_camera *cam, int64_t first, int64_t count,
+                            const double mount[4], void *depth_out, int out_is_device, float *kernel_ms);
+
+/* Device scratch helpers for hosts without their own HIP allocator (ctypes). */
+int afe_device_alloc(int device, uint64_t bytes, void **out);
+int afe_device_free(void *p);
+int afe_device_download(void *host_dst, const void *dev_src, uint64_t bytes);
+
+/* afe_rappids_plan with the depth images already in HBM (one per planner, or
+ * indexed through image_index, which stays a host array). */
+int afe_rappids_plan_device(int device, const afe_planner_config *cfg, int64_t n, const void *dev_depth_images,
+                            int64_t n_images, const int32_t *image_index, const double *vel0, const double *acc0,
+                            const double *grav, const double *cost_vec, const double *samples, int n_tables,
+                            const int32_t *sample_table, int n_candidates, afe_plan_output *out, uint8_t *flags,
+                            float *kernel_ms);
+
 /* ---- stepping -----------------------------------------------------------
  * afe_step replaces the loop body
  *     for (v : vehicles) v->Run();  simTimer.AdvanceMicroSeconds(dt_us);

@@ -381,3 +381,51 @@ def planner_run(cfg, depth, vel0, acc0, grav, samples):
     planner_lib().ora_planner_run(C.byref(cfg), d.ctypes.data, _dp(v), _dp(a), _dp(g), s.ctypes.data, len(s),
                                   C.byref(res), flags.ctypes.data)
     return res, flags
+
+
+# ---------------------------------------------------------------------------
+# depth-camera checker (oracle/agrifly_oracle_render.c), SURVEY 8f row f4
+# ---------------------------------------------------------------------------
+class OraCamera(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("focal_length", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("depth_scale", C.c_double), ("max_count", C.c_int)]
+
+
+_render_bound = False
+
+
+def render_lib():
+    global _render_bound
+    L = lib()
+    if not _render_bound:
+        dp = C.POINTER(C.c_double)
+        L.ora_quat_mul.argtypes = [dp, dp, dp]
+        L.ora_quat_mul.restype = None
+        L.ora_quat_to_matrix.argtypes = [dp, dp]
+        L.ora_quat_to_matrix.restype = None
+        L.ora_render_depth.argtypes = [C.POINTER(OraCamera), C.c_void_p, C.c_int64, dp, dp, dp, C.c_void_p]
+        L.ora_render_depth.restype = None
+        L.ora_render_pixel_depth.argtypes = [C.POINTER(OraCamera), C.c_void_p, C.c_int64, dp, dp, dp, C.c_int, C.c_int]
+        L.ora_render_pixel_depth.restype = C.c_double
+        _render_bound = True
+    return L
+
+
+def render_camera(width, height, focal_length=None, depth_scale=10.0 / 256.0, max_count=255):
+    """main.cpp's camera: focal = width/2, principal point = centre (main.cpp:360,485-486)."""
+    return OraCamera(width, height, width / 2.0 if focal_length is None else focal_length, width / 2.0, height / 2.0,
+                     depth_scale, max_count)
+
+
+def render_depth(cam, triangles, pos, att, mount=(1.0, 0.0, 0.0, 0.0)):
+    t = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
+    out = np.empty((cam.height, cam.width), np.uint16)
+    render_lib().ora_render_depth(C.byref(cam), t.ctypes.data, t.shape[0], _dp(np.ascontiguousarray(pos, dtype=float)),
+                                  _dp(np.ascontiguousarray(att, dtype=float)), _dp(np.ascontiguousarray(mount, dtype=float)), out.ctypes.data)
+    return out
+
+
+def render_pixel_depth(cam, triangles, pos, att, mount, px, py):
+    t = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
+    return render_lib().ora_render_pixel_depth(C.byref(cam), t.ctypes.data, t.shape[0], _dp(np.ascontiguousarray(pos, dtype=float)),
+                                               _dp(np.ascontiguousarray(att, dtype=float)), _dp(np.ascontiguousarray(mount, dtype=float)), px, py)
