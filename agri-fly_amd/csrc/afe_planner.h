@@ -18,12 +18,16 @@ struct PlannerPyramid {   // RectangularPyramidPlanner::Pyramid (Pyramid.hpp:24-
 struct PlannerBatch {
   int64_t n;
   const uint16_t *images;        // [n_images][height][width]
+  uint16_t *images_t;            // [n_images][width][height] scratch, filled by launch_rappids
+  int64_t n_images;
   const int32_t *image_index;    // [n] or null (image i for planner i)
   const double *vel0, *acc0, *grav;  // planar [3][n], camera-fixed frame
   const double *cost_vec;        // planar [3][n] or null (cfg.cost_vec for all)
   const double *samples;         // [n_tables][n_candidates][4] = pixelX, pixelY, depth, time
   const int32_t *sample_table;   // [n] or null (table 0 for all)
   int n_candidates;
+  double *cand_cost;             // [n][n_candidates] scratch: cost of every candidate
+  uint8_t *cand_bits;            // [n][n_candidates] scratch: input-feasible / velocity-admissible bits
   PlannerPyramid *pyramids;      // [n][max_pyramids] scratch
   int max_pyramids;
   PlanOutput *out;               // [n]

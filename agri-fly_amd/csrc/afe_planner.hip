@@ -19,11 +19,24 @@
 // from libm by an ulp.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "afe_planner.h"
 
 namespace afe {
 namespace {
+
+// -DAFE_PLANNER_PROFILE: per-phase cycle totals (s_memtime), printed by launch_rappids; development only
+#ifdef AFE_PLANNER_PROFILE
+__device__ unsigned long long g_prof[8];
+#define PL_T0(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PL_T1(var, slot) do { if (threadIdx.x == 0) atomicAdd(&g_prof[slot], __builtin_readcyclecounter() - var); } while (0)
+#define PL_COUNT(slot, n) do { if (threadIdx.x == 0) atomicAdd(&g_prof[slot], (unsigned long long)(n)); } while (0)
+#else
+#define PL_T0(var)
+#define PL_T1(var, slot)
+#define PL_COUNT(slot, n)
+#endif
 
 #define PL_MIN(a, b) (((b) < (a)) ? (b) : (a))  // std::min / std::max semantics
 #define PL_MAX(a, b) (((a) < (b)) ? (b) : (a))
@@ -316,8 +329,243 @@ struct Shrink {
   int right, left, top, bottom;
 };
 
-// DIP.cpp:456-970
-__device__ bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restrict__ img, int x0, int y0,
+// ---- wave-cooperative pixel scans ------------------------------------------------
+// One wave runs one planner: everything outside the scans below is computed redundantly
+// (and therefore convergently) by all 64 lanes; inside a scan lane l looks at pixel
+// base + l of the reference's scan order.  The reference's loops are sequential -- a
+// pixel's test reads edges that earlier pixels may have moved -- so a chunk is resolved
+// as: ballot the lanes whose test holds under the CURRENT edges, let the first of them
+// (in scan order) apply its update, re-test the lanes after it, repeat.  Between two
+// updates the edges are constant, so this visits exactly the pixels the sequential loop
+// would act on, in the same order.  For the four side scans the ordinary update is a
+// running min / max of one edge (see side_scan), which a wave reduction applies to a whole
+// chunk at once.
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o < v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o > v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ uint64_t lanes_from(int l) { return l >= 64 ? 0ull : (~0ull << l); }
+
+enum { SIDE_RIGHT = 0, SIDE_LEFT = 1, SIDE_TOP = 2, SIDE_BOTTOM = 3 };
+
+// One of the four side scans, DIP.cpp:617-785.  `total` pixels, pixel i at
+// (xa + (i / inner) * dxo + (i % inner) * dxi, ya + ...).  Returns false for the
+// reference's "return false".
+// Scans walk `total` pixels in chunks of 64; kScanBatch chunks are loaded together (the loads do
+// not depend on the edges) and then resolved one after the other, so one memory latency is paid
+// per batch instead of per chunk.  i / inner for i < 2^24, inner <= 2^15 as a multiply-high.
+constexpr int kScanBatch = 4;
+__device__ __forceinline__ unsigned div_magic(int inner) { return (unsigned)(0x100000000ull / (unsigned)inner) + 1u; }
+
+template <int SIDE>
+__device__ bool side_scan(const uint16_t *__restrict__ src, int sx, int sy, int lane, int total, int inner, int xa,
+                          int ya, int dxo, int dyo, int dxi, int dyi, uint16_t ignore, uint16_t maxDepth, int num,
+                          int buf, int x0, int y0, Shrink &s) {
+  const unsigned magic = div_magic(inner);
+  for (int base0 = 0; base0 < total; base0 += 64 * kScanBatch) {
+    int xs[kScanBatch], ys[kScanBatch];
+    uint16_t ds[kScanBatch];
+#pragma unroll
+    for (int c = 0; c < kScanBatch; c++) {
+      const int i = base0 + 64 * c + lane;
+      xs[c] = 0; ys[c] = 0; ds[c] = 0;
+      if (i < total) {
+        const int o = (int)__umulhi((unsigned)i, magic), r = i - o * inner;
+        xs[c] = xa + o * dxo + r * dxi;
+        ys[c] = ya + o * dyo + r * dyi;
+        ds[c] = src[ys[c] * sy + xs[c] * sx];    // (1, W) on the image, (H, 1) on its transpose
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kScanBatch; c++) {
+      const int x = xs[c], y = ys[c];
+      const uint16_t d = ds[c];
+      const bool valid = d > ignore && d < maxDepth;      // lanes past the end loaded 0 <= ignore
+      if (!__ballot(valid)) continue;
+      int k = 0;
+      if (valid) k = (int)(num / d);
+      // the edge this pixel asks for, and whether granting it would cut the seed pixel off
+      int want;
+      bool exceptional;
+      if (SIDE == SIDE_RIGHT) { want = x - k; exceptional = x0 > want - buf; }
+      else if (SIDE == SIDE_LEFT) { want = x + k; exceptional = x0 < want + buf; }
+      else if (SIDE == SIDE_TOP) { want = y + k; exceptional = y0 < want + buf; }
+      else { want = y - k; exceptional = y0 > want - buf; }
+      const uint64_t excMask = __ballot(valid && exceptional);
+      uint64_t todo = ~0ull;
+      for (;;) {
+        bool hit;
+        if (SIDE == SIDE_RIGHT) hit = valid && num > (x - s.right) * (int)d;
+        else if (SIDE == SIDE_LEFT) hit = valid && (s.left - x) * (int)d < num;
+        else if (SIDE == SIDE_TOP) hit = valid && (s.top - y) * (int)d < num;
+        else hit = valid && num > (y - s.bottom) * (int)d;
+        const uint64_t b = __ballot(hit) & todo;
+        if (!b) break;
+        const uint64_t be = b & excMask;
+        const int l = be ? (int)__ffsll((unsigned long long)be) - 1 : 64;
+        const uint64_t pre = b & ~lanes_from(l);
+        if (pre) {
+          // ordinary updates before lane l: `edge = want` under the test is a running min (right,
+          // bottom) or max (left, top) of `want` -- the test holds iff `want` is beyond the edge
+          const bool mine = hit && ((pre >> lane) & 1ull);
+          if (SIDE == SIDE_RIGHT) { const int m = wave_min_i32(mine ? want : 0x7fffffff); s.right = PL_MIN(s.right, m); }
+          else if (SIDE == SIDE_LEFT) { const int m = wave_max_i32(mine ? want : -0x7fffffff); s.left = PL_MAX(s.left, m); }
+          else if (SIDE == SIDE_TOP) { const int m = wave_max_i32(mine ? want : -0x7fffffff); s.top = PL_MAX(s.top, m); }
+          else { const int m = wave_min_i32(mine ? want : 0x7fffffff); s.bottom = PL_MIN(s.bottom, m); }
+          if (l >= 64) break;
+          todo = lanes_from(l);      // lane l is re-tested against the moved edge
+          continue;
+        }
+        // lane l is next in scan order and exceptional: the reference's inner branch
+        const int xl = __shfl(x, l), yl = __shfl(y, l), kl = __shfl(k, l);
+        if (SIDE == SIDE_RIGHT || SIDE == SIDE_LEFT) {
+          const int tT = yl + kl, bT = yl - kl;
+          if (y0 < tT + buf && y0 > bT - buf) return false;
+          else if (y0 < tT + buf) s.bottom = bT;
+          else if (y0 > bT - buf) s.top = tT;
+          else if ((s.bottom - bT) > (tT - s.top)) s.top = tT;
+          else if (SIDE == SIDE_RIGHT) s.right = bT;            // sic, DIP.cpp:648
+          else s.bottom = bT;
+        } else {
+          const int rT = xl - kl, lT = xl + kl;
+          if (x0 > rT - buf && x0 < lT + buf) return false;
+          else if (x0 > rT - buf) s.left = lT;
+          else if (x0 < lT + buf) s.right = rT;
+          else if ((s.right - rT) > (lT - s.left)) s.left = lT;
+          else s.right = rT;
+        }
+        todo = lanes_from(l + 1);
+      }
+    }
+  }
+  return true;
+}
+
+enum { CORNER_TR = 0, CORNER_BR = 1, CORNER_TL = 2, CORNER_BL = 3 };
+
+// One of the four corner scans, DIP.cpp:794-940: rows outward from the top / bottom edge,
+// pixels outward from the right / left edge.
+template <int CORNER>
+__device__ bool corner_scan(const uint16_t *__restrict__ img, int W, int lane, int rows, int inner, int xa, int ya,
+                            uint16_t ignore, uint16_t maxDepth, int num, int buf, int x0, int y0, Shrink &s) {
+  constexpr bool RIGHT = (CORNER == CORNER_TR || CORNER == CORNER_BR);
+  constexpr bool TOP = (CORNER == CORNER_TR || CORNER == CORNER_TL);
+  const int total = rows * inner;
+  const unsigned magic = div_magic(inner);
+  for (int base0 = 0; base0 < total; base0 += 64 * kScanBatch) {
+    int xs[kScanBatch], ys[kScanBatch];
+    uint16_t ds[kScanBatch];
+#pragma unroll
+    for (int c = 0; c < kScanBatch; c++) {
+      const int i = base0 + 64 * c + lane;
+      xs[c] = 0; ys[c] = 0; ds[c] = 0;
+      if (i < total) {
+        const int o = (int)__umulhi((unsigned)i, magic), r = i - o * inner;
+        xs[c] = RIGHT ? xa + r : xa - r;
+        ys[c] = TOP ? ya - o : ya + o;
+        ds[c] = img[ys[c] * W + xs[c]];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kScanBatch; c++) {
+      const int x = xs[c], y = ys[c];
+      const uint16_t d = ds[c];
+      const bool valid = d > ignore && d < maxDepth;
+      if (!__ballot(valid)) continue;
+      int k = 0;
+      if (valid) k = (int)(num / d);
+      uint64_t todo = ~0ull;
+      for (;;) {
+        const bool hx = RIGHT ? num > (x - s.right) * (int)d : (s.left - x) * (int)d < num;
+        const bool hy = TOP ? (s.top - y) * (int)d < num : num > (y - s.bottom) * (int)d;
+        const uint64_t b = __ballot(valid && hx && hy) & todo;
+        if (!b) break;
+        const int l = (int)__ffsll((unsigned long long)b) - 1;
+        const int xl = __shfl(x, l), yl = __shfl(y, l), kl = __shfl(k, l);
+        const int xT = RIGHT ? xl - kl : xl + kl;          // rightTemp / leftTemp
+        const int yT = TOP ? yl + kl : yl - kl;            // topTemp / bottomTemp
+        const bool cutX = RIGHT ? x0 > xT - buf : x0 < xT + buf;
+        const bool cutY = TOP ? y0 < yT + buf : y0 > yT - buf;
+        if (cutX && cutY) return false;
+        bool moveY;
+        if (cutX) moveY = true;
+        else if (cutY) moveY = false;
+        else {
+          const int lossX = RIGHT ? (s.right - xT) : (xT - s.left);
+          const int lossY = TOP ? (yT - s.top) : (s.bottom - yT);
+          moveY = lossX * (s.bottom - s.top) > lossY * (s.right - s.left);
+        }
+        if (moveY) { if (TOP) s.top = yT; else s.bottom = yT; }
+        else { if (RIGHT) s.right = xT; else s.left = xT; }
+        todo = lanes_from(l + 1);
+      }
+    }
+  }
+  return true;
+}
+
+// ---- spiral expansion, DIP.cpp:520-600 ---------------------------------------------------
+// Every ring reads four lines (column R+1, row T-1, column L-1, row B+1).  They are staged into
+// LDS by direct global->LDS loads (global_load_lds_ushort, no VGPRs), rows from the image and
+// columns from its transpose so that both are contiguous, and the NEXT ring is requested before
+// the current one is examined: a side that is still free afterwards has moved by exactly one
+// pixel, so the speculative request (R+2, T-2, L-2, B+2, extents one pixel wider) always covers
+// what the next ring needs.  LDS lines are indexed by absolute pixel coordinate; a sub-dword
+// LDS-DMA writes one zero-extended DWORD per lane (lane x 4 bytes, measured on gfx950), so a staged
+// pixel occupies 32 bits.
+struct RingBuf {
+  uint32_t *top, *bottom, *right, *left;   // LDS; rows hold Wp entries, columns Hp (multiples of 64)
+};
+
+__device__ __forceinline__ void stage_line(const uint16_t *__restrict__ line, int n, uint32_t *lds_line, int lo, int hi,
+                                           int lane) {
+  lo = PL_MAX(lo, 0);
+  hi = PL_MIN(hi, n - 1);
+  for (int c = lo >> 6; c <= hi >> 6; c++) {
+    const int idx = PL_MIN(64 * c + lane, n - 1);    // lanes past the end re-read the last pixel into the padding
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(line + idx),
+                                     (__attribute__((address_space(3))) void *)(lds_line + 64 * c), 2, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void stage_ring(const uint16_t *__restrict__ img, const uint16_t *__restrict__ imgT, int W,
+                                           int H, const RingBuf &rb, int lane, bool r, bool t, bool l, bool b, int xr,
+                                           int yt, int xl, int yb, int xlo, int xhi, int ylo, int yhi) {
+  if (r && xr < W) stage_line(imgT + (int64_t)xr * H, H, rb.right, ylo, yhi, lane);
+  if (t && yt >= 0) stage_line(img + (int64_t)yt * W, W, rb.top, xlo, xhi, lane);
+  if (l && xl >= 0) stage_line(imgT + (int64_t)xl * H, H, rb.left, ylo, yhi, lane);
+  if (b && yb < H) stage_line(img + (int64_t)yb * W, W, rb.bottom, xlo, xhi, lane);
+}
+
+// pixels lo..hi of a staged line; true if one nearer than minDepthPix blocks it.  laneMin collects
+// the depths seen before the blocking pixel (reduced once, after the expansion).
+__device__ __forceinline__ bool line_blocked(const uint32_t *lds_line, int lo, int hi, int lane, uint16_t ignore,
+                                             uint16_t minDepthPix, int &laneMin) {
+  for (int base = lo; base <= hi; base += 64) {
+    const int i = base + lane;
+    const bool in = i <= hi;
+    const uint16_t d = in ? (uint16_t)lds_line[i] : (uint16_t)0;
+    const bool counts = in && d > ignore;
+    const uint64_t blk = __ballot(counts && d < minDepthPix);
+    if (blk) {
+      const int first = (int)__ffsll((unsigned long long)blk) - 1;
+      if (counts && lane < first) laneMin = PL_MIN(laneMin, (int)d);
+      return true;
+    }
+    if (counts) laneMin = PL_MIN(laneMin, (int)d);
+  }
+  return false;
+}
+
+// DIP.cpp:456-970, executed by one wave (lane = 0..63, everything but the scans is uniform)
+__device__ bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restrict__ img,
+                                const uint16_t *__restrict__ imgT, uint32_t *ring_lds, int lane, int x0, int y0,
                                 double minimumDepth, PlannerPyramid &out) {
 #pragma clang fp contract(off)
   const int W = c.width, H = c.height, buf = c.pixel_buffer;
@@ -333,187 +581,90 @@ __device__ bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restri
   if (x0 - initR < edgeOff) { L = edgeOff; R = L + 2 * initR; }
   else { R = PL_MIN(W - edgeOff - 1, x0 + initR); L = R - 2 * initR; }
   const uint16_t ignore = (uint16_t)(c.true_vehicle_radius / c.depth_scale);
-  for (int y = T; y < B; y++)
-    for (int x = L; x < R; x++) {
-      const uint16_t d = img[y * W + x];
-      if (d <= minDepthPix && d > ignore) return false;
+  {  // :505-518, any pixel of [L,R) x [T,B) nearer than minDepthPix
+    const int w = R - L, total = w * (B - T);
+    for (int base = 0; base < total; base += 64) {
+      const int i = base + lane;
+      bool bad = false;
+      if (i < total) {
+        const int o = i / w;
+        const uint16_t d = img[(T + o) * W + L + (i - o * w)];
+        bad = d <= minDepthPix && d > ignore;
+      }
+      if (__ballot(bad)) return false;
     }
-  // spiral expansion, :520-600
-  uint16_t maxDepth = 65535;
+  }
+  PL_T0(t_exp);
+  // spiral expansion, :520-600 (see stage_ring)
+  int laneMin = 65535;
   bool rFree = true, tFree = true, lFree = true, bFree = true;
+  const int Wp = (W + 63) & ~63, Hp = (H + 63) & ~63;
+  RingBuf ring[2];
+  for (int q = 0; q < 2; q++) {
+    uint32_t *base = ring_lds + q * (2 * Wp + 2 * Hp);
+    ring[q].top = base; ring[q].bottom = base + Wp; ring[q].right = base + 2 * Wp; ring[q].left = base + 2 * Wp + Hp;
+  }
+  int cur = 0;
+  stage_ring(img, imgT, W, H, ring[0], lane, true, true, true, true, R + 1, T - 1, L - 1, B + 1, L - 1, R + 1, T - 1, B + 1);
   while (rFree || tFree || lFree || bFree) {
+    PL_COUNT(7, 1);
+    PL_T0(t_wait);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this ring has landed (requested one iteration ago)
+    PL_T1(t_wait, 1);
+    stage_ring(img, imgT, W, H, ring[cur ^ 1], lane, rFree, tFree, lFree, bFree, R + 2, T - 2, L - 2, B + 2, L - 2, R + 2,
+               T - 2, B + 2);
+    const RingBuf &rb = ring[cur];
     if (rFree) {
       if (R < W - edgeOff - 1) {
-        for (int y = T; y <= B; y++) {
-          const uint16_t d = img[y * W + R + 1];
-          if (d > ignore) {
-            if (d < minDepthPix) { rFree = false; R--; break; }
-            maxDepth = PL_MIN(maxDepth, d);
-          }
-        }
+        if (line_blocked(rb.right, T, B, lane, ignore, minDepthPix, laneMin)) { rFree = false; R--; }
         R++;
       } else rFree = false;
     }
     if (tFree) {
       if (T > edgeOff) {
-        for (int x = L; x <= R; x++) {
-          const uint16_t d = img[(T - 1) * W + x];
-          if (d > ignore) {
-            if (d < minDepthPix) { tFree = false; T++; break; }
-            maxDepth = PL_MIN(maxDepth, d);
-          }
-        }
+        if (line_blocked(rb.top, L, R, lane, ignore, minDepthPix, laneMin)) { tFree = false; T++; }
         T--;
       } else tFree = false;
     }
     if (lFree) {
       if (L > edgeOff) {
-        for (int y = T; y <= B; y++) {
-          const uint16_t d = img[y * W + L - 1];
-          if (d > ignore) {
-            if (d < minDepthPix) { lFree = false; L++; break; }
-            maxDepth = PL_MIN(maxDepth, d);
-          }
-        }
+        if (line_blocked(rb.left, T, B, lane, ignore, minDepthPix, laneMin)) { lFree = false; L++; }
         L--;
       } else lFree = false;
     }
     if (bFree) {
       if (B < H - edgeOff - 1) {
-        for (int x = L; x <= R; x++) {
-          const uint16_t d = img[(B + 1) * W + x];
-          if (d > ignore) {
-            if (d < minDepthPix) { bFree = false; B--; break; }
-            maxDepth = PL_MIN(maxDepth, d);
-          }
-        }
+        if (line_blocked(rb.bottom, L, R, lane, ignore, minDepthPix, laneMin)) { bFree = false; B--; }
         B++;
       } else bFree = false;
     }
+    cur ^= 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // retire the last speculative request before LDS is reused
+  const uint16_t maxDepth = (uint16_t)wave_min_i32(laneMin);
+  PL_T1(t_exp, 2);
+  PL_T0(t_side);
   // shrink by the vehicle radius, :602-940
   Shrink s = {W - 1 - edgeOff, edgeOff, edgeOff, H - 1 - edgeOff};
   const int num = (int)(c.focal_length * c.planning_vehicle_radius / c.depth_scale);
-#define PL_PIX(x, y) const uint16_t d = img[(y) * W + (x)]; if (d > ignore && d < maxDepth)
-  for (int x = R; x < W; x++)            // right side, :617-661
-    for (int y = T; y <= B; y++) {
-      PL_PIX(x, y) {
-        if (num > (x - s.right) * d) {
-          const int rT = x - (int)(num / d);
-          if (x0 > rT - buf) {
-            const int tT = y + (int)(num / d), bT = y - (int)(num / d);
-            if (y0 < tT + buf && y0 > bT - buf) return false;
-            else if (y0 < tT + buf) s.bottom = bT;
-            else if (y0 > bT - buf) s.top = tT;
-            else if ((s.bottom - bT) > (tT - s.top)) s.top = tT;
-            else s.right = bT;            // sic, DIP.cpp:648
-          } else s.right = rT;
-        }
-      }
-    }
-  for (int x = L; x >= 0; x--)           // left side, :663-698
-    for (int y = T; y <= B; y++) {
-      PL_PIX(x, y) {
-        if ((s.left - x) * d < num) {
-          const int lT = x + (int)(num / d);
-          if (x0 < lT + buf) {
-            const int tT = y + (int)(num / d), bT = y - (int)(num / d);
-            if (y0 < tT + buf && y0 > bT - buf) return false;
-            else if (y0 < tT + buf) s.bottom = bT;
-            else if (y0 > bT - buf) s.top = tT;
-            else if ((s.bottom - bT) > (tT - s.top)) s.top = tT;
-            else s.bottom = bT;
-          } else s.left = lT;
-        }
-      }
-    }
+  const int ny = B - T + 1, nx = R - L + 1;
+  // right side :617-661 (columns R.. outward, rows T..B); left side :663-698
+  if (!side_scan<SIDE_RIGHT>(imgT, H, 1, lane, (W - R) * ny, ny, R, T, 1, 0, 0, 1, ignore, maxDepth, num, buf, x0, y0, s)) return false;
+  if (!side_scan<SIDE_LEFT>(imgT, H, 1, lane, (L + 1) * ny, ny, L, T, -1, 0, 0, 1, ignore, maxDepth, num, buf, x0, y0, s)) return false;
   if (s.left + buf > s.right - buf) return false;
-  for (int y = T; y >= 0; y--)           // top side, :705-744
-    for (int x = L; x <= R; x++) {
-      PL_PIX(x, y) {
-        if ((s.top - y) * d < num) {
-          const int tT = y + (int)(num / d);
-          if (y0 < tT + buf) {
-            const int rT = x - (int)(num / d), lT = x + (int)(num / d);
-            if (x0 > rT - buf && x0 < lT + buf) return false;
-            else if (x0 > rT - buf) s.left = lT;
-            else if (x0 < lT + buf) s.right = rT;
-            else if ((s.right - rT) > (lT - s.left)) s.left = lT;
-            else s.right = rT;
-          } else s.top = tT;
-        }
-      }
-    }
-  for (int y = B; y < H; y++)            // bottom side, :746-785
-    for (int x = L; x <= R; x++) {
-      PL_PIX(x, y) {
-        if (num > (y - s.bottom) * d) {
-          const int bT = y - (int)(num / d);
-          if (y0 > bT - buf) {
-            const int rT = x - (int)(num / d), lT = x + (int)(num / d);
-            if (x0 > rT - buf && x0 < lT + buf) return false;
-            else if (x0 > rT - buf) s.left = lT;
-            else if (x0 < lT + buf) s.right = rT;
-            else if ((s.right - rT) > (lT - s.left)) s.left = lT;
-            else s.right = rT;
-          } else s.bottom = bT;
-        }
-      }
-    }
+  // top side :705-744 (rows T.. outward, columns L..R); bottom side :746-785
+  if (!side_scan<SIDE_TOP>(img, 1, W, lane, (T + 1) * nx, nx, L, T, 0, -1, 1, 0, ignore, maxDepth, num, buf, x0, y0, s)) return false;
+  if (!side_scan<SIDE_BOTTOM>(img, 1, W, lane, (H - B) * nx, nx, L, B, 0, 1, 1, 0, ignore, maxDepth, num, buf, x0, y0, s)) return false;
   if (s.top + buf > s.bottom - buf) return false;
-  for (int y = T; y >= 0; y--)           // top right corner, :794-829
-    for (int x = R; x < W; x++) {
-      PL_PIX(x, y) {
-        if (num > (x - s.right) * d && (s.top - y) * d < num) {
-          const int rT = x - (int)(num / d), tT = y + (int)(num / d);
-          if (x0 > rT - buf && y0 < tT + buf) return false;
-          else if (x0 > rT - buf) s.top = tT;
-          else if (y0 < tT + buf) s.right = rT;
-          else if ((s.right - rT) * (s.bottom - s.top) > (tT - s.top) * (s.right - s.left)) s.top = tT;
-          else s.right = rT;
-        }
-      }
-    }
-  for (int y = B; y < H; y++)            // bottom right corner, :831-866
-    for (int x = R; x < W; x++) {
-      PL_PIX(x, y) {
-        if (num > (x - s.right) * d && num > (y - s.bottom) * d) {
-          const int rT = x - (int)(num / d), bT = y - (int)(num / d);
-          if (x0 > rT - buf && y0 > bT - buf) return false;
-          else if (x0 > rT - buf) s.bottom = bT;
-          else if (y0 > bT - buf) s.right = rT;
-          else if ((s.right - rT) * (s.bottom - s.top) > (s.bottom - bT) * (s.right - s.left)) s.bottom = bT;
-          else s.right = rT;
-        }
-      }
-    }
-  for (int y = T; y >= 0; y--)           // top left corner, :868-903
-    for (int x = L; x >= 0; x--) {
-      PL_PIX(x, y) {
-        if ((s.left - x) * d < num && (s.top - y) * d < num) {
-          const int lT = x + (int)(num / d), tT = y + (int)(num / d);
-          if (x0 < lT + buf && y0 < tT + buf) return false;
-          else if (x0 < lT + buf) s.top = tT;
-          else if (y0 < tT + buf) s.left = lT;
-          else if ((lT - s.left) * (s.bottom - s.top) > (tT - s.top) * (s.right - s.left)) s.top = tT;
-          else s.left = lT;
-        }
-      }
-    }
-  for (int y = B; y < H; y++)            // bottom left corner, :905-940
-    for (int x = L; x >= 0; x--) {
-      PL_PIX(x, y) {
-        if ((s.left - x) * d < num && num > (y - s.bottom) * d) {
-          const int lT = x + (int)(num / d), bT = y - (int)(num / d);
-          if (x0 < lT + buf && y0 > bT - buf) return false;
-          else if (x0 < lT + buf) s.bottom = bT;
-          else if (y0 > bT - buf) s.left = lT;
-          else if ((lT - s.left) * (s.bottom - s.top) > (s.bottom - bT) * (s.right - s.left)) s.bottom = bT;
-          else s.left = lT;
-        }
-      }
-    }
-#undef PL_PIX
+  PL_T1(t_side, 3);
+  PL_T0(t_corner);
+  // corners :794-940
+  if (!corner_scan<CORNER_TR>(img, W, lane, T + 1, W - R, R, T, ignore, maxDepth, num, buf, x0, y0, s)) return false;
+  if (!corner_scan<CORNER_BR>(img, W, lane, H - B, W - R, R, B, ignore, maxDepth, num, buf, x0, y0, s)) return false;
+  if (!corner_scan<CORNER_TL>(img, W, lane, T + 1, L + 1, L, T, ignore, maxDepth, num, buf, x0, y0, s)) return false;
+  if (!corner_scan<CORNER_BL>(img, W, lane, H - B, L + 1, L, B, ignore, maxDepth, num, buf, x0, y0, s)) return false;
+  PL_T1(t_corner, 4);
+  PL_COUNT(5, 1);
   // :942-966
   const double depth = maxDepth * c.depth_scale - c.planning_vehicle_radius;
   double k0[3], k1[3], k2[3], k3[3];
@@ -564,8 +715,9 @@ __device__ bool deepest_collision_time(const Poly &p, const Section &m, const Pl
 }
 
 // GetMonotonicSections (DIP.cpp:303-354) + IsCollisionFree (:214-301)
-__device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restrict__ img, const Poly &p, double tf,
-                               PlannerPyramid *pyr, int &nPyr, int maxPyr) {
+__device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restrict__ img,
+                               const uint16_t *__restrict__ imgT, uint32_t *ring_lds, int lane, const Poly &p,
+                               double tf, PlannerPyramid *pyr, int &nPyr, int maxPyr) {
 #pragma clang fp contract(off)
   double dc[5];
   for (int i = 0; i < 5; i++) dc[i] = (5 - i) * p.c[i][2];
@@ -611,7 +763,7 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
     if (at < 0) {
       if (nPyr >= maxPyr) return false;                        // _maxNumPyramids, :255-260
       PlannerPyramid fresh;
-      if (!inflate_pyramid(cfg, img, (int)px, (int)py, ez, fresh)) return false;
+      if (!inflate_pyramid(cfg, img, imgT, ring_lds, lane, (int)px, (int)py, ez, fresh)) return false;
       int idx = 0;                                             // std::lower_bound + insert, :269-271
       while (idx < nPyr && pyr[idx].depth < fresh.depth) idx++;
       for (int q = nPyr; q > idx; q--) pyr[q] = pyr[q - 1];
@@ -630,54 +782,116 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
 
 }  // namespace
 
-// FindLowestCostTrajectory, DIP.cpp:91-212, candidate count instead of a time budget
-__global__ void __launch_bounds__(64) afe_rappids_kernel(const PlannerConfig cfg, const PlannerBatch b) {
-#pragma clang fp contract(off)
-  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= b.n) return;
-  const uint16_t *img = b.images + (int64_t)(b.image_index ? b.image_index[i] : i) * cfg.width * cfg.height;
-  const double *samples = b.samples + (int64_t)(b.sample_table ? b.sample_table[i] : 0) * b.n_candidates * 4;
-  PlannerPyramid *pyr = b.pyramids + i * b.max_pyramids;
-  int nPyr = 0;
-  Cand k;
-  double cost_vec[3];
+// ---- FindLowestCostTrajectory, DIP.cpp:91-212, candidate count instead of a time budget ------
+// The reference examines candidates one after the other: cost first, then (only if it beats the
+// best so far) input feasibility, velocity, collision.  Cost, input feasibility and velocity
+// admissibility depend on nothing but the candidate itself, so they are evaluated for ALL
+// candidates of all planners by afe_rappids_candidates_kernel (one lane per candidate), and
+// afe_rappids_search_kernel (one wave per planner) then replays the reference's sequential
+// decisions on those precomputed answers -- the candidates whose cost does not beat the running
+// best are skipped 64 at a time by a ballot -- and runs the collision checks, the only part
+// that needs the image, wave-cooperatively.  Flags and counters come out exactly as the
+// sequential loop would have produced them.
+
+__device__ __forceinline__ void load_planner_state(const PlannerConfig &cfg, const PlannerBatch &b, int64_t i, Cand &k,
+                                                   double cost_vec[3]) {
   for (int a = 0; a < 3; a++) {
     k.v0[a] = b.vel0[a * b.n + i];
     k.a0[a] = b.acc0[a * b.n + i];
     k.grav[a] = b.grav[a * b.n + i];
     cost_vec[a] = b.cost_vec ? b.cost_vec[a * b.n + i] : cfg.cost_vec[a];
   }
-  PlanOutput o;
-  o.found = 0; o.best_index = -1; o.best_cost = 1.7976931348623157e308; o.tf = 0;
-  o.n_generated = o.n_cost_checks = o.n_collision_checks = o.n_velocity_checks = o.n_collision_free = 0;
-  for (int q = 0; q < 6; q++) for (int a = 0; a < 3; a++) o.coeffs[q][a] = 0;
+}
+
+__device__ __forceinline__ double candidate_cost(const PlannerConfig &cfg, const Cand &k, const double cost_vec[3]) {
+#pragma clang fp contract(off)
+  const double dur = k.tf;
+  const double ex = c_pos(k, 0, dur), ey = c_pos(k, 1, dur), ez = c_pos(k, 2, dur);
+  if (cfg.cost_type == 0)            // ExplorationCost::GetCost, DIP.hpp:488-492
+    return -(cost_vec[0] * ex + cost_vec[1] * ey + cost_vec[2] * ez) / dur;
+  // Simulator/Rappids_Simulator/main.cpp:86-107
+  const double gx = cost_vec[0], gy = cost_vec[1], gz = cost_vec[2];
+  const double SG = sqrt((gx - 0) * (gx - 0) + (gy - 0) * (gy - 0) + (gz - 0) * (gz - 0));
+  const double PiG = sqrt((gx - ex) * (gx - ex) + (gy - ey) * (gy - ey) + (gz - ez) * (gz - ez));
+  return -(SG - PiG) / dur;
+}
+
+enum { CAND_INPUT_FEASIBLE = 1, CAND_VELOCITY_OK = 2 };
+
+__global__ void __launch_bounds__(256) afe_rappids_candidates_kernel(const PlannerConfig cfg, const PlannerBatch b) {
+#pragma clang fp contract(off)
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= b.n * b.n_candidates) return;
+  const int64_t i = t / b.n_candidates;
+  const int c = (int)(t - i * b.n_candidates);
+  const double *sample = b.samples + ((int64_t)(b.sample_table ? b.sample_table[i] : 0) * b.n_candidates + c) * 4;
+  Cand k;
+  double cost_vec[3], pf[3];
+  load_planner_state(cfg, b, i, k, cost_vec);
+  deproject(cfg, sample[0], sample[1], sample[2], pf);             // DIP.hpp:393-404
+  c_generate(k, pf, sample[3]);
+  b.cand_cost[t] = candidate_cost(cfg, k, cost_vec);
+  uint8_t bits = 0;
+  if (input_feasible(k, cfg)) {
+    bits |= CAND_INPUT_FEASIBLE;
+    if (velocity_feasible(k, cfg.max_velocity)) bits |= CAND_VELOCITY_OK;
+  }
+  b.cand_bits[t] = bits;
+}
+
+#ifndef AFE_PLANNER_WAVES
+#define AFE_PLANNER_WAVES 4
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFE_PLANNER_WAVES, AFE_PLANNER_WAVES)))
+afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
+#pragma clang fp contract(off)
+  const int64_t i = blockIdx.x;      // one wave per planner
+  PL_T0(t_all);
+  const int lane = threadIdx.x;
+  extern __shared__ uint32_t ring_lds[];   // two rings of staged lines, see stage_ring
+  const int64_t img_off = (int64_t)(b.image_index ? b.image_index[i] : i) * cfg.width * cfg.height;
+  const uint16_t *img = b.images + img_off;
+  const uint16_t *imgT = b.images_t + img_off;
+  const double *samples = b.samples + (int64_t)(b.sample_table ? b.sample_table[i] : 0) * b.n_candidates * 4;
+  const double *cand_cost = b.cand_cost + i * b.n_candidates;
+  const uint8_t *cand_bits = b.cand_bits + i * b.n_candidates;
+  PlannerPyramid *pyr = b.pyramids + i * b.max_pyramids;
+  PlanOutput *out = b.out + i;
+  int nPyr = 0;
+  int n_cost = 0, n_feasible = 0, n_velocity = 0, n_free = 0, best_index = -1;
   double bestCost = 1.7976931348623157e308;
-  for (int c = 0; c < b.n_candidates; c++) {
-    double pf[3];
-    deproject(cfg, samples[4 * c + 0], samples[4 * c + 1], samples[4 * c + 2], pf);   // DIP.hpp:393-404
-    c_generate(k, pf, samples[4 * c + 3]);
-    o.n_generated++;
-    const double dur = k.tf;
-    const double ex = c_pos(k, 0, dur), ey = c_pos(k, 1, dur), ez = c_pos(k, 2, dur);
-    double cost;
-    if (cfg.cost_type == 0) {        // ExplorationCost::GetCost, DIP.hpp:488-492
-      cost = -(cost_vec[0] * ex + cost_vec[1] * ey + cost_vec[2] * ez) / dur;
-    } else {                         // Simulator/Rappids_Simulator/main.cpp:86-107
-      const double gx = cost_vec[0], gy = cost_vec[1], gz = cost_vec[2];
-      const double SG = sqrt((gx - 0) * (gx - 0) + (gy - 0) * (gy - 0) + (gz - 0) * (gz - 0));
-      const double PiG = sqrt((gx - ex) * (gx - ex) + (gy - ey) * (gy - ey) + (gz - ez) * (gz - ez));
-      cost = -(SG - PiG) / dur;
-    }
-    unsigned result = 0;
-    if (cost < bestCost) {
-      result |= 1;
-      o.n_cost_checks++;
-      if (input_feasible(k, cfg)) {
+  if (lane == 0) {                    // the "nothing found" answer; overwritten below
+    out->tf = 0;
+    for (int q = 0; q < 6; q++) for (int a = 0; a < 3; a++) out->coeffs[q][a] = 0;
+  }
+  for (int base = 0; base < b.n_candidates; base += 64) {
+    const int c = base + lane;
+    const bool has = c < b.n_candidates;
+    const double my_cost = has ? cand_cost[c] : 0.0;
+    const unsigned my_bits = has ? cand_bits[c] : 0u;
+    unsigned my_result = 0;
+    uint64_t todo = ~0ull;
+    for (;;) {
+      // candidates of this chunk that beat the best cost so far; the first one is the next the
+      // sequential loop would look into (the best cost only falls, so the others stay skipped)
+      const uint64_t pass = __ballot(has && my_cost < bestCost) & todo;
+      if (!pass) break;
+      const int l = (int)__ffsll((unsigned long long)pass) - 1;
+      const unsigned bits = (unsigned)__shfl((int)my_bits, l);
+      unsigned result = 1;
+      n_cost++;
+      if (bits & CAND_INPUT_FEASIBLE) {
         result |= 2;
-        o.n_collision_checks++;
-        if (velocity_feasible(k, cfg.max_velocity)) {
+        n_feasible++;
+        if (bits & CAND_VELOCITY_OK) {
           result |= 4;
-          o.n_velocity_checks++;
+          n_velocity++;
+          const double *sample = samples + 4 * (base + l);
+          Cand k;
+          double cost_vec[3], pf[3];
+          load_planner_state(cfg, b, i, k, cost_vec);
+          deproject(cfg, sample[0], sample[1], sample[2], pf);
+          c_generate(k, pf, sample[3]);
           Poly p;                    // RTG.hpp GetTrajectory
           for (int a = 0; a < 3; a++) {
             p.c[0][a] = k.al[a] / 120;
@@ -687,28 +901,80 @@ __global__ void __launch_bounds__(64) afe_rappids_kernel(const PlannerConfig cfg
             p.c[4][a] = c_vel(k, a, 0);
             p.c[5][a] = c_pos(k, a, 0);
           }
-          if (collision_free(cfg, img, p, k.tf, pyr, nPyr, b.max_pyramids)) {
+          PL_T0(t_cf);
+          const bool cfree = collision_free(cfg, img, imgT, ring_lds, lane, p, k.tf, pyr, nPyr, b.max_pyramids);
+          PL_T1(t_cf, 6);
+          if (cfree) {
             result |= 8;
-            bestCost = cost;
-            o.found = 1;
-            o.n_collision_free++;
-            o.best_index = c;
-            o.best_cost = cost;
-            o.tf = k.tf;
-            for (int q = 0; q < 6; q++) for (int a = 0; a < 3; a++) o.coeffs[q][a] = p.c[q][a];
+            bestCost = __shfl(my_cost, l);
+            n_free++;
+            best_index = base + l;
+            if (lane == 0) {
+              out->tf = k.tf;
+              for (int q = 0; q < 6; q++) for (int a = 0; a < 3; a++) out->coeffs[q][a] = p.c[q][a];
+            }
           }
         }
       }
+      if (lane == l) my_result = result;
+      todo = lanes_from(l + 1);
     }
-    if (b.flags) b.flags[i * b.n_candidates + c] = (uint8_t)result;
+    if (b.flags && has) b.flags[i * b.n_candidates + c] = (uint8_t)my_result;
   }
-  o.n_pyramids = nPyr;
-  b.out[i] = o;
+  if (lane == 0) {
+    out->found = best_index >= 0;
+    out->best_index = best_index;
+    out->best_cost = bestCost;
+    out->n_generated = b.n_candidates;
+    out->n_cost_checks = n_cost;
+    out->n_collision_checks = n_feasible;
+    out->n_velocity_checks = n_velocity;
+    out->n_collision_free = n_free;
+    out->n_pyramids = nPyr;
+  }
+  PL_T1(t_all, 0);
+}
+
+// images [n][H][W] -> images_t [n][W][H] through 32x32 LDS tiles
+__global__ void __launch_bounds__(256) afe_transpose_images_kernel(const uint16_t *__restrict__ src,
+                                                                   uint16_t *__restrict__ dst, int W, int H) {
+  __shared__ uint16_t tile[32][33];
+  const int64_t off = (int64_t)blockIdx.z * W * H;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int x = blockIdx.x * 32 + tx;
+  for (int r = ty; r < 32; r += 8) {
+    const int y = blockIdx.y * 32 + r;
+    if (x < W && y < H) tile[r][tx] = src[off + (int64_t)y * W + x];
+  }
+  __syncthreads();
+  const int yo = blockIdx.y * 32 + tx;
+  for (int r = ty; r < 32; r += 8) {
+    const int xo = blockIdx.x * 32 + r;
+    if (xo < W && yo < H) dst[off + (int64_t)xo * H + yo] = tile[tx][r];
+  }
 }
 
 int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream) {
   if (b.n <= 0) return 0;
-  hipLaunchKernelGGL(afe_rappids_kernel, dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, cfg, b);
+  hipLaunchKernelGGL(afe_transpose_images_kernel, dim3((cfg.width + 31) / 32, (cfg.height + 31) / 32, (unsigned)b.n_images),
+                     dim3(256), 0, (hipStream_t)stream, b.images, b.images_t, cfg.width, cfg.height);
+  const unsigned ring_bytes = 2u * (2u * ((cfg.width + 63) & ~63) + 2u * ((cfg.height + 63) & ~63)) * sizeof(uint32_t);
+#ifdef AFE_PLANNER_PROFILE
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero));
+#endif
+  const int64_t n_cand = b.n * b.n_candidates;
+  hipLaunchKernelGGL(afe_rappids_candidates_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     cfg, b);
+  hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), ring_bytes, (hipStream_t)stream, cfg, b);
+#ifdef AFE_PLANNER_PROFILE
+  unsigned long long prof[8];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_prof), sizeof(prof));
+  fprintf(stderr, "planner profile (cycles per planner): total %.0f | collision_free %.0f | inflate: ring wait %.0f expansion %.0f "
+          "sides %.0f corners %.0f | completed pyramids/planner %.2f rings/planner %.1f\n", (double)prof[0] / b.n, (double)prof[6] / b.n,
+          (double)prof[1] / b.n, (double)prof[2] / b.n, (double)prof[3] / b.n, (double)prof[4] / b.n, (double)prof[5] / b.n, (double)prof[7] / b.n);
+#endif
   return (int)hipGetLastError();
 }
 
