@@ -352,6 +352,184 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 }
 __device__ __forceinline__ uint64_t lanes_from(int l) { return l >= 64 ? 0ull : (~0ull << l); }
 
+// ---- bit images in LDS ----------------------------------------------------------------------
+// Pyramid inflation asks two yes/no questions of every pixel: "nearer than minDepthPix?" during the
+// spiral expansion (DIP.cpp:520-600) and "nearer than the pyramid's far plane?" during the shrink
+// scans (:602-940).  Each is answered once per pyramid for the whole image by a sweep of fully
+// independent loads (many in flight, no decision in between) that leaves ONE BIT per pixel in LDS:
+// word (y, w) holds pixels x = 64w .. 64w+63 of row y.  The decision loops then run on the bit
+// image -- a ring of the expansion is a handful of LDS reads and ballots, a shrink scan touches
+// HBM only for the few chunks that contain a marked pixel.
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int l) {
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)v, l), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+// i / inner for 0 <= i < 2^24, 1 <= inner <= 2^15 as a multiply-high
+__device__ __forceinline__ unsigned div_magic(int inner) { return (unsigned)(0x100000000ull / (unsigned)inner) + 1u; }
+__device__ __forceinline__ int div_small(int i, int inner, unsigned magic) {
+  return inner == 1 ? i : (int)__umulhi((unsigned)i, magic);
+}
+
+constexpr int kSweepBatch = 8;
+
+// mask(x, y) = lo < d(x, y) < hi for the whole image
+__device__ __forceinline__ unsigned in_open_range(unsigned d, unsigned lo1, unsigned span) {
+  return (d - lo1) < span ? 1u : 0u;          // lo < d < hi with lo1 = lo + 1, span = hi - lo - 1 (unsigned wrap)
+}
+__device__ __forceinline__ unsigned range_bits8(const uint4 q, unsigned lo1, unsigned span) {
+  return in_open_range(q.x & 0xffffu, lo1, span) | in_open_range(q.x >> 16, lo1, span) << 1 |
+         in_open_range(q.y & 0xffffu, lo1, span) << 2 | in_open_range(q.y >> 16, lo1, span) << 3 |
+         in_open_range(q.z & 0xffffu, lo1, span) << 4 | in_open_range(q.z >> 16, lo1, span) << 5 |
+         in_open_range(q.w & 0xffffu, lo1, span) << 6 | in_open_range(q.w >> 16, lo1, span) << 7;
+}
+
+__device__ void build_mask(const uint16_t *__restrict__ img, int W, int H, int lane, uint64_t *mask, int WW, uint16_t lo,
+                           uint16_t hi) {
+  if ((W & 63) == 0 && hi > lo) {
+    // rows are whole 64-pixel words, so the image is one linear run of them: every lane takes
+    // 8 pixels (16 B) per load and writes their 8 bits as one BYTE of the little-endian bit image
+    const uint4 *src = (const uint4 *)img;       // 16-byte aligned: hipMalloc base + k * W * H * 2
+    uint8_t *bytes = (uint8_t *)mask;
+    const int nvec = (W * H) >> 3;
+    const unsigned lo1 = (unsigned)lo + 1u, span = (unsigned)hi - (unsigned)lo - 1u;
+    for (int v0 = 0; v0 < nvec; v0 += 64 * kSweepBatch) {
+      uint4 q[kSweepBatch];
+#pragma unroll
+      for (int u = 0; u < kSweepBatch; u++) {
+        const int v = v0 + 64 * u + lane;
+        q[u] = make_uint4(0, 0, 0, 0);
+        if (v < nvec) q[u] = src[v];
+      }
+#pragma unroll
+      for (int u = 0; u < kSweepBatch; u++) {
+        const int v = v0 + 64 * u + lane;
+        if (v < nvec) bytes[v] = (uint8_t)range_bits8(q[u], lo1, span);
+      }
+    }
+    return;
+  }
+  const int n = WW * H;
+  const unsigned magic = div_magic(WW);
+  for (int c0 = 0; c0 < n; c0 += kSweepBatch) {
+    uint16_t d[kSweepBatch];
+#pragma unroll
+    for (int u = 0; u < kSweepBatch; u++) {
+      const int c = c0 + u;
+      d[u] = 0;
+      if (c < n) {
+        const int y = div_small(c, WW, magic), x = 64 * (c - y * WW) + lane;
+        if (x < W) d[u] = img[y * W + x];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSweepBatch; u++) {
+      const int c = c0 + u;
+      if (c < n) {
+        const uint64_t bits = __ballot(d[u] > lo && d[u] < hi);
+        if (lane == 0) mask[c] = bits;
+      }
+    }
+  }
+}
+
+// first marked pixel of column x, rows ya..yb / of row y, columns xa..xb
+__device__ __forceinline__ bool mask_col_hit(const uint64_t *mask, int WW, int lane, int x, int ya, int yb, int &first) {
+  const int w = x >> 6, sh = x & 63;
+  for (int base = ya; base <= yb; base += 64) {
+    const int y = base + lane;
+    const uint64_t word = y <= yb ? mask[y * WW + w] : 0ull;
+    const uint64_t b = __ballot((word >> sh) & 1ull);
+    if (b) { first = base + (int)__ffsll((unsigned long long)b) - 1; return true; }
+  }
+  return false;
+}
+__device__ __forceinline__ uint64_t clip_word(uint64_t word, int w, int xa, int xb) {
+  if (w == (xa >> 6)) word &= ~0ull << (xa & 63);
+  if (w == (xb >> 6)) word &= ~0ull >> (63 - (xb & 63));
+  return word;
+}
+__device__ __forceinline__ bool mask_row_hit(const uint64_t *mask, int WW, int lane, int y, int xa, int xb, int &first) {
+  const int wa = xa >> 6, wb = xb >> 6;
+  for (int wbase = wa; wbase <= wb; wbase += 64) {
+    const int w = wbase + lane;
+    const uint64_t word = w <= wb ? clip_word(mask[y * WW + w], w, xa, xb) : 0ull;
+    const uint64_t b = __ballot(word != 0);
+    if (b) {
+      const int l = (int)__ffsll((unsigned long long)b) - 1;
+      first = 64 * (wbase + l) + (int)__ffsll((unsigned long long)shfl_u64(word, l)) - 1;
+      return true;
+    }
+  }
+  return false;
+}
+// any marked pixel in [xa, xb] x [ya, yb]?
+__device__ __forceinline__ bool mask_region_any(const uint64_t *mask, int WW, int lane, int xa, int xb, int ya, int yb) {
+  if (xa > xb || ya > yb) return false;
+  const int wa = xa >> 6, nw = (xb >> 6) - wa + 1, total = nw * (yb - ya + 1);
+  const unsigned magic = div_magic(nw);
+  for (int base = 0; base < total; base += 64) {
+    const int p = base + lane;
+    uint64_t word = 0;
+    if (p < total) {
+      const int o = div_small(p, nw, magic), w = wa + (p - o * nw);
+      word = clip_word(mask[(ya + o) * WW + w], w, xa, xb);
+    }
+    if (__ballot(word != 0)) return true;
+  }
+  return false;
+}
+__device__ __forceinline__ bool mask_bit(const uint64_t *mask, int WW, int x, int y) {
+  return (mask[y * WW + (x >> 6)] >> (x & 63)) & 1ull;
+}
+
+// The expansion examines, in ring j (counted from the current rectangle), exactly the pixels at
+// "ring distance" j = max(dx, dy) from it, dx / dy being the distance beyond the rectangle's
+// right / left and top / bottom edge (0 in between) -- as long as every side that is still free keeps
+// advancing.  The first ring in which a free side meets a marked pixel is therefore the smallest
+// ring distance of any marked pixel inside the window the free sides can still reach; all rings
+// before it are clear and can be taken in one step.  Returns that ring index (>= 1) or INT_MAX.
+__device__ int first_blocking_ring(const uint64_t *mask, int WW, int lane, int xlo, int xhi, int ylo, int yhi, int L,
+                                   int R, int T, int B) {
+  const int wa = xlo >> 6, nw = (xhi >> 6) - wa + 1, total = nw * (yhi - ylo + 1);
+  const unsigned magic = div_magic(nw);
+  int best = 0x7fffffff;
+  for (int base = 0; base < total; base += 64) {
+    const int p = base + lane;
+    if (p < total) {
+      const int o = div_small(p, nw, magic), w = wa + (p - o * nw), y = ylo + o;
+      const uint64_t word = clip_word(mask[y * WW + w], w, xlo, xhi);
+      if (word) {
+        const int dy = y < T ? T - y : (y > B ? y - B : 0);
+        const int x_first = 64 * w, x_last = x_first + 63;
+        // bits right of R: the nearest is the lowest one
+        if (x_last > R) {
+          const uint64_t part = x_first > R ? word : word & (~0ull << ((R + 1) & 63));
+          if (part) { const int dx = x_first + (int)__ffsll((unsigned long long)part) - 1 - R; best = PL_MIN(best, PL_MAX(dx, dy)); }
+        }
+        // bits left of L: the nearest is the highest one
+        if (x_first < L) {
+          const uint64_t part = x_last < L ? word : word & ~(~0ull << (L & 63));
+          if (part) { const int dx = L - (x_first + 63 - __clzll((long long)part)); best = PL_MIN(best, PL_MAX(dx, dy)); }
+        }
+        // bits in [L, R]: above or below the rectangle (inside it nothing is examined any more)
+        if (dy > 0 && x_last >= L && x_first <= R && clip_word(word, w, PL_MAX(L, x_first), PL_MIN(R, x_last)))
+          best = PL_MIN(best, dy);
+      }
+    }
+  }
+  return wave_min_i32(best);
+}
+
+// min over d > ignore of n pixels src[0], src[stride], ... (a blocked line's prefix)
+__device__ __forceinline__ void min_line(const uint16_t *__restrict__ src, int stride, int n, int lane, uint16_t ignore,
+                                         int &laneMin) {
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    if (i < n) { const uint16_t d = src[i * stride]; if (d > ignore) laneMin = PL_MIN(laneMin, (int)d); }
+  }
+}
+
+
 enum { SIDE_RIGHT = 0, SIDE_LEFT = 1, SIDE_TOP = 2, SIDE_BOTTOM = 3 };
 
 // One of the four side scans, DIP.cpp:617-785.  `total` pixels, pixel i at
@@ -361,32 +539,37 @@ enum { SIDE_RIGHT = 0, SIDE_LEFT = 1, SIDE_TOP = 2, SIDE_BOTTOM = 3 };
 // not depend on the edges) and then resolved one after the other, so one memory latency is paid
 // per batch instead of per chunk.  i / inner for i < 2^24, inner <= 2^15 as a multiply-high.
 constexpr int kScanBatch = 4;
-__device__ __forceinline__ unsigned div_magic(int inner) { return (unsigned)(0x100000000ull / (unsigned)inner) + 1u; }
 
 template <int SIDE>
-__device__ bool side_scan(const uint16_t *__restrict__ src, int sx, int sy, int lane, int total, int inner, int xa,
-                          int ya, int dxo, int dyo, int dxi, int dyi, uint16_t ignore, uint16_t maxDepth, int num,
-                          int buf, int x0, int y0, Shrink &s) {
+__device__ bool side_scan(const uint16_t *__restrict__ src, int sx, int sy, const uint64_t *mask, int WW, int lane,
+                          int total, int inner, int xa, int ya, int dxo, int dyo, int dxi, int dyi, int num, int buf,
+                          int x0, int y0, Shrink &s) {
   const unsigned magic = div_magic(inner);
   for (int base0 = 0; base0 < total; base0 += 64 * kScanBatch) {
     int xs[kScanBatch], ys[kScanBatch];
+    bool vs[kScanBatch];
     uint16_t ds[kScanBatch];
 #pragma unroll
     for (int c = 0; c < kScanBatch; c++) {
       const int i = base0 + 64 * c + lane;
-      xs[c] = 0; ys[c] = 0; ds[c] = 0;
+      xs[c] = 0; ys[c] = 0; vs[c] = false;
       if (i < total) {
-        const int o = (int)__umulhi((unsigned)i, magic), r = i - o * inner;
+        const int o = div_small(i, inner, magic), r = i - o * inner;
         xs[c] = xa + o * dxo + r * dxi;
         ys[c] = ya + o * dyo + r * dyi;
-        ds[c] = src[ys[c] * sy + xs[c] * sx];    // (1, W) on the image, (H, 1) on its transpose
+        vs[c] = mask_bit(mask, WW, xs[c], ys[c]);          // ignore < d < maxDepth, from the bit image
       }
+    }
+#pragma unroll
+    for (int c = 0; c < kScanBatch; c++) {                  // depths only where a marked pixel needs one
+      ds[c] = 1;
+      if (vs[c]) ds[c] = src[ys[c] * sy + xs[c] * sx];     // (1, W) on the image, (H, 1) on its transpose
     }
 #pragma unroll
     for (int c = 0; c < kScanBatch; c++) {
       const int x = xs[c], y = ys[c];
       const uint16_t d = ds[c];
-      const bool valid = d > ignore && d < maxDepth;      // lanes past the end loaded 0 <= ignore
+      const bool valid = vs[c];
       if (!__ballot(valid)) continue;
       int k = 0;
       if (valid) k = (int)(num / d);
@@ -452,31 +635,37 @@ enum { CORNER_TR = 0, CORNER_BR = 1, CORNER_TL = 2, CORNER_BL = 3 };
 // One of the four corner scans, DIP.cpp:794-940: rows outward from the top / bottom edge,
 // pixels outward from the right / left edge.
 template <int CORNER>
-__device__ bool corner_scan(const uint16_t *__restrict__ img, int W, int lane, int rows, int inner, int xa, int ya,
-                            uint16_t ignore, uint16_t maxDepth, int num, int buf, int x0, int y0, Shrink &s) {
+__device__ bool corner_scan(const uint16_t *__restrict__ img, int W, const uint64_t *mask, int WW, int lane, int rows,
+                            int inner, int xa, int ya, int num, int buf, int x0, int y0, Shrink &s) {
   constexpr bool RIGHT = (CORNER == CORNER_TR || CORNER == CORNER_BR);
   constexpr bool TOP = (CORNER == CORNER_TR || CORNER == CORNER_TL);
   const int total = rows * inner;
   const unsigned magic = div_magic(inner);
   for (int base0 = 0; base0 < total; base0 += 64 * kScanBatch) {
     int xs[kScanBatch], ys[kScanBatch];
+    bool vs[kScanBatch];
     uint16_t ds[kScanBatch];
 #pragma unroll
     for (int c = 0; c < kScanBatch; c++) {
       const int i = base0 + 64 * c + lane;
-      xs[c] = 0; ys[c] = 0; ds[c] = 0;
+      xs[c] = 0; ys[c] = 0; vs[c] = false;
       if (i < total) {
-        const int o = (int)__umulhi((unsigned)i, magic), r = i - o * inner;
+        const int o = div_small(i, inner, magic), r = i - o * inner;
         xs[c] = RIGHT ? xa + r : xa - r;
         ys[c] = TOP ? ya - o : ya + o;
-        ds[c] = img[ys[c] * W + xs[c]];
+        vs[c] = mask_bit(mask, WW, xs[c], ys[c]);
       }
+    }
+#pragma unroll
+    for (int c = 0; c < kScanBatch; c++) {
+      ds[c] = 1;
+      if (vs[c]) ds[c] = img[ys[c] * W + xs[c]];
     }
 #pragma unroll
     for (int c = 0; c < kScanBatch; c++) {
       const int x = xs[c], y = ys[c];
       const uint16_t d = ds[c];
-      const bool valid = d > ignore && d < maxDepth;
+      const bool valid = vs[c];
       if (!__ballot(valid)) continue;
       int k = 0;
       if (valid) k = (int)(num / d);
@@ -510,62 +699,9 @@ __device__ bool corner_scan(const uint16_t *__restrict__ img, int W, int lane, i
   return true;
 }
 
-// ---- spiral expansion, DIP.cpp:520-600 ---------------------------------------------------
-// Every ring reads four lines (column R+1, row T-1, column L-1, row B+1).  They are staged into
-// LDS by direct global->LDS loads (global_load_lds_ushort, no VGPRs), rows from the image and
-// columns from its transpose so that both are contiguous, and the NEXT ring is requested before
-// the current one is examined: a side that is still free afterwards has moved by exactly one
-// pixel, so the speculative request (R+2, T-2, L-2, B+2, extents one pixel wider) always covers
-// what the next ring needs.  LDS lines are indexed by absolute pixel coordinate; a sub-dword
-// LDS-DMA writes one zero-extended DWORD per lane (lane x 4 bytes, measured on gfx950), so a staged
-// pixel occupies 32 bits.
-struct RingBuf {
-  uint32_t *top, *bottom, *right, *left;   // LDS; rows hold Wp entries, columns Hp (multiples of 64)
-};
-
-__device__ __forceinline__ void stage_line(const uint16_t *__restrict__ line, int n, uint32_t *lds_line, int lo, int hi,
-                                           int lane) {
-  lo = PL_MAX(lo, 0);
-  hi = PL_MIN(hi, n - 1);
-  for (int c = lo >> 6; c <= hi >> 6; c++) {
-    const int idx = PL_MIN(64 * c + lane, n - 1);    // lanes past the end re-read the last pixel into the padding
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(line + idx),
-                                     (__attribute__((address_space(3))) void *)(lds_line + 64 * c), 2, 0, 0);
-  }
-}
-
-__device__ __forceinline__ void stage_ring(const uint16_t *__restrict__ img, const uint16_t *__restrict__ imgT, int W,
-                                           int H, const RingBuf &rb, int lane, bool r, bool t, bool l, bool b, int xr,
-                                           int yt, int xl, int yb, int xlo, int xhi, int ylo, int yhi) {
-  if (r && xr < W) stage_line(imgT + (int64_t)xr * H, H, rb.right, ylo, yhi, lane);
-  if (t && yt >= 0) stage_line(img + (int64_t)yt * W, W, rb.top, xlo, xhi, lane);
-  if (l && xl >= 0) stage_line(imgT + (int64_t)xl * H, H, rb.left, ylo, yhi, lane);
-  if (b && yb < H) stage_line(img + (int64_t)yb * W, W, rb.bottom, xlo, xhi, lane);
-}
-
-// pixels lo..hi of a staged line; true if one nearer than minDepthPix blocks it.  laneMin collects
-// the depths seen before the blocking pixel (reduced once, after the expansion).
-__device__ __forceinline__ bool line_blocked(const uint32_t *lds_line, int lo, int hi, int lane, uint16_t ignore,
-                                             uint16_t minDepthPix, int &laneMin) {
-  for (int base = lo; base <= hi; base += 64) {
-    const int i = base + lane;
-    const bool in = i <= hi;
-    const uint16_t d = in ? (uint16_t)lds_line[i] : (uint16_t)0;
-    const bool counts = in && d > ignore;
-    const uint64_t blk = __ballot(counts && d < minDepthPix);
-    if (blk) {
-      const int first = (int)__ffsll((unsigned long long)blk) - 1;
-      if (counts && lane < first) laneMin = PL_MIN(laneMin, (int)d);
-      return true;
-    }
-    if (counts) laneMin = PL_MIN(laneMin, (int)d);
-  }
-  return false;
-}
-
 // DIP.cpp:456-970, executed by one wave (lane = 0..63, everything but the scans is uniform)
 __device__ bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restrict__ img,
-                                const uint16_t *__restrict__ imgT, uint32_t *ring_lds, int lane, int x0, int y0,
+                                const uint16_t *__restrict__ imgT, uint64_t *mask, int lane, int x0, int y0,
                                 double minimumDepth, PlannerPyramid &out) {
 #pragma clang fp contract(off)
   const int W = c.width, H = c.height, buf = c.pixel_buffer;
@@ -595,74 +731,142 @@ __device__ bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restri
     }
   }
   PL_T0(t_exp);
-  // spiral expansion, :520-600 (see stage_ring)
-  int laneMin = 65535;
+  // spiral expansion, :520-600, on the bit image "nearer than minDepthPix"
+  const int WW = (W + 63) >> 6;
+  PL_T0(t_m1);
+  build_mask(img, W, H, lane, mask, WW, ignore, minDepthPix);
+  PL_T1(t_m1, 1);
+  PL_T0(t_ring);
+  const int L0 = L, T0 = T, R0 = R, B0 = B;
+  // a blocked side: the line it was blocked on and how much of it was examined before the hit
+  int rbX = 0, rbFrom = 0, rbN = 0, tbY = 0, tbFrom = 0, tbN = 0, lbX = 0, lbFrom = 0, lbN = 0, bbY = 0, bbFrom = 0, bbN = 0;
   bool rFree = true, tFree = true, lFree = true, bFree = true;
-  const int Wp = (W + 63) & ~63, Hp = (H + 63) & ~63;
-  RingBuf ring[2];
-  for (int q = 0; q < 2; q++) {
-    uint32_t *base = ring_lds + q * (2 * Wp + 2 * Hp);
-    ring[q].top = base; ring[q].bottom = base + Wp; ring[q].right = base + 2 * Wp; ring[q].left = base + 2 * Wp + Hp;
-  }
-  int cur = 0;
-  stage_ring(img, imgT, W, H, ring[0], lane, true, true, true, true, R + 1, T - 1, L - 1, B + 1, L - 1, R + 1, T - 1, B + 1);
   while (rFree || tFree || lFree || bFree) {
-    PL_COUNT(7, 1);
-    PL_T0(t_wait);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this ring has landed (requested one iteration ago)
-    PL_T1(t_wait, 1);
-    stage_ring(img, imgT, W, H, ring[cur ^ 1], lane, rFree, tFree, lFree, bFree, R + 2, T - 2, L - 2, B + 2, L - 2, R + 2,
-               T - 2, B + 2);
-    const RingBuf &rb = ring[cur];
+    int first;
+    {  // take all the clear rings in one step (see first_blocking_ring)
+      const int xlo = lFree ? edgeOff : L, xhi = rFree ? W - edgeOff - 1 : R;
+      const int ylo = tFree ? edgeOff : T, yhi = bFree ? H - edgeOff - 1 : B;
+      const int ring = first_blocking_ring(mask, WW, lane, xlo, xhi, ylo, yhi, L, R, T, B);
+      const int clear = ring == 0x7fffffff ? 0x3fffffff : ring - 1;
+      if (rFree) R = PL_MIN(R + clear, W - edgeOff - 1);
+      if (tFree) T = PL_MAX(T - clear, edgeOff);
+      if (lFree) L = PL_MAX(L - clear, edgeOff);
+      if (bFree) B = PL_MIN(B + clear, H - edgeOff - 1);
+    }
     if (rFree) {
       if (R < W - edgeOff - 1) {
-        if (line_blocked(rb.right, T, B, lane, ignore, minDepthPix, laneMin)) { rFree = false; R--; }
-        R++;
+        if (mask_col_hit(mask, WW, lane, R + 1, T, B, first)) { rFree = false; rbX = R + 1; rbFrom = T; rbN = first - T; }
+        else R++;
       } else rFree = false;
     }
     if (tFree) {
       if (T > edgeOff) {
-        if (line_blocked(rb.top, L, R, lane, ignore, minDepthPix, laneMin)) { tFree = false; T++; }
-        T--;
+        if (mask_row_hit(mask, WW, lane, T - 1, L, R, first)) { tFree = false; tbY = T - 1; tbFrom = L; tbN = first - L; }
+        else T--;
       } else tFree = false;
     }
     if (lFree) {
       if (L > edgeOff) {
-        if (line_blocked(rb.left, T, B, lane, ignore, minDepthPix, laneMin)) { lFree = false; L++; }
-        L--;
+        if (mask_col_hit(mask, WW, lane, L - 1, T, B, first)) { lFree = false; lbX = L - 1; lbFrom = T; lbN = first - T; }
+        else L--;
       } else lFree = false;
     }
     if (bFree) {
       if (B < H - edgeOff - 1) {
-        if (line_blocked(rb.bottom, L, R, lane, ignore, minDepthPix, laneMin)) { bFree = false; B--; }
-        B++;
+        if (mask_row_hit(mask, WW, lane, B + 1, L, R, first)) { bFree = false; bbY = B + 1; bbFrom = L; bbN = first - L; }
+        else B++;
       } else bFree = false;
     }
-    cur ^= 1;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // retire the last speculative request before LDS is reused
+  PL_T1(t_ring, 7);
+  // maxDepth (:531,546,561,576): the nearest d > ignore over every pixel the expansion examined =
+  // the grown rectangle minus the initial one (each growth step adds exactly the line it examined)
+  // plus the examined prefixes of the blocked lines
+  int laneMin = 65535;
+  {
+    if ((W & 63) == 0) {
+      // rows T..B are one linear run; 8 pixels per lane per load, all in one row (W % 8 == 0)
+      const uint4 *src = (const uint4 *)(img + T * W);
+      const int nvec = ((B - T + 1) * W) >> 3;
+      const unsigned magic = div_magic(W >> 3);
+      for (int v0 = 0; v0 < nvec; v0 += 64 * kSweepBatch) {
+        uint4 q[kSweepBatch];
+#pragma unroll
+        for (int u = 0; u < kSweepBatch; u++) {
+          const int v = v0 + 64 * u + lane;
+          q[u] = make_uint4(0, 0, 0, 0);
+          if (v < nvec) q[u] = src[v];
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepBatch; u++) {
+          const int v = v0 + 64 * u + lane;
+          const int o = div_small(v, W >> 3, magic), xb = (v - o * (W >> 3)) << 3, y = T + o;
+          const bool initRow = y >= T0 && y <= B0;
+          const unsigned px[8] = {q[u].x & 0xffffu, q[u].x >> 16, q[u].y & 0xffffu, q[u].y >> 16,
+                                  q[u].z & 0xffffu, q[u].z >> 16, q[u].w & 0xffffu, q[u].w >> 16};
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const int x = xb + j;
+            const bool counted = x >= L && x <= R && !(initRow && x >= L0 && x <= R0) && px[j] > ignore;
+            if (counted) laneMin = PL_MIN(laneMin, (int)px[j]);      // lanes past the end hold 0 <= ignore
+          }
+        }
+      }
+    } else {
+      const int nxf = R - L + 1, total = nxf * (B - T + 1);
+      const unsigned magic = div_magic(nxf);
+      for (int base0 = 0; base0 < total; base0 += 64 * kSweepBatch) {
+        uint16_t d[kSweepBatch];
+#pragma unroll
+        for (int u = 0; u < kSweepBatch; u++) {
+          const int i = base0 + 64 * u + lane;
+          d[u] = 0;
+          if (i < total) {
+            const int o = div_small(i, nxf, magic), x = L + (i - o * nxf), y = T + o;
+            if (!(x >= L0 && x <= R0 && y >= T0 && y <= B0)) d[u] = img[y * W + x];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepBatch; u++)
+          if (d[u] > ignore) laneMin = PL_MIN(laneMin, (int)d[u]);
+      }
+    }
+    min_line(imgT + rbX * H + rbFrom, 1, rbN, lane, ignore, laneMin);
+    min_line(img + tbY * W + tbFrom, 1, tbN, lane, ignore, laneMin);
+    min_line(imgT + lbX * H + lbFrom, 1, lbN, lane, ignore, laneMin);
+    min_line(img + bbY * W + bbFrom, 1, bbN, lane, ignore, laneMin);
+  }
   const uint16_t maxDepth = (uint16_t)wave_min_i32(laneMin);
   PL_T1(t_exp, 2);
   PL_T0(t_side);
-  // shrink by the vehicle radius, :602-940
+  // shrink by the vehicle radius, :602-940, on the bit image "ignore < d < maxDepth"
+  build_mask(img, W, H, lane, mask, WW, ignore, maxDepth);
   Shrink s = {W - 1 - edgeOff, edgeOff, edgeOff, H - 1 - edgeOff};
   const int num = (int)(c.focal_length * c.planning_vehicle_radius / c.depth_scale);
   const int ny = B - T + 1, nx = R - L + 1;
   // right side :617-661 (columns R.. outward, rows T..B); left side :663-698
-  if (!side_scan<SIDE_RIGHT>(imgT, H, 1, lane, (W - R) * ny, ny, R, T, 1, 0, 0, 1, ignore, maxDepth, num, buf, x0, y0, s)) return false;
-  if (!side_scan<SIDE_LEFT>(imgT, H, 1, lane, (L + 1) * ny, ny, L, T, -1, 0, 0, 1, ignore, maxDepth, num, buf, x0, y0, s)) return false;
+  if (mask_region_any(mask, WW, lane, R, W - 1, T, B) &&
+      !side_scan<SIDE_RIGHT>(imgT, H, 1, mask, WW, lane, (W - R) * ny, ny, R, T, 1, 0, 0, 1, num, buf, x0, y0, s)) return false;
+  if (mask_region_any(mask, WW, lane, 0, L, T, B) &&
+      !side_scan<SIDE_LEFT>(imgT, H, 1, mask, WW, lane, (L + 1) * ny, ny, L, T, -1, 0, 0, 1, num, buf, x0, y0, s)) return false;
   if (s.left + buf > s.right - buf) return false;
   // top side :705-744 (rows T.. outward, columns L..R); bottom side :746-785
-  if (!side_scan<SIDE_TOP>(img, 1, W, lane, (T + 1) * nx, nx, L, T, 0, -1, 1, 0, ignore, maxDepth, num, buf, x0, y0, s)) return false;
-  if (!side_scan<SIDE_BOTTOM>(img, 1, W, lane, (H - B) * nx, nx, L, B, 0, 1, 1, 0, ignore, maxDepth, num, buf, x0, y0, s)) return false;
+  if (mask_region_any(mask, WW, lane, L, R, 0, T) &&
+      !side_scan<SIDE_TOP>(img, 1, W, mask, WW, lane, (T + 1) * nx, nx, L, T, 0, -1, 1, 0, num, buf, x0, y0, s)) return false;
+  if (mask_region_any(mask, WW, lane, L, R, B, H - 1) &&
+      !side_scan<SIDE_BOTTOM>(img, 1, W, mask, WW, lane, (H - B) * nx, nx, L, B, 0, 1, 1, 0, num, buf, x0, y0, s)) return false;
   if (s.top + buf > s.bottom - buf) return false;
   PL_T1(t_side, 3);
   PL_T0(t_corner);
   // corners :794-940
-  if (!corner_scan<CORNER_TR>(img, W, lane, T + 1, W - R, R, T, ignore, maxDepth, num, buf, x0, y0, s)) return false;
-  if (!corner_scan<CORNER_BR>(img, W, lane, H - B, W - R, R, B, ignore, maxDepth, num, buf, x0, y0, s)) return false;
-  if (!corner_scan<CORNER_TL>(img, W, lane, T + 1, L + 1, L, T, ignore, maxDepth, num, buf, x0, y0, s)) return false;
-  if (!corner_scan<CORNER_BL>(img, W, lane, H - B, L + 1, L, B, ignore, maxDepth, num, buf, x0, y0, s)) return false;
+  if (mask_region_any(mask, WW, lane, R, W - 1, 0, T) &&
+      !corner_scan<CORNER_TR>(img, W, mask, WW, lane, T + 1, W - R, R, T, num, buf, x0, y0, s)) return false;
+  if (mask_region_any(mask, WW, lane, R, W - 1, B, H - 1) &&
+      !corner_scan<CORNER_BR>(img, W, mask, WW, lane, H - B, W - R, R, B, num, buf, x0, y0, s)) return false;
+  if (mask_region_any(mask, WW, lane, 0, L, 0, T) &&
+      !corner_scan<CORNER_TL>(img, W, mask, WW, lane, T + 1, L + 1, L, T, num, buf, x0, y0, s)) return false;
+  if (mask_region_any(mask, WW, lane, 0, L, B, H - 1) &&
+      !corner_scan<CORNER_BL>(img, W, mask, WW, lane, H - B, L + 1, L, B, num, buf, x0, y0, s)) return false;
   PL_T1(t_corner, 4);
   PL_COUNT(5, 1);
   // :942-966
@@ -716,7 +920,7 @@ __device__ bool deepest_collision_time(const Poly &p, const Section &m, const Pl
 
 // GetMonotonicSections (DIP.cpp:303-354) + IsCollisionFree (:214-301)
 __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restrict__ img,
-                               const uint16_t *__restrict__ imgT, uint32_t *ring_lds, int lane, const Poly &p,
+                               const uint16_t *__restrict__ imgT, uint64_t *mask_lds, int lane, const Poly &p,
                                double tf, PlannerPyramid *pyr, int &nPyr, int maxPyr) {
 #pragma clang fp contract(off)
   double dc[5];
@@ -763,7 +967,7 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
     if (at < 0) {
       if (nPyr >= maxPyr) return false;                        // _maxNumPyramids, :255-260
       PlannerPyramid fresh;
-      if (!inflate_pyramid(cfg, img, imgT, ring_lds, lane, (int)px, (int)py, ez, fresh)) return false;
+      if (!inflate_pyramid(cfg, img, imgT, mask_lds, lane, (int)px, (int)py, ez, fresh)) return false;
       int idx = 0;                                             // std::lower_bound + insert, :269-271
       while (idx < nPyr && pyr[idx].depth < fresh.depth) idx++;
       for (int q = nPyr; q > idx; q--) pyr[q] = pyr[q - 1];
@@ -848,7 +1052,7 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
   const int64_t i = blockIdx.x;      // one wave per planner
   PL_T0(t_all);
   const int lane = threadIdx.x;
-  extern __shared__ uint32_t ring_lds[];   // two rings of staged lines, see stage_ring
+  extern __shared__ uint64_t mask_lds[];   // one bit per pixel of this planner's image, see build_mask
   const int64_t img_off = (int64_t)(b.image_index ? b.image_index[i] : i) * cfg.width * cfg.height;
   const uint16_t *img = b.images + img_off;
   const uint16_t *imgT = b.images_t + img_off;
@@ -902,7 +1106,7 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
             p.c[5][a] = c_pos(k, a, 0);
           }
           PL_T0(t_cf);
-          const bool cfree = collision_free(cfg, img, imgT, ring_lds, lane, p, k.tf, pyr, nPyr, b.max_pyramids);
+          const bool cfree = collision_free(cfg, img, imgT, mask_lds, lane, p, k.tf, pyr, nPyr, b.max_pyramids);
           PL_T1(t_cf, 6);
           if (cfree) {
             result |= 8;
@@ -958,7 +1162,7 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   if (b.n <= 0) return 0;
   hipLaunchKernelGGL(afe_transpose_images_kernel, dim3((cfg.width + 31) / 32, (cfg.height + 31) / 32, (unsigned)b.n_images),
                      dim3(256), 0, (hipStream_t)stream, b.images, b.images_t, cfg.width, cfg.height);
-  const unsigned ring_bytes = 2u * (2u * ((cfg.width + 63) & ~63) + 2u * ((cfg.height + 63) & ~63)) * sizeof(uint32_t);
+  const unsigned mask_bytes = (unsigned)(((cfg.width + 63) >> 6) * cfg.height) * (unsigned)sizeof(uint64_t);
 #ifdef AFE_PLANNER_PROFILE
   unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero));
@@ -966,13 +1170,13 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   const int64_t n_cand = b.n * b.n_candidates;
   hipLaunchKernelGGL(afe_rappids_candidates_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      cfg, b);
-  hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), ring_bytes, (hipStream_t)stream, cfg, b);
+  hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, b);
 #ifdef AFE_PLANNER_PROFILE
   unsigned long long prof[8];
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_prof), sizeof(prof));
-  fprintf(stderr, "planner profile (cycles per planner): total %.0f | collision_free %.0f | inflate: ring wait %.0f expansion %.0f "
-          "sides %.0f corners %.0f | completed pyramids/planner %.2f rings/planner %.1f\n", (double)prof[0] / b.n, (double)prof[6] / b.n,
+  fprintf(stderr, "planner profile (cycles per planner): total %.0f | collision_free %.0f | inflate: mask1 %.0f expansion(all) %.0f "
+          "sides+mask2 %.0f corners %.0f | completed pyramids/planner %.2f ringloop %.0f\n", (double)prof[0] / b.n, (double)prof[6] / b.n,
           (double)prof[1] / b.n, (double)prof[2] / b.n, (double)prof[3] / b.n, (double)prof[4] / b.n, (double)prof[5] / b.n, (double)prof[7] / b.n);
 #endif
   return (int)hipGetLastError();
