@@ -8,14 +8,15 @@
 // SingleAxisTrajectory}.{hpp,cpp} ("RTG", "SAT"), Common/Common/Math/
 // {RootFinder,Trajectory}.hpp.
 //
-// First correct form (round 1): ONE LANE = ONE PLANNER.  The search is
-// sequential by construction -- a candidate is only examined if it beats the best
-// cost so far, and every collision check reads and grows the plan's sorted pyramid
-// list (DIP.cpp:143-190,214-301) -- so the parallel axis is the ensemble.  The
-// pyramid list lives in a per-planner slab in HBM; the depth image is read through
-// the caches (planners sharing an image share its lines).  All arithmetic is
-// double, as in the reference, with FMA contraction off so the polynomial
-// coefficients are bit-identical to a CPU evaluation; only acos/cos/pow differ
+// The search is sequential by construction -- a candidate is only examined if it beats
+// the best cost so far, every collision check reads and grows the plan's sorted pyramid
+// list (DIP.cpp:143-190,214-301), every pixel test of InflatePyramid reads edges that
+// earlier pixels moved -- so the reference's decision order is kept and the parallelism
+// sits underneath it: candidates are pre-evaluated one per lane, then ONE WAVE RUNS ONE
+// PLANNER, with the per-pixel work spread over its 64 lanes (see "bit images in LDS" and
+// "wave-cooperative pixel scans" below).  The pyramid list lives in a per-planner slab in
+// HBM.  All arithmetic is double, as in the reference, with FMA contraction off so the
+// polynomial coefficients are bit-identical to a CPU evaluation; only acos/cos/pow differ
 // from libm by an ulp.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
