@@ -8,14 +8,16 @@
 // (no FMA contraction), so images are compared bit for bit.
 //
 // MI355X mapping
-//   * one wave (64 lanes) per 16x4 pixel tile of one view: neighbouring rays walk the
-//     same part of the tree, so node / triangle loads coalesce into a few lines;
+//   * one wave (64 lanes) per 8x8 pixel tile of one view: neighbouring rays walk the
+//     same part of the tree, so node / triangle loads coalesce into a few lines; box tests in
+//     fp32 against conservatively inflated boxes, triangle tests in fp64;
 //   * the BVH (32-byte nodes, sibling pairs adjacent = one 64-byte line per inner-node
 //     visit) and the 48-byte padded triangles stay in HBM and are served from L2 /
 //     Infinity Cache; the block index is remapped so that each XCD (own L2) renders a
 //     contiguous range of views;
-//   * per-lane traversal stack in LDS, [depth][lane] layout (conflict-free), 32 entries:
-//     the host builder guarantees the tree depth fits;
+//   * per-lane traversal stack in LDS, [depth][lane] layout (conflict-free), 32 entries of
+//     32 bits (8 KB per wave, so LDS does not cap occupancy): the host builder guarantees the
+//     tree depth fits;
 //   * poses are prepared by a small kernel straight from the engine's state slabs, so a
 //     closed loop never leaves the device: step -> render -> plan.
 #include <hip/hip_runtime.h>
@@ -74,7 +76,7 @@ struct Builder {
     // inflate outward: the traversal's slab test may then round either way without ever
     // rejecting a box whose triangles the ray touches
     for (int k = 0; k < 3; k++) {
-      const float eps = 1e-4f + 1e-6f * std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
+      const float eps = 3e-4f + 4e-6f * std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
       n.lo[k] = std::nextafterf(b.lo[k] - eps, -std::numeric_limits<float>::infinity());
       n.hi[k] = std::nextafterf(b.hi[k] + eps, std::numeric_limits<float>::infinity());
     }
@@ -189,7 +191,11 @@ struct Builder {
 // ---------------------------------------------------------------------------------------
 // device
 // ---------------------------------------------------------------------------------------
-constexpr int kTileW = 16, kTileH = 4, kStack = 32;
+#ifndef AFE_TILE_W
+#define AFE_TILE_W 8
+#define AFE_TILE_H 8
+#endif
+constexpr int kTileW = AFE_TILE_W, kTileH = AFE_TILE_H, kStack = 32;
 
 struct PoseArgs {
   const void *pos, *att;      // planar, `stride` elements between components
@@ -246,17 +252,21 @@ struct RenderArgs {
   int max_count;
 };
 
-// slab test against one node's (inflated) box; returns the entry distance or +inf
-__device__ __forceinline__ double box_entry(const BvhNode &n, const double o[3], const double inv[3], double best) {
-  double tmin = 0.0, tmax = best;
+// Slab test against one node's box in fp32; returns a lower bound of the entry distance or +inf.
+// The builder inflates every box by 3e-4 m + 4e-6 |coordinate| -- two orders of magnitude more than
+// what rounding the ray to fp32 can move it -- and the comparisons below carry a relative slack of
+// 1e-5, so the test only ever errs towards visiting a box: which triangles a ray reaches, and
+// therefore the fp64 hit distance, cannot depend on it.
+__device__ __forceinline__ float box_entry(const BvhNode &n, const float o[3], const float inv[3], float best) {
+  float tmin = 0.0f, tmax = best;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const double t0 = ((double)n.lo[k] - o[k]) * inv[k];
-    const double t1 = ((double)n.hi[k] - o[k]) * inv[k];
-    tmin = fmax(tmin, fmin(t0, t1));
-    tmax = fmin(tmax, fmax(t0, t1));
+    const float t0 = (n.lo[k] - o[k]) * inv[k];
+    const float t1 = (n.hi[k] - o[k]) * inv[k];
+    tmin = fmaxf(tmin, fminf(t0, t1));
+    tmax = fminf(tmax, fmaxf(t0, t1));
   }
-  return tmin <= tmax ? tmin : INFINITY;
+  return tmin * 0.99999f <= tmax * 1.00001f ? tmin * 0.99999f : INFINITY;
 }
 
 __device__ __forceinline__ double ray_triangle(const double o[3], const double d[3], const float4 a, const float4 b,
@@ -283,7 +293,6 @@ __device__ __forceinline__ double ray_triangle(const double o[3], const double d
 __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(RenderArgs a) {
 #pragma clang fp contract(off)
   __shared__ int32_t stack_node[kStack][kTileW * kTileH];
-  __shared__ float stack_t[kStack][kTileW * kTileH];
 
   // XCD-aware order: hardware block b runs on XCD b % 8; give each XCD a contiguous run
   // of logical blocks (= consecutive tiles of consecutive views) so that its L2 keeps the
@@ -304,43 +313,45 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   const double v = (py - a.cy) / a.focal;
   const double d[3] = {pose[3] * u + pose[4] * v + pose[5], pose[6] * u + pose[7] * v + pose[8],
                        pose[9] * u + pose[10] * v + pose[11]};
-  const double inv[3] = {1.0 / d[0], 1.0 / d[1], 1.0 / d[2]};
+  const float of[3] = {(float)o[0], (float)o[1], (float)o[2]};
+  const float inv[3] = {1.0f / (float)d[0], 1.0f / (float)d[1], 1.0f / (float)d[2]};
 
   double best = INFINITY;
+  float best_f = INFINITY;             // best rounded up: the pruning bound of the fp32 box tests
   int sp = 0;
-  int32_t node = 0;
-  bool live = box_entry(a.nodes[0], o, inv, best) < INFINITY;
+  // A popped node is re-tested against the hit distance found since it was pushed (its box is in
+  // the node itself), which keeps the stack at one 32-bit entry per level.
+  bool live = true, retest = true;
+  BvhNode n = a.nodes[0];
   while (live) {
-    const BvhNode n = a.nodes[node];
     bool descended = false;
-    if (n.b > 0) {
+    if (retest && !(box_entry(n, of, inv, best_f) < INFINITY)) {
+      // culled
+    } else if (n.b > 0) {
       for (int k = 0; k < n.b; k++) {
         const float4 *t = a.tris + 3 * (int64_t)(n.a + k);
         const double th = ray_triangle(o, d, t[0], t[1], t[2]);
-        if (th < best) best = th;
+        if (th < best) { best = th; best_f = __double2float_ru(th); }
       }
     } else {
       const BvhNode l = a.nodes[n.a], r = a.nodes[n.a + 1];
-      const double tl = box_entry(l, o, inv, best), tr = box_entry(r, o, inv, best);
+      const float tl = box_entry(l, of, inv, best_f), tr = box_entry(r, of, inv, best_f);
       const bool hl = tl < INFINITY, hr = tr < INFINITY;
       if (hl && hr) {
         const bool left_first = tl <= tr;
         stack_node[sp][lane] = left_first ? n.a + 1 : n.a;
-        stack_t[sp][lane] = __double2float_rd(left_first ? tr : tl);
         sp++;
-        node = left_first ? n.a : n.a + 1;
+        n = left_first ? l : r;          // the child is already in registers
         descended = true;
       } else if (hl || hr) {
-        node = hl ? n.a : n.a + 1;
+        n = hl ? l : r;
         descended = true;
       }
     }
+    retest = !descended;
     if (descended) continue;
-    live = false;
-    while (sp > 0) {
-      sp--;
-      if ((double)stack_t[sp][lane] < best) { node = stack_node[sp][lane]; live = true; break; }
-    }
+    live = sp > 0;
+    if (live) n = a.nodes[stack_node[--sp][lane]];
   }
 
   uint16_t count = (uint16_t)a.max_count;
