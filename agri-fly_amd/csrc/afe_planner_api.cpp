@@ -1,6 +1,7 @@
 // afe_planner_api.cpp -- host side of the batched RAPPIDS planner (C ABI).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -67,6 +68,12 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
       n_candidates <= 0 || !out || cfg->max_pyramids <= 0 || cfg->width <= 0 || cfg->height <= 0)
     return AFE_ERR_INVALID_ARG;
   if (!image_index && n_images < n) return AFE_ERR_INVALID_ARG;
+  // the search kernel keeps one bit per pixel in LDS (64 KB of dynamic LDS at most) and indexes
+  // pixels with 24-bit arithmetic; device-resident images must allow 16-byte loads
+  if ((int64_t)((cfg->width + 63) / 64) * cfg->height * 8 > 65536 || (int64_t)cfg->width * cfg->height >= (1 << 24))
+    return AFE_ERR_OUT_OF_RANGE;
+  if (depth_on_device && ((uintptr_t)depth_images & 15u)) return AFE_ERR_INVALID_ARG;
+  if (cfg->focal_length * cfg->planning_vehicle_radius / cfg->depth_scale >= (double)(1 << 22)) return AFE_ERR_OUT_OF_RANGE;
   if (image_index)
     for (int64_t i = 0; i < n; i++) if (image_index[i] < 0 || image_index[i] >= n_images) return AFE_ERR_OUT_OF_RANGE;
   if (sample_table)

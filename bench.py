@@ -117,6 +117,46 @@ def committed_traffic(n_local):
     return None, None
 
 
+def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
+    """SURVEY 8f rows f4 + f3 on the config-5 / config-3 shapes, bounded to a fraction of a second:
+    depth camera over a procedural orchard, then the RAPPIDS planner on those images (kept in HBM)."""
+    tris = afa.scenarios.orchard_mesh(rows=32, cols=32, seed=1)
+    scene = afa.Scene(tris)
+    cam = afa.camera_default(320, 240)
+    mount = afa.camera_default_mount()
+    rng = np.random.default_rng(4)
+    pos = np.stack([rng.uniform(-5, 90, n_views), rng.uniform(-5, 120, n_views), rng.uniform(0.8, 2.5, n_views)])
+    yaw = rng.uniform(-np.pi, np.pi, n_views)
+    att = np.stack([np.cos(yaw / 2), 0 * yaw, 0 * yaw, np.sin(yaw / 2)])
+    e = afa.Ensemble(n_views, precision=afa.AFE_F32)
+    e.set_type_table([afa.params_from_type(5)])
+    e.set_state(pos, np.zeros((3, n_views)), att, np.zeros((3, n_views)), np.zeros((4, n_views)))
+    buf = afa.DeviceBuffer(n_views * 240 * 320 * 2)
+    scene.render_engine(e, cam, mount, out=buf)
+    ms_render = min(scene.render_engine(e, cam, mount, out=buf) for _ in range(3))
+    cfg = afa.planner_default_config(320, 240, cam.depth_scale, cam.focal_length, 0.116, 0.174, 0.5)
+    idx = (np.arange(n_planners) % n_views).astype(np.int32)
+    vel0 = np.stack([rng.normal(0, 0.3, n_planners), rng.normal(0, 0.2, n_planners), rng.uniform(0, 2.0, n_planners)])
+    acc0 = rng.normal(0, 0.3, (3, n_planners))
+    grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n_planners))
+    samples = afa.planner_samples(0, 320, 240, n_candidates)
+    ms_plan, found = 1e30, 0.0
+    for _ in range(2):
+        out, _, ms = afa.rappids_plan(cfg, buf, vel0, acc0, grav, samples, image_index=idx)
+        ms_plan = min(ms_plan, ms)
+    found = float(np.mean([o.found for o in out]))
+    buf.close()
+    e.close()
+    info = scene.info()
+    return {"depth_camera": {"views": n_views, "image": "320x240", "triangles": int(info["n_tri"]),
+                             "kernel_ms": ms_render, "rays_per_s": n_views * 76800 / (ms_render * 1e-3)},
+            "rappids_planner": {"planners": n_planners, "candidates": n_candidates, "distinct_images": n_views,
+                                "kernel_ms": ms_plan, "plans_per_s": n_planners / (ms_plan * 1e-3),
+                                "fraction_found": found},
+            "note": "images rendered from engine state and planned on without leaving HBM; results are "
+                    "bit-identical to the CPU checkers in tests/test_gpu_render.py / test_gpu_planner.py"}
+
+
 def cpu_baseline(afa, budget_vehicle_steps=100_000_000):
     """the oracle (double, scalar C, 1 thread) on a bounded sample of the same
     workload; test infrastructure used here only as the reported baseline"""
@@ -265,6 +305,7 @@ def main():
                 closed.append({"vehicles": n, "vsteps_per_s": n * k / t1, "vsteps_per_s_fused10": n * k / t10})
                 es.close()
             out["closed_loop_on_device"] = closed
+            out["perception_rows"] = perception_rows(afa)
             out["sweep"] = sweep
             out["sweep_note"] = ("vsteps_per_s = one launch per step issued from Python; native_loop = the same "
                                  "launches issued by afe_step's C++ loop (afe_set_max_fused_steps(1)); fused2 = two 1 ms steps per launch (nothing is observable between 500 Hz logic "

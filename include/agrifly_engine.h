@@ -297,7 +297,9 @@ int afe_planner_samples(uint32_t seed, int width, int height, int n_candidates, 
  *   vel0, acc0, grav: planar [3][n]; cost_vec planar [3][n] or NULL (cfg->cost_vec)
  *   samples [n_tables][n_candidates][4]; sample_table[n] or NULL (table 0)
  *   out[n]; flags [n][n_candidates] or NULL: TrajectoryTestResult bits per candidate
- *   (1 LowCost, 2 DynamicsFeasible, 4 VelocityAdmissible, 8 CollisionFree). */
+ *   (1 LowCost, 2 DynamicsFeasible, 4 VelocityAdmissible, 8 CollisionFree).
+ * Image size: ceil(width/64) * height <= 8192 (one bit per pixel is kept in LDS;
+ * e.g. 640x480, 1024x512), else AFE_ERR_OUT_OF_RANGE. */
 int afe_rappids_plan(int device, const afe_planner_config *cfg, int64_t n, const uint16_t *depth_images,
                      int64_t n_images, const int32_t *image_index, const double *vel0, const double *acc0,
                      const double *grav, const double *cost_vec, const double *samples, int n_tables,
@@ -362,7 +364,8 @@ int afe_device_free(void *p);
 int afe_device_download(void *host_dst, const void *dev_src, uint64_t bytes);
 
 /* afe_rappids_plan with the depth images already in HBM (one per planner, or
- * indexed through image_index, which stays a host array). */
+ * indexed through image_index, which stays a host array).  The pointer must be
+ * 16-byte aligned (anything from afe_device_alloc / hipMalloc is). */
 int afe_rappids_plan_device(int device, const afe_planner_config *cfg, int64_t n, const void *dev_depth_images,
                             int64_t n_images, const int32_t *image_index, const double *vel0, const double *acc0,
                             const double *grav, const double *cost_vec, const double *samples, int n_tables,

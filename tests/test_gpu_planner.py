@@ -131,3 +131,37 @@ def test_config3_shape_65536_planners():
     refs = [ora.planner_run(ocfg, images[image_index[i]], vel0[:, i], acc0[:, i], grav[:, i], samples) for i in idx]
     _compare([out[i] for i in idx], flags[idx], refs)
     print("config-3 shape: %d planners x %d candidates in %.1f ms (%.3g plans/s)" % (n, m, ms, n / (ms * 1e-3)))
+
+
+@pytest.mark.parametrize("size", [(200, 150), (136, 100), (384, 200)])
+def test_image_sizes_off_the_fast_path(ora, size):
+    """Widths that are not a multiple of 64 take the generic bit-image / maxDepth sweeps (the 320-wide
+    config uses the 8-pixels-per-lane ones); 384 is another fast-path width."""
+    w, h = size
+    rng = np.random.default_rng(w)
+    n, m = 24, 96
+    f = w / 2.0
+    images = np.stack([afa.scenarios.synthetic_depth_image(width=w, height=h, seed=500 + k, n_trunks=3 + k)
+                       for k in range(3)])
+    ocfg = ora.planner_config(w, h, 10.0 / 256.0, f, 0.116, 0.174, 0.5)
+    ocfg.max_pyramids = 64
+    ocfg.cost_type = 1
+    ocfg.cost_vec[2] = 120.0
+    image_index = rng.integers(0, 3, n).astype(np.int32)
+    vel0 = np.stack([rng.normal(0, 0.4, n), rng.normal(0, 0.2, n), rng.uniform(0, 2.0, n)])
+    acc0 = rng.normal(0, 0.3, (3, n))
+    grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n))
+    samples = ora.planner_samples(3, w, h, m)
+    refs = [ora.planner_run(ocfg, images[image_index[i]], vel0[:, i], acc0[:, i], grav[:, i], samples) for i in range(n)]
+    out, flags, _ = afa.rappids_plan(_cfg(ocfg), images, vel0, acc0, grav, samples, image_index=image_index,
+                                     want_flags=True)
+    _compare(out, flags, refs)
+    assert sum(r[0].n_pyramids for r in refs) > 0
+
+
+def test_image_too_large_for_the_bit_image_is_refused():
+    cfg = afa.planner_default_config(2048, 1536, 10.0 / 256.0, 1024.0, 0.116, 0.174, 0.5)
+    img = np.full((1, 1536, 2048), 255, np.uint16)
+    z = np.zeros((3, 1))
+    with pytest.raises(afa.AfeError):
+        afa.rappids_plan(cfg, img, z, z, z, afa.planner_samples(0, 2048, 1536, 4))
