@@ -196,13 +196,16 @@ def _icosphere(subdiv):
 
 
 def orchard_mesh(rows=8, cols=8, row_spacing=4.0, tree_spacing=3.0, seed=0, trunk_sides=8, canopy_subdiv=1,
-                 margin=10.0, jitter=0.3):
+                 margin=10.0, jitter=0.3, return_layout=False):
     """Stand-in for the Helios orchard scene the reference renders through AirSim/Unity (not in
     the reference tree): a ground plane at z = 0 and rows x cols
     trees (a prism trunk and an ellipsoidal canopy each) on a jittered lattice, rows along +x.
-    World frame z up, metres.  Returns float32 [n_tri, 9] (v0 v1 v2).  Seeded (numpy PCG64)."""
+    World frame z up, metres.  Returns float32 [n_tri, 9] (v0 v1 v2); with return_layout also the
+    analytic trees, one row each: trunk x, y, radius, height, canopy centre xyz, canopy semi-axes xyz
+    (the mesh is inscribed in these shapes).  Seeded (numpy PCG64)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     tris = []
+    layout = []
     x1, y1 = (cols - 1) * tree_spacing + margin, (rows - 1) * row_spacing + margin
     g = np.array([[-margin, -margin, 0], [x1, -margin, 0], [x1, y1, 0], [-margin, y1, 0]], float)
     tris += [np.concatenate([g[0], g[1], g[2]]), np.concatenate([g[0], g[2], g[3]])]
@@ -224,4 +227,6 @@ def orchard_mesh(rows=8, cols=8, row_spacing=4.0, tree_spacing=3.0, seed=0, trun
             pv = sv * rad + centre
             for f in sf:
                 tris.append(pv[f].reshape(9))
-    return np.asarray(tris, dtype=np.float32)
+            layout.append([cx, cy, tr, th, *centre, *rad])
+    mesh = np.asarray(tris, dtype=np.float32)
+    return (mesh, np.asarray(layout)) if return_layout else mesh
