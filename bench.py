@@ -174,10 +174,24 @@ def cpu_baseline(afa, budget_vehicle_steps=100_000_000):
     t0 = time.perf_counter()
     b.step(DT_US * 1e-6, steps, ticks=ticks)
     dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "vehicle-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d vehicles x %d steps of the same workload (gust force, IMU+noise every 2nd step), "
-                      "oracle/agrifly_oracle.c double precision, gcc -O2, 1 thread, %.1f s" % (n, steps, dt),
-            "host_cpus": os.cpu_count()}
+    out = {"value": n * steps / dt, "unit": "vehicle-steps/s", "cores": 1, "kind": "port",
+           "sample": "%d vehicles x %d steps of the same workload (gust force, IMU+noise every 2nd step), "
+                     "oracle/agrifly_oracle.c double precision, gcc -O2, 1 thread, %.1f s" % (n, steps, dt),
+           "host_cpus": os.cpu_count()}
+    # the same port spread over every host core (OpenMP over vehicles), SURVEY 8d CPU-baseline (ii)
+    threads = os.cpu_count() or 1
+    if threads > 1:
+        oracle_py.lib().ora_set_batch_threads(threads)
+        b.step(DT_US * 1e-6, 10, ticks=ticks[:10])
+        steps_mt = steps * min(threads, 32) // 4
+        ticks_mt, _ = afa.plan_ticks(LOGIC_PERIOD, 0, DT_US, steps_mt)
+        t0 = time.perf_counter()
+        b.step(DT_US * 1e-6, steps_mt, ticks=ticks_mt)
+        dt_mt = time.perf_counter() - t0
+        oracle_py.lib().ora_set_batch_threads(1)
+        out["all_cores"] = {"value": n * steps_mt / dt_mt, "unit": "vehicle-steps/s", "cores": threads,
+                            "sample": "%d vehicles x %d steps, %d OpenMP threads, %.1f s" % (n, steps_mt, threads, dt_mt)}
+    return out
 
 
 def main():

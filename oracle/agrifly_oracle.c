@@ -515,6 +515,10 @@ void ora_clock_advance(ora_clock *c, uint64_t dt_us) { c->now_us += dt_us; }
 /* ------------------------------------------------------------------------ */
 /* Batched SoA driver                                                        */
 
+static int g_batch_threads = 1;
+/* threads ora_step_batch spreads the vehicles over (OpenMP); 1 = the scalar port */
+void ora_set_batch_threads(int n) { g_batch_threads = n > 0 ? n : 1; }
+
 void ora_step_batch(int64_t n, int n_steps, const ora_params *table,
                     const uint8_t *types, double *pos, double *vel,
                     double *att, double *ang_vel, double *motor_speed,
@@ -522,6 +526,7 @@ void ora_step_batch(int64_t n, int n_steps, const ora_params *table,
                     const double *ext_force, const double *ext_torque,
                     double dt, const uint8_t *tick_per_step, float *gyro,
                     float *acc) {
+#pragma omp parallel for schedule(static) num_threads(g_batch_threads) if (g_batch_threads > 1)
   for (int64_t i = 0; i < n; i++) {
     const ora_params *p = &table[types ? types[i] : 0];
     ora_state s;

@@ -115,6 +115,8 @@ def lib():
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ora_step_batch.restype = None
+        L.ora_set_batch_threads.argtypes = [C.c_int]
+        L.ora_set_batch_threads.restype = None
         _lib = L
     return _lib
 
