@@ -69,6 +69,7 @@ struct StepView {
   // speed is then a pure function of the command, Motor.cpp:54-66, and is not
   // read back (it is still written, for GetMotorForce / afe_get_state)
   int motor_stateless;
+  int motor_write;   // 0: the rotor-speed slab is not written (it is clamp(cmd), rebuilt on demand)
   // on-device rates logic (null when disabled)
   float *lpf;               // 12 comps: xm0[3] xm1[3] ym0[3] ym1[3]
   const float *rates_cmd;   // 4 comps: thrust_norm, wx, wy, wz
@@ -90,6 +91,11 @@ int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, const DevPar
                     const DevLogic *uniform_logic, void *stream);
 int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> *uniform,
                     const DevLogic *uniform_logic, void *stream);
+// rotor speeds of stateless motors from the commands: w = clamp(max(0, cmd), w_min, w_max)
+int launch_motor_from_cmd_f32(float *motor, const float *cmd, const uint8_t *type, const DevParams<float> *table,
+                              int64_t stride, int64_t n, void *stream);
+int launch_motor_from_cmd_f64(double *motor, const float *cmd, const uint8_t *type, const DevParams<double> *table,
+                              int64_t stride, int64_t n, void *stream);
 int launch_pack_positions_f32(const float *pos, int64_t stride, int64_t n, float *out, void *stream);
 int launch_pack_positions_f64(const double *pos, int64_t stride, int64_t n, float *out, void *stream);
 int launch_nearest_neighbour(const float *self_xyz, int64_t n_self, int64_t first_global,

@@ -55,6 +55,9 @@ struct afe_engine {
   double sigma_gyro = 0.1, sigma_acc = 0.2;  // Quadcopter_T.cpp:5-6
   int seed_policy = AFE_SEED_REFERENCE;
   bool has_ext_force = false, has_ext_torque = false;
+  // stateless motors (tau_m == 0, J_m == 0) driven by held commands: the rotor-speed slab is not
+  // written by the step kernel; motor_stale says it has to be rebuilt from the commands first
+  bool motor_stale = false;
 
   // clock (ManualTimer + Timer semantics)
   uint64_t now_us = 0;
@@ -125,12 +128,15 @@ int get_field(afe_engine *e, const void *dev, int comps, int64_t first, int64_t 
   return AFE_OK;
 }
 
+int materialize_motor(afe_engine *e);   // defined below
+
 template <typename H>
 int set_state_any(afe_engine *e, int64_t first, int64_t count, const H *pos3, const H *vel3,
                   const H *att4, const H *ang_vel3, const H *motor4) {
   int rc = check_range(e, first, count);
   if (rc) return rc;
   AFE_HIP(e, hipSetDevice(e->device));
+  if (motor4 && (rc = materialize_motor(e))) return rc;   // the rest of the slab must be current
   if (e->precision == AFE_F64) {
     if ((rc = set_field<double>(e, e->pos, 3, first, count, pos3))) return rc;
     if ((rc = set_field<double>(e, e->vel, 3, first, count, vel3))) return rc;
@@ -153,6 +159,7 @@ int get_state_any(afe_engine *e, int64_t first, int64_t count, H *pos3, H *vel3,
   int rc = check_range(e, first, count);
   if (rc) return rc;
   AFE_HIP(e, hipSetDevice(e->device));
+  if (motor4 && (rc = materialize_motor(e))) return rc;
   if (e->precision == AFE_F64) {
     if ((rc = get_field<double>(e, e->pos, 3, first, count, pos3))) return rc;
     if ((rc = get_field<double>(e, e->vel, 3, first, count, vel3))) return rc;
@@ -222,6 +229,30 @@ int refresh_logic(afe_engine *e) {
   return AFE_OK;
 }
 
+bool motors_stateless(const afe_engine *e) {
+  if (e->table.empty()) return false;
+  for (const HostParams &h : e->table) if (h.tau_m != 0 || h.Jm != 0) return false;
+  return true;
+}
+// the step kernel may skip the rotor-speed store: the speed is clamp(cmd) and the commands
+// stay what they were during the step (the on-device logic rewrites them at every tick)
+bool motor_lazy(const afe_engine *e) { return motors_stateless(e) && !e->logic_on; }
+
+// rebuild the rotor-speed slab from the commands of the last step, if it was skipped
+int materialize_motor(afe_engine *e) {
+  if (!e->motor_stale) return AFE_OK;
+  AFE_HIP(e, hipSetDevice(e->device));
+  // the device table holds the parameters the last step ran with (refresh_table precedes every launch)
+  const int lrc = e->precision == AFE_F64
+      ? launch_motor_from_cmd_f64((double *)e->motor, e->cmd, e->types_uniform ? nullptr : e->type,
+                                  (const DevParams<double> *)e->dev_table, e->stride, e->n, e->stream)
+      : launch_motor_from_cmd_f32((float *)e->motor, e->cmd, e->types_uniform ? nullptr : e->type,
+                                  (const DevParams<float> *)e->dev_table, e->stride, e->n, e->stream);
+  if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("rotor-speed rebuild: ") + hipGetErrorString((hipError_t)lrc));
+  e->motor_stale = false;
+  return AFE_OK;
+}
+
 template <typename R>
 void fill_view(const afe_engine *e, StepView<R> &v) {
   v.lpf = e->lpf; v.rates_cmd = e->rates_cmd; v.have_cmd = e->have_cmd; v.imu_init = e->imu_init;
@@ -233,8 +264,8 @@ void fill_view(const afe_engine *e, StepView<R> &v) {
   v.table = (const DevParams<R> *)e->dev_table;
   v.n_types = (int)e->table.size();
   v.n = e->n; v.stride = e->stride;
-  v.motor_stateless = 1;
-  for (const HostParams &h : e->table) if (h.tau_m != 0 || h.Jm != 0) v.motor_stateless = 0;
+  v.motor_stateless = motors_stateless(e);
+  v.motor_write = !motor_lazy(e);
   v.sigma_gyro = (float)e->sigma_gyro;  // float(_stdDevRateGyroNoise), Quadcopter_T.cpp:170
   v.sigma_acc = (float)e->sigma_acc;
 }
@@ -348,6 +379,7 @@ extern "C" int afe_set_stream(afe_engine *e, void *hip_stream) {
 }
 
 extern "C" int afe_set_type_table(afe_engine *e, const afe_vehicle_params *table, int n_types) {
+  if (e) { const int mrc = materialize_motor(e); if (mrc) return mrc; }   // with the parameters the last step used
   if (!e || !table || n_types < 1 || n_types > 256) return fail(e, AFE_ERR_INVALID_ARG, "type table must hold 1..256 records");
   std::vector<HostParams> t((size_t)n_types);
   for (int k = 0; k < n_types; k++) {
@@ -363,6 +395,7 @@ extern "C" int afe_set_type_table(afe_engine *e, const afe_vehicle_params *table
 extern "C" int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count, const uint8_t *type_index) {
   int rc = check_range(e, first, count);
   if (rc) return rc;
+  if ((rc = materialize_motor(e))) return rc;
   if (!type_index) return fail(e, AFE_ERR_INVALID_ARG, "type_index is NULL");
   for (int64_t k = 0; k < count; k++)
     if (type_index[k] >= e->table.size())
@@ -446,6 +479,7 @@ extern "C" int afe_set_motor_cmds(afe_engine *e, int64_t first, int64_t count, c
   if (rc) return rc;
   if (!cmd4) return fail(e, AFE_ERR_INVALID_ARG, "cmd4 is NULL");
   AFE_HIP(e, hipSetDevice(e->device));
+  if ((rc = materialize_motor(e))) return rc;   // the speeds of the last step come from the OLD commands
   return copy_in(e, e->cmd, 4, 4, first, count, cmd4);
 }
 extern "C" int afe_get_motor_cmds(afe_engine *e, int64_t first, int64_t count, float *cmd4) {
@@ -459,6 +493,7 @@ extern "C" int afe_get_motor_cmds(afe_engine *e, int64_t first, int64_t count, f
 extern "C" int afe_set_rates_logic(afe_engine *e, const afe_rates_logic_params *table, int n_types) {
   if (!e) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
+  { const int mrc = materialize_motor(e); if (mrc) return mrc; }   // from here on the logic rewrites the commands
   if (!table) {
     AFE_HIP(e, hipStreamSynchronize(e->stream));
     e->logic_on = false;
@@ -587,6 +622,7 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
       lrc = launch_step_f32(v, f, e->types_uniform ? &e->table_f32[0] : nullptr, ulogic, e->stream);
     }
     if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+    if (motor_lazy(e)) e->motor_stale = true;
     done += chunk;
   }
   return AFE_OK;
@@ -648,6 +684,7 @@ void engine_stream_device(afe_engine *e, void **stream, int *device) {
 
 extern "C" int afe_get_device_view(afe_engine *e, afe_device_view *out) {
   if (!e || !out) return AFE_ERR_INVALID_ARG;
+  { const int mrc = materialize_motor(e); if (mrc) return mrc; }   // motor_speed is current as of this call
   out->n_vehicles = e->n;
   out->stride = e->stride;
   out->state_elem_size = (int)elem(e);
@@ -665,7 +702,8 @@ extern "C" int afe_algorithmic_bytes_per_step(const afe_engine *e, int imu_tick,
   double b = 17 * es * 2;      // state read + write (pos3 vel3 att4 angvel3 motor4)
   bool stateless = !e->table.empty();
   for (const HostParams &h : e->table) if (h.tau_m != 0 || h.Jm != 0) stateless = false;
-  if (stateless) b -= 4 * es;  // tau_m == 0, J_m == 0: rotor speeds are written but never read
+  if (stateless) b -= 4 * es;  // tau_m == 0, J_m == 0: rotor speeds are never read ...
+  if (motor_lazy(e)) b -= 4 * es;  // ... and with held commands not written either (rebuilt from the commands on demand)
   b += 4 * 4;                  // motor commands (float)
   if (!e->types_uniform) b += 1;  // type index (heterogeneous ensembles only)
   if (e->has_ext_force) b += 3 * es;
@@ -726,6 +764,7 @@ extern "C" int afe_save_checkpoint(afe_engine *e, void *host_buffer, uint64_t by
   if (!e || !host_buffer || afe_checkpoint_size(e, &need) != AFE_OK) return AFE_ERR_INVALID_ARG;
   if (bytes < need) return fail(e, AFE_ERR_INVALID_ARG, "checkpoint buffer too small");
   AFE_HIP(e, hipSetDevice(e->device));
+  { const int mrc = materialize_motor(e); if (mrc) return mrc; }
   AFE_HIP(e, hipStreamSynchronize(e->stream));
   CheckpointHeader h = {kCheckpointMagic, (uint64_t)e->n, (uint64_t)e->stride, (uint64_t)e->precision,
                         (uint64_t)e->arena_bytes, e->logic_on ? (uint64_t)logic_arena_bytes(e) : 0,
@@ -763,6 +802,7 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
   // the arena also holds the device copy of the type table for the checkpoint's dt: rebuild on next step
   e->table_dirty = true;
   e->logic_table_period = -1.0f;
+  e->motor_stale = false;   // the checkpoint's rotor-speed slab was current when it was taken
   return AFE_OK;
 }
 

@@ -498,7 +498,9 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   AFE_ST(R, v.vel, 0, off, vx); AFE_ST(R, v.vel, 1, off, vy); AFE_ST(R, v.vel, 2, off, vz);
   AFE_ST(R, v.att, 0, off, q0); AFE_ST(R, v.att, 1, off, q1); AFE_ST(R, v.att, 2, off, q2); AFE_ST(R, v.att, 3, off, q3);
   AFE_ST(R, v.ang_vel, 0, off, wx); AFE_ST(R, v.ang_vel, 1, off, wy); AFE_ST(R, v.ang_vel, 2, off, wz);
-  AFE_ST(R, v.motor, 0, off, ms[0]); AFE_ST(R, v.motor, 1, off, ms[1]); AFE_ST(R, v.motor, 2, off, ms[2]); AFE_ST(R, v.motor, 3, off, ms[3]);
+  if (v.motor_write) {  // wave-uniform; off for stateless motors driven by held commands (see afe_motor_from_cmd_kernel)
+    AFE_ST(R, v.motor, 0, off, ms[0]); AFE_ST(R, v.motor, 1, off, ms[1]); AFE_ST(R, v.motor, 2, off, ms[2]); AFE_ST(R, v.motor, 3, off, ms[3]);
+  }
   if (have_imu) {
     AFE_ST(float, v.gyro, 0, off4, gx); AFE_ST(float, v.gyro, 1, off4, gy); AFE_ST(float, v.gyro, 2, off4, gz);
     AFE_ST(float, v.acc, 0, off4, ax_m); AFE_ST(float, v.acc, 1, off4, ay_m); AFE_ST(float, v.acc, 2, off4, az_m);
@@ -612,6 +614,38 @@ afe_seed_kernel(uint32_t *rng, int64_t n, int64_t first_global, int policy) {
     if (s == 0) s = 1u;
   }
   rng[i] = s;
+}
+
+// With tau_m == 0 and J_m == 0 the speed a motor had during the last step is a function of the
+// command alone (Motor.cpp:48-66 with c = 0): w = clamp(max(0, cmd), w_min, w_max).  Engines whose
+// commands are held between host calls therefore do not store it every step; this kernel rebuilds
+// the slab when somebody asks for it.
+template <typename R>
+__global__ void __launch_bounds__(256) afe_motor_from_cmd_kernel(R *motor, const float *cmd, const uint8_t *type,
+                                                                  const DevParams<R> *table, int64_t stride, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const DevParams<R> &P = table[type ? type[i] : 0];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    R w = (R)cmd[m * stride + i];
+    if (w < 0) w = 0;
+    if (w > P.wmax) w = P.wmax; else if (w < P.wmin) w = P.wmin;
+    motor[m * stride + i] = w;
+  }
+}
+
+int launch_motor_from_cmd_f32(float *motor, const float *cmd, const uint8_t *type, const DevParams<float> *table,
+                              int64_t stride, int64_t n, void *stream) {
+  hipLaunchKernelGGL(afe_motor_from_cmd_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     motor, cmd, type, table, stride, n);
+  return (int)hipGetLastError();
+}
+int launch_motor_from_cmd_f64(double *motor, const float *cmd, const uint8_t *type, const DevParams<double> *table,
+                              int64_t stride, int64_t n, void *stream) {
+  hipLaunchKernelGGL(afe_motor_from_cmd_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     motor, cmd, type, table, stride, n);
+  return (int)hipGetLastError();
 }
 
 int launch_seed_rng(uint32_t *rng, int64_t n, int64_t first_global, int policy, void *stream) {

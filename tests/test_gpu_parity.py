@@ -420,3 +420,38 @@ def test_max_fused_steps_setting_is_bitwise_neutral():
             np.testing.assert_array_equal(st[key], outs[0][0][key])
         np.testing.assert_array_equal(rng, outs[0][1])
         assert ticks == outs[0][2]
+
+
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+def test_rotor_speeds_are_those_of_the_last_step_even_though_they_are_not_stored_every_step(precision):
+    """Stateless motors (tau_m = J_m = 0, every shipped type) driven by held commands: the step kernel
+    skips the rotor-speed store and the engine rebuilds the slab from the commands on demand.  The
+    observable value must still be clamp(max(0, cmd OF THE LAST STEP)) -- also after the host has
+    written new commands, through the device view, and through a checkpoint."""
+    n = 700
+    rng = np.random.default_rng(12)
+    p = afa.params_from_type(5)
+    e = afa.Ensemble(n, precision=precision)
+    e.set_type_table([p])
+    e.set_state(np.zeros((3, n)), np.zeros((3, n)), np.tile([[1.0], [0], [0], [0]], (1, n)), np.zeros((3, n)),
+                np.full((4, n), 123.0))
+    es = 4 if precision == afa.AFE_F32 else 8
+    assert e.algorithmic_bytes_per_step(False) == 13 * es * 2 + 16           # state r/w + commands, no rotor speeds
+    cmd_a = rng.uniform(-200, 1.3 * p.motor_max_speed, (4, n)).astype(np.float32)
+    cmd_b = rng.uniform(0, p.motor_max_speed, (4, n)).astype(np.float32)
+    want_a = np.clip(np.maximum(cmd_a.astype(np.float64), 0), p.motor_min_speed, p.motor_max_speed)
+    want_b = np.clip(np.maximum(cmd_b.astype(np.float64), 0), p.motor_min_speed, p.motor_max_speed)
+    e.set_motor_cmds(cmd_a)
+    np.testing.assert_array_equal(e.get_state()["motor_speed"], 123.0)     # nothing stepped yet
+    e.step(1000, 3)
+    e.set_motor_cmds(cmd_b)                                                 # must not leak into the past
+    got = e.get_state()["motor_speed"]
+    np.testing.assert_allclose(got, want_a, rtol=1e-7 if precision == afa.AFE_F32 else 0)
+    ck = e.save_checkpoint()
+    e.step(1000, 2)
+    np.testing.assert_allclose(e.get_state()["motor_speed"], want_b, rtol=1e-7 if precision == afa.AFE_F32 else 0)
+    e.load_checkpoint(ck)
+    np.testing.assert_allclose(e.get_state()["motor_speed"], want_a, rtol=1e-7 if precision == afa.AFE_F32 else 0)
+    e.step(1000, 1)
+    np.testing.assert_allclose(e.get_state(5, 9)["motor_speed"], want_b[:, 5:14], rtol=1e-7 if precision == afa.AFE_F32 else 0)
+    e.close()
