@@ -8,16 +8,12 @@
 // (no FMA contraction), so images are compared bit for bit.
 //
 // MI355X mapping
-//   * one wave (64 lanes) per 8x8 pixel tile of one view: neighbouring rays walk the
-//     same part of the tree, so node / triangle loads coalesce into a few lines; box tests in
-//     fp32 against conservatively inflated boxes, triangle tests in fp64;
-//   * the BVH (32-byte nodes, sibling pairs adjacent = one 64-byte line per inner-node
-//     visit) and the 48-byte padded triangles stay in HBM and are served from L2 /
-//     Infinity Cache; the block index is remapped so that each XCD (own L2) renders a
-//     contiguous range of views;
-//   * per-lane traversal stack in LDS, [depth][lane] layout (conflict-free), 32 entries of
-//     32 bits (8 KB per wave, so LDS does not cap occupancy): the host builder guarantees the
-//     tree depth fits;
+//   * one wave (64 lanes) per 8x8 pixel tile of one view, and the 64 rays walk the tree together:
+//     one node index and one stack per wave, nodes (32 bytes, sibling pairs adjacent) and
+//     triangles (48 bytes padded) fetched by scalar loads once per wave; box tests in fp32
+//     against conservatively inflated boxes, triangle tests in fp64;
+//   * the BVH and the triangles stay in HBM and are served from L2 / Infinity Cache; the block
+//     index is remapped so that each XCD (own L2) renders a contiguous range of views;
 //   * poses are prepared by a small kernel straight from the engine's state slabs, so a
 //     closed loop never leaves the device: step -> render -> plan.
 #include <hip/hip_runtime.h>
@@ -292,7 +288,11 @@ __device__ __forceinline__ double ray_triangle(const double o[3], const double d
 
 __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(RenderArgs a) {
 #pragma clang fp contract(off)
+#ifdef AFE_RENDER_PER_LANE
   __shared__ int32_t stack_node[kStack][kTileW * kTileH];
+#else
+  __shared__ int32_t stack_node[kStack];     // one stack for the wave
+#endif
 
   // XCD-aware order: hardware block b runs on XCD b % 8; give each XCD a contiguous run
   // of logical blocks (= consecutive tiles of consecutive views) so that its L2 keeps the
@@ -305,7 +305,10 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   const int lane = threadIdx.x;
   const int px = (tile % a.tiles_x) * kTileW + (lane % kTileW);
   const int py = (tile / a.tiles_x) * kTileH + (lane / kTileW);
-  if (px >= a.width || py >= a.height) return;
+  const bool in_image = px < a.width && py < a.height;
+#ifdef AFE_RENDER_PER_LANE
+  if (!in_image) return;
+#endif
 
   const double *pose = a.poses + 12 * view;
   const double o[3] = {pose[0], pose[1], pose[2]};
@@ -317,7 +320,11 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   const float inv[3] = {1.0f / (float)d[0], 1.0f / (float)d[1], 1.0f / (float)d[2]};
 
   double best = INFINITY;
-  float best_f = INFINITY;             // best rounded up: the pruning bound of the fp32 box tests
+  // pruning bound of the fp32 box tests: the best hit so far, rounded up.  A hit at or beyond
+  // max_count * depth_scale saturates to max_count exactly like a miss, so nothing farther than
+  // that needs to be found at all.
+  float best_f = __double2float_ru((double)a.max_count * a.depth_scale * 1.000001);
+#ifdef AFE_RENDER_PER_LANE
   int sp = 0;
   // A popped node is re-tested against the hit distance found since it was pushed (its box is in
   // the node itself), which keeps the stack at one 32-bit entry per level.
@@ -353,13 +360,59 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
     live = sp > 0;
     if (live) n = a.nodes[stack_node[--sp][lane]];
   }
+#else
+  // The 64 rays of a tile walk the tree TOGETHER: one node index for the wave (so nodes and
+  // triangles arrive by scalar loads, once per wave instead of once per lane), every lane tests
+  // its own ray against the boxes, a child is entered if any lane's ray enters it, the nearer
+  // child by majority vote.  `mine` says whether this lane's ray is inside the node being visited;
+  // lanes that are not skip its triangles.  The closest hit is still a minimum over the triangles
+  // each ray reaches, so the result does not depend on the order.
+  int sp = 0;
+  int node = 0;
+  bool mine = in_image, fresh = true;      // fresh: `mine` has to be established by a box test (root, popped nodes)
+  for (;;) {
+    const BvhNode n = a.nodes[node];
+    if (fresh) mine = in_image && box_entry(n, of, inv, best_f) < INFINITY;
+    int next = -1;
+    if (__ballot(mine)) {
+      if (n.b > 0) {
+        for (int k = 0; k < n.b; k++) {
+          const float4 *t = a.tris + 3 * (int64_t)(n.a + k);
+          const float4 t0 = t[0], t1 = t[1], t2 = t[2];
+          if (mine) {
+            const double th = ray_triangle(o, d, t0, t1, t2);
+            if (th < best) { best = th; best_f = __double2float_ru(th); }
+          }
+        }
+      } else {
+        const BvhNode l = a.nodes[n.a], r = a.nodes[n.a + 1];
+        const float tl = mine ? box_entry(l, of, inv, best_f) : INFINITY;
+        const float tr = mine ? box_entry(r, of, inv, best_f) : INFINITY;
+        const bool hl = tl < INFINITY, hr = tr < INFINITY;
+        const uint64_t ml = __ballot(hl), mr = __ballot(hr);
+        if (ml | mr) {
+          const int votes_l = __popcll(__ballot(hl && (!hr || tl <= tr)));
+          const int votes_r = __popcll(__ballot(hr && (!hl || tr < tl)));
+          const bool left_first = mr == 0 || (ml != 0 && votes_l >= votes_r);
+          if (ml && mr) { stack_node[sp] = left_first ? n.a + 1 : n.a; sp++; }
+          next = left_first ? n.a : n.a + 1;
+          mine = left_first ? hl : hr;
+        }
+      }
+    }
+    if (next >= 0) { node = next; fresh = false; continue; }
+    if (sp == 0) break;
+    node = __builtin_amdgcn_readfirstlane(stack_node[--sp]);
+    fresh = true;
+  }
+#endif
 
   uint16_t count = (uint16_t)a.max_count;
   if (best < INFINITY) {
     const double c = floor(best / a.depth_scale);
     if (c < (double)a.max_count) count = (uint16_t)c;
   }
-  a.out[(view * a.height + py) * (int64_t)a.width + px] = count;
+  if (in_image) a.out[(view * a.height + py) * (int64_t)a.width + px] = count;
 }
 
 }  // namespace afe
