@@ -60,7 +60,10 @@ struct Builder {
   bool median_only = false;
 
   static constexpr int kBins = 16;
-  static constexpr int kLeaf = 4;
+#ifndef AFE_BVH_LEAF
+#define AFE_BVH_LEAF 4
+#endif
+  static constexpr int kLeaf = AFE_BVH_LEAF;
 
   Box range_box(int64_t first, int64_t count) const {
     Box b; b.reset();
@@ -288,11 +291,7 @@ __device__ __forceinline__ double ray_triangle(const double o[3], const double d
 
 __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(RenderArgs a) {
 #pragma clang fp contract(off)
-#ifdef AFE_RENDER_PER_LANE
-  __shared__ int32_t stack_node[kStack][kTileW * kTileH];
-#else
   __shared__ int32_t stack_node[kStack];     // one stack for the wave
-#endif
 
   // XCD-aware order: hardware block b runs on XCD b % 8; give each XCD a contiguous run
   // of logical blocks (= consecutive tiles of consecutive views) so that its L2 keeps the
@@ -305,10 +304,7 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   const int lane = threadIdx.x;
   const int px = (tile % a.tiles_x) * kTileW + (lane % kTileW);
   const int py = (tile / a.tiles_x) * kTileH + (lane / kTileW);
-  const bool in_image = px < a.width && py < a.height;
-#ifdef AFE_RENDER_PER_LANE
-  if (!in_image) return;
-#endif
+  const bool in_image = px < a.width && py < a.height;   // lanes outside still take part in the wave's votes
 
   const double *pose = a.poses + 12 * view;
   const double o[3] = {pose[0], pose[1], pose[2]};
@@ -324,43 +320,6 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   // max_count * depth_scale saturates to max_count exactly like a miss, so nothing farther than
   // that needs to be found at all.
   float best_f = __double2float_ru((double)a.max_count * a.depth_scale * 1.000001);
-#ifdef AFE_RENDER_PER_LANE
-  int sp = 0;
-  // A popped node is re-tested against the hit distance found since it was pushed (its box is in
-  // the node itself), which keeps the stack at one 32-bit entry per level.
-  bool live = true, retest = true;
-  BvhNode n = a.nodes[0];
-  while (live) {
-    bool descended = false;
-    if (retest && !(box_entry(n, of, inv, best_f) < INFINITY)) {
-      // culled
-    } else if (n.b > 0) {
-      for (int k = 0; k < n.b; k++) {
-        const float4 *t = a.tris + 3 * (int64_t)(n.a + k);
-        const double th = ray_triangle(o, d, t[0], t[1], t[2]);
-        if (th < best) { best = th; best_f = __double2float_ru(th); }
-      }
-    } else {
-      const BvhNode l = a.nodes[n.a], r = a.nodes[n.a + 1];
-      const float tl = box_entry(l, of, inv, best_f), tr = box_entry(r, of, inv, best_f);
-      const bool hl = tl < INFINITY, hr = tr < INFINITY;
-      if (hl && hr) {
-        const bool left_first = tl <= tr;
-        stack_node[sp][lane] = left_first ? n.a + 1 : n.a;
-        sp++;
-        n = left_first ? l : r;          // the child is already in registers
-        descended = true;
-      } else if (hl || hr) {
-        n = hl ? l : r;
-        descended = true;
-      }
-    }
-    retest = !descended;
-    if (descended) continue;
-    live = sp > 0;
-    if (live) n = a.nodes[stack_node[--sp][lane]];
-  }
-#else
   // The 64 rays of a tile walk the tree TOGETHER: one node index for the wave (so nodes and
   // triangles arrive by scalar loads, once per wave instead of once per lane), every lane tests
   // its own ray against the boxes, a child is entered if any lane's ray enters it, the nearer
@@ -405,7 +364,6 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
     node = __builtin_amdgcn_readfirstlane(stack_node[--sp]);
     fresh = true;
   }
-#endif
 
   uint16_t count = (uint16_t)a.max_count;
   if (best < INFINITY) {
