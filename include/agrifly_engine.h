@@ -423,7 +423,11 @@ int afe_plan_ticks(double logic_period_s, uint64_t *elapsed_us, uint64_t dt_us,
 /* ---- zero-copy device view ---------------------------------------------
  * Raw device pointers to the SoA slabs for HIP-side consumers (renderers,
  * planners, torch via __cuda_array_interface__).  Each field is planar with
- * `stride` elements between components.  state_elem_size is 4 or 8. */
+ * `stride` elements between components.  state_elem_size is 4 or 8.
+ * motor_speed is current as of this call: for stateless motors (tau_m = J_m =
+ * 0) driven by held commands the step kernel does not store the rotor speeds
+ * (they are clamp(max(0, cmd))); ask for the view again, or use afe_get_state,
+ * after further steps. */
 typedef struct afe_device_view {
   int64_t n_vehicles;
   int64_t stride;
@@ -437,9 +441,11 @@ typedef struct afe_device_view {
 } afe_device_view;
 int afe_get_device_view(afe_engine *e, afe_device_view *out);
 
-/* Algorithmic HBM bytes one vehicle-step of the current configuration moves
- * (176 B for fp32 state + cmds + IMU, +12 per active wrench
- * array, ...); what bench.py's roofline is computed from. */
+/* Algorithmic HBM bytes one vehicle-step of the current configuration moves:
+ * the slab accesses the step kernel actually makes (SURVEY 8d's 176 B for fp32
+ * state + cmds + IMU, minus the rotor-speed read / store the configuration
+ * lets it skip, +12 per active wrench array, IMU / RNG / logic bytes on a tick;
+ * DESIGN.md section 3); what bench.py's roofline is computed from. */
 int afe_algorithmic_bytes_per_step(const afe_engine *e, int imu_tick, double *bytes);
 
 /* Self-test hook for the IMU noise generator: for each of n minstd_rand0 words
