@@ -384,8 +384,12 @@ __device__ __forceinline__ unsigned range_bits8(const uint4 q, unsigned lo1, uns
          in_open_range(q.w & 0xffffu, lo1, span) << 6 | in_open_range(q.w >> 16, lo1, span) << 7;
 }
 
-__device__ void build_mask(const uint16_t *__restrict__ img, int W, int H, int lane, uint64_t *mask, int WW, uint16_t lo,
-                           uint16_t hi) {
+// WANT_MIN: also return the smallest marked depth (65535 if none) -- the shrink scans stop where
+// even that depth could not reach an edge any more
+template <bool WANT_MIN>
+__device__ int build_mask(const uint16_t *__restrict__ img, int W, int H, int lane, uint64_t *mask, int WW, uint16_t lo,
+                          uint16_t hi) {
+  int lane_min = 65535;
   if ((W & 63) == 0 && hi > lo) {
     // rows are whole 64-pixel words, so the image is one linear run of them: every lane takes
     // 8 pixels (16 B) per load and writes their 8 bits as one BYTE of the little-endian bit image
@@ -404,10 +408,19 @@ __device__ void build_mask(const uint16_t *__restrict__ img, int W, int H, int l
 #pragma unroll
       for (int u = 0; u < kSweepBatch; u++) {
         const int v = v0 + 64 * u + lane;
-        if (v < nvec) bytes[v] = (uint8_t)range_bits8(q[u], lo1, span);
+        if (v < nvec) {
+          const unsigned bits = range_bits8(q[u], lo1, span);
+          bytes[v] = (uint8_t)bits;
+          if (WANT_MIN && bits) {
+            const unsigned px[8] = {q[u].x & 0xffffu, q[u].x >> 16, q[u].y & 0xffffu, q[u].y >> 16,
+                                    q[u].z & 0xffffu, q[u].z >> 16, q[u].w & 0xffffu, q[u].w >> 16};
+#pragma unroll
+            for (int j = 0; j < 8; j++) if ((bits >> j) & 1u) lane_min = PL_MIN(lane_min, (int)px[j]);
+          }
+        }
       }
     }
-    return;
+    return WANT_MIN ? wave_min_i32(lane_min) : 65535;
   }
   const int n = WW * H;
   const unsigned magic = div_magic(WW);
@@ -426,11 +439,14 @@ __device__ void build_mask(const uint16_t *__restrict__ img, int W, int H, int l
     for (int u = 0; u < kSweepBatch; u++) {
       const int c = c0 + u;
       if (c < n) {
-        const uint64_t bits = __ballot(d[u] > lo && d[u] < hi);
+        const bool marked = d[u] > lo && d[u] < hi;
+        const uint64_t bits = __ballot(marked);
         if (lane == 0) mask[c] = bits;
+        if (WANT_MIN && marked) lane_min = PL_MIN(lane_min, (int)d[u]);
       }
     }
   }
+  return WANT_MIN ? wave_min_i32(lane_min) : 65535;
 }
 
 // first marked pixel of column x, rows ya..yb / of row y, columns xa..xb
@@ -544,9 +560,19 @@ constexpr int kScanBatch = 4;
 template <int SIDE>
 __device__ bool side_scan(const uint16_t *__restrict__ src, int sx, int sy, const uint64_t *mask, int WW, int lane,
                           int total, int inner, int xa, int ya, int dxo, int dyo, int dxi, int dyi, int num, int buf,
-                          int x0, int y0, Shrink &s) {
+                          int x0, int y0, int dmin, Shrink &s) {
   const unsigned magic = div_magic(inner);
   for (int base0 = 0; base0 < total; base0 += 64 * kScanBatch) {
+    {  // lines run outward from the rectangle: once even the nearest marked depth cannot reach the
+       // (current) edge from this line, no later pixel of the scan can act
+      const int o0 = div_small(base0, inner, magic);
+      int dist;
+      if (SIDE == SIDE_RIGHT) dist = xa + o0 * dxo - s.right;
+      else if (SIDE == SIDE_LEFT) dist = s.left - (xa + o0 * dxo);
+      else if (SIDE == SIDE_TOP) dist = s.top - (ya + o0 * dyo);
+      else dist = ya + o0 * dyo - s.bottom;
+      if (dist > 0 && dist * dmin >= num) break;
+    }
     int xs[kScanBatch], ys[kScanBatch];
     bool vs[kScanBatch];
     uint16_t ds[kScanBatch];
@@ -637,12 +663,23 @@ enum { CORNER_TR = 0, CORNER_BR = 1, CORNER_TL = 2, CORNER_BL = 3 };
 // pixels outward from the right / left edge.
 template <int CORNER>
 __device__ bool corner_scan(const uint16_t *__restrict__ img, int W, const uint64_t *mask, int WW, int lane, int rows,
-                            int inner, int xa, int ya, int num, int buf, int x0, int y0, Shrink &s) {
+                            int inner, int xa, int ya, int num, int buf, int x0, int y0, int dmin, Shrink &s) {
   constexpr bool RIGHT = (CORNER == CORNER_TR || CORNER == CORNER_BR);
   constexpr bool TOP = (CORNER == CORNER_TR || CORNER == CORNER_TL);
+  {  // within a corner scan the right edge only moves left (the left edge only right), so pixels
+     // farther out than ceil(num / dmin) from where it stands now can never act: narrow the rows
+    const int reach = (num + dmin - 1) / dmin;
+    inner = PL_MIN(inner, RIGHT ? s.right + reach - xa : xa - s.left + reach);
+    if (inner <= 0) return true;
+  }
   const int total = rows * inner;
   const unsigned magic = div_magic(inner);
   for (int base0 = 0; base0 < total; base0 += 64 * kScanBatch) {
+    {  // rows run outward from the top / bottom edge: see side_scan
+      const int o0 = div_small(base0, inner, magic);
+      const int dist = TOP ? s.top - (ya - o0) : (ya + o0) - s.bottom;
+      if (dist > 0 && dist * dmin >= num) break;
+    }
     int xs[kScanBatch], ys[kScanBatch];
     bool vs[kScanBatch];
     uint16_t ds[kScanBatch];
@@ -735,7 +772,7 @@ __device__ bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restri
   // spiral expansion, :520-600, on the bit image "nearer than minDepthPix"
   const int WW = (W + 63) >> 6;
   PL_T0(t_m1);
-  build_mask(img, W, H, lane, mask, WW, ignore, minDepthPix);
+  build_mask<false>(img, W, H, lane, mask, WW, ignore, minDepthPix);
   PL_T1(t_m1, 1);
   PL_T0(t_ring);
   const int L0 = L, T0 = T, R0 = R, B0 = B;
@@ -841,33 +878,35 @@ __device__ bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restri
   PL_T1(t_exp, 2);
   PL_T0(t_side);
   // shrink by the vehicle radius, :602-940, on the bit image "ignore < d < maxDepth"
-  build_mask(img, W, H, lane, mask, WW, ignore, maxDepth);
+  // dmin: the nearest marked pixel anywhere; (distance from an edge) * dmin >= num means no pixel
+  // at that distance or beyond can move the edge (num / d <= num / dmin), so a scan stops there
+  const int dmin = build_mask<true>(img, W, H, lane, mask, WW, ignore, maxDepth);
   Shrink s = {W - 1 - edgeOff, edgeOff, edgeOff, H - 1 - edgeOff};
   const int num = (int)(c.focal_length * c.planning_vehicle_radius / c.depth_scale);
   const int ny = B - T + 1, nx = R - L + 1;
   // right side :617-661 (columns R.. outward, rows T..B); left side :663-698
   if (mask_region_any(mask, WW, lane, R, W - 1, T, B) &&
-      !side_scan<SIDE_RIGHT>(imgT, H, 1, mask, WW, lane, (W - R) * ny, ny, R, T, 1, 0, 0, 1, num, buf, x0, y0, s)) return false;
+      !side_scan<SIDE_RIGHT>(imgT, H, 1, mask, WW, lane, (W - R) * ny, ny, R, T, 1, 0, 0, 1, num, buf, x0, y0, dmin, s)) return false;
   if (mask_region_any(mask, WW, lane, 0, L, T, B) &&
-      !side_scan<SIDE_LEFT>(imgT, H, 1, mask, WW, lane, (L + 1) * ny, ny, L, T, -1, 0, 0, 1, num, buf, x0, y0, s)) return false;
+      !side_scan<SIDE_LEFT>(imgT, H, 1, mask, WW, lane, (L + 1) * ny, ny, L, T, -1, 0, 0, 1, num, buf, x0, y0, dmin, s)) return false;
   if (s.left + buf > s.right - buf) return false;
   // top side :705-744 (rows T.. outward, columns L..R); bottom side :746-785
   if (mask_region_any(mask, WW, lane, L, R, 0, T) &&
-      !side_scan<SIDE_TOP>(img, 1, W, mask, WW, lane, (T + 1) * nx, nx, L, T, 0, -1, 1, 0, num, buf, x0, y0, s)) return false;
+      !side_scan<SIDE_TOP>(img, 1, W, mask, WW, lane, (T + 1) * nx, nx, L, T, 0, -1, 1, 0, num, buf, x0, y0, dmin, s)) return false;
   if (mask_region_any(mask, WW, lane, L, R, B, H - 1) &&
-      !side_scan<SIDE_BOTTOM>(img, 1, W, mask, WW, lane, (H - B) * nx, nx, L, B, 0, 1, 1, 0, num, buf, x0, y0, s)) return false;
+      !side_scan<SIDE_BOTTOM>(img, 1, W, mask, WW, lane, (H - B) * nx, nx, L, B, 0, 1, 1, 0, num, buf, x0, y0, dmin, s)) return false;
   if (s.top + buf > s.bottom - buf) return false;
   PL_T1(t_side, 3);
   PL_T0(t_corner);
   // corners :794-940
   if (mask_region_any(mask, WW, lane, R, W - 1, 0, T) &&
-      !corner_scan<CORNER_TR>(img, W, mask, WW, lane, T + 1, W - R, R, T, num, buf, x0, y0, s)) return false;
+      !corner_scan<CORNER_TR>(img, W, mask, WW, lane, T + 1, W - R, R, T, num, buf, x0, y0, dmin, s)) return false;
   if (mask_region_any(mask, WW, lane, R, W - 1, B, H - 1) &&
-      !corner_scan<CORNER_BR>(img, W, mask, WW, lane, H - B, W - R, R, B, num, buf, x0, y0, s)) return false;
+      !corner_scan<CORNER_BR>(img, W, mask, WW, lane, H - B, W - R, R, B, num, buf, x0, y0, dmin, s)) return false;
   if (mask_region_any(mask, WW, lane, 0, L, 0, T) &&
-      !corner_scan<CORNER_TL>(img, W, mask, WW, lane, T + 1, L + 1, L, T, num, buf, x0, y0, s)) return false;
+      !corner_scan<CORNER_TL>(img, W, mask, WW, lane, T + 1, L + 1, L, T, num, buf, x0, y0, dmin, s)) return false;
   if (mask_region_any(mask, WW, lane, 0, L, B, H - 1) &&
-      !corner_scan<CORNER_BL>(img, W, mask, WW, lane, H - B, L + 1, L, B, num, buf, x0, y0, s)) return false;
+      !corner_scan<CORNER_BL>(img, W, mask, WW, lane, H - B, L + 1, L, B, num, buf, x0, y0, dmin, s)) return false;
   PL_T1(t_corner, 4);
   PL_COUNT(5, 1);
   // :942-966
