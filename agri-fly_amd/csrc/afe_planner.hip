@@ -926,36 +926,51 @@ __device__ bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restri
 }
 
 // DIP.cpp:382-454
-__device__ bool deepest_collision_time(const Poly &p, const Section &m, const PlannerPyramid &pyr, double &tOut) {
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)u, m), hi = (unsigned)__shfl_xor((int)(unsigned)(u >> 32), m);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// The reference walks the four lateral faces one after the other, keeping the deepest crossing
+// found so far (increasing section: the largest root in (t0, t1]; decreasing: the smallest in
+// [t0, t1)).  That running extreme is order-independent, so the four quartics are solved side by
+// side -- lane l takes face l & 3 -- and combined with two shuffles; every lane ends with the result.
+__device__ bool deepest_collision_time(const Poly &p, const Section &m, const PlannerPyramid &pyr, int lane,
+                                       double &tOut) {
 #pragma clang fp contract(off)
-  bool collides = false;
-  tOut = m.increasing ? m.t0 : m.t1;
-  for (int f = 0; f < 4; f++) {
-    double c[5] = {0, 0, 0, 0, 0};
-    for (int dim = 0; dim < 3; dim++)
-      for (int q = 0; q < 5; q++) c[q] += pyr.normal[f][dim] * p.c[q][dim];
-    double roots[4];
-    unsigned n;
-    if (fabs(c[0]) > 1e-6) n = solve_quartic(c[1] / c[0], c[2] / c[0], c[3] / c[0], c[4] / c[0], roots);
-    else n = solve_cubic(c[2] / c[1], c[3] / c[1], c[4] / c[1], roots);
-    sort_small(roots, (int)n);
-    if (m.increasing) {
-      for (int i = (int)n - 1; i >= 0; i--) {
-        if (roots[i] > m.t1) continue;
-        else if (roots[i] > m.t0) {
-          if (roots[i] > tOut) { tOut = roots[i]; collides = true; break; }
-        } else break;
-      }
-    } else {
-      for (int i = 0; i < (int)n; i++) {
-        if (roots[i] < m.t0) continue;
-        else if (roots[i] < m.t1) {
-          if (roots[i] < tOut) { tOut = roots[i]; collides = true; break; }
-        } else break;
-      }
+  const int f = lane & 3;
+  double c[5] = {0, 0, 0, 0, 0};
+  for (int dim = 0; dim < 3; dim++) {
+    const double nf = pyr.normal[f][dim];
+    for (int q = 0; q < 5; q++) c[q] += nf * p.c[q][dim];
+  }
+  double roots[4];
+  unsigned n;
+  if (fabs(c[0]) > 1e-6) n = solve_quartic(c[1] / c[0], c[2] / c[0], c[3] / c[0], c[4] / c[0], roots);
+  else n = solve_cubic(c[2] / c[1], c[3] / c[1], c[4] / c[1], roots);
+  sort_small(roots, (int)n);
+  double cand = m.increasing ? m.t0 : m.t1;
+  if (m.increasing) {
+    for (int i = (int)n - 1; i >= 0; i--) {
+      if (roots[i] > m.t1) continue;
+      if (roots[i] > m.t0) cand = roots[i];
+      break;
+    }
+  } else {
+    for (int i = 0; i < (int)n; i++) {
+      if (roots[i] < m.t0) continue;
+      if (roots[i] < m.t1) cand = roots[i];
+      break;
     }
   }
-  return collides;
+#pragma unroll
+  for (int x = 1; x <= 2; x <<= 1) {
+    const double o = shfl_xor_f64(cand, x);
+    cand = m.increasing ? (o > cand ? o : cand) : (o < cand ? o : cand);
+  }
+  tOut = cand;
+  return m.increasing ? cand > m.t0 : cand < m.t1;
 }
 
 // GetMonotonicSections (DIP.cpp:303-354) + IsCollisionFree (:214-301)
@@ -1016,7 +1031,7 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
       at = idx;
     }
     double tcol;
-    if (deepest_collision_time(p, m, pyr[at], tcol)) {
+    if (deepest_collision_time(p, m, pyr[at], lane, tcol)) {
       if (ns >= 8) return false;
       sec[ns++] = m.increasing ? make_section(p, m.t0, tcol) : make_section(p, tcol, m.t1);
     }
