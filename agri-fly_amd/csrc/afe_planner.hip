@@ -823,33 +823,54 @@ __device__ bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restri
   int laneMin = 65535;
   {
     if ((W & 63) == 0) {
-      // rows T..B are one linear run; 8 pixels per lane per load, all in one row (W % 8 == 0)
-      const uint4 *src = (const uint4 *)(img + T * W);
-      const int nvec = ((B - T + 1) * W) >> 3;
-      const unsigned magic = div_magic(W >> 3);
+      // 8 pixels (one 16-byte vector, never straddling a row since W % 8 == 0) per lane per load,
+      // only the vectors that overlap columns L..R.  A vector that lies wholly inside the counted
+      // region takes the packed path: t = d - (ignore + 1) in 16-bit wrap-around arithmetic maps
+      // the ignored depths (d <= ignore) ABOVE every counted one, so a packed unsigned minimum of
+      // t needs no per-pixel test.
+      typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+      const uint4 *src = (const uint4 *)img;
+      const int rowv = W >> 3, vL = L >> 3, nvr = (R >> 3) - vL + 1, nvec = nvr * (B - T + 1);
+      const unsigned magic = div_magic(nvr);
+      const unsigned short bias1 = (unsigned short)(ignore + 1);
+      const u16x2 bias = {bias1, bias1};
+      u16x2 packed_min = {(unsigned short)0xffff, (unsigned short)0xffff};
       for (int v0 = 0; v0 < nvec; v0 += 64 * kSweepBatch) {
         uint4 q[kSweepBatch];
 #pragma unroll
         for (int u = 0; u < kSweepBatch; u++) {
           const int v = v0 + 64 * u + lane;
           q[u] = make_uint4(0, 0, 0, 0);
-          if (v < nvec) q[u] = src[v];
+          if (v < nvec) {
+            const int o = div_small(v, nvr, magic);
+            q[u] = src[(T + o) * rowv + vL + (v - o * nvr)];
+          }
         }
 #pragma unroll
         for (int u = 0; u < kSweepBatch; u++) {
           const int v = v0 + 64 * u + lane;
-          const int o = div_small(v, W >> 3, magic), xb = (v - o * (W >> 3)) << 3, y = T + o;
+          if (v >= nvec) continue;
+          const int o = div_small(v, nvr, magic), xb = (vL + (v - o * nvr)) << 3, y = T + o;
           const bool initRow = y >= T0 && y <= B0;
-          const unsigned px[8] = {q[u].x & 0xffffu, q[u].x >> 16, q[u].y & 0xffffu, q[u].y >> 16,
-                                  q[u].z & 0xffffu, q[u].z >> 16, q[u].w & 0xffffu, q[u].w >> 16};
+          if (xb >= L && xb + 7 <= R && !(initRow && xb + 7 >= L0 && xb <= R0)) {
+            packed_min = __builtin_elementwise_min(packed_min, __builtin_bit_cast(u16x2, q[u].x) - bias);
+            packed_min = __builtin_elementwise_min(packed_min, __builtin_bit_cast(u16x2, q[u].y) - bias);
+            packed_min = __builtin_elementwise_min(packed_min, __builtin_bit_cast(u16x2, q[u].z) - bias);
+            packed_min = __builtin_elementwise_min(packed_min, __builtin_bit_cast(u16x2, q[u].w) - bias);
+          } else {
+            const unsigned px[8] = {q[u].x & 0xffffu, q[u].x >> 16, q[u].y & 0xffffu, q[u].y >> 16,
+                                    q[u].z & 0xffffu, q[u].z >> 16, q[u].w & 0xffffu, q[u].w >> 16};
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const int x = xb + j;
-            const bool counted = x >= L && x <= R && !(initRow && x >= L0 && x <= R0) && px[j] > ignore;
-            if (counted) laneMin = PL_MIN(laneMin, (int)px[j]);      // lanes past the end hold 0 <= ignore
+            for (int j = 0; j < 8; j++) {
+              const int x = xb + j;
+              const bool counted = x >= L && x <= R && !(initRow && x >= L0 && x <= R0) && px[j] > ignore;
+              if (counted) laneMin = PL_MIN(laneMin, (int)px[j]);
+            }
           }
         }
       }
+      const int t = PL_MIN((int)packed_min.x, (int)packed_min.y);
+      if (t <= 65534 - (int)ignore) laneMin = PL_MIN(laneMin, t + (int)ignore + 1);   // else: only ignored depths seen
     } else {
       const int nxf = R - L + 1, total = nxf * (B - T + 1);
       const unsigned magic = div_magic(nxf);
