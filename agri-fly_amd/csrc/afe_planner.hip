@@ -330,6 +330,13 @@ struct Shrink {
   int right, left, top, bottom;
 };
 
+// NOTE on `noinline` below (build_mask, first_blocking_ring, side_scan, corner_scan): with these
+// helpers inlined into the one very large search kernel, hipcc (ROCm 7.2) produced code in which
+// some of the guarded corner scans were skipped although their guard held -- same inputs, same
+// bit image, isolated copies of the same functions correct (found with a 640-plan campaign against
+// the oracle on rendered orchard images, now tests/test_gpu_planner.py::test_campaign_...).  Keeping
+// the wave-cooperative pieces as separate functions gives the structurizer small, reducible bodies;
+// it costs ~5 % and the campaign is the regression test.
 // ---- wave-cooperative pixel scans ------------------------------------------------
 // One wave runs one planner: everything outside the scans below is computed redundantly
 // (and therefore convergently) by all 64 lanes; inside a scan lane l looks at pixel
@@ -387,7 +394,7 @@ __device__ __forceinline__ unsigned range_bits8(const uint4 q, unsigned lo1, uns
 // WANT_MIN: also return the smallest marked depth (65535 if none) -- the shrink scans stop where
 // even that depth could not reach an edge any more
 template <bool WANT_MIN>
-__device__ int build_mask(const uint16_t *__restrict__ img, int W, int H, int lane, uint64_t *mask, int WW, uint16_t lo,
+__device__ __attribute__((noinline)) int build_mask(const uint16_t *__restrict__ img, int W, int H, int lane, uint64_t *mask, int WW, uint16_t lo,
                           uint16_t hi) {
   int lane_min = 65535;
   if ((W & 63) == 0 && hi > lo) {
@@ -505,7 +512,7 @@ __device__ __forceinline__ bool mask_bit(const uint64_t *mask, int WW, int x, in
 // advancing.  The first ring in which a free side meets a marked pixel is therefore the smallest
 // ring distance of any marked pixel inside the window the free sides can still reach; all rings
 // before it are clear and can be taken in one step.  Returns that ring index (>= 1) or INT_MAX.
-__device__ int first_blocking_ring(const uint64_t *mask, int WW, int lane, int xlo, int xhi, int ylo, int yhi, int L,
+__device__ __attribute__((noinline)) int first_blocking_ring(const uint64_t *mask, int WW, int lane, int xlo, int xhi, int ylo, int yhi, int L,
                                    int R, int T, int B) {
   const int wa = xlo >> 6, nw = (xhi >> 6) - wa + 1, total = nw * (yhi - ylo + 1);
   const unsigned magic = div_magic(nw);
@@ -558,7 +565,7 @@ enum { SIDE_RIGHT = 0, SIDE_LEFT = 1, SIDE_TOP = 2, SIDE_BOTTOM = 3 };
 constexpr int kScanBatch = 4;
 
 template <int SIDE>
-__device__ bool side_scan(const uint16_t *__restrict__ src, int sx, int sy, const uint64_t *mask, int WW, int lane,
+__device__ __attribute__((noinline)) bool side_scan(const uint16_t *__restrict__ src, int sx, int sy, const uint64_t *mask, int WW, int lane,
                           int total, int inner, int xa, int ya, int dxo, int dyo, int dxi, int dyi, int num, int buf,
                           int x0, int y0, int dmin, Shrink &s) {
   const unsigned magic = div_magic(inner);
@@ -662,7 +669,7 @@ enum { CORNER_TR = 0, CORNER_BR = 1, CORNER_TL = 2, CORNER_BL = 3 };
 // One of the four corner scans, DIP.cpp:794-940: rows outward from the top / bottom edge,
 // pixels outward from the right / left edge.
 template <int CORNER>
-__device__ bool corner_scan(const uint16_t *__restrict__ img, int W, const uint64_t *mask, int WW, int lane, int rows,
+__device__ __attribute__((noinline)) bool corner_scan(const uint16_t *__restrict__ img, int W, const uint64_t *mask, int WW, int lane, int rows,
                             int inner, int xa, int ya, int num, int buf, int x0, int y0, int dmin, Shrink &s) {
   constexpr bool RIGHT = (CORNER == CORNER_TR || CORNER == CORNER_BR);
   constexpr bool TOP = (CORNER == CORNER_TR || CORNER == CORNER_TL);
