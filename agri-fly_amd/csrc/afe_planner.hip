@@ -330,7 +330,7 @@ struct Shrink {
   int right, left, top, bottom;
 };
 
-// NOTE on `noinline` below (build_mask, first_blocking_ring, side_scan, corner_scan): with these
+// NOTE on `noinline` below (build_mask, first_blocking_ring, side_scan, corner_scan, inflate_pyramid): with these
 // helpers inlined into the one very large search kernel, hipcc (ROCm 7.2) produced code in which
 // some of the guarded corner scans were skipped although their guard held -- same inputs, same
 // bit image, isolated copies of the same functions correct (found with a 640-plan campaign against
@@ -745,7 +745,7 @@ __device__ __attribute__((noinline)) bool corner_scan(const uint16_t *__restrict
 }
 
 // DIP.cpp:456-970, executed by one wave (lane = 0..63, everything but the scans is uniform)
-__device__ bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restrict__ img,
+__device__ __attribute__((noinline)) bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restrict__ img,
                                 const uint16_t *__restrict__ imgT, uint64_t *mask, int lane, int x0, int y0,
                                 double minimumDepth, PlannerPyramid &out) {
 #pragma clang fp contract(off)
