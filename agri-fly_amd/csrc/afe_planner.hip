@@ -336,7 +336,7 @@ struct Shrink {
 // bit image, isolated copies of the same functions correct (found with a 640-plan campaign against
 // the oracle on rendered orchard images, now tests/test_gpu_planner.py::test_campaign_...).  Keeping
 // the wave-cooperative pieces as separate functions gives the structurizer small, reducible bodies;
-// it costs ~5 % and the campaign is the regression test.
+// it costs nothing measurable and the campaign is the regression test.
 // ---- wave-cooperative pixel scans ------------------------------------------------
 // One wave runs one planner: everything outside the scans below is computed redundantly
 // (and therefore convergently) by all 64 lanes; inside a scan lane l looks at pixel
