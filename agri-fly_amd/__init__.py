@@ -43,6 +43,7 @@ from .engine import (  # noqa: F401
     radio_create_rates_command,
     radio_decode,
     rates_logic_params_from_type,
+    scene_check_hierarchy,
     type_from_id,
 )
 from . import scenarios  # noqa: F401

@@ -522,6 +522,51 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
   return AFE_OK;
 }
 
+// Pure host: build the hierarchy for a mesh and verify it (every triangle in exactly one leaf, every
+// leaf's and inner node's box containing what hangs below it); no GPU needed.
+extern "C" int afe_scene_check_hierarchy(const float *triangles, int64_t n_tri, int64_t *n_nodes, int *depth,
+                                         int *max_leaf) {
+  if (!triangles || n_tri <= 0 || n_tri > 0x3fffffff) return AFE_ERR_INVALID_ARG;
+  for (int64_t i = 0; i < 9 * n_tri; i++) if (!std::isfinite(triangles[i])) return AFE_ERR_INVALID_ARG;
+  Builder b;
+  b.tri = triangles;
+  b.build(n_tri);
+  if (b.max_depth > kStack) { b.median_only = true; b.build(n_tri); }
+  if (b.max_depth > kStack) return AFE_ERR_OUT_OF_RANGE;
+  std::vector<int> seen((size_t)n_tri, 0);
+  int worst_leaf = 0;
+  // children's boxes inside the parent's, leaves cover their triangles
+  for (size_t k = 0; k < b.nodes.size(); k++) {
+    const BvhNode &nd = b.nodes[k];
+    if (nd.b > 0) {
+      worst_leaf = std::max(worst_leaf, (int)nd.b);
+      for (int q = 0; q < nd.b; q++) {
+        const int32_t t = b.order[(size_t)nd.a + q];
+        seen[(size_t)t]++;
+        for (int v = 0; v < 3; v++)
+          for (int a = 0; a < 3; a++) {
+            const float c = triangles[9 * (int64_t)t + 3 * v + a];
+            if (!(c > nd.lo[a] && c < nd.hi[a])) return AFE_ERR_OUT_OF_RANGE;   // strictly inside the inflated box
+          }
+      }
+    } else {
+      if (nd.a <= (int32_t)k || (size_t)nd.a + 1 >= b.nodes.size()) return AFE_ERR_OUT_OF_RANGE;
+      for (int c = 0; c < 2; c++)
+        for (int a = 0; a < 3; a++) {
+          const BvhNode &ch = b.nodes[(size_t)nd.a + c];
+          // a child's inflation is computed from a smaller magnitude, so allow it the same slack again
+          const float slack = 3e-4f + 4e-6f * std::max(std::fabs(nd.lo[a]), std::fabs(nd.hi[a]));
+          if (ch.lo[a] < nd.lo[a] - slack || ch.hi[a] > nd.hi[a] + slack) return AFE_ERR_OUT_OF_RANGE;
+        }
+    }
+  }
+  for (int64_t i = 0; i < n_tri; i++) if (seen[(size_t)i] != 1) return AFE_ERR_OUT_OF_RANGE;
+  if (n_nodes) *n_nodes = (int64_t)b.nodes.size();
+  if (depth) *depth = b.max_depth;
+  if (max_leaf) *max_leaf = worst_leaf;
+  return AFE_OK;
+}
+
 extern "C" void afe_scene_destroy(afe_scene *s) {
   if (!s) return;
   if (s->nodes) (void)hipFree(s->nodes);

@@ -38,7 +38,7 @@ ABI_FUNCTIONS = [
     "afe_set_max_fused_steps", "afe_planner_default_config", "afe_planner_samples", "afe_rappids_plan",
     "afe_rappids_plan_device", "afe_camera_default", "afe_camera_default_mount", "afe_scene_create",
     "afe_scene_destroy", "afe_scene_info", "afe_render_depth", "afe_render_depth_engine",
-    "afe_device_alloc", "afe_device_free", "afe_device_download",
+    "afe_device_alloc", "afe_device_free", "afe_device_download", "afe_scene_check_hierarchy",
 ]
 
 
@@ -234,6 +234,7 @@ def library():
         "afe_camera_default_mount": [vp],
         "afe_scene_create": [ci, vp, i64, C.POINTER(vp)],
         "afe_scene_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(ci), vp],
+        "afe_scene_check_hierarchy": [vp, i64, C.POINTER(i64), C.POINTER(ci), C.POINTER(ci)],
         "afe_render_depth": [vp, C.POINTER(Camera), i64, vp, vp, vp, vp, C.POINTER(C.c_float)],
         "afe_render_depth_engine": [eng, vp, C.POINTER(Camera), i64, i64, vp, vp, ci, C.POINTER(C.c_float)],
         "afe_device_alloc": [ci, u64, C.POINTER(vp)],
@@ -458,6 +459,16 @@ class Scene:
         if rc:
             raise AfeError(rc, library().afe_status_string(rc).decode())
         return (img, ms.value) if out is None else ms.value
+
+
+def scene_check_hierarchy(triangles):
+    """Host-only: (n_nodes, depth, max_leaf) of the BVH for a mesh, after verifying its invariants."""
+    t = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
+    nn, d, ml = C.c_int64(), C.c_int(), C.c_int()
+    rc = library().afe_scene_check_hierarchy(t.ctypes.data, t.shape[0], C.byref(nn), C.byref(d), C.byref(ml))
+    if rc:
+        raise AfeError(rc, library().afe_status_string(rc).decode())
+    return nn.value, d.value, ml.value
 
 
 def type_from_id(vehicle_id):

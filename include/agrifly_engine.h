@@ -338,6 +338,10 @@ int afe_camera_default_mount(double mount[4]);
 /* triangles: n_tri x 9 floats (v0, v1, v2).  device < 0: current device. */
 int afe_scene_create(int device, const float *triangles, int64_t n_tri, afe_scene **out);
 void afe_scene_destroy(afe_scene *s);
+/* Pure host (no GPU): builds the hierarchy afe_scene_create would build and verifies it --
+ * every triangle in exactly one leaf, every box containing what hangs below it, depth within
+ * the traversal stack; returns its node count, depth and largest leaf. */
+int afe_scene_check_hierarchy(const float *triangles, int64_t n_tri, int64_t *n_nodes, int *depth, int *max_leaf);
 /* n_tri, number of BVH nodes, tree depth, world bounds {min xyz, max xyz} */
 int afe_scene_info(const afe_scene *s, int64_t *n_tri, int64_t *n_nodes, int *depth, double bounds[6]);
 

@@ -80,3 +80,25 @@ def test_orchard_mesh_shape_and_regression(ora, scen, golden_dir):
     gold = np.load(os.path.join(golden_dir, "render_regression.npz"))
     assert np.array_equal(gold["triangles"], tris)
     assert np.array_equal(gold["image"], img)
+
+
+def test_bvh_builder_invariants_on_the_host(afa, scen):
+    """afe_scene_check_hierarchy builds the hierarchy the GPU traverses and verifies it without a GPU:
+    every triangle in exactly one leaf, boxes containing what hangs below them, depth within the
+    traversal stack -- for the orchard, for coincident / degenerate triangles (median-split fallback)
+    and for a single triangle."""
+    tris = scen.orchard_mesh(rows=6, cols=8, seed=3)
+    n_nodes, depth, max_leaf = afa.scene_check_hierarchy(tris)
+    assert n_nodes > len(tris) // 4 and depth <= 32 and 1 <= max_leaf <= 4
+    one = np.array([[3, -1, 0, 3, 1, 0, 3, 0, 2]], np.float32)
+    assert afa.scene_check_hierarchy(one) == (1, 1, 1)
+    many = np.concatenate([np.repeat(one, 300, 0), np.array([[2, -1, 1, 2, 1, 1, 2, 1, 1.0000001]], np.float32),
+                           np.array([[4, 0, 0, 4, 0, 0, 4, 0, 0]], np.float32)])
+    n_nodes, depth, max_leaf = afa.scene_check_hierarchy(many)
+    assert depth <= 32 and max_leaf <= 4
+    rng = np.random.default_rng(0)
+    soup = rng.uniform(-50, 50, (5000, 9)).astype(np.float32)          # long, overlapping triangles
+    n_nodes, depth, max_leaf = afa.scene_check_hierarchy(soup)
+    assert depth <= 32
+    with pytest.raises(afa.AfeError):
+        afa.scene_check_hierarchy(np.full((1, 9), np.inf, np.float32))
