@@ -1015,7 +1015,7 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
   if (fabs(dc[0]) > 1e-6) n = solve_quartic(dc[1] / dc[0], dc[2] / dc[0], dc[3] / dc[0], dc[4] / dc[0], roots + 2);
   else n = solve_cubic(dc[2] / dc[1], dc[3] / dc[1], dc[4] / dc[1], roots + 2);
   sort_small(roots, (int)n + 2);
-  Section sec[8];
+  Section sec[16];   // pending sections (a std::vector in the reference; 16 like the CPU checker)
   int ns = 0;
   for (unsigned i = 0; i < n + 1; i++) {
     if (roots[i] < 0) continue;
@@ -1060,7 +1060,7 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
     }
     double tcol;
     if (deepest_collision_time(p, m, pyr[at], lane, tcol)) {
-      if (ns >= 8) return false;
+      if (ns >= 16) return false;
       sec[ns++] = m.increasing ? make_section(p, m.t0, tcol) : make_section(p, tcol, m.t1);
     }
   }

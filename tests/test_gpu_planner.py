@@ -171,10 +171,13 @@ def test_campaign_on_rendered_orchard_images(ora):
     """640 plans on 60 depth images rendered from random poses inside the orchard (cluttered: up to
     64 pyramids per plan, a quarter of the plans find nothing) plus 20 synthetic ones, random states.
     Every candidate's TrajectoryTestResult bits and the winner must equal the oracle's for EVERY plan.
-    The pyramid count may differ for a few plans: a section that starts at a collision time has a root
-    of the same face polynomial exactly on its boundary, so `root > t0` is decided by the last bit of
-    acos / cos / pow, which the device and glibc do not share (a literal one-lane port of the oracle
-    shows the same 8 plans of this set); more than 3 % would mean the scans themselves are off."""
+    The pyramid count may differ for a few plans, for a reason inherent to the algorithm: when a section
+    is cut at a collision time, its new end point lies ON a lateral face of the pyramid, i.e. on a plane
+    through the camera centre whose image is an integer pixel column / row, so the seed of the next
+    pyramid, (int)(x f / z + cx), truncates a value that is an integer up to the last bits of the quartic
+    root -- and acos / cos / pow on the device and in glibc do not share those (traced call by call: the
+    first divergence is always such a seed, 280 vs 281 with identical depth; a literal one-lane port of
+    the oracle shows the same 8 plans of this set).  More than 3 % would mean the scans themselves are off."""
     rng = np.random.default_rng(2026)
     tris = afa.scenarios.orchard_mesh(rows=8, cols=10, seed=11)
     scene = afa.Scene(tris)
