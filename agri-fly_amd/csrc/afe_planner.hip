@@ -348,15 +348,17 @@ struct Shrink {
 // would act on, in the same order.  For the four side scans the ordinary update is a
 // running min / max of one edge (see side_scan), which a wave reduction applies to a whole
 // chunk at once.
+// (the result is the same in every lane; readfirstlane tells the compiler so, which moves whatever is
+// derived from it -- edges, loop bounds, addresses -- into scalar registers and the scalar ALU)
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o < v ? o : v; }
-  return v;
+  return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o > v ? o : v; }
-  return v;
+  return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ __forceinline__ uint64_t lanes_from(int l) { return l >= 64 ? 0ull : (~0ull << l); }
 
@@ -369,7 +371,7 @@ __device__ __forceinline__ uint64_t lanes_from(int l) { return l >= 64 ? 0ull : 
 // image -- a ring of the expansion is a handful of LDS reads and ballots, a shrink scan touches
 // HBM only for the few chunks that contain a marked pixel.
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int l) {
-  const unsigned lo = (unsigned)__shfl((int)(unsigned)v, l), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), l);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
   return ((uint64_t)hi << 32) | lo;
 }
 // i / inner for 0 <= i < 2^24, 1 <= inner <= 2^15 as a multiply-high
@@ -640,7 +642,7 @@ __device__ __attribute__((noinline)) bool side_scan(const uint16_t *__restrict__
           continue;
         }
         // lane l is next in scan order and exceptional: the reference's inner branch
-        const int xl = __shfl(x, l), yl = __shfl(y, l), kl = __shfl(k, l);
+        const int xl = __builtin_amdgcn_readlane(x, l), yl = __builtin_amdgcn_readlane(y, l), kl = __builtin_amdgcn_readlane(k, l);
         if (SIDE == SIDE_RIGHT || SIDE == SIDE_LEFT) {
           const int tT = yl + kl, bT = yl - kl;
           if (y0 < tT + buf && y0 > bT - buf) return false;
@@ -721,7 +723,7 @@ __device__ __attribute__((noinline)) bool corner_scan(const uint16_t *__restrict
         const uint64_t b = __ballot(valid && hx && hy) & todo;
         if (!b) break;
         const int l = (int)__ffsll((unsigned long long)b) - 1;
-        const int xl = __shfl(x, l), yl = __shfl(y, l), kl = __shfl(k, l);
+        const int xl = __builtin_amdgcn_readlane(x, l), yl = __builtin_amdgcn_readlane(y, l), kl = __builtin_amdgcn_readlane(k, l);
         const int xT = RIGHT ? xl - kl : xl + kl;          // rightTemp / leftTemp
         const int yT = TOP ? yl + kl : yl - kl;            // topTemp / bottomTemp
         const bool cutX = RIGHT ? x0 > xT - buf : x0 < xT + buf;
@@ -1164,7 +1166,7 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
       const uint64_t pass = __ballot(has && my_cost < bestCost) & todo;
       if (!pass) break;
       const int l = (int)__ffsll((unsigned long long)pass) - 1;
-      const unsigned bits = (unsigned)__shfl((int)my_bits, l);
+      const unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)my_bits, l);
       unsigned result = 1;
       n_cost++;
       if (bits & CAND_INPUT_FEASIBLE) {
