@@ -217,7 +217,19 @@ def main():
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: RCCL even for one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout is reserved
+        # for the one JSON line, so the communicator is created (first barrier) with fd 1 -> fd 2
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     def barrier():
         if dist is not None:
