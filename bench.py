@@ -291,7 +291,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": n_local * bytes_step,
-                "kernel": "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, RENORM=1> -- the timed region "
+                "kernel": "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, LOGIC=0, SINGLE=1> -- the timed region "
                           "alternates NOISE=0 (no logic tick) and NOISE=1 (tick: IMU + six Gaussian draws) launches",
                 "kernel_us": t_kernel * 1e6,
                 "algorithmic_bytes_per_vehicle_step": bytes_step,
