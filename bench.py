@@ -147,8 +147,41 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
     found = float(np.mean([o.found for o in out]))
     buf.close()
     e.close()
+    # one camera frame of the closed perception loop (config 3 / 5): 33 ms of physics with the rates
+    # logic on the device, one depth image per vehicle, one plan per vehicle on it -- all from engine state
+    n_loop = 4096
+    lane = rng.integers(0, 31, n_loop)
+    p0 = np.stack([rng.uniform(-6.0, -3.0, n_loop), lane * 4.0 + 2.0 + rng.uniform(-0.8, 0.8, n_loop), np.full(n_loop, 1.2)])
+    q0 = np.tile(np.array([[1.0], [0.0], [0.0], [0.0]]), (1, n_loop))
+    params = afa.params_from_type(5)
+    el = afa.Ensemble(n_loop, precision=afa.AFE_F32)
+    el.set_type_table([params])
+    el.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+    el.set_rates_logic([afa.rates_logic_params_from_type(5)])
+    el.set_state(p0, np.zeros((3, n_loop)), q0, np.zeros((3, n_loop)), np.full((4, n_loop), afa.scenarios.hover_speed(params)))
+    el.set_rates_commands(np.full(n_loop, 9.81, np.float32), np.zeros((3, n_loop), np.float32))
+    bl = afa.DeviceBuffer(n_loop * 240 * 320 * 2)
+    v_c = np.stack([np.zeros(n_loop), np.zeros(n_loop), np.full(n_loop, 1.0)])
+    zeros = np.zeros((3, n_loop))
+    g_c = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n_loop))
+    samples_l = afa.planner_samples(0, 320, 240, 192)
+    frame = {}
+    for _ in range(2):
+        t0 = time.perf_counter()
+        el.step(1000, 33)
+        el.sync()
+        t1 = time.perf_counter()
+        ms_r = scene.render_engine(el, cam, mount, out=bl)
+        outl, _, ms_p = afa.rappids_plan(cfg, bl, v_c, zeros, g_c, samples_l)
+        frame = {"vehicles": n_loop, "physics_33_steps_ms": (t1 - t0) * 1e3, "render_ms": ms_r, "plan_ms": ms_p,
+                 "candidates": 192, "fraction_found": float(np.mean([o.found for o in outl]))}
+    frame["frame_ms"] = frame["physics_33_steps_ms"] + frame["render_ms"] + frame["plan_ms"]
+    frame["realtime_factor_at_30Hz"] = 33.0 / frame["frame_ms"]
+    bl.close()
+    el.close()
     info = scene.info()
-    return {"depth_camera": {"views": n_views, "image": "320x240", "triangles": int(info["n_tri"]),
+    return {"closed_perception_loop_frame": frame,
+            "depth_camera": {"views": n_views, "image": "320x240", "triangles": int(info["n_tri"]),
                              "kernel_ms": ms_render, "rays_per_s": n_views * 76800 / (ms_render * 1e-3)},
             "rappids_planner": {"planners": n_planners, "candidates": n_candidates, "distinct_images": n_views,
                                 "kernel_ms": ms_plan, "plans_per_s": n_planners / (ms_plan * 1e-3),
