@@ -256,12 +256,14 @@ struct RenderArgs {
 // what rounding the ray to fp32 can move it -- and the comparisons below carry a relative slack of
 // 1e-5, so the test only ever errs towards visiting a box: which triangles a ray reaches, and
 // therefore the fp64 hit distance, cannot depend on it.
-__device__ __forceinline__ float box_entry(const BvhNode &n, const float o[3], const float inv[3], float best) {
+// (oi = o * inv is precomputed per ray, so a slab costs two FMAs; where that turns a zero direction
+// component into a NaN the fminf / fmaxf below ignore it, which again can only let a box through.)
+__device__ __forceinline__ float box_entry(const BvhNode &n, const float oi[3], const float inv[3], float best) {
   float tmin = 0.0f, tmax = best;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const float t0 = (n.lo[k] - o[k]) * inv[k];
-    const float t1 = (n.hi[k] - o[k]) * inv[k];
+    const float t0 = __builtin_fmaf(n.lo[k], inv[k], -oi[k]);
+    const float t1 = __builtin_fmaf(n.hi[k], inv[k], -oi[k]);
     tmin = fmaxf(tmin, fminf(t0, t1));
     tmax = fminf(tmax, fmaxf(t0, t1));
   }
@@ -312,8 +314,8 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   const double v = (py - a.cy) / a.focal;
   const double d[3] = {pose[3] * u + pose[4] * v + pose[5], pose[6] * u + pose[7] * v + pose[8],
                        pose[9] * u + pose[10] * v + pose[11]};
-  const float of[3] = {(float)o[0], (float)o[1], (float)o[2]};
   const float inv[3] = {1.0f / (float)d[0], 1.0f / (float)d[1], 1.0f / (float)d[2]};
+  const float of[3] = {(float)o[0] * inv[0], (float)o[1] * inv[1], (float)o[2] * inv[2]};   // o * inv, see box_entry
 
   double best = INFINITY;
   // pruning bound of the fp32 box tests: the best hit so far, rounded up.  A hit at or beyond
