@@ -18,9 +18,11 @@ from .engine import (  # noqa: F401
     AFE_SEED_REFERENCE,
     AfeError,
     Camera,
+    Comm,
     DeviceBuffer,
     DeviceView,
     Ensemble,
+    Group,
     PlanOutput,
     PlannerConfig,
     RADIO_PACKET_SIZE,
@@ -29,6 +31,7 @@ from .engine import (  # noqa: F401
     Scene,
     TELEMETRY_PACKET_SIZE,
     TelemetryPacket,
+    UwbNetwork,
     VehicleParams,
     build_library,
     camera_default,

@@ -11,6 +11,7 @@
 
 #include "afe_host.h"
 #include "afe_render.h"
+#include "afe_world.h"
 
 using namespace afe;
 
@@ -36,6 +37,7 @@ struct afe_engine {
   std::vector<DevParams<double>> table_f64;
   bool types_uniform = true;  // every vehicle uses record 0 (kernel-argument fast path)
   float *pack_scratch = nullptr;  // 3*n floats, lazily allocated
+  afe_world *world = nullptr;     // shared-world query scratch (uniform grid), lazily created
   // on-device rates logic (allocated by afe_set_rates_logic)
   bool logic_on = false;
   void *logic_arena = nullptr;
@@ -360,6 +362,7 @@ extern "C" int afe_destroy(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   (void)hipSetDevice(e->device);
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+  if (e->world) world_destroy(e->world);
   if (e->pack_scratch) (void)hipFree(e->pack_scratch);
   if (e->logic_arena) (void)hipFree(e->logic_arena);
   if (e->arena) (void)hipFree(e->arena);
@@ -680,6 +683,19 @@ void engine_stream_device(afe_engine *e, void **stream, int *device) {
   *stream = (void *)e->stream;
   *device = e->device;
 }
+void engine_shard(const afe_engine *e, int64_t *first_global, int64_t *n) {
+  *first_global = e->first_global;
+  *n = e->n;
+}
+// this shard's positions as planar fp32 [3][n] in the engine's own scratch, on its stream
+int engine_pack_to_scratch(afe_engine *e, float **scratch) {
+  AFE_HIP(e, hipSetDevice(e->device));
+  if (!e->pack_scratch) AFE_HIP(e, hipMalloc((void **)&e->pack_scratch, (size_t)e->n * 3 * sizeof(float)));
+  const int rc = afe_pack_positions(e, e->pack_scratch);
+  if (rc) return rc;
+  *scratch = e->pack_scratch;
+  return AFE_OK;
+}
 }  // namespace afe
 
 extern "C" int afe_get_device_view(afe_engine *e, afe_device_view *out) {
@@ -741,15 +757,50 @@ extern "C" int afe_event_elapsed_ms(void *start, void *stop, float *ms) {
 }
 
 namespace {
+// Everything a step depends on that is not in the arenas travels in (or is verified through) the
+// header: the clock, which optional inputs are live, the noise / seeding / logic-period
+// configuration (restored on load), and fingerprints of the expanded type and logic tables
+// (verified on load: a checkpoint cannot carry the tables' host-side source records, so the
+// receiving engine must have been given the same ones).
 struct CheckpointHeader {
   uint64_t magic, n, stride, precision, arena_bytes, logic_bytes;
   uint64_t now_us, logic_elapsed_us, n_ticks;
   uint64_t has_ext_force, has_ext_torque, logic_on;
+  uint64_t n_types, table_hash, logic_hash;
+  uint64_t noise, seed_policy;
+  double sigma_gyro, sigma_acc, logic_period;
 };
-const uint64_t kCheckpointMagic = 0x4146452d434b5031ull;  // "AFE-CKP1"
+const uint64_t kCheckpointMagic = 0x4146452d434b5032ull;  // "AFE-CKP2"
 size_t logic_arena_bytes(const afe_engine *e) {
   const size_t S = (size_t)e->stride;
   return e->logic_arena ? S * 12 * 4 + S * 4 * 4 + S * 2 + 256 * sizeof(DevLogic) : 0;
+}
+inline void fnv(uint64_t &h, const void *p, size_t n) {
+  const unsigned char *b = (const unsigned char *)p;
+  for (size_t k = 0; k < n; k++) { h ^= b[k]; h *= 1099511628211ull; }
+}
+// field by field: struct padding is not part of the fingerprint
+uint64_t table_fingerprint(const afe_engine *e) {
+  uint64_t h = 1469598103934665603ull;
+  for (const HostParams &t : e->table) {
+    fnv(h, &t.mass, sizeof(t.mass)); fnv(h, t.I, sizeof(t.I)); fnv(h, t.Iinv, sizeof(t.Iinv));
+    fnv(h, t.mp, sizeof(t.mp)); fnv(h, &t.kf, sizeof(t.kf)); fnv(h, &t.ktau, sizeof(t.ktau));
+    fnv(h, &t.tau_m, sizeof(t.tau_m)); fnv(h, &t.Jm, sizeof(t.Jm)); fnv(h, &t.wmin, sizeof(t.wmin));
+    fnv(h, &t.wmax, sizeof(t.wmax)); fnv(h, t.drag, sizeof(t.drag)); fnv(h, t.Rimu, sizeof(t.Rimu));
+  }
+  return h;
+}
+uint64_t logic_fingerprint(const afe_engine *e) {
+  uint64_t h = 1469598103934665603ull;
+  if (!e->logic_on) return 0;
+  for (const afe_rates_logic_params &t : e->logic_params) {
+    fnv(h, &t.mass, sizeof(t.mass)); fnv(h, t.inertia, sizeof(t.inertia));
+    fnv(h, &t.ang_vel_time_const_xy, 4); fnv(h, &t.ang_vel_time_const_z, 4); fnv(h, &t.arm_length, 4);
+    fnv(h, &t.prop_thrust_from_speed_sqr, 4); fnv(h, &t.prop_torque_from_thrust, 4); fnv(h, &t.prop0_spin_dir, 4);
+    fnv(h, &t.max_thrust_per_propeller, 4); fnv(h, &t.min_thrust_per_propeller, 4); fnv(h, &t.max_cmd_total_thrust, 4);
+    fnv(h, &t.imu_yaw, 4); fnv(h, &t.imu_pitch, 4); fnv(h, &t.imu_roll, 4); fnv(h, &t.gyro_lowpass_cutoff, 4);
+  }
+  return h;
 }
 }  // namespace
 
@@ -766,10 +817,14 @@ extern "C" int afe_save_checkpoint(afe_engine *e, void *host_buffer, uint64_t by
   AFE_HIP(e, hipSetDevice(e->device));
   { const int mrc = materialize_motor(e); if (mrc) return mrc; }
   AFE_HIP(e, hipStreamSynchronize(e->stream));
-  CheckpointHeader h = {kCheckpointMagic, (uint64_t)e->n, (uint64_t)e->stride, (uint64_t)e->precision,
-                        (uint64_t)e->arena_bytes, e->logic_on ? (uint64_t)logic_arena_bytes(e) : 0,
-                        e->now_us, e->logic_elapsed_us, e->n_ticks,
-                        e->has_ext_force, e->has_ext_torque, e->logic_on};
+  CheckpointHeader h = {};
+  h.magic = kCheckpointMagic; h.n = (uint64_t)e->n; h.stride = (uint64_t)e->stride; h.precision = (uint64_t)e->precision;
+  h.arena_bytes = (uint64_t)e->arena_bytes; h.logic_bytes = e->logic_on ? (uint64_t)logic_arena_bytes(e) : 0;
+  h.now_us = e->now_us; h.logic_elapsed_us = e->logic_elapsed_us; h.n_ticks = e->n_ticks;
+  h.has_ext_force = e->has_ext_force; h.has_ext_torque = e->has_ext_torque; h.logic_on = e->logic_on;
+  h.n_types = (uint64_t)e->table.size(); h.table_hash = table_fingerprint(e); h.logic_hash = logic_fingerprint(e);
+  h.noise = e->noise; h.seed_policy = (uint64_t)e->seed_policy;
+  h.sigma_gyro = e->sigma_gyro; h.sigma_acc = e->sigma_acc; h.logic_period = e->logic_period;
   char *p = (char *)host_buffer;
   std::memcpy(p, &h, sizeof(h));
   p += sizeof(h);
@@ -783,11 +838,21 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
   if (!e || !host_buffer || bytes < sizeof(CheckpointHeader)) return AFE_ERR_INVALID_ARG;
   CheckpointHeader h;
   std::memcpy(&h, host_buffer, sizeof(h));
-  if (h.magic != kCheckpointMagic || h.n != (uint64_t)e->n || h.stride != (uint64_t)e->stride ||
-      h.precision != (uint64_t)e->precision || h.arena_bytes != e->arena_bytes ||
-      h.logic_on != (uint64_t)e->logic_on || (h.logic_on && h.logic_bytes != logic_arena_bytes(e)) ||
-      bytes < sizeof(h) + h.arena_bytes + h.logic_bytes)
-    return fail(e, AFE_ERR_INVALID_ARG, "checkpoint does not match this engine's size / precision / logic configuration");
+  if (h.magic != kCheckpointMagic) return fail(e, AFE_ERR_INVALID_ARG, "not an engine checkpoint (or one of another format version)");
+  if (h.n != (uint64_t)e->n || h.stride != (uint64_t)e->stride || h.precision != (uint64_t)e->precision ||
+      h.arena_bytes != e->arena_bytes)
+    return fail(e, AFE_ERR_INVALID_ARG, "checkpoint does not match this engine's size / precision");
+  if ((h.logic_on != 0) != e->logic_on || h.logic_bytes != (e->logic_on ? (uint64_t)logic_arena_bytes(e) : 0))
+    return fail(e, AFE_ERR_INVALID_ARG, "checkpoint and engine disagree about the on-device logic (afe_set_rates_logic)");
+  if (h.logic_bytes > bytes || h.arena_bytes > bytes || bytes < sizeof(h) + h.arena_bytes + h.logic_bytes)
+    return fail(e, AFE_ERR_INVALID_ARG, "checkpoint buffer is truncated");
+  if (h.n_types != (uint64_t)e->table.size() || h.table_hash != table_fingerprint(e))
+    return fail(e, AFE_ERR_INVALID_ARG, "checkpoint was taken with a different vehicle type table (afe_set_type_table first)");
+  if (h.logic_hash != logic_fingerprint(e))
+    return fail(e, AFE_ERR_INVALID_ARG, "checkpoint was taken with different on-device logic parameters");
+  if ((h.seed_policy != AFE_SEED_REFERENCE && h.seed_policy != AFE_SEED_DECORRELATED) || !(h.logic_period > 0) ||
+      !(h.sigma_gyro >= 0) || !(h.sigma_acc >= 0))
+    return fail(e, AFE_ERR_INVALID_ARG, "checkpoint header holds an invalid configuration");
   AFE_HIP(e, hipSetDevice(e->device));
   AFE_HIP(e, hipStreamSynchronize(e->stream));
   const char *p = (const char *)host_buffer + sizeof(h);
@@ -799,6 +864,24 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
   e->n_ticks = h.n_ticks;
   e->has_ext_force = h.has_ext_force != 0;
   e->has_ext_torque = h.has_ext_torque != 0;
+  e->noise = h.noise != 0;
+  e->seed_policy = (int)h.seed_policy;   // the RNG words themselves came with the arena
+  e->sigma_gyro = h.sigma_gyro;
+  e->sigma_acc = h.sigma_acc;
+  e->logic_period = h.logic_period;
+  // the kernel-argument fast path is only valid when every vehicle uses record 0: decide from the
+  // restored per-vehicle type slab, not from what this engine was told before the load
+  {
+    std::vector<uint8_t> types((size_t)e->n);
+    const char *type_in_ckp = (const char *)host_buffer + sizeof(h) + ((const char *)e->type - (const char *)e->arena);
+    std::memcpy(types.data(), type_in_ckp, (size_t)e->n);
+    bool all_zero = true;
+    for (size_t k = 0; k < types.size(); k++) {
+      if (types[k] >= e->table.size()) return fail(e, AFE_ERR_INVALID_ARG, "checkpoint holds a type index outside the type table");
+      all_zero = all_zero && types[k] == 0;
+    }
+    e->types_uniform = all_zero;
+  }
   // the arena also holds the device copy of the type table for the checkpoint's dt: rebuild on next step
   e->table_dirty = true;
   e->logic_table_period = -1.0f;
@@ -839,13 +922,35 @@ extern "C" int afe_pack_positions(afe_engine *e, float *device_xyz) {
 
 extern "C" int afe_nearest_neighbour(afe_engine *e, const float *all_xyz, int64_t n_all, float *dist2_out,
                                      int32_t *index_out) {
+  return afe_nearest_neighbour_grid(e, all_xyz, n_all, 0.0f, dist2_out, index_out);
+}
+
+extern "C" int afe_nearest_neighbour_grid(afe_engine *e, const float *all_xyz, int64_t n_all, float cell_size,
+                                          float *dist2_out, int32_t *index_out) {
   if (!e || !all_xyz || n_all <= 0 || !dist2_out || !index_out)
     return fail(e, AFE_ERR_INVALID_ARG, "bad nearest-neighbour arguments");
+  if (e->first_global + e->n > n_all)
+    return fail(e, AFE_ERR_OUT_OF_RANGE, "the gathered ensemble is smaller than this shard's global range");
   AFE_HIP(e, hipSetDevice(e->device));
-  if (!e->pack_scratch) AFE_HIP(e, hipMalloc((void **)&e->pack_scratch, (size_t)e->n * 3 * sizeof(float)));
-  int rc = afe_pack_positions(e, e->pack_scratch);
-  if (rc) return rc;
-  if (launch_nearest_neighbour(e->pack_scratch, e->n, e->first_global, all_xyz, n_all, dist2_out, index_out, e->stream))
-    return fail(e, AFE_ERR_HIP, "nearest-neighbour kernel launch failed");
+  if (!e->world) { const int rc = world_create(e->device, &e->world); if (rc) return fail(e, rc, "shared-world scratch"); }
+  const int rc = world_nearest(e->world, (void *)e->stream, all_xyz, n_all, e->first_global, e->n, cell_size, dist2_out, index_out);
+  if (rc) return fail(e, rc, world_last_error(e->world));
+  return AFE_OK;
+}
+
+extern "C" int afe_neighbour_grid_info(const afe_engine *e, int dims[3], float *cell_size, int64_t *n_cells) {
+  if (!e || !e->world) return AFE_ERR_NOT_CONFIGURED;
+  return world_grid_info(e->world, dims, cell_size, n_cells);
+}
+
+extern "C" int afe_nearest_neighbour_bruteforce(afe_engine *e, const float *all_xyz, int64_t n_all, const int32_t *dev_queries,
+                                                int64_t n_queries, float *dist2_out, int32_t *index_out) {
+  if (!e || !all_xyz || n_all <= 0 || !dev_queries || n_queries <= 0 || !dist2_out || !index_out)
+    return fail(e, AFE_ERR_INVALID_ARG, "bad nearest-neighbour arguments");
+  AFE_HIP(e, hipSetDevice(e->device));
+  if (!e->world) { const int rc = world_create(e->device, &e->world); if (rc) return fail(e, rc, "shared-world scratch"); }
+  const int rc = world_nearest_bruteforce(e->world, (void *)e->stream, all_xyz, n_all, e->first_global, dev_queries, n_queries,
+                                          dist2_out, index_out);
+  if (rc) return fail(e, rc, world_last_error(e->world));
   return AFE_OK;
 }

@@ -193,13 +193,17 @@ __device__ __forceinline__ void rotvec_to_quat(float rx, float ry, float rz,
   float t = fm(rz, rz, fm(ry, ry, rx * rx));  // theta^2
   const float kMin2 = 4.84813681e-6f * 4.84813681e-6f;
   d0 = 1; d1 = 0; d2 = 0; d3 = 0;
-  if (t >= kMin2) {
+  if (!(t < kMin2)) {   // as the reference's `theta < MIN_ANGLE`: a NaN angle takes the general branch and poisons the lane
     // larger angles: evaluate the series for r / 2^k and square the unit
     // quaternion k times, (c, s r') -> (c^2 - s^2 |r'|^2, (c s) 2r').  Rare
     // (needs |w| dt >= 0.5 rad), so the lane-divergent loops cost nothing in
     // normal flight; no library sin/cos/sqrt and no division anywhere.
+    // The halving loop is bounded: FLT_MAX needs 65 quarterings, and an infinite
+    // theta^2 (overflowed squares of a diverged vehicle) must not spin for ever --
+    // it falls through after 80 and the series then yields the same non-finite
+    // quaternion the reference's sin/cos of an infinite angle would.
     int k = 0;
-    while (t >= 0.25f) { t *= 0.25f; k++; }
+    while (t >= 0.25f && k < 80) { t *= 0.25f; k++; }
     const float h2 = 0.25f * t;  // (theta/2)^2 of the scaled vector
     float cs = fm(h2, fm(h2, fm(h2, fm(h2, 2.4801587e-5f, -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
     float sc = 0.5f * fm(h2, fm(h2, fm(h2, fm(h2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.0f);
@@ -578,8 +582,15 @@ static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevPara
       hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
     else if (uniform)                                                                                      \
       hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, false>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
-    else                                                                                                   \
-      hipLaunchKernelGGL((afe_step_kernel_table<R, FE, TE, NO, LO>), dim3(grid), dim3(256), lds, st, v);      \
+    else {                                                                                                 \
+      /* a large type table (up to 256 records: 83 KB fp32 / 124 KB fp64 with the logic records) needs   \
+         more than the default 64 KB of dynamic LDS; gfx950 has 160 KB per CU */                          \
+      if (lds > 65536 &&                                                                                   \
+          hipFuncSetAttribute(reinterpret_cast<const void *>(&afe_step_kernel_table<R, FE, TE, NO, LO>),  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)         \
+        return (int)hipErrorInvalidValue;                                                                  \
+      hipLaunchKernelGGL((afe_step_kernel_table<R, FE, TE, NO, LO>), dim3(grid), dim3(256), lds, st, v);   \
+    }                                                                                                      \
   } while (0)
 #define AFE_SEL_LO(FE, TE, NO) do { if (f.logic) AFE_LAUNCH(FE, TE, NO, true); else AFE_LAUNCH(FE, TE, NO, false); } while (0)
 #define AFE_SEL_NO(FE, TE) do { if (f.noise) AFE_SEL_LO(FE, TE, true); else AFE_SEL_LO(FE, TE, false); } while (0)
@@ -698,44 +709,6 @@ int launch_pack_positions_f64(const double *pos, int64_t stride, int64_t n, floa
   if (n <= 0) return 0;
   hipLaunchKernelGGL(afe_pack_positions_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, pos, stride, n, out);
-  return (int)hipGetLastError();
-}
-
-// Brute-force nearest neighbour of each local vehicle among the gathered
-// ensemble: candidates are streamed through LDS in 256-vehicle tiles so each
-// global position is read once per workgroup, not once per lane.
-__global__ void __launch_bounds__(256)
-afe_nearest_kernel(const float *self_xyz, int64_t n_self, int64_t first_global,
-                   const float *all_xyz, int64_t n_all, float *dist2, int32_t *index) {
-  __shared__ float tx[256], ty[256], tz[256];
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = i < n_self;
-  float x = 0, y = 0, z = 0;
-  if (live) { x = self_xyz[i]; y = self_xyz[n_self + i]; z = self_xyz[2 * n_self + i]; }
-  const int64_t me = first_global + i;
-  float best = 3.4e38f;
-  int32_t best_j = -1;
-  for (int64_t base = 0; base < n_all; base += 256) {
-    const int64_t j = base + threadIdx.x;
-    if (j < n_all) { tx[threadIdx.x] = all_xyz[j]; ty[threadIdx.x] = all_xyz[n_all + j]; tz[threadIdx.x] = all_xyz[2 * n_all + j]; }
-    __syncthreads();
-    const int lim = (int)((n_all - base) < 256 ? (n_all - base) : 256);
-    for (int k = 0; k < lim; k++) {
-      const float dx = tx[k] - x, dy = ty[k] - y, dz = tz[k] - z;
-      const float d = dx * dx + dy * dy + dz * dz;
-      if (d < best && (base + k) != me) { best = d; best_j = (int32_t)(base + k); }
-    }
-    __syncthreads();
-  }
-  if (live) { dist2[i] = best; index[i] = best_j; }
-}
-
-int launch_nearest_neighbour(const float *self_xyz, int64_t n_self, int64_t first_global,
-                             const float *all_xyz, int64_t n_all, float *dist2,
-                             int32_t *index, void *stream) {
-  if (n_self <= 0) return 0;
-  hipLaunchKernelGGL(afe_nearest_kernel, dim3((unsigned)((n_self + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, self_xyz, n_self, first_global, all_xyz, n_all, dist2, index);
   return (int)hipGetLastError();
 }
 

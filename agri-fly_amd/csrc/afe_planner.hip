@@ -399,6 +399,11 @@ template <bool WANT_MIN>
 __device__ __attribute__((noinline)) int build_mask(const uint16_t *__restrict__ img, int W, int H, int lane, uint64_t *mask, int WW, uint16_t lo,
                           uint16_t hi) {
   int lane_min = 65535;
+  // The bit image is written by one set of lanes and read by others.  The block is a single wave,
+  // so these barriers cost nothing, but they are what orders the LDS traffic: readers of the
+  // previous image are done before it is overwritten, and the new image is complete (and the
+  // compiler may not move LDS reads across) before anyone looks at it.
+  __syncthreads();
   if ((W & 63) == 0 && hi > lo) {
     // rows are whole 64-pixel words, so the image is one linear run of them: every lane takes
     // 8 pixels (16 B) per load and writes their 8 bits as one BYTE of the little-endian bit image
@@ -429,6 +434,7 @@ __device__ __attribute__((noinline)) int build_mask(const uint16_t *__restrict__
         }
       }
     }
+    __syncthreads();
     return WANT_MIN ? wave_min_i32(lane_min) : 65535;
   }
   const int n = WW * H;
@@ -455,6 +461,7 @@ __device__ __attribute__((noinline)) int build_mask(const uint16_t *__restrict__
       }
     }
   }
+  __syncthreads();
   return WANT_MIN ? wave_min_i32(lane_min) : 65535;
 }
 
@@ -1245,8 +1252,13 @@ __global__ void __launch_bounds__(256) afe_transpose_images_kernel(const uint16_
 
 int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream) {
   if (b.n <= 0) return 0;
-  hipLaunchKernelGGL(afe_transpose_images_kernel, dim3((cfg.width + 31) / 32, (cfg.height + 31) / 32, (unsigned)b.n_images),
-                     dim3(256), 0, (hipStream_t)stream, b.images, b.images_t, cfg.width, cfg.height);
+  // grid.z is limited to 65535: one launch per run of that many images (config 3 has one image per planner, 65536)
+  for (int64_t i0 = 0; i0 < b.n_images; i0 += 65535) {
+    const int64_t cnt = (b.n_images - i0) < 65535 ? (b.n_images - i0) : 65535;
+    const int64_t off = i0 * cfg.width * cfg.height;
+    hipLaunchKernelGGL(afe_transpose_images_kernel, dim3((cfg.width + 31) / 32, (cfg.height + 31) / 32, (unsigned)cnt),
+                       dim3(256), 0, (hipStream_t)stream, b.images + off, b.images_t + off, cfg.width, cfg.height);
+  }
   const unsigned mask_bytes = (unsigned)(((cfg.width + 63) >> 6) * cfg.height) * (unsigned)sizeof(uint64_t);
 #ifdef AFE_PLANNER_PROFILE
   unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -1,0 +1,609 @@
+// afe_world.hip -- shared-world queries on the gathered position buffer:
+// the consumers of the one inter-vehicle exchange the path has.
+//
+//   * nearest neighbour of every local vehicle among the whole ensemble, by a uniform grid
+//     (cell list built by a counting sort on the device, 3x3x3 cell search, exact: rings are
+//     added until no unvisited cell can hold a closer point);
+//   * UWB-style ranging between requester / responder pairs, the batched form of
+//     Simulation::UWBNetwork::Run (Components/Components/Simulation/UWBNetwork.cpp:22-89).
+//
+// Both read the planar fp32 xyz buffer afe_pack_positions / afe_gather_positions produce
+// (12 B per vehicle, the all-gather payload of SURVEY 8e).  HBM / cache-latency bound integer and
+// fp32 work; no contraction anywhere, hence no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "afe_render.h"   // engine_stream_device
+#include "afe_world.h"
+
+namespace afe {
+namespace {
+
+struct GridDesc {
+  float min[3];
+  float inv_h, h;
+  int n[3];          // cells per axis
+  int64_t n_cells;   // n[0]*n[1]*n[2]; bin n_cells collects non-finite positions (never searched)
+};
+
+__device__ __forceinline__ int ordered(float f) {
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__host__ __device__ __forceinline__ float unordered(int i) {
+  const int j = i >= 0 ? i : i ^ 0x7fffffff;
+  float f;
+  memcpy(&f, &j, 4);
+  return f;
+}
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+  return fabsf(x) < 3.0e38f && fabsf(y) < 3.0e38f && fabsf(z) < 3.0e38f;   // false for NaN and inf
+}
+
+// min / max of the finite positions: lo[3], hi[3] as order-preserving ints
+__global__ void __launch_bounds__(256) world_bounds_kernel(const float *__restrict__ xyz, int64_t n, int *__restrict__ lohi) {
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float x = xyz[i], y = xyz[n + i], z = xyz[2 * n + i];
+    if (finite3(x, y, z)) {
+      const int ox = ordered(x), oy = ordered(y), oz = ordered(z);
+      lo[0] = min(lo[0], ox); hi[0] = max(hi[0], ox);
+      lo[1] = min(lo[1], oy); hi[1] = max(hi[1], oy);
+      lo[2] = min(lo[2], oz); hi[2] = max(hi[2], oz);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+      lo[c] = min(lo[c], __shfl_xor(lo[c], s));
+      hi[c] = max(hi[c], __shfl_xor(hi[c], s));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { atomicMin(&lohi[c], lo[c]); atomicMax(&lohi[3 + c], hi[c]); }
+  }
+}
+
+__device__ __forceinline__ void cell_of(const GridDesc &g, float x, float y, float z, int &cx, int &cy, int &cz) {
+#pragma clang fp contract(off)
+  cx = (int)((x - g.min[0]) * g.inv_h);
+  cy = (int)((y - g.min[1]) * g.inv_h);
+  cz = (int)((z - g.min[2]) * g.inv_h);
+  cx = cx < 0 ? 0 : (cx >= g.n[0] ? g.n[0] - 1 : cx);
+  cy = cy < 0 ? 0 : (cy >= g.n[1] ? g.n[1] - 1 : cy);
+  cz = cz < 0 ? 0 : (cz >= g.n[2] ? g.n[2] - 1 : cz);
+}
+
+// counting sort, pass 1: cell of every point, histogram, slot of the point inside its cell
+__global__ void __launch_bounds__(256) world_count_kernel(const float *__restrict__ xyz, int64_t n, GridDesc g,
+                                                          uint32_t *__restrict__ counts, uint32_t *__restrict__ cell,
+                                                          uint32_t *__restrict__ slot) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = xyz[i], y = xyz[n + i], z = xyz[2 * n + i];
+  uint32_t c = (uint32_t)g.n_cells;
+  if (finite3(x, y, z)) {
+    int cx, cy, cz;
+    cell_of(g, x, y, z, cx, cy, cz);
+    c = (uint32_t)(((int64_t)cz * g.n[1] + cy) * g.n[0] + cx);
+  }
+  cell[i] = c;
+  slot[i] = atomicAdd(&counts[c], 1u);
+}
+
+// exclusive scan of m counts in three launches (1024 per block)
+__global__ void __launch_bounds__(256) world_scan_local_kernel(const uint32_t *in, uint32_t *out,   // in == out: each thread rewrites only what it read
+                                                               uint32_t *__restrict__ block_sums, int64_t m) {
+  __shared__ uint32_t wave_tot[4];
+  const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+  uint32_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = (base + k < m) ? in[base + k] : 0u;
+  const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+  uint32_t incl = mine;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const uint32_t t = __shfl_up(incl, s);
+    if (lane >= s) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t off = 0;
+  for (int w = 0; w < wave; w++) off += wave_tot[w];
+  uint32_t run = off + incl - mine;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (base + k < m) out[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 255) block_sums[blockIdx.x] = off + incl;
+}
+// scan of the block sums by one workgroup (sequential over chunks of 256)
+__global__ void __launch_bounds__(256) world_scan_blocks_kernel(uint32_t *__restrict__ block_sums, int64_t nb) {
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t b0 = 0; b0 < nb; b0 += 256) {
+    const int64_t i = b0 + threadIdx.x;
+    const uint32_t mine = i < nb ? block_sums[i] : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const uint32_t t = __shfl_up(incl, s);
+      if (lane >= s) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t off = carry_s;
+    for (int w = 0; w < wave; w++) off += wave_tot[w];
+    if (i < nb) block_sums[i] = off + incl - mine;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = off + incl;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) world_scan_add_kernel(uint32_t *__restrict__ out, const uint32_t *__restrict__ block_sums, int64_t m) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < m) out[i] += block_sums[i >> 10];
+}
+
+// counting sort, pass 2: points into cell order as (x, y, z, global index)
+__global__ void __launch_bounds__(256) world_scatter_kernel(const float *__restrict__ xyz, int64_t n, const uint32_t *__restrict__ starts,
+                                                            const uint32_t *__restrict__ cell, const uint32_t *__restrict__ slot,
+                                                            uint4 *__restrict__ sorted) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  sorted[starts[cell[i]] + slot[i]] = make_uint4(__float_as_uint(xyz[i]), __float_as_uint(xyz[n + i]), __float_as_uint(xyz[2 * n + i]), (uint32_t)i);
+}
+
+// squared distance exactly as the brute-force definition rounds it (three products, two sums, fp32)
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float x, float y, float z) {
+#pragma clang fp contract(off)
+  const float dx = ax - x, dy = ay - y, dz = az - z;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+// the closest point wins; among equally close ones the lowest global index (what a 0..n-1 scan with `<` keeps)
+__device__ __forceinline__ void consider(float d, int j, int me, float &best, int &best_j) {
+  if (j != me && (d < best || (d == best && j < best_j))) { best = d; best_j = j; }
+}
+
+__device__ __forceinline__ void scan_range(const uint4 *__restrict__ sorted, uint32_t a, uint32_t b, float x, float y, float z, int me,
+                                           float &best, int &best_j) {
+  for (uint32_t k = a; k < b; k++) {
+    const uint4 p = sorted[k];   // (x, y, z) bits and the global index
+    consider(dist2(__uint_as_float(p.x), __uint_as_float(p.y), __uint_as_float(p.z), x, y, z), (int)p.w, me, best, best_j);
+  }
+}
+
+#define AFE_WORLD_MAX_RING 3
+
+// One lane per point IN CELL ORDER (neighbouring lanes sit in the same or adjacent cells, so their
+// reads share cache lines); lanes whose point is not one of this shard's vehicles retire at once.
+// Exactness: every point outside the (2r+1)^3 block of cells around the query's cell is at least
+// r*h away, so once the best squared distance is below (r h)^2 (with a margin for the fp32 cell
+// assignment) no unvisited cell can improve it.  Queries still unresolved after AFE_WORLD_MAX_RING
+// rings (isolated vehicles) go to a leftover list that a brute-force kernel finishes.
+__global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restrict__ sorted, int64_t n_all, const uint32_t *__restrict__ starts,
+                                                          GridDesc g, int64_t first_global, int64_t n_self, float *__restrict__ dist2_out,
+                                                          int32_t *__restrict__ index_out, uint32_t *__restrict__ leftover_count,
+                                                          int32_t *__restrict__ leftover) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_all) return;
+  const uint4 qb = sorted[s];
+  const float3 q = make_float3(__uint_as_float(qb.x), __uint_as_float(qb.y), __uint_as_float(qb.z));
+  const int me = (int)qb.w;
+  const int64_t local = (int64_t)me - first_global;
+  if (local < 0 || local >= n_self) return;
+  float best = 3.4e38f;
+  int best_j = -1;
+  if (!finite3(q.x, q.y, q.z)) { dist2_out[local] = best; index_out[local] = best_j; return; }
+  int cx, cy, cz;
+  cell_of(g, q.x, q.y, q.z, cx, cy, cz);
+  const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
+  bool done = false;
+  for (int r = 1; r <= AFE_WORLD_MAX_RING && !done; r++) {
+    for (int dz = -r; dz <= r; dz++) {
+      const int z = cz + dz;
+      if (z < 0 || z >= nz) continue;
+      for (int dy = -r; dy <= r; dy++) {
+        const int y = cy + dy;
+        if (y < 0 || y >= ny) continue;
+        const int64_t row = ((int64_t)z * ny + y) * nx;
+        const bool shell_row = (dz == -r || dz == r || dy == -r || dy == r) || r == 1;
+        if (shell_row) {   // the whole x-run of the row is new: its cells are contiguous in the cell order
+          const int xa = max(cx - r, 0), xb = min(cx + r, nx - 1);
+          scan_range(sorted, starts[row + xa], starts[row + xb + 1], q.x, q.y, q.z, me, best, best_j);
+        } else {           // interior row of a wider ring: only its two end cells are new
+          if (cx - r >= 0) scan_range(sorted, starts[row + cx - r], starts[row + cx - r + 1], q.x, q.y, q.z, me, best, best_j);
+          if (cx + r < nx) scan_range(sorted, starts[row + cx + r], starts[row + cx + r + 1], q.x, q.y, q.z, me, best, best_j);
+        }
+      }
+    }
+    const float reach = (float)r * g.h;
+    const bool covers_all = cx - r <= 0 && cx + r >= nx - 1 && cy - r <= 0 && cy + r >= ny - 1 && cz - r <= 0 && cz + r >= nz - 1;
+    done = covers_all || best < reach * reach * 0.998f;
+  }
+  if (done) { dist2_out[local] = best; index_out[local] = best_j; }
+  else leftover[atomicAdd(leftover_count, 1u)] = (int32_t)local;
+}
+
+// brute force for listed queries, one workgroup per query: every thread strides over the ensemble,
+// then (distance, index) pairs are reduced keeping the lowest index among equals
+__global__ void __launch_bounds__(256) world_brute_kernel(const float *__restrict__ all_xyz, int64_t n_all, const int32_t *__restrict__ queries,
+                                                          const uint32_t *__restrict__ n_queries, int64_t first_global,
+                                                          float *__restrict__ dist2_out, int32_t *__restrict__ index_out) {
+  __shared__ float sd[4];
+  __shared__ int sj[4];
+  for (uint32_t qi = blockIdx.x; qi < *n_queries; qi += gridDim.x) {
+    const int64_t local = queries[qi];
+    const int me = (int)(first_global + local);
+    const float x = all_xyz[me], y = all_xyz[n_all + me], z = all_xyz[2 * n_all + me];
+    float best = 3.4e38f;
+    int best_j = -1;
+    if (finite3(x, y, z)) {
+      for (int64_t j = threadIdx.x; j < n_all; j += 256)
+        consider(dist2(all_xyz[j], all_xyz[n_all + j], all_xyz[2 * n_all + j], x, y, z), (int)j, me, best, best_j);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+      const float od = __shfl_xor(best, s);
+      const int oj = __shfl_xor(best_j, s);
+      if (oj >= 0 && (od < best || (od == best && (best_j < 0 || oj < best_j)))) { best = od; best_j = oj; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sd[threadIdx.x >> 6] = best; sj[threadIdx.x >> 6] = best_j; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; w++)
+        if (sj[w] >= 0 && (sd[w] < best || (sd[w] == best && (best_j < 0 || sj[w] < best_j)))) { best = sd[w]; best_j = sj[w]; }
+      dist2_out[local] = best;
+      index_out[local] = best_j;
+    }
+  }
+}
+
+// UWBNetwork::Run, UWBNetwork.cpp:66-71, for a batch of completed transactions: the noise draws do not
+// depend on the positions, so the host made them in stream order (afe_uwb_range); here only
+//   meas.range = float( outlier ? n * outlierStdDev : |p_req - p_res| + n * addNoiseStdDev )
+// with the difference, squares, sums and square root in double like Vec3d::GetNorm2 (Vec3.hpp:113-116).
+__global__ void __launch_bounds__(256) world_uwb_range_kernel(const float *__restrict__ all_xyz, int64_t n_all, const int32_t *__restrict__ req,
+                                                              const int32_t *__restrict__ res, const double *__restrict__ noise_term,
+                                                              const uint8_t *__restrict__ outlier, int64_t n_pairs, float *__restrict__ range) {
+#pragma clang fp contract(off)
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_pairs) return;
+  double r = noise_term[k];
+  if (!outlier[k]) {
+    const int a = req[k], b = res[k];
+    const double dx = (double)all_xyz[a] - (double)all_xyz[b];
+    const double dy = (double)all_xyz[n_all + a] - (double)all_xyz[n_all + b];
+    const double dz = (double)all_xyz[2 * n_all + a] - (double)all_xyz[2 * n_all + b];
+    r = sqrt(dx * dx + dy * dy + dz * dz) + r;
+  }
+  range[k] = (float)r;
+}
+
+}  // namespace
+}  // namespace afe
+
+using namespace afe;
+
+// ---------------------------------------------------------------------------
+// host side
+
+struct afe_world {
+  int device = 0;
+  int64_t cap_points = 0;      // capacity of the per-point scratch
+  int64_t cap_cells = 0;       // capacity of the per-cell scratch (cells + 1 dead bin + 1 end)
+  uint32_t *counts = nullptr;  // per cell, becomes the exclusive scan (starts)
+  uint32_t *block_sums = nullptr;
+  uint32_t *cell = nullptr, *slot = nullptr;
+  uint4 *sorted = nullptr;
+  int32_t *leftover = nullptr;
+  int *lohi = nullptr;         // 6 ints + leftover counter
+  int64_t cap_self = 0;
+  float *self_scratch = nullptr;
+  GridDesc grid = {};
+  uint32_t last_leftover = 0;
+  std::string err;
+};
+
+namespace {
+const int64_t kMaxCells = int64_t(1) << 22;
+
+int wfail(afe_world *w, int status, const std::string &m) {
+  if (w) w->err = m;
+  return status;
+}
+#define W_HIP(w, call)                                                                                 \
+  do {                                                                                                 \
+    hipError_t err__ = (call);                                                                         \
+    if (err__ != hipSuccess) return wfail((w), AFE_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err__)); \
+  } while (0)
+
+void free_points(afe_world *w) {
+  if (w->cell) (void)hipFree(w->cell);
+  if (w->slot) (void)hipFree(w->slot);
+  if (w->sorted) (void)hipFree(w->sorted);
+  if (w->leftover) (void)hipFree(w->leftover);
+  w->cell = w->slot = nullptr; w->sorted = nullptr; w->leftover = nullptr;
+}
+
+// Cell size: the caller's, or one that puts about two vehicles in a cell of the occupied box --
+// flat ensembles (an orchard flight: everybody within a few metres of altitude) get a 2-D grid
+// because an axis thinner than a cell collapses to one layer.
+void choose_grid(const float lo[3], const float hi[3], int64_t n, float cell_size, GridDesc &g) {
+  double ext[3];
+  for (int c = 0; c < 3; c++) ext[c] = std::max(0.0, (double)hi[c] - (double)lo[c]);
+  double h = cell_size;
+  if (!(h > 0)) {
+    bool active[3] = {true, true, true};
+    h = 1.0;
+    for (int iter = 0; iter < 4; iter++) {
+      double vol = 1.0;
+      int dims = 0;
+      for (int c = 0; c < 3; c++) if (active[c]) { vol *= std::max(ext[c], 1e-6); dims++; }
+      if (dims == 0) { h = 1.0; break; }
+      h = std::pow(vol * 2.0 / (double)std::max<int64_t>(n, 1), 1.0 / dims);
+      bool changed = false;
+      for (int c = 0; c < 3; c++) if (active[c] && ext[c] < h) { active[c] = false; changed = true; }
+      if (!changed) break;
+    }
+    if (!(h > 1e-6)) h = 1e-6;
+  }
+  for (;;) {
+    int64_t cells = 1;
+    for (int c = 0; c < 3; c++) {
+      const double k = std::floor(ext[c] / h) + 1.0;
+      g.n[c] = (int)std::min(k, 2097152.0);
+      cells *= g.n[c];
+      if (cells > (int64_t(1) << 40)) break;
+    }
+    if (cells <= kMaxCells) { g.n_cells = cells; break; }
+    h *= 1.26;   // ~ a factor 2 fewer cells per try in 3-D
+  }
+  g.h = (float)h;
+  g.inv_h = (float)(1.0 / h);
+  for (int c = 0; c < 3; c++) g.min[c] = lo[c];
+}
+
+int ensure_capacity(afe_world *w, int64_t n_all, int64_t n_cells_total) {
+  if (n_all > w->cap_points) {
+    free_points(w);
+    const int64_t cap = n_all + n_all / 8 + 1024;
+    W_HIP(w, hipMalloc((void **)&w->cell, (size_t)cap * 4));
+    W_HIP(w, hipMalloc((void **)&w->slot, (size_t)cap * 4));
+    W_HIP(w, hipMalloc((void **)&w->sorted, (size_t)cap * sizeof(uint4)));
+    W_HIP(w, hipMalloc((void **)&w->leftover, (size_t)cap * 4));
+    w->cap_points = cap;
+  }
+  if (n_cells_total > w->cap_cells) {
+    if (w->counts) (void)hipFree(w->counts);
+    if (w->block_sums) (void)hipFree(w->block_sums);
+    w->counts = w->block_sums = nullptr;
+    const int64_t cap = n_cells_total + 4096;
+    W_HIP(w, hipMalloc((void **)&w->counts, (size_t)cap * 4));
+    W_HIP(w, hipMalloc((void **)&w->block_sums, (size_t)((cap + 1023) / 1024 + 1) * 4));
+    w->cap_cells = cap;
+  }
+  if (!w->lohi) W_HIP(w, hipMalloc((void **)&w->lohi, 8 * sizeof(int)));
+  return AFE_OK;
+}
+
+}  // namespace
+
+int afe::world_create(int device, afe_world **out) {
+  if (!out) return AFE_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return AFE_ERR_NO_DEVICE;
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return AFE_ERR_NO_DEVICE;
+  if (device >= n_dev) return AFE_ERR_NO_DEVICE;
+  afe_world *w = new afe_world();
+  w->device = device;
+  *out = w;
+  return AFE_OK;
+}
+
+void afe::world_destroy(afe_world *w) {
+  if (!w) return;
+  (void)hipSetDevice(w->device);
+  free_points(w);
+  if (w->counts) (void)hipFree(w->counts);
+  if (w->block_sums) (void)hipFree(w->block_sums);
+  if (w->lohi) (void)hipFree(w->lohi);
+  if (w->self_scratch) (void)hipFree(w->self_scratch);
+  delete w;
+}
+
+const char *afe::world_last_error(const afe_world *w) { return w ? w->err.c_str() : "null world"; }
+
+int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int64_t n_all, int64_t first_global,
+                                 int64_t n_self, float cell_size, float *dist2_out, int32_t *index_out) {
+  if (!w || !all_xyz || n_all <= 0 || n_self <= 0 || first_global < 0 || first_global + n_self > n_all || !dist2_out || !index_out ||
+      n_all > 0x7fffffff)
+    return wfail(w, AFE_ERR_INVALID_ARG, "bad nearest-neighbour arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  W_HIP(w, hipSetDevice(w->device));
+  int rc = ensure_capacity(w, n_all, 0);
+  if (rc) return rc;
+  // 1. bounds of the finite positions (one small read-back: the grid shape is a host decision)
+  const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
+  W_HIP(w, hipMemcpyAsync(w->lohi, init, sizeof(init), hipMemcpyHostToDevice, st));
+  const unsigned blocks = (unsigned)std::min<int64_t>((n_all + 255) / 256, 2048);
+  hipLaunchKernelGGL(world_bounds_kernel, dim3(blocks), dim3(256), 0, st, all_xyz, n_all, w->lohi);
+  int lohi[6];
+  W_HIP(w, hipMemcpyAsync(lohi, w->lohi, sizeof(lohi), hipMemcpyDeviceToHost, st));
+  W_HIP(w, hipStreamSynchronize(st));
+  float lo[3], hi[3];
+  for (int c = 0; c < 3; c++) { lo[c] = unordered(lohi[c]); hi[c] = unordered(lohi[3 + c]); }
+  if (lohi[0] == 0x7fffffff) { for (int c = 0; c < 3; c++) lo[c] = hi[c] = 0.0f; }   // no finite position at all
+  choose_grid(lo, hi, n_all, cell_size, w->grid);
+  const GridDesc g = w->grid;
+  const int64_t m = g.n_cells + 2;   // cells, the dead bin, and the end sentinel
+  if ((rc = ensure_capacity(w, n_all, m))) return rc;
+  // 2. counting sort by cell
+  W_HIP(w, hipMemsetAsync(w->counts, 0, (size_t)m * 4, st));
+  const unsigned pb = (unsigned)((n_all + 255) / 256);
+  hipLaunchKernelGGL(world_count_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, g, w->counts, w->cell, w->slot);
+  const int64_t nb = (m + 1023) / 1024;
+  hipLaunchKernelGGL(world_scan_local_kernel, dim3((unsigned)nb), dim3(256), 0, st, w->counts, w->counts, w->block_sums, m);
+  hipLaunchKernelGGL(world_scan_blocks_kernel, dim3(1), dim3(256), 0, st, w->block_sums, nb);
+  hipLaunchKernelGGL(world_scan_add_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w->counts, w->block_sums, m);
+  hipLaunchKernelGGL(world_scatter_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, w->counts, w->cell, w->slot, w->sorted);
+  // 3. queries in cell order; isolated vehicles finish in the brute-force kernel
+  uint32_t *left_count = (uint32_t *)(w->lohi + 6);
+  hipLaunchKernelGGL(world_query_kernel, dim3(pb), dim3(256), 0, st, w->sorted, n_all, w->counts, g, first_global, n_self, dist2_out,
+                     index_out, left_count, w->leftover);
+  hipLaunchKernelGGL(world_brute_kernel, dim3(1024), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global, dist2_out,
+                     index_out);
+  W_HIP(w, hipGetLastError());
+  return AFE_OK;
+}
+
+int afe::world_grid_info(const afe_world *w, int dims[3], float *cell_size, int64_t *n_cells) {
+  if (!w) return AFE_ERR_INVALID_ARG;
+  if (dims) for (int c = 0; c < 3; c++) dims[c] = w->grid.n[c];
+  if (cell_size) *cell_size = w->grid.h;
+  if (n_cells) *n_cells = w->grid.n_cells;
+  return AFE_OK;
+}
+
+// brute force over the whole ensemble for `n_queries` listed local vehicles (device array of local indices);
+// the cross-check of the grid at sizes where an O(N^2) CPU loop is out of reach
+int afe::world_nearest_bruteforce(afe_world *w, void *hip_stream, const float *all_xyz, int64_t n_all, int64_t first_global,
+                                            const int32_t *dev_queries, int64_t n_queries, float *dist2_out, int32_t *index_out) {
+  if (!w || !all_xyz || n_all <= 0 || !dev_queries || n_queries <= 0 || !dist2_out || !index_out)
+    return wfail(w, AFE_ERR_INVALID_ARG, "bad brute-force arguments");
+  hipStream_t st = (hipStream_t)hip_stream;
+  W_HIP(w, hipSetDevice(w->device));
+  int rc = ensure_capacity(w, 1, 0);
+  if (rc) return rc;
+  const uint32_t nq = (uint32_t)n_queries;
+  uint32_t *cnt = (uint32_t *)(w->lohi + 7);
+  W_HIP(w, hipMemcpyAsync(cnt, &nq, 4, hipMemcpyHostToDevice, st));
+  W_HIP(w, hipStreamSynchronize(st));   // nq lives on this stack frame
+  hipLaunchKernelGGL(world_brute_kernel, dim3((unsigned)std::min<int64_t>(n_queries, 4096)), dim3(256), 0, st, all_xyz, n_all, dev_queries, cnt,
+                     first_global, dist2_out, index_out);
+  W_HIP(w, hipGetLastError());
+  return AFE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// UWB ranging network (reference Components/Components/Simulation/UWBNetwork.{hpp,cpp})
+
+struct afe_uwb_network {
+  // the reference's file-scope generator and distributions, UWBNetwork.cpp:4-6 -- the same libstdc++
+  // classes, so the stream (engine words, generate_canonical, the polar method's cached second value)
+  // is the reference's by construction
+  std::mt19937 rng;
+  std::uniform_real_distribution<double> dist_uniform{0, 1};
+  std::normal_distribution<double> dist_normal{0, 1};
+  double add_noise_std = 0, outlier_prob = 0, outlier_std = 0;   // UWBNetwork.cpp:15-17
+  // device scratch
+  int device = -1;
+  int64_t cap = 0;
+  int32_t *d_req = nullptr, *d_res = nullptr;
+  double *d_noise = nullptr;
+  uint8_t *d_out = nullptr;
+  float *d_range = nullptr;
+  std::vector<double> noise;
+  std::vector<uint8_t> outlier;
+};
+
+extern "C" int afe_uwb_create(afe_uwb_network **out) {
+  if (!out) return AFE_ERR_INVALID_ARG;
+  afe_uwb_network *u = new afe_uwb_network();
+  u->rng.seed(0);   // UWBNetwork.cpp:19 "to be repeatible"
+  *out = u;
+  return AFE_OK;
+}
+extern "C" void afe_uwb_destroy(afe_uwb_network *u) {
+  if (!u) return;
+  if (u->device >= 0) {
+    (void)hipSetDevice(u->device);
+    if (u->d_req) (void)hipFree(u->d_req);
+    if (u->d_res) (void)hipFree(u->d_res);
+    if (u->d_noise) (void)hipFree(u->d_noise);
+    if (u->d_out) (void)hipFree(u->d_out);
+    if (u->d_range) (void)hipFree(u->d_range);
+  }
+  delete u;
+}
+extern "C" int afe_uwb_set_noise(afe_uwb_network *u, double noise_std_dev, double outlier_probability, double outlier_std_dev) {
+  if (!u) return AFE_ERR_INVALID_ARG;
+  u->add_noise_std = noise_std_dev;       // UWBNetwork.hpp:28-33
+  u->outlier_prob = outlier_probability;
+  u->outlier_std = outlier_std_dev;
+  return AFE_OK;
+}
+
+// the draws of n_pairs consecutive completed transactions, in stream order (UWBNetwork.cpp:66-71)
+extern "C" int afe_uwb_draw(afe_uwb_network *u, int64_t n_pairs, double *noise_term, uint8_t *is_outlier) {
+  if (!u || n_pairs < 0 || !noise_term || !is_outlier) return AFE_ERR_INVALID_ARG;
+  for (int64_t k = 0; k < n_pairs; k++) {
+    if (u->dist_uniform(u->rng) < u->outlier_prob) {
+      is_outlier[k] = 1;
+      noise_term[k] = u->dist_normal(u->rng) * u->outlier_std;
+    } else {
+      is_outlier[k] = 0;
+      noise_term[k] = u->dist_normal(u->rng) * u->add_noise_std;
+    }
+  }
+  return AFE_OK;
+}
+
+extern "C" int afe_uwb_range(afe_uwb_network *u, afe_engine *e, const float *dev_all_xyz, int64_t n_all,
+                             const int32_t *requester, const int32_t *responder, int64_t n_pairs, float *range_out,
+                             uint8_t *outlier_out) {
+  if (!u || !e || !dev_all_xyz || n_all <= 0 || !requester || !responder || n_pairs <= 0 || !range_out) return AFE_ERR_INVALID_ARG;
+  for (int64_t k = 0; k < n_pairs; k++)
+    if (requester[k] < 0 || requester[k] >= n_all || responder[k] < 0 || responder[k] >= n_all) return AFE_ERR_OUT_OF_RANGE;
+  void *stream_v = nullptr;
+  int device = 0;
+  engine_stream_device(e, &stream_v, &device);
+  if (u->device >= 0 && u->device != device) return AFE_ERR_INVALID_ARG;
+  if (hipSetDevice(device) != hipSuccess) return AFE_ERR_NO_DEVICE;
+  u->device = device;
+  if (n_pairs > u->cap) {
+    if (u->d_req) (void)hipFree(u->d_req);
+    if (u->d_res) (void)hipFree(u->d_res);
+    if (u->d_noise) (void)hipFree(u->d_noise);
+    if (u->d_out) (void)hipFree(u->d_out);
+    if (u->d_range) (void)hipFree(u->d_range);
+    u->d_req = u->d_res = nullptr; u->d_noise = nullptr; u->d_out = nullptr; u->d_range = nullptr; u->cap = 0;
+    const size_t cap = (size_t)n_pairs + 1024;
+    if (hipMalloc((void **)&u->d_req, cap * 4) != hipSuccess || hipMalloc((void **)&u->d_res, cap * 4) != hipSuccess ||
+        hipMalloc((void **)&u->d_noise, cap * 8) != hipSuccess || hipMalloc((void **)&u->d_out, cap) != hipSuccess ||
+        hipMalloc((void **)&u->d_range, cap * 4) != hipSuccess)
+      return AFE_ERR_HIP;
+    u->cap = (int64_t)cap;
+  }
+  u->noise.resize((size_t)n_pairs);
+  u->outlier.resize((size_t)n_pairs);
+  afe_uwb_draw(u, n_pairs, u->noise.data(), u->outlier.data());
+  hipStream_t st = (hipStream_t)stream_v;
+  if (hipMemcpyAsync(u->d_req, requester, (size_t)n_pairs * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(u->d_res, responder, (size_t)n_pairs * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(u->d_noise, u->noise.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(u->d_out, u->outlier.data(), (size_t)n_pairs, hipMemcpyHostToDevice, st) != hipSuccess)
+    return AFE_ERR_HIP;
+  hipLaunchKernelGGL(world_uwb_range_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, dev_all_xyz, n_all, u->d_req,
+                     u->d_res, u->d_noise, u->d_out, n_pairs, u->d_range);
+  if (hipMemcpyAsync(range_out, u->d_range, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return AFE_ERR_HIP;
+  if (outlier_out) std::memcpy(outlier_out, u->outlier.data(), (size_t)n_pairs);
+  return AFE_OK;
+}

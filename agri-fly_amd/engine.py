@@ -39,6 +39,11 @@ ABI_FUNCTIONS = [
     "afe_rappids_plan_device", "afe_camera_default", "afe_camera_default_mount", "afe_scene_create",
     "afe_scene_destroy", "afe_scene_info", "afe_render_depth", "afe_render_depth_engine",
     "afe_device_alloc", "afe_device_free", "afe_device_download", "afe_scene_check_hierarchy",
+    "afe_comm_unique_id", "afe_comm_create", "afe_comm_info", "afe_comm_destroy", "afe_comm_last_error",
+    "afe_gather_positions", "afe_group_create", "afe_group_destroy", "afe_group_size", "afe_group_shard",
+    "afe_group_step", "afe_group_sync", "afe_group_gather_positions", "afe_group_last_error",
+    "afe_nearest_neighbour_grid", "afe_neighbour_grid_info", "afe_nearest_neighbour_bruteforce",
+    "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
 ]
 
 
@@ -243,6 +248,25 @@ def library():
         "afe_checkpoint_size": [eng, C.POINTER(u64)],
         "afe_save_checkpoint": [eng, vp, u64],
         "afe_load_checkpoint": [eng, vp, u64],
+        "afe_comm_unique_id": [vp],
+        "afe_comm_create": [C.POINTER(vp), vp, ci, ci, ci],
+        "afe_comm_info": [vp, C.POINTER(ci), C.POINTER(ci)],
+        "afe_comm_destroy": [vp],
+        "afe_gather_positions": [eng, vp, vp, vp],
+        "afe_group_create": [C.POINTER(vp), i64, ci, vp, ci],
+        "afe_group_destroy": [vp],
+        "afe_group_size": [vp, C.POINTER(ci), C.POINTER(i64)],
+        "afe_group_shard": [vp, ci, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)],
+        "afe_group_step": [vp, u64, ci],
+        "afe_group_sync": [vp],
+        "afe_group_gather_positions": [vp, vp],
+        "afe_nearest_neighbour_grid": [eng, vp, i64, C.c_float, vp, vp],
+        "afe_neighbour_grid_info": [eng, vp, C.POINTER(C.c_float), C.POINTER(i64)],
+        "afe_nearest_neighbour_bruteforce": [eng, vp, i64, vp, i64, vp, vp],
+        "afe_uwb_create": [C.POINTER(vp)],
+        "afe_uwb_set_noise": [vp, C.c_double, C.c_double, C.c_double],
+        "afe_uwb_draw": [vp, i64, vp, vp],
+        "afe_uwb_range": [vp, eng, vp, i64, vp, vp, i64, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -250,6 +274,11 @@ def library():
         fn.restype = ci
     L.afe_scene_destroy.argtypes = [vp]
     L.afe_scene_destroy.restype = None
+    L.afe_uwb_destroy.argtypes = [vp]
+    L.afe_uwb_destroy.restype = None
+    for name in ("afe_comm_last_error", "afe_group_last_error"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = C.c_char_p
     L.afe_last_error.argtypes = [eng]
     L.afe_last_error.restype = C.c_char_p
     L.afe_status_string.argtypes = [ci]
@@ -498,8 +527,15 @@ def _planar(a, comps, count, dtype):
 class Ensemble:
     """One engine = one vehicle ensemble (or one rank's shard of it) on one GPU."""
 
-    def __init__(self, n_vehicles, precision=AFE_F32, device=-1, first_global_index=0):
+    def __init__(self, n_vehicles, precision=AFE_F32, device=-1, first_global_index=0, _borrowed=None):
         self._L = library()
+        self._owned = _borrowed is None
+        if _borrowed is not None:   # a shard of a Group: the group owns the engine
+            self._h = _borrowed
+            self.n = int(n_vehicles)
+            self.precision = precision
+            self.first_global_index = int(first_global_index)
+            return
         self._h = C.c_void_p()
         rc = self._L.afe_create(C.byref(self._h), int(n_vehicles), int(precision), int(device),
                                 int(first_global_index))
@@ -519,7 +555,8 @@ class Ensemble:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.afe_destroy(self._h)
+            if self._owned:
+                self._L.afe_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -728,10 +765,177 @@ class Ensemble:
         self._ck(self._L.afe_selftest_normals(self._h, s.ctypes.data, s.size, out.ctypes.data, st.ctypes.data))
         return out, st
 
-    # -- shared-world query -------------------------------------------------
+    # -- shared-world exchange and queries ------------------------------------
     def pack_positions(self, device_ptr):
         self._ck(self._L.afe_pack_positions(self._h, C.c_void_p(int(device_ptr))))
 
-    def nearest_neighbour(self, all_xyz_ptr, n_all, dist2_ptr, index_ptr):
-        self._ck(self._L.afe_nearest_neighbour(self._h, C.c_void_p(int(all_xyz_ptr)), int(n_all),
-                                               C.c_void_p(int(dist2_ptr)), C.c_void_p(int(index_ptr))))
+    def gather_positions(self, comm, out_ptr, counts=None):
+        """pack + RCCL all-gather on the engine's stream into a device buffer of 3*n_all floats"""
+        cnt = None if counts is None else np.ascontiguousarray(counts, dtype=np.int64)
+        rc = self._L.afe_gather_positions(self._h, comm.handle, None if cnt is None else cnt.ctypes.data,
+                                          C.c_void_p(int(out_ptr)))
+        if rc:
+            raise AfeError(rc, (self._L.afe_comm_last_error(comm.handle) or b"").decode() or
+                           self._L.afe_status_string(rc).decode())
+
+    def nearest_neighbour(self, all_xyz_ptr, n_all, dist2_ptr, index_ptr, cell_size=0.0):
+        self._ck(self._L.afe_nearest_neighbour_grid(self._h, C.c_void_p(int(all_xyz_ptr)), int(n_all), float(cell_size),
+                                                    C.c_void_p(int(dist2_ptr)), C.c_void_p(int(index_ptr))))
+
+    def nearest_neighbour_bruteforce(self, all_xyz_ptr, n_all, queries_ptr, n_queries, dist2_ptr, index_ptr):
+        self._ck(self._L.afe_nearest_neighbour_bruteforce(self._h, C.c_void_p(int(all_xyz_ptr)), int(n_all),
+                                                          C.c_void_p(int(queries_ptr)), int(n_queries),
+                                                          C.c_void_p(int(dist2_ptr)), C.c_void_p(int(index_ptr))))
+
+    def neighbour_grid_info(self):
+        dims = (C.c_int * 3)()
+        h, nc = C.c_float(0), C.c_int64(0)
+        self._ck(self._L.afe_neighbour_grid_info(self._h, dims, C.byref(h), C.byref(nc)))
+        return {"dims": tuple(dims), "cell_size": h.value, "n_cells": nc.value}
+
+
+class Comm:
+    """afe_comm: an RCCL communicator for the one-process-per-GPU layout."""
+
+    @staticmethod
+    def unique_id():
+        uid = np.zeros(128, np.uint8)
+        rc = library().afe_comm_unique_id(uid.ctypes.data)
+        if rc:
+            raise AfeError(rc, "afe_comm_unique_id (is RCCL loadable?)")
+        return uid
+
+    def __init__(self, unique_id, rank, n_ranks, device=-1):
+        self._h = C.c_void_p()
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert uid.size == 128
+        rc = library().afe_comm_create(C.byref(self._h), uid.ctypes.data, int(rank), int(n_ranks), int(device))
+        if rc:
+            self._h = None
+            raise AfeError(rc, "afe_comm_create: " + library().afe_status_string(rc).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        r, n = C.c_int(0), C.c_int(0)
+        rc = library().afe_comm_info(self._h, C.byref(r), C.byref(n))
+        if rc:
+            raise AfeError(rc, "afe_comm_info")
+        return r.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            library().afe_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Group:
+    """afe_group: one process, several devices (or logical shards of one device)."""
+
+    def __init__(self, n_vehicles, precision=AFE_F32, devices=(0,)):
+        self._L = library()
+        self._h = C.c_void_p()
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        rc = self._L.afe_group_create(C.byref(self._h), int(n_vehicles), int(precision), dev.ctypes.data, dev.size)
+        if rc:
+            self._h = None
+            raise AfeError(rc, self._L.afe_status_string(rc).decode())
+        self.n = int(n_vehicles)
+        self.shards = []
+        for k in range(dev.size):
+            e, first, count = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+            self._ck(self._L.afe_group_shard(self._h, k, C.byref(e), C.byref(first), C.byref(count)))
+            self.shards.append(Ensemble(count.value, precision, first_global_index=first.value, _borrowed=e))
+
+    def _ck(self, rc):
+        if rc:
+            raise AfeError(rc, (self._L.afe_group_last_error(self._h) or b"").decode() or
+                           self._L.afe_status_string(rc).decode())
+
+    def ranges(self):
+        return [(s.first_global_index, s.n) for s in self.shards]
+
+    def step(self, dt_us, n_steps=1):
+        self._ck(self._L.afe_group_step(self._h, int(dt_us), int(n_steps)))
+
+    def sync(self):
+        self._ck(self._L.afe_group_sync(self._h))
+
+    def gather_positions(self):
+        """device pointers (one per shard) of the planar fp32 [3][n] gathered positions"""
+        ptrs = (C.c_void_p * len(self.shards))()
+        self._ck(self._L.afe_group_gather_positions(self._h, ptrs))
+        return [int(p) for p in ptrs]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for s in self.shards:
+                s.close()
+            self._L.afe_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class UwbNetwork:
+    """afe_uwb_network == Simulation::UWBNetwork (UWBNetwork.cpp:8-89), batched."""
+
+    def __init__(self, noise_std=0.0, outlier_prob=0.0, outlier_std=0.0):
+        self._h = C.c_void_p()
+        rc = library().afe_uwb_create(C.byref(self._h))
+        if rc:
+            raise AfeError(rc, "afe_uwb_create")
+        library().afe_uwb_set_noise(self._h, float(noise_std), float(outlier_prob), float(outlier_std))
+
+    def set_noise(self, noise_std, outlier_prob, outlier_std):
+        library().afe_uwb_set_noise(self._h, float(noise_std), float(outlier_prob), float(outlier_std))
+
+    def draw(self, n_pairs):
+        """the stream alone: (noise_term float64[n], is_outlier uint8[n]); host only"""
+        noise = np.empty(n_pairs, np.float64)
+        out = np.empty(n_pairs, np.uint8)
+        rc = library().afe_uwb_draw(self._h, int(n_pairs), noise.ctypes.data, out.ctypes.data)
+        if rc:
+            raise AfeError(rc, "afe_uwb_draw")
+        return noise, out
+
+    def range(self, ensemble, all_xyz_ptr, n_all, requester, responder):
+        req = np.ascontiguousarray(requester, dtype=np.int32)
+        res = np.ascontiguousarray(responder, dtype=np.int32)
+        assert req.shape == res.shape and req.ndim == 1
+        rng = np.empty(req.size, np.float32)
+        out = np.empty(req.size, np.uint8)
+        rc = library().afe_uwb_range(self._h, ensemble.handle, C.c_void_p(int(all_xyz_ptr)), int(n_all), req.ctypes.data,
+                                     res.ctypes.data, req.size, rng.ctypes.data, out.ctypes.data)
+        if rc:
+            raise AfeError(rc, library().afe_status_string(rc).decode())
+        return rng, out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            library().afe_uwb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

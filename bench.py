@@ -10,9 +10,15 @@ config-4 shape of BASELINE.json -- a hovering MINIQUAD ensemble with a
 per-vehicle wind-gust force through the SetExternalForce port, IMU synthesis
 with on-device libstdc++-compatible noise at the 500 Hz onboard-logic cadence --
 1,048,576 vehicles PER GPU (weak scaling; inputs resident in HBM before the
-timed region).  For N > 1 the driver launches one rank per GPU under
-torch.distributed.run; ranks own contiguous shards and step them with no
-collective (the path has none); only the timing uses a barrier and a MAX.
+timed region).  For N > 1 there is one rank process per GPU: either the caller
+starts them (python -m torch.distributed.run ... bench.py --gpus N: RANK /
+WORLD_SIZE are in the environment) or `python bench.py --gpus N` starts them
+itself (child processes, before this process has touched a GPU) and relays
+rank 0's line.  Ranks own contiguous shards and step them with no collective
+(the path has none); only the timing uses a barrier and a MAX.  The one exchange
+the path has -- the shared-world query: RCCL all-gather of positions + the
+neighbour / UWB-ranging consumers, at 100 Hz of simulated time -- is timed
+separately in `shared_world`.
 
 Prints ONE JSON line on rank 0 (see the repo task contract), including
   roofline     -- algorithmic HBM bytes / measured kernel time vs 8 TB/s
@@ -37,10 +43,11 @@ DT_US = 1000
 LOGIC_PERIOD = 1.0 / 500.0
 
 
-def build_shard(afa, n_local, first_global, n_global, device, fext=True):
+def build_shard(afa, n_local, first_global, n_global, device, fext=True, precision=None):
     p = afa.params_from_type(5)  # QC_TYPE_CF_MINIQUAD: vehicle id 1 of every shipped main
     data = afa.scenarios.gust_ensemble(n_local, p, seed=4, first_global=first_global, n_global=n_global)
-    e = afa.Ensemble(n_local, precision=afa.AFE_F32, device=device, first_global_index=first_global)
+    e = afa.Ensemble(n_local, precision=afa.AFE_F32 if precision is None else precision, device=device,
+                     first_global_index=first_global)
     e.set_type_table([p])
     e.set_logic_period(LOGIC_PERIOD)
     e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
@@ -101,6 +108,47 @@ def per_kernel_breakdown(afa, n_local, device):
         res[name] = {"kernel_us": t * 1e6, "bytes_per_vehicle_step": b, "achieved_GBs": n_local * b / t / 1e9}
         e.close()
     return res
+
+
+def companion_rows(afa, n_local, device, sync, barrier):
+    """Two companions of the headline on the same workload and ensemble size:
+    fused_logic_period -- one launch per onboard-logic period (2 steps of 1 ms at 500 Hz): nothing is
+      observable between two logic ticks (commands and wrench are held, the IMU is sampled at the tick),
+      so this is what afe_step(dt, 2) does for a host that drives its logic at the tick cadence;
+    f64 -- the same kernel in the reference's own precision (AFE_F64), one launch per step."""
+    rows = {}
+    e = build_shard(afa, n_local, 0, n_local, device)
+    k = 1000
+    time_steps(e, 100, 2, sync, barrier)
+    t = time_steps(e, k, 2, sync, barrier)
+    ev0, ev1 = e.event(), e.event()
+    e.sync()
+    e.record(ev0)
+    for _ in range(300):
+        e.step(DT_US, 2)
+    e.record(ev1)
+    t_launch = e.elapsed_ms(ev0, ev1) * 1e-3 / 300
+    b = e.algorithmic_bytes_per_step(True)      # one pass over the state with one tick in it
+    rows["fused_logic_period"] = {"value": n_local * k / t, "unit": "vehicle-steps/s", "steps_per_launch": 2,
+                                  "kernel_us": t_launch * 1e6, "algorithmic_bytes_per_launch_per_vehicle": b,
+                                  "achieved_GBs": n_local * b / t_launch / 1e9, "frac": n_local * b / t_launch / 1e9 / HBM_PEAK_GBS,
+                                  "note": "bitwise the same trajectory as the headline (tests/test_gpu_parity.py::"
+                                          "test_fused_steps_equal_single_steps_bitwise); VALU-bound on the six libstdc++-exact "
+                                          "Gaussian draws, not on HBM"}
+    e.destroy_event(ev0)
+    e.destroy_event(ev1)
+    e.close()
+    e = build_shard(afa, n_local, 0, n_local, device, precision=afa.AFE_F64)
+    time_steps(e, 50, 1, sync, barrier)
+    k = 400
+    t = time_steps(e, k, 1, sync, barrier)
+    t_kernel = kernel_time_events(e, 200)
+    bytes_step, _ = mean_bytes_per_step(e, afa, k)
+    rows["f64"] = {"value": n_local * k / t, "unit": "vehicle-steps/s", "dtype": "f64", "kernel_us": t_kernel * 1e6,
+                   "algorithmic_bytes_per_vehicle_step": bytes_step, "achieved_GBs": n_local * bytes_step / t_kernel / 1e9,
+                   "frac": n_local * bytes_step / t_kernel / 1e9 / HBM_PEAK_GBS}
+    e.close()
+    return rows
 
 
 def committed_traffic(n_local):
@@ -227,6 +275,95 @@ def cpu_baseline(afa, budget_vehicle_steps=100_000_000):
     return out
 
 
+def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, barrier):
+    """The path's only exchange, at its cadence: every 10 ms of simulated time (100 Hz) the shards
+    all-gather their positions (afe_gather_positions: pack + ncclAllGather on the engine's stream)
+    and run the consumers on the gathered buffer (uniform-grid nearest neighbour for every local
+    vehicle; 1024 UWB ranging transactions).  Reports the HIP-event time of one query and the
+    whole-job rate with a query every 10 steps."""
+    n_all = n_local * world
+    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        uid.copy_(torch.from_numpy(afa.Comm.unique_id()))
+    if dist is not None:
+        dist.broadcast(uid, 0)
+    comm = afa.Comm(uid.cpu().numpy(), rank, world, device=local_rank)
+    xyz = torch.empty((3, n_all), dtype=torch.float32, device="cuda")
+    d2 = torch.empty(n_local, dtype=torch.float32, device="cuda")
+    idx = torch.empty(n_local, dtype=torch.int32, device="cuda")
+    net = afa.UwbNetwork(0.05, 0.01, 3.0)
+    rng = np.random.default_rng(7)
+    req = rng.integers(0, n_all, 1024).astype(np.int32)
+    res = rng.integers(0, n_all, 1024).astype(np.int32)
+    torch.cuda.synchronize()
+
+    def query(with_uwb=True):
+        e.gather_positions(comm, xyz.data_ptr())
+        e.nearest_neighbour(xyz.data_ptr(), n_all, d2.data_ptr(), idx.data_ptr())
+        if with_uwb:
+            net.range(e, xyz.data_ptr(), n_all, req, res)
+
+    for _ in range(3):
+        query()
+    sync()
+    barrier()
+    parts = {}
+    for name, fn in (("allgather_ms", lambda: e.gather_positions(comm, xyz.data_ptr())),
+                     ("nearest_neighbour_ms", lambda: e.nearest_neighbour(xyz.data_ptr(), n_all, d2.data_ptr(), idx.data_ptr())),
+                     ("uwb_1024_ranges_ms", lambda: net.range(e, xyz.data_ptr(), n_all, req, res))):
+        ev0, ev1 = e.event(), e.event()
+        barrier()
+        e.record(ev0)
+        for _ in range(10):
+            fn()
+        e.record(ev1)
+        parts[name] = e.elapsed_ms(ev0, ev1) / 10
+        e.destroy_event(ev0)
+        e.destroy_event(ev1)
+    # physics with a query every 10 steps (100 Hz at dt = 1 ms) vs physics alone
+    def run(k_steps, every):
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        for s in range(k_steps):
+            e.step(DT_US, 1)
+            if every and (s + 1) % every == 0:
+                query(with_uwb=False)     # the UWB read-back would serialise the host; timed above on its own
+        sync()
+        barrier()
+        return time.perf_counter() - t0
+    run(50, 10)
+    k = 400
+    t_with, t_without = run(k, 10), run(k, 0)
+    if dist is not None:
+        t = torch.tensor([t_with, t_without], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_with, t_without = float(t[0]), float(t[1])
+    info = e.neighbour_grid_info()
+    out = dict(parts)
+    out.update({
+        "rccl_ranks": comm.info()[1],
+        "vehicles_gathered": n_all,
+        "allgather_bytes_per_rank": 12 * n_local,
+        "query_cadence": "every 10 steps of 1 ms (100 Hz simulated time)",
+        "query_ms": parts["allgather_ms"] + parts["nearest_neighbour_ms"],
+        "vsteps_per_s_with_queries": n_all * k / t_with,
+        "vsteps_per_s_physics_only": n_all * k / t_without,
+        "neighbour_grid": {"dims": list(info["dims"]), "cell_size_m": info["cell_size"]},
+        "min_separation_m": float(torch.sqrt(d2.min()).item()),
+    })
+    net.close()
+    comm.close()
+    return out
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes here (agri-fly_amd/launch.py).
+    This process never imports torch and never touches a GPU; it relays rank 0's JSON line and the exit codes."""
+    launch = importlib.import_module("agri-fly_amd.launch")
+    print(launch.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,14 +372,20 @@ def main():
     ap.add_argument("--vehicles", type=int, default=1 << 20, help="vehicles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-shared-world", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)     # before torch / the engine are imported: this process stays off the GPUs
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -364,6 +507,7 @@ def main():
                 closed.append({"vehicles": n, "vsteps_per_s": n * k / t1, "vsteps_per_s_fused10": n * k / t10})
                 es.close()
             out["closed_loop_on_device"] = closed
+            out["companions"] = companion_rows(afa, n_local, local_rank, sync, barrier)
             out["perception_rows"] = perception_rows(afa)
             out["sweep"] = sweep
             out["sweep_note"] = ("vsteps_per_s = one launch per step issued from Python; native_loop = the same "
@@ -371,6 +515,10 @@ def main():
                                  "ticks); fused50 = 50 steps per launch, state in registers (open-loop commands)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(afa)
+    if not args.no_shared_world:
+        sw = shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, barrier)   # collective: every rank
+        if rank == 0:
+            out["shared_world"] = sw
     e.close()
     if dist is not None:
         dist.barrier()

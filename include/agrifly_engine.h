@@ -411,9 +411,12 @@ int afe_get_imu(afe_engine *e, int64_t first, int64_t count, float *gyro3, float
  * accessor).  Here the SoA slabs ARE the checkpoint: state,
  * motor speeds and commands, wrench, last IMU sample, RNG words, on-device logic
  * state and the engine clock.  afe_checkpoint_size gives the byte count for the
- * current configuration; a checkpoint can only be loaded into an engine created
- * with the same n_vehicles / precision and configured the same way (type table,
- * logic on/off). */
+ * current configuration.  A checkpoint loads into any engine (the one that saved
+ * it or a freshly created one) with the same n_vehicles / precision that has been
+ * given the same type table and on-device logic table: both are fingerprinted in
+ * the header and a mismatch is refused (AFE_ERR_INVALID_ARG).  The per-vehicle
+ * type indices, noise switch, sigmas, seed policy, logic period, wrench flags and
+ * the clock are restored from the checkpoint. */
 int afe_checkpoint_size(const afe_engine *e, uint64_t *bytes);
 int afe_save_checkpoint(afe_engine *e, void *host_buffer, uint64_t bytes);
 int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint64_t bytes);
@@ -467,20 +470,100 @@ int afe_event_destroy(void *event);
 int afe_event_record(afe_engine *e, void *event);
 int afe_event_elapsed_ms(void *start, void *stop, float *ms);
 
-/* ---- multi-GPU shared-world query ---------------------------------------
- * The only inter-vehicle exchange of the path (the reference's analogue is
- * UWBNetwork::Run reading other vehicles' positions, Components/Components/
- * Simulation/UWBNetwork.cpp:54-84).  One process per GPU; the all-gather
- * itself is done by the host's communicator (RCCL through torch.distributed
- * in bench.py / the Python host).  afe_pack_positions
- * writes this shard's positions as fp32 planar xyz into a caller-provided
- * DEVICE buffer of 3*n_vehicles floats, on the engine's stream. */
+/* ---- multi-GPU shared-world exchange ------------------------------------
+ * The step reads no other vehicle (Quadcopter_T.cpp:85-203), so shards step with
+ * no data-path collective.  The only inter-vehicle exchange of the path is the
+ * shared-world query -- the reference's analogue is UWBNetwork::Run reading other
+ * vehicles' true positions (Components/Components/Simulation/UWBNetwork.cpp:
+ * 54-84) -- and its payload is the positions, 12 B per vehicle, gathered onto
+ * every GPU at query cadence (<= 100 Hz), never per step.
+ *
+ * afe_pack_positions writes this shard's positions as fp32 planar xyz into a
+ * caller-provided DEVICE buffer of 3*n_vehicles floats, on the engine's stream
+ * (for hosts that bring their own collective, e.g. torch.distributed). */
 int afe_pack_positions(afe_engine *e, float *device_xyz);
-/* Shared-world consumer: for each local vehicle the squared distance to, and
- * global index of, its nearest neighbour among all_xyz (device, fp32 planar,
- * n_all vehicles, the gathered ensemble).  Outputs are device buffers. */
+
+/* One process per GPU: afe_comm wraps an RCCL communicator (RCCL is loaded at
+ * run time; AFE_ERR_COMM when it is absent).  Rank 0 makes the id, the host
+ * hands it to the other ranks by whatever means it has (MPI, a file, a socket,
+ * torch.distributed), every rank calls afe_comm_create -- collectively, like
+ * ncclCommInitRank. */
+typedef struct afe_comm afe_comm;
+#define AFE_COMM_ID_BYTES 128
+int afe_comm_unique_id(uint8_t id[AFE_COMM_ID_BYTES]);
+int afe_comm_create(afe_comm **out, const uint8_t id[AFE_COMM_ID_BYTES], int rank, int n_ranks, int device);
+int afe_comm_info(const afe_comm *c, int *rank, int *n_ranks); /* as the communicator reports them */
+int afe_comm_destroy(afe_comm *c);
+const char *afe_comm_last_error(const afe_comm *c);
+/* The all-gather: pack + ncclAllGather (per component, one group) on the engine's
+ * stream.  counts[r] = vehicles of rank r, or NULL when every rank holds as many
+ * as this one.  dev_xyz_all: DEVICE buffer of 3*n_all floats, planar [3][n_all],
+ * vehicles in global order (rank 0's block first).  Asynchronous like afe_step. */
+int afe_gather_positions(afe_engine *e, afe_comm *c, const int64_t *counts, float *dev_xyz_all);
+
+/* One process, several GPUs -- the reference's own process model, one loop over a
+ * std::vector of vehicles (AIFS_ROS/hiperlab_rostools/src/Simulator/main.cpp:
+ * 58-95,323-325): the ensemble is cut into contiguous shards, shard i lives on
+ * devices[i] (a device may be listed more than once: logical shards), each with
+ * its own engine, stream and RNG words; first_global_index is set so that seeds
+ * and neighbour indices are those of the unsharded ensemble.  Results are bit-
+ * identical to one engine holding all vehicles. */
+typedef struct afe_group afe_group;
+int afe_group_create(afe_group **out, int64_t n_vehicles, int precision, const int *devices, int n_devices);
+int afe_group_destroy(afe_group *g);
+int afe_group_size(const afe_group *g, int *n_shards, int64_t *n_vehicles);
+/* shard -> its engine (configure / fill / read it with the afe_* calls above) and global range */
+int afe_group_shard(afe_group *g, int shard, afe_engine **engine, int64_t *first, int64_t *count);
+int afe_group_step(afe_group *g, uint64_t dt_us, int n_steps); /* afe_step on every shard; launches overlap */
+int afe_group_sync(afe_group *g);
+/* every shard's positions onto every shard's device by direct peer copies (xGMI):
+ * dev_xyz_all_out[i] (optional) = shard i's planar [3][n_vehicles] buffer, owned by the group */
+int afe_group_gather_positions(afe_group *g, float **dev_xyz_all_out);
+const char *afe_group_last_error(const afe_group *g);
+
+/* ---- shared-world consumers of the gathered buffer -----------------------
+ * Nearest neighbour (collision / separation monitoring): for each local vehicle
+ * the squared distance (fp32: ((dx*dx + dy*dy) + dz*dz), each operation rounded)
+ * to, and global index of, its nearest other vehicle among all_xyz (device, fp32
+ * planar, n_all vehicles); the lowest index wins among equally near ones; -1 /
+ * 3.4e38 when there is none or the vehicle's own position is not finite.
+ * Outputs are DEVICE buffers of n_vehicles entries.  Implementation: uniform
+ * grid (counting sort by cell on the device, 3x3x3 search, further rings until
+ * no unvisited cell can be closer, isolated vehicles by brute force) -- exact.
+ * cell_size <= 0 (and afe_nearest_neighbour): chosen from the occupied box,
+ * about two vehicles per cell. */
 int afe_nearest_neighbour(afe_engine *e, const float *all_xyz, int64_t n_all,
                           float *dist2_out, int32_t *index_out);
+int afe_nearest_neighbour_grid(afe_engine *e, const float *all_xyz, int64_t n_all, float cell_size,
+                               float *dist2_out, int32_t *index_out);
+int afe_neighbour_grid_info(const afe_engine *e, int dims[3], float *cell_size, int64_t *n_cells);
+/* The O(n_queries * n_all) definition itself, for listed local vehicles (DEVICE
+ * array of local indices): the cross-check of the grid at full ensemble size.
+ * dist2_out / index_out are indexed by local vehicle like above. */
+int afe_nearest_neighbour_bruteforce(afe_engine *e, const float *all_xyz, int64_t n_all, const int32_t *dev_queries,
+                                     int64_t n_queries, float *dist2_out, int32_t *index_out);
+
+/* UWB ranging network: Simulation::UWBNetwork (Components/Components/Simulation/
+ * UWBNetwork.hpp:16-50, UWBNetwork.cpp:8-89).  afe_uwb_create = the constructor's
+ * rng.seed(0) (:19); afe_uwb_set_noise = SetNoiseProperties (UWBNetwork.hpp:28-33).
+ * afe_uwb_range completes n_pairs ranging transactions in order, each exactly as
+ * Run() does (:66-71): one uniform draw decides outlier or not, one normal draw
+ * gives the noise, range = float(|p_requester - p_responder| + noise) or
+ * float(normal * outlierStdDev) -- same generator and distribution classes
+ * (std::mt19937, uniform_real_distribution, normal_distribution incl. its cached
+ * second value), one stream for the network's lifetime.  The true positions come
+ * from the gathered buffer (requester / responder are GLOBAL vehicle indices, host
+ * arrays); the norm is evaluated in double like Vec3d::GetNorm2.  range_out
+ * (host, n_pairs floats) is what every radio "hears" (:77-80); outlier_out is
+ * optional.  afe_uwb_draw exposes the stream alone (host only, no GPU). */
+typedef struct afe_uwb_network afe_uwb_network;
+int afe_uwb_create(afe_uwb_network **out);
+void afe_uwb_destroy(afe_uwb_network *u);
+int afe_uwb_set_noise(afe_uwb_network *u, double noise_std_dev, double outlier_probability, double outlier_std_dev);
+int afe_uwb_draw(afe_uwb_network *u, int64_t n_pairs, double *noise_term, uint8_t *is_outlier);
+int afe_uwb_range(afe_uwb_network *u, afe_engine *e, const float *dev_all_xyz, int64_t n_all,
+                  const int32_t *requester, const int32_t *responder, int64_t n_pairs, float *range_out,
+                  uint8_t *outlier_out);
 
 #ifdef __cplusplus
 }

@@ -57,9 +57,10 @@ class OraClock(C.Structure):
 
 def build(force=False):
     """Compile the checker (and the _ref probes when /root/reference exists)."""
-    if force or not os.path.exists(_LIB_PATH) or (
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "agrifly_oracle.c"))):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libagrifly_oracle.so"])
+    if force and os.path.exists(_LIB_PATH):
+        os.remove(_LIB_PATH)
+    # make decides staleness (every .c / .h of the checker is a prerequisite of the library)
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libagrifly_oracle.so"])
     subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
 
 
@@ -69,8 +70,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        build()   # a no-op when up to date; an edited planner / render / logic .c never leaves a stale checker
         L = C.CDLL(_LIB_PATH)
         dp = C.POINTER(C.c_double)
         fp = C.POINTER(C.c_float)
@@ -431,3 +431,74 @@ def render_pixel_depth(cam, triangles, pos, att, mount, px, py):
     t = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 9)
     return render_lib().ora_render_pixel_depth(C.byref(cam), t.ctypes.data, t.shape[0], _dp(np.ascontiguousarray(pos, dtype=float)),
                                                _dp(np.ascontiguousarray(att, dtype=float)), _dp(np.ascontiguousarray(mount, dtype=float)), px, py)
+
+
+# ---- shared-world consumers (agrifly_oracle_world.h) ---------------------------
+
+class OraUwb(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int), ("saved_available", C.c_int), ("saved", C.c_double),
+                ("noise_std", C.c_double), ("outlier_prob", C.c_double), ("outlier_std", C.c_double)]
+
+
+_world_bound = False
+
+
+def world_lib():
+    global _world_bound
+    L = lib()
+    if not _world_bound:
+        dp = C.POINTER(C.c_double)
+        L.ora_nearest_neighbour.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        L.ora_nearest_neighbour.restype = None
+        L.ora_uwb_init.argtypes = [C.POINTER(OraUwb), C.c_double, C.c_double, C.c_double]
+        L.ora_uwb_init.restype = None
+        L.ora_uwb_range.argtypes = [C.POINTER(OraUwb), dp, dp, C.POINTER(C.c_int)]
+        L.ora_uwb_range.restype = C.c_float
+        L.ora_uwb_draw.argtypes = [C.POINTER(OraUwb), C.POINTER(C.c_int)]
+        L.ora_uwb_draw.restype = C.c_double
+        L.ora_uwb_mt_next.argtypes = [C.POINTER(OraUwb)]
+        L.ora_uwb_mt_next.restype = C.c_uint32
+        L.ora_uwb_canonical.argtypes = [C.POINTER(OraUwb)]
+        L.ora_uwb_canonical.restype = C.c_double
+        L.ora_uwb_normal.argtypes = [C.POINTER(OraUwb)]
+        L.ora_uwb_normal.restype = C.c_double
+        _world_bound = True
+    return L
+
+
+def nearest_neighbour(all_xyz, first=0, count=None):
+    """O(n^2) definition: (dist2 float32[count], index int32[count])"""
+    a = np.ascontiguousarray(all_xyz, dtype=np.float32)
+    n_all = a.shape[1]
+    count = n_all - first if count is None else count
+    d = np.empty(count, np.float32)
+    i = np.empty(count, np.int32)
+    world_lib().ora_nearest_neighbour(a.ctypes.data, n_all, first, count, d.ctypes.data, i.ctypes.data)
+    return d, i
+
+
+class UwbNetwork:
+    """Simulation::UWBNetwork's completion branch, UWBNetwork.cpp:66-71."""
+
+    def __init__(self, noise_std=0.0, outlier_prob=0.0, outlier_std=0.0):
+        self.u = OraUwb()
+        world_lib().ora_uwb_init(C.byref(self.u), noise_std, outlier_prob, outlier_std)
+
+    def range(self, p_req, p_res):
+        out = C.c_int(0)
+        r = world_lib().ora_uwb_range(C.byref(self.u), _dp(np.ascontiguousarray(p_req, dtype=float)),
+                                      _dp(np.ascontiguousarray(p_res, dtype=float)), C.byref(out))
+        return np.float32(r), out.value
+
+    def draw(self):
+        out = C.c_int(0)
+        return world_lib().ora_uwb_draw(C.byref(self.u), C.byref(out)), out.value
+
+    def raw(self):
+        return world_lib().ora_uwb_mt_next(C.byref(self.u))
+
+    def canonical(self):
+        return world_lib().ora_uwb_canonical(C.byref(self.u))
+
+    def normal(self):
+        return world_lib().ora_uwb_normal(C.byref(self.u))

@@ -19,6 +19,9 @@ Run in the build container (needs /root/reference for the timer probe):
   TelemetryPacket.hpp (stand-alone header): packets -> 30-byte wire form -> back.
 * planner_math_kat.json <- oracle/_ref/traj_probe: the REFERENCE's own RootFinder.hpp
   and SingleAxisTrajectory.{hpp,cpp} (stand-alone sources) + libstdc++ mt19937.
+* uwb_kat.json        <- oracle/_ref/uwb_probe: libstdc++'s std::mt19937 +
+  uniform_real_distribution + normal_distribution in the statement sequence of
+  the reference's UWBNetwork::Run completion branch (UWBNetwork.cpp:4-6,19,66-71).
 * oracle_regression.npz <- the oracle itself (NOT the reference): seeded
   single-step / rollout vectors that freeze the restatement so later edits of
   oracle/agrifly_oracle.c cannot drift silently.  It pins nothing against the
@@ -96,6 +99,13 @@ def main():
                        "place; libstdc++ mt19937 + uniform_real_distribution in the planner's call shape)")
     with open(os.path.join(HERE, "planner_math_kat.json"), "w") as f:
         json.dump(pm, f, indent=0)
+
+    uwb = []
+    for args in (["200", "0.05", "0.1", "3.0"], ["200", "0.0", "0.0", "0.0"], ["101", "0.25", "0.5", "10.0"]):
+        uwb.append(json.loads(subprocess.check_output([os.path.join(ref, "uwb_probe")] + args)))
+    with open(os.path.join(HERE, "uwb_kat.json"), "w") as f:
+        json.dump({"generator": "oracle/_ref/uwb_probe (libstdc++ <random>, g++; call-site shape of UWBNetwork.cpp:66-71; "
+                                "true range of transaction k = 1 + k/8 m)", "cases": uwb}, f, indent=0)
 
     # --- oracle regression vectors (oracle-generated; not a reference pin) ---
     from tests.scenarios import random_ensemble

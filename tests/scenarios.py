@@ -58,7 +58,43 @@ def random_ensemble(n, seed, **kw):
 
 
 def rel_err(a, b, floor):
-    """max |a-b| / max(|b|, floor) -- the tolerance definition used throughout"""
+    """max |a-b| / max(|b|, floor), component by component"""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def rel_err_vec(a, b, floor):
+    """The parity definition for vector-valued state fields (planar [comps, n]): per vehicle
+    ||a_i - b_i||_2 / max(||b_i||_2, floor), worst vehicle.  A non-finite reference row must be
+    matched by a non-finite engine row (a diverged vehicle diverges in both) and is then skipped."""
+    a = np.atleast_2d(np.asarray(a, np.float64))
+    b = np.atleast_2d(np.asarray(b, np.float64))
+    ok = np.isfinite(b).all(axis=0)
+    assert not np.isfinite(a[:, ~ok]).all(axis=0).any(), "engine finite where the reference is not"
+    if not ok.any():
+        return 0.0
+    num = np.linalg.norm(a[:, ok] - b[:, ok], axis=0)
+    den = np.maximum(np.linalg.norm(b[:, ok], axis=0), floor)
+    return float(np.max(num / den))
+
+
+# ---- measured-parity ledger (dumped by tests/conftest.py at session end) ----
+# floors: the absolute scale below which a field's error is judged absolutely instead of
+# relatively -- 1e-2 of the field's natural unit (1 m, 1 m/s, 1 rad/s; 1e-3 of the ~1e3 rad/s rotor
+# speeds); unit quaternions need none.  Tolerance 1e-5 (BASELINE.json) on top.
+FLOORS = dict(pos=1e-2, vel=1e-2, att=1.0, ang_vel=1e-2, motor_speed=1.0, gyro=1e-2, acc=1e-1)
+PROBE_FLOORS = (1.0, 1e-1, 1e-2, 1e-3)
+LEDGER = {}
+
+
+def record_parity(test, precision, field, a, b):
+    """measured worst relative error of one field in one test, at the asserted floor and at the probe
+    floors (so the ledger shows how much headroom a tighter or looser definition would have)"""
+    key = "%s[%s]" % (test, "f64" if precision == afa.AFE_F64 else "f32")
+    rec = LEDGER.setdefault(key, {})
+    fl = FLOORS[field]
+    rec[field] = {"rel_err": rel_err_vec(a, b, fl), "floor": fl,
+                  "at_floor": {repr(f): rel_err_vec(a, b, f) for f in PROBE_FLOORS},
+                  "max_abs_err": float(np.nanmax(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))}
+    return rec[field]["rel_err"]

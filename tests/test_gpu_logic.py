@@ -52,8 +52,9 @@ def test_closed_loop_matches_oracle(precision, tol):
         cmds = e.get_motor_cmds()
         rng = e.get_rng_state()
     np.testing.assert_array_equal(rng, b.rng)
+    from tests.scenarios import record_parity
     for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, motor_speed=b.motor_speed).items():
-        err = rel_err(st[k], ref, 1.0)
+        err = record_parity("closed loop with the on-device rates logic, 60 steps", precision, k, st[k], ref)
         assert err <= tol, (k, err)
     # motor commands are float in the reference; 1e-5 of ~3e3 rad/s
     assert rel_err(cmds, b.motor_cmd, 1.0) <= max(tol, 1e-6)

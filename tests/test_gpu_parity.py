@@ -1,31 +1,42 @@
 """Parity of the HIP engine (through the C ABI) against the CPU oracle on the
 same seeded inputs.  Needs an MI355X: run with -m gpu.
 
-Tolerance definition (BASELINE.json: <= 1e-5 relative state error):
-  rel = max |engine - oracle| / max(|oracle|, floor), floor = 1e-3 of the
-  field's natural scale (1 m, 1 m/s, 1 for quaternions, 1 rad/s, 1 rad/s for
-  rotor speeds ~1e3) -- teacher-forced single steps and <= 100-step open-loop
-  rollouts.  The fp64 instantiation runs the same code in the reference's own
-  precision and must agree to 1e-12.
+Tolerance definition (BASELINE.json: <= 1e-5 relative state error), tests/scenarios.py:
+  per vehicle and per field  ||engine - oracle||_2 / max(||oracle||_2, floor), worst vehicle,
+  with floor = 1e-2 of the field's natural unit (0.01 m, 0.01 m/s, 0.01 rad/s; 1 rad/s for
+  rotor speeds ~1e3; none for the unit quaternion) -- teacher-forced single steps and
+  <= 100-step open-loop rollouts.  The fp64 instantiation runs the same code in the
+  reference's own precision and must agree to 1e-12 (single step) / 1e-11 (rollouts).
+Every comparison also lands in the parity ledger (measured worst error per test and field, at
+the asserted floor and at looser / tighter ones), committed as profiles/parity_r02.json.
 """
 import os
 
 import numpy as np
 import pytest
 
-from tests.scenarios import afa, random_ensemble, rel_err
+from tests.scenarios import FLOORS, afa, random_ensemble, record_parity, rel_err
 
 pytestmark = pytest.mark.gpu
 
 F32_TOL = 1e-5
-FLOORS = dict(pos=1.0, vel=1.0, att=1.0, ang_vel=1.0, motor_speed=1.0)
 
 
-def _cmp_state(st, b, tol, what=""):
+def _cmp_state(st, b, tol, what="", imu=None):
+    """state (and optionally the IMU sample) against the oracle batch, per-field floors; ledgered"""
+    precision = afa.AFE_F64 if tol < 1e-8 else afa.AFE_F32
     pairs = dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, motor_speed=b.motor_speed)
+    if imu is not None:
+        st = dict(st, gyro=imu[0], acc=imu[1])
+        pairs.update(gyro=b.gyro, acc=b.acc)
+    worst = {}
     for k, ref in pairs.items():
-        e = rel_err(st[k], ref, FLOORS[k])
-        assert e <= tol, "%s %s: rel err %.3g > %.1g" % (what, k, e, tol)
+        worst[k] = record_parity(what, precision, k, st[k], ref)
+    for k, e in worst.items():
+        # the IMU sample is float arithmetic on float-narrowed inputs in every build (Quadcopter_T.cpp:165-180):
+        # a 1e-16 difference upstream can flip one float rounding, so its bound is never below a float ulp
+        t = max(tol, 1e-6) if k in ("gyro", "acc") else tol
+        assert e <= t, "%s %s: rel err %.3g > %.1g (floor %g)" % (what, k, e, t, FLOORS[k])
 
 
 def _ticks(afa_mod, period, dt_us, n):
@@ -46,11 +57,8 @@ def test_single_step_teacher_forced(precision, tol):
         assert e.logic_ticks == 1 and e.time_us == 1000
         rng = e.get_rng_state()
     b.step(1000 * 1e-6, 1, ticks=[1])
-    _cmp_state(st, b, tol, "single step")
     # IMU: noise-free part to tolerance, noise identical (same libstdc++ stream)
-    imu_tol = 1e-12 if precision == afa.AFE_F64 else F32_TOL
-    assert rel_err(gyro, b.gyro, 1.0) <= max(imu_tol, 2e-7)
-    assert rel_err(acc, b.acc, 10.0) <= max(imu_tol, 2e-7)
+    _cmp_state(st, b, tol, "single step", imu=(gyro, acc))
     np.testing.assert_array_equal(rng, b.rng)
 
 
@@ -85,10 +93,8 @@ def test_rollout_100_steps_open_loop(precision, tol):
         assert e.logic_ticks == int(ticks.sum())
         rng = e.get_rng_state()
     b.step(1000 * 1e-6, 100, ticks=ticks)
-    _cmp_state(st, b, tol, "100-step rollout")
+    _cmp_state(st, b, tol, "100-step rollout", imu=(gyro, acc))
     np.testing.assert_array_equal(rng, b.rng)
-    assert rel_err(gyro, b.gyro, 1.0) <= max(tol, 1e-6)
-    assert rel_err(acc, b.acc, 10.0) <= max(tol, 1e-6)
 
 
 def test_fused_steps_equal_single_steps_bitwise():
@@ -121,7 +127,7 @@ def test_more_than_64_fused_steps_and_clock():
         assert e.logic_ticks == int(ticks.sum())
         st = e.get_state()
     b.step(2000 * 1e-6, 150, ticks=ticks)
-    _cmp_state(st, b, 1e-10, "150 x 2 ms")
+    _cmp_state(st, b, 1e-10, "150 steps of 2 ms")
 
 
 def test_zero_dt_is_the_early_return():
@@ -151,7 +157,7 @@ def test_ground_contact_and_small_angle_edge_cases():
     np.testing.assert_array_equal(st["pos"][2][hit], 0.0)
     np.testing.assert_array_equal(st["vel"][2][hit], 0.0)
     np.testing.assert_array_equal(st["ang_vel"][:, hit], 0.0)
-    _cmp_state(st, bb, 1e-12, "ground")
+    _cmp_state(st, bb, 1e-12, "ground contact / small angle")
     # noise-free IMU of grounded vehicles: gyro exactly 0, acc = R^T (ax, ay, g)
     np.testing.assert_array_equal(gyro[:, hit], 0.0)
 
@@ -265,9 +271,7 @@ def test_motor_lag_types():
             e.step(1000, 20)
             st = e.get_state()
             gyro, acc = e.get_imu()
-        _cmp_state(st, b, tol, "lag types p%d" % precision)
-        assert rel_err(gyro, b.gyro, 1.0) <= max(tol, 1e-6)
-        assert rel_err(acc, b.acc, 10.0) <= max(tol, 1e-6)
+        _cmp_state(st, b, tol, "motor lag / J_m / CoM / inertia / IMU mount", imu=(gyro, acc))
 
 
 def test_oracle_regression_fixture_on_gpu(golden_dir):
@@ -280,10 +284,9 @@ def test_oracle_regression_fixture_on_gpu(golden_dir):
         st = e.get_state()
         gyro, acc = e.get_imu()
     for k, key in (("pos", "s1_pos"), ("vel", "s1_vel"), ("att", "s1_att"), ("ang_vel", "s1_ang_vel"),
-                   ("motor_speed", "s1_motor")):
-        assert rel_err(st[k], g[key], 1.0) <= F32_TOL, k
-    assert rel_err(gyro, g["s1_gyro"], 1.0) <= F32_TOL
-    assert rel_err(acc, g["s1_acc"], 10.0) <= F32_TOL
+                   ("motor_speed", "s1_motor"), ("gyro", "s1_gyro"), ("acc", "s1_acc")):
+        got = st[k] if k in st else (gyro if k == "gyro" else acc)
+        assert record_parity("committed fixture, single step", afa.AFE_F32, k, got, g[key]) <= F32_TOL, k
 
 
 def test_full_size_properties_1m_vehicles():
@@ -318,9 +321,9 @@ def test_full_size_properties_1m_vehicles():
     b = TestEnsemble(sub).to_oracle_batch()
     b.rng[:] = 1 + idx
     b.step(1e-3, 100, ticks=_ticks(afa, 1 / 500, 1000, 100))
-    for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel).items():
-        assert rel_err(st[k][:, idx], ref, 1.0) <= F32_TOL, k
-    assert rel_err(gyro[:, idx], b.gyro, 1.0) <= 1e-5
+    for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, gyro=b.gyro).items():
+        got = gyro if k == "gyro" else st[k]
+        assert record_parity("2^20 vehicles x 100 steps, 512-vehicle subsample", afa.AFE_F32, k, got[:, idx], ref) <= F32_TOL, k
     # noise statistics over the decorrelated ensemble
     assert abs(float(gyro[2].std()) - 0.1) < 2e-3
 
@@ -387,6 +390,159 @@ def test_checkpoint_resume_is_bitwise():
                 other.load_checkpoint(ck)
 
 
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+@pytest.mark.parametrize("logic", [False, True])
+def test_checkpoint_resumes_in_a_fresh_engine(precision, logic):
+    """save, destroy, create, load: a HETEROGENEOUS ensemble (4 vehicle types) must continue bit for bit in
+    a new engine that was only given the type (and logic) tables -- per-vehicle type indices, noise switch,
+    sigmas, seed policy, logic period, wrench flags and the clock all come from the checkpoint; mismatching
+    tables or a tampered header are refused."""
+    n = 1200
+    ens = random_ensemble(n, seed=43)
+    d = ens.data
+    table = [afa.params_from_type(t) for t in d.type_ids]
+    ltable = [afa.rates_logic_params_from_type(t) for t in d.type_ids]
+    e = ens.to_engine(precision)
+    e.set_imu_noise(True, 0.13, 0.27, afa.AFE_SEED_DECORRELATED)
+    e.set_logic_period(1.0 / 250.0)
+    if logic:
+        e.set_rates_logic(ltable)
+        e.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
+    e.step(1000, 23)
+    ck = e.save_checkpoint()
+    t0, k0 = e.time_us, e.logic_ticks
+    e.step(1000, 31)
+    want = e.get_state()
+    want_rng, want_cmd, want_imu = e.get_rng_state(), e.get_motor_cmds(), e.get_imu()
+    e.close()
+
+    f = afa.Ensemble(n, precision=precision)
+    f.set_type_table(table)                      # NOT told the per-vehicle types, noise, period, wrench ...
+    if logic:
+        f.set_rates_logic(ltable)
+    f.load_checkpoint(ck)
+    assert f.time_us == t0 and f.logic_ticks == k0
+    f.step(1000, 31)
+    got = f.get_state()
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    np.testing.assert_array_equal(f.get_rng_state(), want_rng)
+    np.testing.assert_array_equal(f.get_motor_cmds(), want_cmd)
+    np.testing.assert_array_equal(f.get_imu()[0], want_imu[0])
+    np.testing.assert_array_equal(f.get_imu()[1], want_imu[1])
+    f.close()
+
+    # a different type table (same count) is refused; so is the wrong logic on/off state
+    g = afa.Ensemble(n, precision=precision)
+    other = [afa.params_from_type(t) for t in d.type_ids]
+    other[2].mass *= 1.01
+    g.set_type_table(other)
+    if logic:
+        g.set_rates_logic(ltable)
+    with pytest.raises(afa.AfeError):
+        g.load_checkpoint(ck)
+    g.set_type_table(table)
+    if logic:
+        g.set_rates_logic(None)
+    else:
+        g.set_rates_logic(ltable)
+    with pytest.raises(afa.AfeError):
+        g.load_checkpoint(ck)
+    # header tampering: logic_bytes != 0 with the logic off, truncated buffers
+    g.set_rates_logic(ltable if logic else None)
+    bad = ck.copy()
+    bad[40:48] = np.frombuffer(np.uint64(12345).tobytes(), np.uint8)     # header.logic_bytes
+    with pytest.raises(afa.AfeError):
+        g.load_checkpoint(bad)
+    with pytest.raises(afa.AfeError):
+        g.load_checkpoint(ck[:len(ck) // 2])
+    g.load_checkpoint(ck)                                                # and the intact one still loads
+    g.close()
+
+
+def test_diverged_vehicles_do_not_hang_the_step():
+    """A lane whose |w| dt overflows (inf / 1e25 / NaN body rates, e.g. a tumbling vehicle that diverged)
+    must poison itself like the reference (sin/cos of a non-finite angle -> NaN state) and the launch must
+    RETURN: the fp32 series evaluation halves theta^2 in a loop that an infinite value never leaves unless
+    bounded.  Healthy neighbours in the same wave are untouched."""
+    n = 256
+    ens = random_ensemble(n, seed=77, type_ids=(5,))
+    d = ens.data
+    d.pos[2] += 10
+    d.ang_vel[:, 3] = (1e25, 0.0, 0.0)
+    d.ang_vel[:, 64] = (np.inf, 1.0, 0.0)
+    d.ang_vel[:, 65] = (np.nan, 0.0, 0.0)
+    d.ang_vel[:, 130] = (3e19, -3e19, 3e19)     # finite, squares overflow
+    d.ang_vel[:, 200] = (400.0, -300.0, 800.0)  # large but legitimate: |w| dt ~ 0.94 rad, squaring path
+    bad = [3, 64, 65, 130]
+    ref = ens.to_oracle_batch()
+    ref.step(1e-3, 1)
+    for precision in (afa.AFE_F32, afa.AFE_F64):
+        with ens.to_engine(precision) as e:
+            e.set_imu_noise(False)
+            e.step(1000, 1)
+            e.step(1000, 4)
+            e.sync()                              # returns (the test harness would time out otherwise)
+            with ens.to_engine(precision) as e1:
+                e1.set_imu_noise(False)
+                e1.step(1000, 1)
+                st = e1.get_state()
+        good = np.setdiff1d(np.arange(n), bad)
+        for k, r in dict(pos=ref.pos, vel=ref.vel, att=ref.att, ang_vel=ref.ang_vel).items():
+            assert record_parity("healthy lanes beside diverged ones", precision, k, st[k][:, good], r[:, good]) <= \
+                (F32_TOL if precision == afa.AFE_F32 else 1e-12), k
+        # inf / NaN rates poison the lane exactly like the reference restatement (sin / cos of a non-finite
+        # angle); 1e25 rad/s is a finite angle in double but overflows theta^2 in fp32 (poisoned there too);
+        # 3e19 rad/s stays finite in both (a meaningless but harmless attitude)
+        assert not np.isfinite(st["att"][:, [64, 65]]).all(axis=0).any()
+        assert not np.isfinite(ref.att[:, [64, 65]]).all(axis=0).any()
+        if precision == afa.AFE_F32:
+            assert not np.isfinite(st["att"][:, 3]).all()
+        assert np.isfinite(st["att"][:, 130]).all()
+
+
+def test_largest_type_table():
+    """256 vehicle types: the table kernel needs 83 KB (fp32) / 124 KB (fp64 + logic records) of LDS"""
+    from oracle import oracle_py
+    n, T = 4096, 256
+    rng = np.random.default_rng(9)
+    plist, olist = [], []
+    for k in range(T):
+        p = afa.params_from_type([1, 2, 4, 5][k % 4])
+        p.mass *= float(rng.uniform(0.9, 1.1))
+        p.lin_drag_coeff_b[0] = float(rng.uniform(0, 0.2))
+        plist.append(p)
+        olist.append(oracle_py.params_init(p.mass, list(p.inertia), p.arm_length, list(p.com_error), p.motor_min_speed,
+                                           p.motor_max_speed, p.prop_thrust_from_speed_sqr, p.prop_torque_from_speed_sqr,
+                                           p.motor_time_const, p.motor_inertia, list(p.lin_drag_coeff_b),
+                                           (p.imu_yaw, p.imu_pitch, p.imu_roll)))
+    ens = random_ensemble(n, seed=78, type_ids=(5,))
+    d = ens.data
+    d.pos[2] += 10
+    types = rng.integers(0, T, n).astype(np.uint8)
+    types[:T] = np.arange(T)
+    b = oracle_py.Batch(n, olist, types)
+    b.pos[:], b.vel[:], b.att[:], b.ang_vel[:] = d.pos, d.vel, d.att, d.ang_vel
+    b.motor_speed[:], b.motor_cmd[:] = d.motor_speed, np.minimum(d.motor_cmd, 1000.0)
+    b.ext_force[:], b.ext_torque[:] = d.ext_force, d.ext_torque
+    b.step(1e-3, 5, ticks=_ticks(afa, 1 / 500, 1000, 5))
+    for precision, tol in ((afa.AFE_F64, 1e-11), (afa.AFE_F32, F32_TOL)):
+        with afa.Ensemble(n, precision=precision) as e:
+            e.set_type_table(plist)
+            e.set_vehicle_types(types)
+            e.set_state(d.pos, d.vel, d.att, d.ang_vel, d.motor_speed)
+            e.set_motor_cmds(np.minimum(d.motor_cmd, 1000.0))
+            e.set_external_force(d.ext_force)
+            e.set_external_torque(d.ext_torque)
+            e.step(1000, 5)
+            _cmp_state(e.get_state(), b, tol, "256 vehicle types")
+            # with the logic records on top (the largest LDS footprint): must launch and stay finite
+            e.set_rates_logic([afa.rates_logic_params_from_type([1, 2, 4, 5][k % 4]) for k in range(T)])
+            e.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
+            e.step(1000, 6)
+            assert np.isfinite(e.get_state()["att"]).all()
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 257, 1000])
 def test_ragged_sizes(n):
     """ensemble sizes that are not a multiple of the wave / workgroup / slab granule"""
@@ -401,8 +557,7 @@ def test_ragged_sizes(n):
         assert e.device_view().stride % 512 == 256                    # 256 x odd
     b.rng[:] = 1 + np.arange(n)
     b.step(1e-3, 6, ticks=_ticks(afa, 1 / 500, 1000, 6))
-    _cmp_state(st, b, 1e-11, "n=%d" % n)
-    assert rel_err(g, b.gyro, 1.0) < 1e-6
+    _cmp_state(st, b, 1e-11, "ragged n=%d" % n, imu=(g, a))
 
 
 def test_max_fused_steps_setting_is_bitwise_neutral():

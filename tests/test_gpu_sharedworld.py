@@ -1,7 +1,8 @@
-"""Shared-world query path on the GPU: afe_pack_positions, the RCCL all-gather
-(world size 1 here; the multi-rank logic is covered by the gloo tests) and
-afe_nearest_neighbour, with torch only as the device-buffer / communicator
-plumbing.  Needs an MI355X."""
+"""Shared-world path on the GPU, through the C ABI: afe_pack_positions, the exchange in its two host
+shapes (afe_comm / afe_gather_positions over RCCL -- world size 1 on this box, the multi-rank logic
+is covered by the gloo tests -- and afe_group's peer copies between logical shards), and the two
+consumers of the gathered buffer: the uniform-grid nearest neighbour and the UWB ranging network.
+torch only provides device buffers.  Needs an MI355X."""
 import os
 import socket
 
@@ -21,8 +22,17 @@ def _free_port():
     return p
 
 
+def _nn(e, world_t, n_all, cell_size=0.0):
+    import torch
+    d2 = torch.empty(e.n, dtype=torch.float32, device="cuda")
+    idx = torch.empty(e.n, dtype=torch.int32, device="cuda")
+    e.nearest_neighbour(world_t.data_ptr(), n_all, d2.data_ptr(), idx.data_ptr(), cell_size)
+    e.sync()
+    return d2.cpu().numpy(), idx.cpu().numpy()
+
+
 @pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
-def test_pack_positions_and_nearest_neighbour(precision):
+def test_pack_positions_and_nearest_neighbour(precision, ora):
     import torch
     n = 3000
     ens = random_ensemble(n, seed=21)
@@ -31,38 +41,186 @@ def test_pack_positions_and_nearest_neighbour(precision):
         e.pack_positions(xyz.data_ptr())
         e.sync()
         np.testing.assert_array_equal(xyz.cpu().numpy(), ens.data.pos.astype(np.float32))
-        # pretend this shard is vehicles [first, first+n) of a bigger gathered world
-        first = 0
-        d2 = torch.empty(n, dtype=torch.float32, device="cuda")
-        idx = torch.empty(n, dtype=torch.int32, device="cuda")
-        e.nearest_neighbour(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr())
-        e.sync()
-        ref_d, ref_i = afa.sharding.nearest_neighbour_reference(ens.data.pos.astype(np.float32), first, n)
-        np.testing.assert_array_equal(idx.cpu().numpy(), ref_i)
-        np.testing.assert_allclose(d2.cpu().numpy(), ref_d, rtol=1e-5)
+        d2, idx = _nn(e, xyz, n)
+        ref_d, ref_i = ora.nearest_neighbour(ens.data.pos.astype(np.float32))
+        np.testing.assert_array_equal(idx, ref_i)
+        np.testing.assert_array_equal(d2, ref_d)          # the same fp32 roundings: bit-identical
 
 
-def test_nearest_neighbour_in_a_sharded_world():
+def test_nearest_neighbour_in_a_sharded_world(ora):
     """shard = the middle third of a gathered ensemble: self-exclusion must use
     the GLOBAL index (first_global_index + i)"""
     import torch
     n_all, first, n = 3000, 1000, 1000
     ens = random_ensemble(n_all, seed=22)
     world = torch.from_numpy(ens.data.pos.astype(np.float32)).cuda().contiguous()
-    part = afa.scenarios.EnsembleData(n)
-    part.pos = np.ascontiguousarray(ens.data.pos[:, first:first + n])
     with afa.Ensemble(n, first_global_index=first) as e:
         e.set_type_table([afa.params_from_type(5)])
-        e.set_state(pos=part.pos)
-        d2 = torch.empty(n, dtype=torch.float32, device="cuda")
-        idx = torch.empty(n, dtype=torch.int32, device="cuda")
-        e.nearest_neighbour(world.data_ptr(), n_all, d2.data_ptr(), idx.data_ptr())
+        e.set_state(pos=np.ascontiguousarray(ens.data.pos[:, first:first + n]))
+        d2, idx = _nn(e, world, n_all)
+    ref_d, ref_i = ora.nearest_neighbour(ens.data.pos.astype(np.float32), first, n)
+    np.testing.assert_array_equal(idx, ref_i)
+    np.testing.assert_array_equal(d2, ref_d)
+
+
+def _worlds():
+    rng = np.random.default_rng(31)
+    n = 6000
+    out = {}
+    out["uniform_box"] = rng.uniform(-20, 20, (3, n))
+    flat = rng.uniform(0, 120, (3, n))
+    flat[2] = 1.2 + rng.normal(0, 0.05, n)                       # an orchard flight: everybody at one altitude
+    out["flat"] = flat
+    cl = np.concatenate([np.array(c, float)[:, None] + rng.normal(0, 0.3, (3, n // 4)) for c in ((0, 0, 2), (50, 0, 2), (0, 80, 3), (300, 300, 30))], axis=1)
+    out["clusters_far_apart"] = cl                               # mostly empty cells, isolated groups
+    dup = rng.uniform(-5, 5, (3, n))
+    dup[:, 1000:2000] = dup[:, :1000]                            # coincident pairs: distance 0, index tie-break
+    dup[:, 2000:2100] = dup[:, 0:1]                              # 100 vehicles on one point
+    out["duplicates"] = dup
+    lat = np.stack(np.meshgrid(np.arange(20.0), np.arange(20.0), np.arange(15.0), indexing="ij")).reshape(3, -1)
+    out["lattice_all_ties"] = lat                                # every vehicle has up to 6 equally near neighbours
+    lone = rng.uniform(-2, 2, (3, n))
+    lone[:, 7] = (5000.0, -4000.0, 900.0)                        # a fly-away: far beyond any ring
+    lone[:, 8] = (np.nan, 0.0, 0.0)                              # diverged vehicles neither find nor are found
+    lone[:, 9] = (np.inf, 0.0, 1.0)
+    out["outlier_and_nonfinite"] = lone
+    out["two_vehicles"] = np.array([[0.0, 3.0], [0.0, 4.0], [1.0, 1.0]])
+    out["one_vehicle"] = np.array([[1.0], [2.0], [3.0]])
+    out["all_coincident"] = np.ones((3, 500))
+    return out
+
+
+@pytest.mark.parametrize("name", list(_worlds()))
+@pytest.mark.parametrize("cell_size", [0.0, 0.37, 25.0])
+def test_grid_equals_the_definition_on_awkward_worlds(name, cell_size, ora):
+    """clusters, planar ensembles, coincident points, ties, fly-aways, NaN / inf positions, tiny
+    ensembles -- with the automatic cell size and with cells far too small / far too large"""
+    import torch
+    pos = _worlds()[name].astype(np.float32)
+    n = pos.shape[1]
+    world = torch.from_numpy(np.ascontiguousarray(pos)).cuda()
+    with afa.Ensemble(n) as e:
+        e.set_type_table([afa.params_from_type(5)])
+        e.set_state(pos=np.nan_to_num(pos.astype(np.float64), nan=0.0, posinf=0.0))   # queries come from the gathered buffer
+        d2, idx = _nn(e, world, n, cell_size)
+        info = e.neighbour_grid_info()
+    ref_d, ref_i = ora.nearest_neighbour(pos)
+    np.testing.assert_array_equal(idx, ref_i, err_msg="%s, grid %r" % (name, info))
+    np.testing.assert_array_equal(d2, ref_d)
+
+
+def test_full_size_neighbour_query_is_exact_and_under_a_millisecond():
+    """config-4 size on one GPU: 2^20 vehicles queried against 2^20; the grid result equals the
+    brute-force definition (run on the GPU for a 4096-vehicle subsample plus the extremes) bit for
+    bit, symmetric-distance and self-exclusion properties hold everywhere, and the whole query
+    (bounds, counting sort, search) takes < 1 ms of GPU time"""
+    import torch
+    n = 1 << 20
+    rng = np.random.default_rng(32)
+    side = 4.0 * 1024          # 4 m spacing on a 1024 x 1024 lattice, jittered, three flight levels
+    pos = np.stack([rng.uniform(0, side, n), rng.uniform(0, side, n), rng.choice([1.2, 2.0, 3.5], n) + rng.normal(0, 0.1, n)])
+    pos = pos.astype(np.float32)
+    world = torch.from_numpy(pos).cuda()
+    with afa.Ensemble(n) as e:
+        e.set_type_table([afa.params_from_type(5)])
+        e.set_state(pos=pos.astype(np.float64))
+        d2_t = torch.empty(n, dtype=torch.float32, device="cuda")
+        idx_t = torch.empty(n, dtype=torch.int32, device="cuda")
+        for _ in range(3):
+            e.nearest_neighbour(world.data_ptr(), n, d2_t.data_ptr(), idx_t.data_ptr())
         e.sync()
-    ref_d, ref_i = afa.sharding.nearest_neighbour_reference(ens.data.pos.astype(np.float32), first, n)
-    np.testing.assert_array_equal(idx.cpu().numpy(), ref_i)
+        ev0, ev1 = e.event(), e.event()
+        e.record(ev0)
+        reps = 10
+        for _ in range(reps):
+            e.nearest_neighbour(world.data_ptr(), n, d2_t.data_ptr(), idx_t.data_ptr())
+        e.record(ev1)
+        ms = e.elapsed_ms(ev0, ev1) / reps
+        info = e.neighbour_grid_info()
+        d2, idx = d2_t.cpu().numpy(), idx_t.cpu().numpy()
+        # the definition, on the GPU, for a subsample
+        q = np.unique(np.concatenate([rng.choice(n, 4096, replace=False), [0, n - 1, int(np.argmax(d2)), int(np.argmin(d2))]])).astype(np.int32)
+        q_t = torch.from_numpy(q).cuda()
+        bd = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+        bi = torch.full((n,), -2, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()                     # torch's fills run on another stream than the engine's
+        e.nearest_neighbour_bruteforce(world.data_ptr(), n, q_t.data_ptr(), q.size, bd.data_ptr(), bi.data_ptr())
+        e.sync()
+        np.testing.assert_array_equal(idx[q], bi.cpu().numpy()[q])
+        np.testing.assert_array_equal(d2[q], bd.cpu().numpy()[q])
+    # properties at full size
+    assert (idx >= 0).all() and (idx != np.arange(n)).all()
+    diff = pos[:, idx] - pos
+    assert np.array_equal(d2, (diff[0] * diff[0] + diff[1] * diff[1]) + diff[2] * diff[2])
+    assert (d2[idx] <= d2).all()                     # my nearest neighbour's nearest is no farther than I am
+    print("2^20-vehicle neighbour query: %.3f ms per query, grid %r" % (ms, info))
+    assert ms < 1.0, "neighbour query took %.3f ms" % ms
+
+
+def test_uwb_ranging_matches_the_reference_restatement(ora):
+    """afe_uwb_range on gathered positions == UWBNetwork.cpp:66-71 transaction by transaction
+    (noise stream pinned to libstdc++ by tests/test_world_oracle.py), bit for bit, across calls"""
+    import torch
+    n = 5000
+    ens = random_ensemble(n, seed=41)
+    pos32 = ens.data.pos.astype(np.float32)
+    world = torch.from_numpy(pos32).cuda()
+    rng = np.random.default_rng(42)
+    with ens.to_engine(afa.AFE_F32) as e:
+        net = afa.UwbNetwork(0.05, 0.1, 3.0)
+        u = ora.UwbNetwork(0.05, 0.1, 3.0)
+        n_out = 0
+        for k in (1, 1, 7, 1000, 3):                  # odd batch sizes: the cached normal crosses call boundaries
+            req = rng.integers(0, n, k).astype(np.int32)
+            res = rng.integers(0, n, k).astype(np.int32)
+            got, out = net.range(e, world.data_ptr(), n, req, res)
+            for j in range(k):
+                want, o = u.range(pos32[:, req[j]].astype(np.float64), pos32[:, res[j]].astype(np.float64))
+                assert o == out[j]
+                assert got[j] == want, "transaction %d of batch %d: %r vs %r" % (j, k, got[j], want)
+                n_out += o
+        assert 50 < n_out < 160                       # ~10 % outliers
+        # noise-free network: the range is the true distance, narrowed to float
+        clean = afa.UwbNetwork(0.0, 0.0, 0.0)
+        req = np.arange(0, 100, dtype=np.int32)
+        res = np.arange(100, 200, dtype=np.int32)
+        got, out = clean.range(e, world.data_ptr(), n, req, res)
+        d = pos32[:, req].astype(np.float64) - pos32[:, res].astype(np.float64)
+        np.testing.assert_array_equal(got, np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]).astype(np.float32))
+        assert not out.any()
+        with pytest.raises(afa.AfeError):
+            clean.range(e, world.data_ptr(), n, np.array([n], np.int32), np.array([0], np.int32))
+        net.close()
+        clean.close()
+
+
+def test_library_all_gather_world_size_1():
+    """afe_comm / afe_gather_positions: the RCCL path of the C ABI (one rank on this box)"""
+    import torch
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    n = 4096
+    ens = random_ensemble(n, seed=23)
+    uid = afa.Comm.unique_id()
+    comm = afa.Comm(uid, 0, 1, device=0)
+    try:
+        assert comm.info() == (0, 1)
+        with ens.to_engine(afa.AFE_F32) as e:
+            out = torch.zeros((3, n), dtype=torch.float32, device="cuda")
+            e.gather_positions(comm, out.data_ptr())
+            e.sync()
+            np.testing.assert_array_equal(out.cpu().numpy(), ens.data.pos.astype(np.float32))
+            e.step(1000, 5)
+            e.gather_positions(comm, out.data_ptr(), counts=[n])
+            e.sync()
+            np.testing.assert_array_equal(out.cpu().numpy(), e.get_state(dtype=np.float32)["pos"])
+            with pytest.raises(afa.AfeError):
+                e.gather_positions(comm, out.data_ptr(), counts=[n + 1])
+    finally:
+        comm.close()
 
 
 def test_rccl_gather_positions_world_size_1():
+    """the same exchange for hosts that bring their own collective (torch.distributed)"""
     import torch
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -82,9 +240,78 @@ def test_rccl_gather_positions_world_size_1():
         dist.destroy_process_group()
 
 
+def _configure(e, d, noise_policy, logic):
+    e.set_type_table([afa.params_from_type(t) for t in d.type_ids])
+    e.set_vehicle_types(d.types)
+    e.set_imu_noise(True, 0.1, 0.2, noise_policy)
+    if logic:
+        e.set_rates_logic([afa.rates_logic_params_from_type(t) for t in d.type_ids])
+    e.set_state(d.pos, d.vel, d.att, d.ang_vel, d.motor_speed)
+    e.set_motor_cmds(d.motor_cmd)
+    e.set_external_force(d.ext_force)
+    e.set_external_torque(d.ext_torque)
+    if logic:
+        e.set_rates_commands(np.full(d.n, 9.81, np.float32), np.zeros((3, d.n), np.float32))
+
+
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+@pytest.mark.parametrize("shards", [2, 4, 8])
+@pytest.mark.parametrize("logic", [False, True])
+def test_logical_shards_are_bitwise_the_unsharded_ensemble(precision, shards, logic):
+    """G logical shards (afe_group, one engine each with its first_global_index) must
+    reproduce the unsharded run exactly -- state, IMU, motor commands and the RNG words -- for a
+    heterogeneous ensemble with wrench, decorrelated noise (seed = 1 + GLOBAL index) and, in one
+    variant, the on-device logic; then the gathered buffer of every shard is the concatenation."""
+    import torch
+    n = 10007                      # prime: uneven shards
+    ens = random_ensemble(n, seed=50 + shards)
+    d = ens.data
+    with afa.Ensemble(n, precision=precision) as whole, afa.Group(n, precision, devices=[0] * shards) as grp:
+        _configure(whole, d, afa.AFE_SEED_DECORRELATED, logic)
+        assert grp.ranges() == afa.sharding.all_shard_ranges(n, shards)
+        for s in grp.shards:
+            _configure(s, d.slice(s.first_global_index, s.n), afa.AFE_SEED_DECORRELATED, logic)
+        for dt_us, k in ((1000, 7), (2000, 3), (1000, 20)):
+            whole.step(dt_us, k)
+            grp.step(dt_us, k)
+        grp.sync()
+        ref = whole.get_state()
+        ref_g, ref_a = whole.get_imu()
+        ref_rng, ref_cmd = whole.get_rng_state(), whole.get_motor_cmds()
+        assert whole.logic_ticks > 0
+        for s in grp.shards:
+            sl = slice(s.first_global_index, s.first_global_index + s.n)
+            st = s.get_state()
+            for key in ref:
+                assert np.array_equal(st[key], ref[key][:, sl]), key
+            g, a = s.get_imu()
+            assert np.array_equal(g, ref_g[:, sl]) and np.array_equal(a, ref_a[:, sl])
+            assert np.array_equal(s.get_rng_state(), ref_rng[sl])
+            assert np.array_equal(s.get_motor_cmds(), ref_cmd[:, sl])
+            assert s.logic_ticks == whole.logic_ticks and s.time_us == whole.time_us
+        # exchange: every shard ends up with every position, in global order
+        ptrs = grp.gather_positions()
+        grp.sync()
+        want = whole.get_state(dtype=np.float32)["pos"] if precision == afa.AFE_F32 else ref["pos"].astype(np.float32)
+        for p in ptrs:
+            got = np.empty((3, n), np.float32)
+            rc = afa.library().afe_device_download(got.ctypes.data, p, got.nbytes)
+            assert rc == 0
+            assert np.array_equal(got, want)
+        # and the consumer on a shard == the consumer on the whole ensemble
+        whole_xyz = torch.from_numpy(want).cuda()
+        d2w, iw = _nn(whole, whole_xyz, n)
+        s = grp.shards[shards // 2]
+        d2 = torch.empty(s.n, dtype=torch.float32, device="cuda")
+        ix = torch.empty(s.n, dtype=torch.int32, device="cuda")
+        s.nearest_neighbour(ptrs[shards // 2], n, d2.data_ptr(), ix.data_ptr())
+        s.sync()
+        sl = slice(s.first_global_index, s.first_global_index + s.n)
+        assert np.array_equal(ix.cpu().numpy(), iw[sl]) and np.array_equal(d2.cpu().numpy(), d2w[sl])
+
+
 def test_device_view_matches_host_getters():
     """zero-copy view: torch can wrap the engine's slabs without a copy"""
-    import ctypes
     import torch
     n = 1000
     ens = random_ensemble(n, seed=24)

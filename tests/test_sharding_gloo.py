@@ -90,3 +90,30 @@ def test_nearest_neighbour_reference_helper(afa):
     d, i = afa.sharding.nearest_neighbour_reference(xyz, 0, 4)
     assert i.tolist() == [1, 0, 3, 2]
     np.testing.assert_allclose(d, [1, 1, 0.25, 0.25])
+
+
+def test_launcher_starts_ranks_relays_rank0_and_propagates_failure(afa):
+    """bench.py --gpus N without torch.distributed.run: agri-fly_amd/launch.py starts the ranks itself.
+    World size 2 over gloo here; the rank program is tests/rank_probe.py."""
+    import importlib
+    import json
+    launch = importlib.import_module("agri-fly_amd.launch")
+    probe = os.path.join(ROOT, "tests", "rank_probe.py")
+    line = launch.launch_ranks(probe, [], 2)
+    rec = json.loads(line)
+    assert rec == {"n_ranks": 2, "sum": 3.0, "local_rank": "0"}
+    with pytest.raises(SystemExit) as ei:
+        launch.launch_ranks(probe, ["--fail-rank", "1"], 2)
+    assert "rank 1 exited with status 7" in str(ei.value)
+
+
+def test_bench_parent_stays_off_the_gpu_when_it_launches():
+    """the self-launch branch of bench.py runs before torch or the engine library are imported"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("launch_ranks(args)") < main.index("import torch")
+    assert main.index("launch_ranks(args)") < main.index('importlib.import_module("agri-fly_amd")')
+    top = src[:src.index("def build_shard")]
+    assert "import torch" not in top
+    launch_src = open(os.path.join(ROOT, "agri-fly_amd", "launch.py")).read()
+    assert "import torch" not in launch_src and "hip" not in launch_src.replace("HIP call", "")
