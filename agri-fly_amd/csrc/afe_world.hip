@@ -46,9 +46,12 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
   return fabsf(x) < 3.0e38f && fabsf(y) < 3.0e38f && fabsf(z) < 3.0e38f;   // false for NaN and inf
 }
 
-// min / max of the finite positions: lo[3], hi[3] as order-preserving ints
-__global__ void __launch_bounds__(256) world_bounds_kernel(const float *__restrict__ xyz, int64_t n, int *__restrict__ lohi) {
+// min / max of the finite positions (lo[3], hi[3] as order-preserving ints) and their first two
+// moments (stats: sum x y z, sum xx yy zz, count; double)
+__global__ void __launch_bounds__(256) world_bounds_kernel(const float *__restrict__ xyz, int64_t n, int *__restrict__ lohi,
+                                                           double *__restrict__ stats) {
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  double m[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float x = xyz[i], y = xyz[n + i], z = xyz[2 * n + i];
     if (finite3(x, y, z)) {
@@ -56,6 +59,9 @@ __global__ void __launch_bounds__(256) world_bounds_kernel(const float *__restri
       lo[0] = min(lo[0], ox); hi[0] = max(hi[0], ox);
       lo[1] = min(lo[1], oy); hi[1] = max(hi[1], oy);
       lo[2] = min(lo[2], oz); hi[2] = max(hi[2], oz);
+      m[0] += x; m[1] += y; m[2] += z;
+      m[3] += (double)x * x; m[4] += (double)y * y; m[5] += (double)z * z;
+      m[6] += 1.0;
     }
   }
 #pragma unroll
@@ -66,9 +72,16 @@ __global__ void __launch_bounds__(256) world_bounds_kernel(const float *__restri
       hi[c] = max(hi[c], __shfl_xor(hi[c], s));
     }
   }
+#pragma unroll
+  for (int c = 0; c < 7; c++) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m[c] += __shfl_xor(m[c], s);
+  }
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int c = 0; c < 3; c++) { atomicMin(&lohi[c], lo[c]); atomicMax(&lohi[3 + c], hi[c]); }
+#pragma unroll
+    for (int c = 0; c < 7; c++) atomicAdd(&stats[c], m[c]);
   }
 }
 
@@ -191,8 +204,8 @@ __device__ __forceinline__ void scan_range(const uint4 *__restrict__ sorted, uin
 // One lane per point IN CELL ORDER (neighbouring lanes sit in the same or adjacent cells, so their
 // reads share cache lines); lanes whose point is not one of this shard's vehicles retire at once.
 // Exactness: every point outside the (2r+1)^3 block of cells around the query's cell is at least
-// r*h away, so once the best squared distance is below (r h)^2 (with a margin for the fp32 cell
-// assignment) no unvisited cell can improve it.  Queries still unresolved after AFE_WORLD_MAX_RING
+// r*h away, so once the best squared distance is below ((r - 0.05) h)^2 (the margin covers the fp32
+// cell assignment) no unvisited cell can improve it.  Queries still unresolved after AFE_WORLD_MAX_RING
 // rings (isolated vehicles) go to a leftover list that a brute-force kernel finishes.
 __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restrict__ sorted, int64_t n_all, const uint32_t *__restrict__ starts,
                                                           GridDesc g, int64_t first_global, int64_t n_self, float *__restrict__ dist2_out,
@@ -230,9 +243,9 @@ __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restric
         }
       }
     }
-    const float reach = (float)r * g.h;
+    const float reach = ((float)r - 0.05f) * g.h;   // 0.05 h: slack for the fp32 cell coordinates (<= 65536 per axis)
     const bool covers_all = cx - r <= 0 && cx + r >= nx - 1 && cy - r <= 0 && cy + r >= ny - 1 && cz - r <= 0 && cz + r >= nz - 1;
-    done = covers_all || best < reach * reach * 0.998f;
+    done = covers_all || best < reach * reach;
   }
   if (done) { dist2_out[local] = best; index_out[local] = best_j; }
   else leftover[atomicAdd(leftover_count, 1u)] = (int32_t)local;
@@ -312,6 +325,7 @@ struct afe_world {
   uint4 *sorted = nullptr;
   int32_t *leftover = nullptr;
   int *lohi = nullptr;         // 6 ints + leftover counter
+  double *stats = nullptr;     // 7 doubles: first two moments of the finite positions
   int64_t cap_self = 0;
   float *self_scratch = nullptr;
   GridDesc grid = {};
@@ -340,12 +354,28 @@ void free_points(afe_world *w) {
   w->cell = w->slot = nullptr; w->sorted = nullptr; w->leftover = nullptr;
 }
 
-// Cell size: the caller's, or one that puts about two vehicles in a cell of the occupied box --
-// flat ensembles (an orchard flight: everybody within a few metres of altitude) get a 2-D grid
-// because an axis thinner than a cell collapses to one layer.
-void choose_grid(const float lo[3], const float hi[3], int64_t n, float cell_size, GridDesc &g) {
-  double ext[3];
-  for (int c = 0; c < 3; c++) ext[c] = std::max(0.0, (double)hi[c] - (double)lo[c]);
+// The grid covers the CORE of the ensemble: the bounding box cut to mean +- 6 sigma per axis.  Points
+// outside it are clamped into its boundary cells -- clamping never increases a cell distance, so
+// the exactness argument of the query holds unchanged -- and a single fly-away vehicle no longer
+// stretches the grid until everybody else shares a handful of cells.  Cell size: the caller's, or
+// one that puts about two vehicles in a cell of a 4-sigma box (a uniform box is 3.5 sigma wide, a
+// Gaussian blob is denser than that in its middle); flat ensembles (an orchard flight: everybody
+// within a few metres of altitude) get a 2-D grid because an axis thinner than a cell collapses to
+// one layer.
+void choose_grid(const float lo[3], const float hi[3], const double stats[7], int64_t n, float cell_size, GridDesc &g) {
+  double ext[3], core[3], rlo[3];
+  const double cnt = stats[6] > 0 ? stats[6] : 1.0;
+  for (int c = 0; c < 3; c++) {
+    const double mean = stats[c] / cnt;
+    const double var = std::max(0.0, stats[3 + c] / cnt - mean * mean);
+    const double sd = std::sqrt(var);
+    double a = lo[c], b = hi[c];
+    if (sd > 0 && std::isfinite(sd)) { a = std::max(a, mean - 6.0 * sd); b = std::min(b, mean + 6.0 * sd); }
+    if (!(b >= a)) { a = lo[c]; b = hi[c]; }
+    rlo[c] = a;
+    ext[c] = std::max(0.0, b - a);
+    core[c] = std::min(ext[c], 4.0 * sd);
+  }
   double h = cell_size;
   if (!(h > 0)) {
     bool active[3] = {true, true, true};
@@ -353,29 +383,32 @@ void choose_grid(const float lo[3], const float hi[3], int64_t n, float cell_siz
     for (int iter = 0; iter < 4; iter++) {
       double vol = 1.0;
       int dims = 0;
-      for (int c = 0; c < 3; c++) if (active[c]) { vol *= std::max(ext[c], 1e-6); dims++; }
+      for (int c = 0; c < 3; c++) if (active[c]) { vol *= std::max(core[c], 1e-6); dims++; }
       if (dims == 0) { h = 1.0; break; }
       h = std::pow(vol * 2.0 / (double)std::max<int64_t>(n, 1), 1.0 / dims);
       bool changed = false;
-      for (int c = 0; c < 3; c++) if (active[c] && ext[c] < h) { active[c] = false; changed = true; }
+      for (int c = 0; c < 3; c++) if (active[c] && core[c] < h) { active[c] = false; changed = true; }
       if (!changed) break;
     }
     if (!(h > 1e-6)) h = 1e-6;
   }
   for (;;) {
     int64_t cells = 1;
+    bool axis_ok = true;
     for (int c = 0; c < 3; c++) {
       const double k = std::floor(ext[c] / h) + 1.0;
-      g.n[c] = (int)std::min(k, 2097152.0);
+      // <= 65536 cells per axis: the fp32 cell coordinate (x - min) / h is then exact to ~0.01 cell,
+      // which the query's stopping rule allows for (it trusts a ring only up to (r - 0.05) h)
+      if (k > 65536.0) axis_ok = false;
+      g.n[c] = (int)std::min(k, 65536.0);
       cells *= g.n[c];
-      if (cells > (int64_t(1) << 40)) break;
     }
-    if (cells <= kMaxCells) { g.n_cells = cells; break; }
+    if (axis_ok && cells <= kMaxCells) { g.n_cells = cells; break; }
     h *= 1.26;   // ~ a factor 2 fewer cells per try in 3-D
   }
   g.h = (float)h;
   g.inv_h = (float)(1.0 / h);
-  for (int c = 0; c < 3; c++) g.min[c] = lo[c];
+  for (int c = 0; c < 3; c++) g.min[c] = (float)rlo[c];
 }
 
 int ensure_capacity(afe_world *w, int64_t n_all, int64_t n_cells_total) {
@@ -398,6 +431,7 @@ int ensure_capacity(afe_world *w, int64_t n_all, int64_t n_cells_total) {
     w->cap_cells = cap;
   }
   if (!w->lohi) W_HIP(w, hipMalloc((void **)&w->lohi, 8 * sizeof(int)));
+  if (!w->stats) W_HIP(w, hipMalloc((void **)&w->stats, 8 * sizeof(double)));
   return AFE_OK;
 }
 
@@ -423,6 +457,7 @@ void afe::world_destroy(afe_world *w) {
   if (w->counts) (void)hipFree(w->counts);
   if (w->block_sums) (void)hipFree(w->block_sums);
   if (w->lohi) (void)hipFree(w->lohi);
+  if (w->stats) (void)hipFree(w->stats);
   if (w->self_scratch) (void)hipFree(w->self_scratch);
   delete w;
 }
@@ -439,17 +474,20 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   int rc = ensure_capacity(w, n_all, 0);
   if (rc) return rc;
   // 1. bounds of the finite positions (one small read-back: the grid shape is a host decision)
-  const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
+  static const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
   W_HIP(w, hipMemcpyAsync(w->lohi, init, sizeof(init), hipMemcpyHostToDevice, st));
-  const unsigned blocks = (unsigned)std::min<int64_t>((n_all + 255) / 256, 2048);
-  hipLaunchKernelGGL(world_bounds_kernel, dim3(blocks), dim3(256), 0, st, all_xyz, n_all, w->lohi);
+  W_HIP(w, hipMemsetAsync(w->stats, 0, 8 * sizeof(double), st));
+  const unsigned blocks = (unsigned)std::min<int64_t>((n_all + 255) / 256, 1024);
+  hipLaunchKernelGGL(world_bounds_kernel, dim3(blocks), dim3(256), 0, st, all_xyz, n_all, w->lohi, w->stats);
   int lohi[6];
+  double stats[7];
   W_HIP(w, hipMemcpyAsync(lohi, w->lohi, sizeof(lohi), hipMemcpyDeviceToHost, st));
+  W_HIP(w, hipMemcpyAsync(stats, w->stats, sizeof(stats), hipMemcpyDeviceToHost, st));
   W_HIP(w, hipStreamSynchronize(st));
   float lo[3], hi[3];
   for (int c = 0; c < 3; c++) { lo[c] = unordered(lohi[c]); hi[c] = unordered(lohi[3 + c]); }
   if (lohi[0] == 0x7fffffff) { for (int c = 0; c < 3; c++) lo[c] = hi[c] = 0.0f; }   // no finite position at all
-  choose_grid(lo, hi, n_all, cell_size, w->grid);
+  choose_grid(lo, hi, stats, n_all, cell_size, w->grid);
   const GridDesc g = w->grid;
   const int64_t m = g.n_cells + 2;   // cells, the dead bin, and the end sentinel
   if ((rc = ensure_capacity(w, n_all, m))) return rc;

@@ -108,14 +108,20 @@ def hover_ensemble(n, params, height=3.5):
     return e
 
 
-def gust_ensemble(n, params, seed=4, sigma_max=0.5, height=3.5, first_global=0, n_global=None):
+def gust_ensemble(n, params, seed=4, sigma_max=0.5, height=3.5, first_global=0, n_global=None, spacing=None):
     """Config 4: hovering ensemble with a per-vehicle constant wind-gust force
     F ~ N(0, sigma_i^2) per axis, sigma_i swept 0..sigma_max over the GLOBAL
     ensemble (so a shard [first_global, first_global+n) of a bigger ensemble
-    reproduces exactly the rows an unsharded run would have)."""
+    reproduces exactly the rows an unsharded run would have).
+    spacing: None = every vehicle hovers over the origin (independent Monte-Carlo replicas);
+    a length = the vehicles share one world, on a square lattice of that pitch, 1024 per row, indexed
+    by GLOBAL vehicle index (what a shared-world neighbour query needs to be meaningful)."""
     n_global = n if n_global is None else n_global
     e = hover_ensemble(n, params, height)
     idx = np.arange(first_global, first_global + n)
+    if spacing is not None:
+        e.pos[0] = (idx % 1024) * float(spacing)
+        e.pos[1] = (idx // 1024) * float(spacing)
     sigma = sigma_max * idx / max(1, n_global - 1)
     # counter-based: vehicle i's gust depends only on (seed, i)
     f = np.empty((3, n))

@@ -45,7 +45,8 @@ LOGIC_PERIOD = 1.0 / 500.0
 
 def build_shard(afa, n_local, first_global, n_global, device, fext=True, precision=None):
     p = afa.params_from_type(5)  # QC_TYPE_CF_MINIQUAD: vehicle id 1 of every shipped main
-    data = afa.scenarios.gust_ensemble(n_local, p, seed=4, first_global=first_global, n_global=n_global)
+    # one shared world: 4 m lattice by global index (the dynamics are translation invariant)
+    data = afa.scenarios.gust_ensemble(n_local, p, seed=4, first_global=first_global, n_global=n_global, spacing=4.0)
     e = afa.Ensemble(n_local, precision=afa.AFE_F32 if precision is None else precision, device=device,
                      first_global_index=first_global)
     e.set_type_table([p])
@@ -275,6 +276,24 @@ def cpu_baseline(afa, budget_vehicle_steps=100_000_000):
     return out
 
 
+class stdout_to_stderr:
+    """stdout carries exactly one JSON line.  RCCL prints a version banner through C stdio when a
+    communicator comes up (and it may sit in the C buffer until exit), so communicators are created
+    with fd 1 pointing at fd 2, and the C buffers are flushed before fd 1 is restored."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, barrier):
     """The path's only exchange, at its cadence: every 10 ms of simulated time (100 Hz) the shards
     all-gather their positions (afe_gather_positions: pack + ncclAllGather on the engine's stream)
@@ -287,7 +306,10 @@ def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, ba
         uid.copy_(torch.from_numpy(afa.Comm.unique_id()))
     if dist is not None:
         dist.broadcast(uid, 0)
-    comm = afa.Comm(uid.cpu().numpy(), rank, world, device=local_rank)
+    with stdout_to_stderr():
+        comm = afa.Comm(uid.cpu().numpy(), rank, world, device=local_rank)
+        e.gather_positions(comm, torch.empty((3, n_all), dtype=torch.float32, device="cuda").data_ptr())
+        e.sync()
     xyz = torch.empty((3, n_all), dtype=torch.float32, device="cuda")
     d2 = torch.empty(n_local, dtype=torch.float32, device="cuda")
     idx = torch.empty(n_local, dtype=torch.int32, device="cuda")
@@ -353,7 +375,8 @@ def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, ba
         "min_separation_m": float(torch.sqrt(d2.min()).item()),
     })
     net.close()
-    comm.close()
+    with stdout_to_stderr():
+        comm.close()
     return out
 
 
@@ -393,19 +416,10 @@ def main():
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: RCCL even for one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL prints a version banner on stdout when its communicator comes up; stdout is reserved
-        # for the one JSON line, so the communicator is created (first barrier) with fd 1 -> fd 2
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():     # RCCL's banner must not land on stdout
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
 
     def barrier():
         if dist is not None:

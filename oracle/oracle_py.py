@@ -7,6 +7,7 @@ path (agri-fly_amd/) never imports anything from oracle/.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -60,8 +61,9 @@ def build(force=False):
     if force and os.path.exists(_LIB_PATH):
         os.remove(_LIB_PATH)
     # make decides staleness (every .c / .h of the checker is a prerequisite of the library)
-    subprocess.check_call(["make", "-s", "-C", _HERE, "libagrifly_oracle.so"])
-    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    # make's chatter goes to stderr: bench.py's stdout carries exactly one JSON line
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libagrifly_oracle.so"], stdout=sys.stderr)
+    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"], stdout=sys.stderr)
 
 
 _lib = None

@@ -45,7 +45,7 @@ def pytest_sessionfinish(session, exitstatus):
         from tests import scenarios
     except Exception:
         return
-    if not scenarios.LEDGER:
+    if not scenarios.LEDGER and not scenarios.MEASUREMENTS:
         return
     import json
     out = os.path.join(ROOT, "gpurun_out")
@@ -53,4 +53,4 @@ def pytest_sessionfinish(session, exitstatus):
     with open(os.path.join(out, "parity_ledger.json"), "w") as f:
         json.dump({"definition": "per vehicle ||engine - oracle||_2 / max(||oracle||_2, floor), worst vehicle; "
                                  "tolerance 1e-5 for the fp32 engine, <= 1e-10 for the fp64 engine",
-                   "floors": scenarios.FLOORS, "tests": scenarios.LEDGER}, f, indent=1, sort_keys=True)
+                   "floors": scenarios.FLOORS, "tests": scenarios.LEDGER, "measurements": scenarios.MEASUREMENTS}, f, indent=1, sort_keys=True)

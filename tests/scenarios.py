@@ -86,14 +86,15 @@ def rel_err_vec(a, b, floor):
 FLOORS = dict(pos=1e-2, vel=1e-2, att=1.0, ang_vel=1e-2, motor_speed=1.0, gyro=1e-2, acc=1e-1)
 PROBE_FLOORS = (1.0, 1e-1, 1e-2, 1e-3)
 LEDGER = {}
+MEASUREMENTS = {}     # timings and sizes the GPU tests observe (neighbour query ms, render ms ...), same dump
 
 
-def record_parity(test, precision, field, a, b):
+def record_parity(test, precision, field, a, b, floor=None):
     """measured worst relative error of one field in one test, at the asserted floor and at the probe
     floors (so the ledger shows how much headroom a tighter or looser definition would have)"""
     key = "%s[%s]" % (test, "f64" if precision == afa.AFE_F64 else "f32")
     rec = LEDGER.setdefault(key, {})
-    fl = FLOORS[field]
+    fl = FLOORS[field] if floor is None else floor
     rec[field] = {"rel_err": rel_err_vec(a, b, fl), "floor": fl,
                   "at_floor": {repr(f): rel_err_vec(a, b, f) for f in PROBE_FLOORS},
                   "max_abs_err": float(np.nanmax(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))}
