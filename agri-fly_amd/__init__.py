@@ -42,6 +42,7 @@ from .engine import (  # noqa: F401
     plan_ticks,
     planner_default_config,
     planner_samples,
+    plans_as_array,
     rappids_plan,
     radio_create_rates_command,
     radio_decode,

@@ -172,7 +172,7 @@ __device__ __forceinline__ void rotvec_to_quat(double rx, double ry, double rz,
 #pragma clang fp contract(off)
   const double theta = sqrt(rx * rx + ry * ry + rz * rz);
   d0 = 1; d1 = 0; d2 = 0; d3 = 0;
-  if (theta >= 4.84813681e-6) {
+  if (!(theta < 4.84813681e-6)) {   // the reference's test: a NaN angle takes the general branch (and poisons the lane)
     double sn, cs;
     sincos(theta * 0.5, &sn, &cs);
     d0 = cs;

@@ -423,22 +423,33 @@ bool camera_ok(const afe_camera *c) {
 int launch_render(const afe_scene *s, const afe_camera *cam, int64_t count, const double *poses, uint16_t *out_dev,
                   hipStream_t stream, float *kernel_ms) {
   RenderArgs r;
-  r.nodes = s->nodes; r.tris = s->tris; r.poses = poses; r.out = out_dev;
-  r.n_views = count;
+  r.nodes = s->nodes; r.tris = s->tris;
   r.width = cam->width; r.height = cam->height;
   r.tiles_x = (cam->width + kTileW - 1) / kTileW;
   r.tiles_per_view = r.tiles_x * ((cam->height + kTileH - 1) / kTileH);
-  r.n_blocks = count * r.tiles_per_view;
-  r.blocks_per_xcd = (r.n_blocks + 7) / 8;
   r.focal = cam->focal_length; r.cx = cam->cx; r.cy = cam->cy; r.depth_scale = cam->depth_scale;
   r.max_count = cam->max_count;
-  const int64_t grid = r.blocks_per_xcd * 8;
-  if (grid <= 0 || grid > 0x7fffffffLL) return AFE_ERR_OUT_OF_RANGE;
+  // A launch may not exceed 2^32 threads in all (HIP truncates the product silently): 65 536 views of
+  // 320 x 240 are 78.6 M tiles x 64 lanes = 5.0e9.  Views go out in runs that stay below 2^31 threads.
+  const int64_t max_blocks = (int64_t(1) << 31) / (kTileW * kTileH);
+  if (r.tiles_per_view > max_blocks) return AFE_ERR_OUT_OF_RANGE;
+  const int64_t views_per_launch = max_blocks / r.tiles_per_view;
+  const size_t px = (size_t)cam->width * cam->height;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (kernel_ms && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return AFE_ERR_HIP;
   if (kernel_ms) (void)hipEventRecord(e0, stream);
-  hipLaunchKernelGGL(afe_render_depth_kernel, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
-  int rc = hipGetLastError() == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+  int rc = AFE_OK;
+  for (int64_t v0 = 0; v0 < count && rc == AFE_OK; v0 += views_per_launch) {
+    const int64_t nv = (count - v0) < views_per_launch ? (count - v0) : views_per_launch;
+    r.poses = poses + 12 * v0;
+    r.out = out_dev + (size_t)v0 * px;
+    r.n_views = nv;
+    r.n_blocks = nv * r.tiles_per_view;
+    r.blocks_per_xcd = (r.n_blocks + 7) / 8;
+    const int64_t grid = r.blocks_per_xcd * 8;
+    hipLaunchKernelGGL(afe_render_depth_kernel, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
+    rc = hipGetLastError() == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+  }
   if (kernel_ms) {
     (void)hipEventRecord(e1, stream);
     if (rc == AFE_OK && hipEventSynchronize(e1) != hipSuccess) rc = AFE_ERR_HIP;

@@ -129,6 +129,19 @@ class PlanOutput(C.Structure):
                 ("n_collision_free", C.c_int), ("n_pyramids", C.c_int)]
 
 
+# PlanOutput as a numpy record (same layout), for hosts that consume 10^4..10^5 plans per frame
+PLAN_DTYPE = np.dtype([("found", np.int32), ("best_index", np.int32), ("best_cost", np.float64),
+                       ("coeffs", np.float64, (6, 3)), ("tf", np.float64), ("n_generated", np.int32),
+                       ("n_cost_checks", np.int32), ("n_collision_checks", np.int32), ("n_velocity_checks", np.int32),
+                       ("n_collision_free", np.int32), ("n_pyramids", np.int32)])
+
+
+def plans_as_array(out):
+    """zero-copy numpy view of the PlanOutput array rappids_plan returns"""
+    assert PLAN_DTYPE.itemsize == C.sizeof(PlanOutput)
+    return np.frombuffer(out, dtype=PLAN_DTYPE)
+
+
 class DeviceView(C.Structure):
     _fields_ = [
         ("n_vehicles", C.c_int64), ("stride", C.c_int64), ("state_elem_size", C.c_int),
@@ -406,10 +419,10 @@ class DeviceBuffer:
         if rc:
             raise AfeError(rc, library().afe_status_string(rc).decode())
 
-    def download(self, dtype, shape):
+    def download(self, dtype, shape, offset_bytes=0):
         out = np.empty(shape, dtype)
-        assert out.nbytes <= self.nbytes
-        rc = library().afe_device_download(out.ctypes.data, self.ptr, out.nbytes)
+        assert offset_bytes >= 0 and offset_bytes + out.nbytes <= self.nbytes
+        rc = library().afe_device_download(out.ctypes.data, C.c_void_p(self.ptr.value + int(offset_bytes)), out.nbytes)
         if rc:
             raise AfeError(rc, library().afe_status_string(rc).decode())
         return out

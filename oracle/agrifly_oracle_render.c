@@ -83,6 +83,8 @@ void ora_render_depth(const ora_camera *cam, const float *triangles, int64_t n_t
                       const double att[4], const double mount[4], uint16_t *out) {
   double R[9];
   camera_frame(att, mount, R);
+  /* rows are independent: the same per-pixel arithmetic whatever the thread count */
+#pragma omp parallel for schedule(dynamic, 4)
   for (int py = 0; py < cam->height; py++)
     for (int px = 0; px < cam->width; px++)
       out[(int64_t)py * cam->width + px] = quantise(cam, pixel_depth(cam, triangles, n_tri, cam_pos, R, px, py));

@@ -111,7 +111,11 @@ def clearance(layout, pos):
 
 
 def fly_orchard(afa, n=48, seconds=6.0, seed=0, n_candidates=192, rows=6, cols=10, altitude=1.2, plan_every=3,
-                log_every=2, start_planning=0.5):
+                log_every=2, start_planning=0.5, on_plan=None, on_tick=None, want_flags=False):
+    """on_plan(frame): called after every render -> plan with a dict of everything that went in and came
+    out (engine, scene, camera, device image buffer, planner inputs, outputs, flags) -- the hook the
+    full-size in-loop test checks its subsample through; on_tick(tick, t, engine, state) after every
+    10 ms of physics."""
     sc = afa.scenarios
     tris, layout = sc.orchard_mesh(rows=rows, cols=cols, seed=seed, return_layout=True)
     scene = afa.Scene(tris)
@@ -157,6 +161,8 @@ def fly_orchard(afa, n=48, seconds=6.0, seed=0, n_candidates=192, rows=6, cols=1
         t = now * 1e-6
         st = e.get_state()
         pos, vel, att = st["pos"], st["vel"], st["att"]
+        if on_tick is not None:
+            on_tick(tick, t, e, st)
         R_att = rot_matrix64(att)
         if t >= start_planning and tick % plan_every == 0:
             cam_q = quat_mul64(att, np.tile(mount[:, None], (1, n)))
@@ -168,11 +174,16 @@ def fly_orchard(afa, n=48, seconds=6.0, seed=0, n_candidates=192, rows=6, cols=1
             grav_c = rotate64(R_cam, np.tile(np.array([[0.0], [0.0], [-9.81]]), (1, n)), inverse=True)
             goal_c = rotate64(R_cam, goal - pos, inverse=True)
             ms_r = scene.render_engine(e, cam, mount, out=buf)
-            out, _, ms_p = afa.rappids_plan(cfg, buf, vel_c, acc_c, grav_c, samples, cost_vec=goal_c)
-            found = np.array([o.found for o in out], bool)
-            for i in np.nonzero(found)[0]:
-                coeffs[i] = np.array([[out[i].coeffs[q][a] for a in range(3)] for q in range(6)])
-                tf[i] = out[i].tf
+            out, flags, ms_p = afa.rappids_plan(cfg, buf, vel_c, acc_c, grav_c, samples, cost_vec=goal_c,
+                                                want_flags=want_flags)
+            plans = afa.plans_as_array(out)
+            found = plans["found"].astype(bool)
+            coeffs[found] = plans["coeffs"][found]
+            tf[found] = plans["tf"][found]
+            if on_plan is not None:
+                on_plan(dict(tick=tick, t=t, engine=e, scene=scene, tris=tris, cam=cam, mount=mount, buf=buf, cfg=cfg,
+                             samples=samples, state=st, vel_c=vel_c, acc_c=acc_c, grav_c=grav_c, goal_c=goal_c,
+                             plans=plans, flags=flags, render_ms=ms_r, plan_ms=ms_p))
             t_plan[found] = t
             traj_R[:, :, found] = R_cam[:, :, found]
             traj_off[:, found] = pos[:, found]

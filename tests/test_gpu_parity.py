@@ -324,11 +324,11 @@ def test_full_size_properties_1m_vehicles():
     # A hovering ensemble: velocities and body rates are ZERO by construction (up to the gust, which starts at
     # sigma = 0) -- the velocity is the integral of thrust/m - g, two ~9.81 m/s^2 terms, over 0.1 s, the rate the
     # integral of four cancelling motor torques.  Their errors (1e-6 m/s, 2e-7 rad/s) are judged against those
-    # integrated magnitudes: floor 0.1 instead of the general 0.01.
+    # integrated magnitudes: floor 0.1 instead of the general 0.01 (the gyro sample is that rate plus noise).
     for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, gyro=b.gyro).items():
         got = gyro if k == "gyro" else st[k]
         assert record_parity("2^20 vehicles x 100 steps, 512-vehicle subsample", afa.AFE_F32, k, got[:, idx], ref,
-                             floor=0.1 if k in ("vel", "ang_vel") else None) <= F32_TOL, k
+                             floor=0.1 if k in ("vel", "ang_vel", "gyro") else None) <= F32_TOL, k
     # noise statistics over the decorrelated ensemble
     assert abs(float(gyro[2].std()) - 0.1) < 2e-3
 
