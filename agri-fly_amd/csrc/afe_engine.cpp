@@ -938,9 +938,9 @@ extern "C" int afe_nearest_neighbour_grid(afe_engine *e, const float *all_xyz, i
   return AFE_OK;
 }
 
-extern "C" int afe_neighbour_grid_info(const afe_engine *e, int dims[3], float *cell_size, int64_t *n_cells) {
+extern "C" int afe_neighbour_grid_info(const afe_engine *e, int dims[3], float *cell_size, int64_t *n_cells, int64_t *n_bruteforce) {
   if (!e || !e->world) return AFE_ERR_NOT_CONFIGURED;
-  return world_grid_info(e->world, dims, cell_size, n_cells);
+  return world_grid_info(e->world, dims, cell_size, n_cells, n_bruteforce);
 }
 
 extern "C" int afe_nearest_neighbour_bruteforce(afe_engine *e, const float *all_xyz, int64_t n_all, const int32_t *dev_queries,

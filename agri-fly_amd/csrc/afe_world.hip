@@ -199,7 +199,7 @@ __device__ __forceinline__ void scan_range(const uint4 *__restrict__ sorted, uin
   }
 }
 
-#define AFE_WORLD_MAX_RING 3
+#define AFE_WORLD_MAX_RING 6
 
 // One lane per point IN CELL ORDER (neighbouring lanes sit in the same or adjacent cells, so their
 // reads share cache lines); lanes whose point is not one of this shard's vehicles retire at once.
@@ -510,8 +510,15 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   return AFE_OK;
 }
 
-int afe::world_grid_info(const afe_world *w, int dims[3], float *cell_size, int64_t *n_cells) {
+int afe::world_grid_info(const afe_world *w, int dims[3], float *cell_size, int64_t *n_cells, int64_t *n_bruteforce) {
   if (!w) return AFE_ERR_INVALID_ARG;
+  if (n_bruteforce) {   // how many queries of the last call the rings could not settle (synchronises)
+    uint32_t left = 0;
+    if (!w->lohi || hipSetDevice(w->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(&left, w->lohi + 6, 4, hipMemcpyDeviceToHost) != hipSuccess)
+      return AFE_ERR_HIP;
+    *n_bruteforce = left;
+  }
   if (dims) for (int c = 0; c < 3; c++) dims[c] = w->grid.n[c];
   if (cell_size) *cell_size = w->grid.h;
   if (n_cells) *n_cells = w->grid.n_cells;

@@ -274,7 +274,7 @@ def library():
         "afe_group_sync": [vp],
         "afe_group_gather_positions": [vp, vp],
         "afe_nearest_neighbour_grid": [eng, vp, i64, C.c_float, vp, vp],
-        "afe_neighbour_grid_info": [eng, vp, C.POINTER(C.c_float), C.POINTER(i64)],
+        "afe_neighbour_grid_info": [eng, vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64)],
         "afe_nearest_neighbour_bruteforce": [eng, vp, i64, vp, i64, vp, vp],
         "afe_uwb_create": [C.POINTER(vp)],
         "afe_uwb_set_noise": [vp, C.c_double, C.c_double, C.c_double],
@@ -802,9 +802,9 @@ class Ensemble:
 
     def neighbour_grid_info(self):
         dims = (C.c_int * 3)()
-        h, nc = C.c_float(0), C.c_int64(0)
-        self._ck(self._L.afe_neighbour_grid_info(self._h, dims, C.byref(h), C.byref(nc)))
-        return {"dims": tuple(dims), "cell_size": h.value, "n_cells": nc.value}
+        h, nc, nb = C.c_float(0), C.c_int64(0), C.c_int64(0)
+        self._ck(self._L.afe_neighbour_grid_info(self._h, dims, C.byref(h), C.byref(nc), C.byref(nb)))
+        return {"dims": tuple(dims), "cell_size": h.value, "n_cells": nc.value, "n_bruteforce": nb.value}
 
 
 class Comm:

@@ -371,7 +371,8 @@ def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, ba
         "query_ms": parts["allgather_ms"] + parts["nearest_neighbour_ms"],
         "vsteps_per_s_with_queries": n_all * k / t_with,
         "vsteps_per_s_physics_only": n_all * k / t_without,
-        "neighbour_grid": {"dims": list(info["dims"]), "cell_size_m": info["cell_size"]},
+        "neighbour_grid": {"dims": list(info["dims"]), "cell_size_m": info["cell_size"],
+                           "queries_finished_by_brute_force": info["n_bruteforce"]},
         "min_separation_m": float(torch.sqrt(d2.min()).item()),
     })
     net.close()

@@ -15,8 +15,13 @@
 // aborts with the engine's message, the closest equivalent.
 //
 // Two shapes:
-//   agrifly::Quadcopter_T<logicType>  one vehicle = one 1-vehicle ensemble;
-//       behaves like the reference object (BaseTimer-driven dt, strict-> gate).
+//   agrifly::Quadcopter_T<logicType>  one vehicle = one 1-vehicle ensemble; IS-A
+//       Simulation::SimulationObject6DOF, so `std::shared_ptr<Simulation::SimulationObject6DOF>`
+//       holders (AIFS_ROS/hiperlab_rostools/src/Simulator/main.cpp:83) take it unchanged;
+//       behaves like the reference object (BaseTimer-driven dt, strict-> gate, state in the base's
+//       _pos/_vel/_att/_angVel members, UWB radio hand-off).  It is a VIEW for drop-in use: every
+//       Run() is a kernel launch plus a few small copies and synchronisations, orders of magnitude
+//       slower than the CPU reference at N = 1 -- the batched Fleet / C ABI is the real interface.
 //   agrifly::Fleet<logicType>         N vehicles in ONE ensemble, N host logic
 //       objects: the `for (v : vehicles) v->Run();` of AIFS_ROS/.../Simulator/
 //       main.cpp:323-325 as one launch + one batched IMU/command exchange.
@@ -26,12 +31,11 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../agrifly_engine.h"
-#ifndef AGRIFLY_USE_REFERENCE_TYPES
-#include "standalone_types.hpp"
-#endif
+#include "SimulationObject6DOF.hpp"   // the tree's own header under AGRIFLY_USE_REFERENCE_TYPES
 
 namespace agrifly {
 
@@ -100,6 +104,7 @@ class Fleet {
   afe_engine *engine() { return _e; }
   int64_t size() const { return _n; }
   logicType &logic(int64_t i) { return _logic[(size_t)i]; }
+  uint64_t ticks() { uint64_t t = 0; check(_e, afe_logic_ticks(_e, &t), "afe_logic_ticks"); return t; }
 
   // `for (v : vehicles) v->Run();` -- one Quadcopter_T::Run() per vehicle
   void Run() {
@@ -166,7 +171,7 @@ class Fleet {
 // ---------------------------------------------------------------------------
 // Drop-in for Simulation::Quadcopter_T<logicType> (one vehicle).
 template <class logicType>
-class Quadcopter_T {
+class Quadcopter_T : public Simulation::SimulationObject6DOF {
  public:
   // Same argument list as Quadcopter_T.hpp:24-32.  inertiaMatrix: anything with
   // operator()(i,j) (Eigen::Matrix<double,3,3> in the agri-fly tree).
@@ -180,7 +185,8 @@ class Quadcopter_T {
                double motorInertia, Vec3d linDragCoeffB, uint8_t id, QuadcopterTypeT quadcopterType,
                double onboardLogicPeriod, int precision = AFE_F32, float lowBatteryThreshold = 0.0f,
                float imuYaw = 0, float imuPitch = 0, float imuRoll = 0)
-      : _fleet(masterTimer, 1,
+      : Simulation::SimulationObject6DOF(masterTimer),
+        _fleet(masterTimer, 1,
                std::vector<afe_vehicle_params>(1, MakeParams(mass, inertiaMatrix, armLength, centreOfMassError,
                                                              motorMinSpeed, motorMaxSpeed, propThrustFromSpeedSqr,
                                                              propTorqueFromSpeedSqr, motorTimeConst, motorInertia,
@@ -188,20 +194,29 @@ class Quadcopter_T {
                std::vector<uint8_t>(), onboardLogicPeriod, precision, -1,
                1.2f * lowBatteryThreshold),  // Quadcopter_T.cpp:72
         _kThrust(propThrustFromSpeedSqr) {
-    _fleet.logic(0).Initialise(quadcopterType, id);  // Quadcopter_T.cpp:82
+    _radio.reset(new Simulation::UWBRadio(masterTimer, id));   // Quadcopter_T.cpp:68
+    _fleet.logic(0).Initialise(quadcopterType, id);              // Quadcopter_T.cpp:82
+    remember();
   }
   virtual ~Quadcopter_T() {}
 
-  virtual void Run() { _fleet.Run(); }
-
-  Vec3d GetPosition() { return _fleet.GetPosition(0); }
-  Vec3d GetVelocity() { return _fleet.GetVelocity(0); }
-  Rotationd GetAttitude() { return _fleet.GetAttitude(0); }
-  Vec3d GetAngularVelocity() { return _fleet.GetAngularVelocity(0); }
-  void SetPosition(Vec3d in) { _fleet.SetPosition(0, in); }
-  void SetVelocity(Vec3d in) { _fleet.SetVelocity(0, in); }
-  void SetAttitude(Rotationd in) { _fleet.SetAttitude(0, in); }
-  void SetAngularVelocity(Vec3d in) { _fleet.SetAngularVelocity(0, in); }
+  // The reference's Run() works on the base's _pos/_vel/_att/_angVel members (set through the base's
+  // non-virtual setters) and writes them back (Quadcopter_T.cpp:140-156).  Here: members that changed
+  // since the last read-back go to the device, the step runs there, the new state comes back.
+  virtual void Run() {
+    push();
+    const uint64_t before = _fleet.ticks();
+    _fleet.Run();
+    pull();
+    if (_fleet.ticks() != before && _radio) {   // the UWB hand-off of a logic tick, Quadcopter_T.cpp:191-199
+      _radio->SetPosition(_pos);
+      _radio->SetNextRangingTarget(_fleet.logic(0).GetNextUWBRangingTarget());
+      if (_radio->GetHaveNewMeasurement()) {
+        Simulation::UWBRadio::RangingMeasurement meas = _radio->GetMeasurement();
+        _fleet.logic(0).SetUWBMeasurement(meas.range, meas.responderId, meas.failure);
+      }
+    }
+  }
 
   // Quadcopter_T.hpp:39-42: z component of motor i's thrust = k_f w |w|
   double GetMotorForce(unsigned i) {
@@ -213,10 +228,8 @@ class Quadcopter_T {
 
   // pass-throughs to the onboard logic (Quadcopter_T.hpp:53-83)
   void GetEstimate(Vec3f &pos, Vec3f &vel, Rotationf &att, Vec3f &angVel) { _fleet.logic(0).GetEstimate(pos, vel, att, angVel); }
-  template <class IdT>
-  void AddUWBRadioTarget(IdT id, Vec3f pos) { _fleet.logic(0).AddRangingTargetId(id, pos); }
-  template <class RawMessageT>
-  void SetCommandRadioMsg(RawMessageT const raw) {
+  virtual void AddUWBRadioTarget(uint8_t id, Vec3f pos) { _fleet.logic(0).AddRangingTargetId(id, pos); }
+  virtual void SetCommandRadioMsg(RadioTypes::RadioMessageDecoded::RawMessage const raw) {
 #ifdef AGRIFLY_USE_REFERENCE_TYPES
     RadioTypes::RadioMessageDecoded msg = RadioTypes::RadioMessageDecoded(raw.raw);  // Quadcopter_T.hpp:64-66
     _fleet.logic(0).SetRadioMessage(msg);
@@ -224,17 +237,43 @@ class Quadcopter_T {
     _fleet.logic(0).SetRadioMessage(raw);
 #endif
   }
-  template <class PacketT>
-  void GetTelemetryDataPackets(PacketT &dataPacket1, PacketT &dataPacket2) { _fleet.logic(0).GetTelemetryDataPackets(dataPacket1, dataPacket2); }
-  void GetAccelerometer(Vec3d &acc) { acc = Vec3d(_fleet.logic(0).GetAccelerometer()); }
-  void GetRateGyro(Vec3d &rateGyro) { rateGyro = Vec3d(_fleet.logic(0).GetRateGyro()); }
+  virtual void GetTelemetryDataPackets(TelemetryPacket::data_packet_t &dataPacket1,
+                                       TelemetryPacket::data_packet_t &dataPacket2) {
+    _fleet.logic(0).GetTelemetryDataPackets(dataPacket1, dataPacket2);
+  }
+  virtual void GetAccelerometer(Vec3d &acc) { acc = Vec3d(_fleet.logic(0).GetAccelerometer()); }
+  virtual void GetRateGyro(Vec3d &rateGyro) { rateGyro = Vec3d(_fleet.logic(0).GetRateGyro()); }
 
   logicType &Logic() { return _fleet.logic(0); }
   afe_engine *engine() { return _fleet.engine(); }
 
  private:
+  static bool same(const double *a, const double *b, int n) { return std::memcmp(a, b, sizeof(double) * (size_t)n) == 0; }
+  void members(double p[3], double v[3], double q[4], double w[3]) const {
+    for (int k = 0; k < 3; k++) { p[k] = _pos[k]; v[k] = _vel[k]; w[k] = _angVel[k]; }
+    for (unsigned k = 0; k < 4; k++) q[k] = _att[k];
+  }
+  void remember() { members(_sp, _sv, _sq, _sw); }
+  void push() {   // only what the caller changed through the base's setters
+    double p[3], v[3], q[4], w[3];
+    members(p, v, q, w);
+    const bool dp = !same(p, _sp, 3), dv = !same(v, _sv, 3), dq = !same(q, _sq, 4), dw = !same(w, _sw, 3);
+    if (dp || dv || dq || dw)
+      check(_fleet.engine(), afe_set_state(_fleet.engine(), 0, 1, dp ? p : 0, dv ? v : 0, dq ? q : 0, dw ? w : 0, 0), "afe_set_state");
+  }
+  void pull() {
+    double p[3], v[3], q[4], w[3];
+    check(_fleet.engine(), afe_get_state(_fleet.engine(), 0, 1, p, v, q, w, 0), "afe_get_state");
+    _pos = Vec3d(p[0], p[1], p[2]);
+    _vel = Vec3d(v[0], v[1], v[2]);
+    _att = Rotationd(q[0], q[1], q[2], q[3]);
+    _angVel = Vec3d(w[0], w[1], w[2]);
+    remember();
+  }
+
   Fleet<logicType> _fleet;
   double _kThrust;
+  double _sp[3], _sv[3], _sq[4], _sw[3];   // the state as of the last read-back
 };
 
 }  // namespace agrifly

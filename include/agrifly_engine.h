@@ -536,7 +536,9 @@ int afe_nearest_neighbour(afe_engine *e, const float *all_xyz, int64_t n_all,
                           float *dist2_out, int32_t *index_out);
 int afe_nearest_neighbour_grid(afe_engine *e, const float *all_xyz, int64_t n_all, float cell_size,
                                float *dist2_out, int32_t *index_out);
-int afe_neighbour_grid_info(const afe_engine *e, int dims[3], float *cell_size, int64_t *n_cells);
+/* shape of the grid the last query used, and how many of its queries fell through to brute force
+ * (isolated vehicles; reading that count synchronises the device).  Any pointer may be NULL. */
+int afe_neighbour_grid_info(const afe_engine *e, int dims[3], float *cell_size, int64_t *n_cells, int64_t *n_bruteforce);
 /* The O(n_queries * n_all) definition itself, for listed local vehicles (DEVICE
  * array of local indices): the cross-check of the grid at full ensemble size.
  * dist2_out / index_out are indexed by local vehicle like above. */

@@ -1,0 +1,123 @@
+// tests/cpp/test_base_pointer.cpp -- the facade held the way the reference's loops hold a vehicle:
+//   std::shared_ptr<Simulation::SimulationObject6DOF> vehicle     (AIFS_ROS/.../Simulator/main.cpp:83)
+// Everything goes through the base class: the non-virtual state setters / getters that work on the
+// base's members, the virtual Run / SetCommandRadioMsg / GetTelemetryDataPackets / GetAccelerometer /
+// GetRateGyro / AddUWBRadioTarget / GetRadio, and a Simulation::UWBNetwork ranging between two
+// vehicles' radios.  Prints a JSON trace; tests/test_gpu_facade.py checks it against the direct
+// (derived-class) trace and the oracle.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "agrifly/Quadcopter_T.hpp"
+#include "agrifly/UWBNetwork.hpp"
+
+struct TapLogic {
+  float cmd[4];
+  Vec3f gyro, acc;
+  int runs, n_radio, n_uwb;
+  uint8_t last_radio_type, target, my_id, uwb_responder;
+  float uwb_range;
+  TapLogic(BaseTimer *, float) : gyro(0, 0, 0), acc(0, 0, 0), runs(0), n_radio(0), n_uwb(0), last_radio_type(0), target(0),
+                                 my_id(0), uwb_responder(0), uwb_range(0) {
+    for (int i = 0; i < 4; i++) cmd[i] = 0;
+  }
+  void Initialise(int, uint8_t id) { my_id = id; }
+  void GetEstimate(Vec3f &, Vec3f &, Rotationf &, Vec3f &) const {}
+  int AddRangingTargetId(uint8_t id, Vec3f) { target = id; return 0; }
+  void SetRadioMessage(RadioTypes::RadioMessageDecoded::RawMessage const m) { n_radio++; last_radio_type = m.raw[0]; }
+  void GetTelemetryDataPackets(TelemetryPacket::data_packet_t &a, TelemetryPacket::data_packet_t &b) {
+    std::memset(&a, 0, sizeof(a));
+    std::memset(&b, 0, sizeof(b));
+    a.type = 0; b.type = 1;
+    a.packetNumber = b.packetNumber = (uint8_t)runs;
+  }
+  Vec3f GetAccelerometer() const { return acc; }
+  Vec3f GetRateGyro() const { return gyro; }
+  void SetBatteryMeasurement(float, float) {}
+  void SetIMUMeasurementRateGyro(float x, float y, float z) { gyro = Vec3f(x, y, z); }
+  void SetIMUMeasurementAccelerometer(float x, float y, float z) { acc = Vec3f(x, y, z); }
+  void SetIMUMeasurementTemperature(float) {}
+  void Run() { runs++; }
+  float GetMotorSpeedCmd(unsigned i) const { return cmd[i]; }
+  uint8_t GetNextUWBRangingTarget() const { return target; }
+  void SetUWBMeasurement(float range, uint8_t responder, bool) { n_uwb++; uwb_range = range; uwb_responder = responder; }
+};
+
+typedef agrifly::Quadcopter_T<TapLogic> Quad;
+
+static std::shared_ptr<Quad> make(BaseTimer *t, uint8_t id, int precision, double period) {
+  afe_vehicle_params c;
+  afe_params_from_type(afe_type_from_id(1), &c);
+  agrifly::Matrix33 I;
+  for (int k = 0; k < 9; k++) I.m[k] = c.inertia[k];
+  return std::make_shared<Quad>(t, c.mass, I, c.arm_length, Vec3d(0, 0, 0), c.motor_min_speed, c.motor_max_speed,
+                                c.prop_thrust_from_speed_sqr, c.prop_torque_from_speed_sqr, c.motor_time_const,
+                                c.motor_inertia, Vec3d(0.1, 0.1, 0.1), id, 5, period, precision);
+}
+
+int main(int argc, char **argv) {
+  const int precision = (argc > 1 && !std::strcmp(argv[1], "f64")) ? AFE_F64 : AFE_F32;
+  const uint64_t dt_us = argc > 2 ? (uint64_t)atoll(argv[2]) : 1000;
+  const double period = argc > 3 ? atof(argv[3]) : 0.0005;
+  const int runs = argc > 4 ? atoi(argv[4]) : 4;
+
+  ManualTimer simTimer;
+  std::shared_ptr<Quad> q1 = make(&simTimer, 1, precision, period), q2 = make(&simTimer, 2, precision, period);
+  // what the loops hold
+  std::vector<std::shared_ptr<Simulation::SimulationObject6DOF> > vehicles;
+  vehicles.push_back(q1);
+  vehicles.push_back(q2);
+  afe_vehicle_params c;
+  afe_params_from_type(5, &c);
+  const double wh = std::sqrt(c.mass * 9.81 / (4 * c.prop_thrust_from_speed_sqr));
+  for (size_t k = 0; k < vehicles.size(); k++) {
+    Simulation::SimulationObject6DOF &v = *vehicles[k];
+    v.SetPosition(Vec3d(0 + 3.0 * k, 0 - 1.0 * k, 1 + 0.5 * k));
+    v.SetAttitude(Rotationd::FromEulerYPR(0.3, 0.1, -0.2));
+    v.SetVelocity(Vec3d(1, -2, 0.5));
+    v.SetAngularVelocity(Vec3d(0.5, -0.4, 0.3));
+    Quad &q = k == 0 ? *q1 : *q2;
+    q.Logic().cmd[0] = float(wh * 1.02); q.Logic().cmd[1] = float(wh * 0.99);
+    q.Logic().cmd[2] = float(wh * 1.01); q.Logic().cmd[3] = float(wh * 0.98);
+  }
+  vehicles[0]->AddUWBRadioTarget(2, Vec3f(0, 0, 0));   // vehicle 1 wants to range to radio 2
+  Simulation::UWBNetwork net(&simTimer, 0.0015);
+  net.SetNoiseProperties(0.05, 0.0, 3.0);
+  for (size_t k = 0; k < vehicles.size(); k++) net.AddRadio(vehicles[k]->GetRadio());
+  RadioTypes::RadioMessageDecoded::RawMessage raw;
+  const float w0[3] = {0.1f, -0.2f, 0.3f};
+  afe_radio_create_rates_command(0, 9.81f, w0, raw.raw);
+
+  std::printf("{\"precision\": %d, \"trace\": [\n", precision);
+  for (int s = 0; s < runs; s++) {
+    for (size_t k = 0; k < vehicles.size(); k++) vehicles[k]->Run();   // main.cpp:323-325
+    net.Run();
+    simTimer.AdvanceMicroSeconds(dt_us);
+    if (s == 1) vehicles[0]->SetCommandRadioMsg(raw);
+    if (s == 2) vehicles[1]->SetVelocity(Vec3d(0, 0, 0));              // a setter between two Run()s must take effect
+    Vec3d g, a;
+    vehicles[0]->GetRateGyro(g);
+    vehicles[0]->GetAccelerometer(a);
+    TelemetryPacket::data_packet_t t1, t2;
+    vehicles[0]->GetTelemetryDataPackets(t1, t2);
+    std::printf(" {");
+    for (size_t k = 0; k < vehicles.size(); k++) {
+      const Vec3d p = vehicles[k]->GetPosition(), v = vehicles[k]->GetVelocity(), w = vehicles[k]->GetAngularVelocity();
+      const Rotationd q = vehicles[k]->GetAttitude();
+      std::printf("\"pos%zu\": [%.17g, %.17g, %.17g], \"vel%zu\": [%.17g, %.17g, %.17g], \"att%zu\": [%.17g, %.17g, %.17g, %.17g], "
+                  "\"ang_vel%zu\": [%.17g, %.17g, %.17g], ", k, p.x, p.y, p.z, k, v.x, v.y, v.z, k, q[0], q[1], q[2], q[3], k, w.x, w.y, w.z);
+    }
+    std::printf("\"gyro\": [%.9g, %.9g, %.9g], \"acc\": [%.9g, %.9g, %.9g], \"runs\": %d, \"n_radio\": %d, \"radio_type\": %d, "
+                "\"telemetry\": [%d, %d, %d], \"n_uwb\": [%d, %d], \"uwb_range\": %.9g, \"uwb_responder\": %d, "
+                "\"radio_pos\": [%.17g, %.17g, %.17g]}%s\n",
+                g.x, g.y, g.z, a.x, a.y, a.z, q1->Logic().runs, q1->Logic().n_radio, q1->Logic().last_radio_type, t1.type, t2.type,
+                t1.packetNumber, q1->Logic().n_uwb, q2->Logic().n_uwb, q1->Logic().uwb_range, q1->Logic().uwb_responder,
+                vehicles[1]->GetRadio()->GetPosition().x, vehicles[1]->GetRadio()->GetPosition().y,
+                vehicles[1]->GetRadio()->GetPosition().z, s + 1 < runs ? "," : "");
+  }
+  std::printf("]}\n");
+  return 0;
+}

@@ -81,3 +81,40 @@ def test_facade_reproduces_survey_tap_trace():
         np.testing.assert_allclose(tr[s + 1]["pos"], SURVEY_TAP_POS[s], rtol=1e-13)
         np.testing.assert_allclose(tr[s + 1]["ang_vel"], SURVEY_TAP_W[s], rtol=1e-12)
     assert tr[0]["runs"] == 0 and tr[1]["runs"] == 1   # first Run() is the dt == 0 early return
+
+
+BASE_EXE = os.path.join(ROOT, "tests", "cpp", "test_base_pointer")
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_facade_through_the_simulationobject6dof_base_pointer(ora, precision):
+    """tests/cpp/test_base_pointer.cpp holds two vehicles as std::shared_ptr<Simulation::SimulationObject6DOF>
+    (AIFS_ROS/.../Simulator/main.cpp:83) and uses nothing but the base class: the trace of vehicle 0 must be the
+    one the derived class gives directly (same scenario as test_facade), setters between Run()s take effect,
+    radio / telemetry / IMU virtuals reach the logic, and a Simulation::UWBNetwork over GetRadio() delivers
+    the range the reference's completion branch would (UWBNetwork.cpp:66-71, noise stream seeded 0)."""
+    for exe in (EXE, BASE_EXE):
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    runs = 8
+    direct = json.loads(subprocess.check_output([EXE, precision, "1000", "0.0005", str(runs)]))["trace"]
+    base = json.loads(subprocess.check_output([BASE_EXE, precision, "1000", "0.0005", str(runs)]))["trace"]
+    assert len(base) == runs
+    for s in range(runs):
+        for k in ("pos", "vel", "att", "ang_vel"):
+            assert base[s][k + "0"] == direct[s][k], (s, k)          # bit for bit the derived-class path
+        assert base[s]["gyro"] == direct[s]["gyro"] and base[s]["acc"] == direct[s]["acc"]
+        assert base[s]["runs"] == direct[s]["runs"]
+        assert base[s]["telemetry"] == [0, 1, base[s]["runs"] % 256]
+        assert base[s]["n_radio"] == (1 if s >= 1 else 0) and base[s]["radio_type"] == (5 if s >= 1 else 0)
+    # SetVelocity(0) on vehicle 1 after Run #3: the next step starts from rest (only gravity / thrust / drag act)
+    assert np.linalg.norm(base[2]["vel1"]) > 2.0 and np.linalg.norm(base[3]["vel1"]) < 0.05
+    # UWB: request seen at t = 2 ms, completed at t = 4 ms (0.0015 s period), delivered to the logic on the next tick
+    assert [b["n_uwb"][0] for b in base] == [0, 0, 0, 0, 0, 1, 1, 1]
+    assert [b["n_uwb"][1] for b in base][-1] == 1                    # everyone "hears" the measurement
+    assert base[5]["uwb_responder"] == 2
+    u = ora.UwbNetwork(0.05, 0.0, 3.0)
+    want, outlier = u.range(base[4]["pos0"], base[4]["radio_pos"])
+    assert outlier == 0
+    assert np.float32(base[5]["uwb_range"]) == want
+    assert base[4]["radio_pos"] == base[4]["pos1"]                   # the radio carries the vehicle's true position
