@@ -1,0 +1,259 @@
+// rappids_headless -- the Rappids_Simulator loop (Simulator/Rappids_Simulator/main.cpp:116-749) for a
+// whole ensemble, headless, over the C ABI of the MI355X engine.
+//
+// What is the reference's:  the loop order and cadences (:140-142,174-178,330,391-392,451-476,611-673,
+//   737-739), the Timer / strict-'>' gates, the 16-bit radio uplink and its 30 ms CommunicationsDelay,
+//   the CSV log with exactly the columns of :266-270 written exactly as :676-733 writes them.
+// What runs on the GPU:     quad->Run() for every vehicle -- physics, motors, IMU synthesis and the
+//   rates-control slice of Onboard::QuadcopterLogic (afe_set_rates_logic) -- one launch per step.
+// What is stubbed, and says so in the log header comment line when --verbose:
+//   * AirSim / Unity (:183-184,300-321,331-389,397-438): absent; with --scene orchard the depth image
+//     comes from the engine's own depth camera and the RAPPIDS planner runs on the GPU (afe_rappids_plan).
+//   * MocapStateEstimator (:221-224,451-457,468-469): the estimate handed to the controller is the
+//     TRUE state sampled at the offboard tick (caller-side GNC is out of scope, SURVEY section 2 row 10;
+//     inside the agri-fly tree the reference's estimator and controller drop in here unchanged).
+//   * QuadcopterController::Run (:625-627): restated below (float, QuadcopterController.cpp:11-74)
+//     because the tree's Offboard/ sources are not part of this repository.
+//   * telemetry (:459-466,659-664): m1..m4 are the commanded motor forces k_f cmd^2 put through the
+//     reference's telemetry quantisation (afe_telemetry_encode / _decode); panic is always 0.
+//
+//   rappids_headless [--vehicles N] [--seconds T] [--dt-us 2000] [--precision f32|f64]
+//                    [--seeds reference|decorrelated] [--log-vehicle i] [--digits D] [--out simulation.csv]
+// Defaults are the reference's own: 1 vehicle, dt = 1/500 s, 8 s, 6 significant digits (ofstream default).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "agrifly/Wire.hpp"
+
+namespace {
+
+template <typename Real>
+std::string toCSV(const Vec3<Real> v, int digits) {   // main.cpp:55-60
+  std::stringstream ss;
+  ss << std::setprecision(digits) << v.x << "," << v.y << "," << v.z << ",";
+  return ss.str();
+}
+
+// Offboard::QuadcopterController::Run, QuadcopterController.cpp:11-74, with the position controller
+// of Logic/QuadcopterPositionController.hpp:22-28 and the attitude controller of
+// Logic/QuadcopterAttitudeController.hpp:35-68 -- float, like the reference.
+struct HoverController {
+  float natFreq, damping, tc_xy, tc_z;
+  float minVerticalProperAcceleration, maxProperAcc, minProperAcc;
+  HoverController() : natFreq(2.0f), damping(0.7f), tc_xy(0.08f), tc_z(0.4f),   // QuadcopterConstants.hpp:214-226
+                      minVerticalProperAcceleration(0.5f * 9.81f), maxProperAcc(20), minProperAcc(-1) {}
+
+  Vec3f GetDesiredAngularVelocity(const Rotationf desAttitude, const Rotationf estAttitude) const {
+    Rotationf errAtt = (desAttitude.Inverse() * estAttitude);
+    const Vec3f desRotVec = errAtt.ToRotationVector();
+    Vec3f desRedAttRotAx = Vec3f(errAtt.Inverse() * Vec3f(0, 0, 1)).Cross(Vec3f(0, 0, 1));
+    float desRedAttRotAn_cos = Vec3f(errAtt.Inverse() * Vec3f(0, 0, 1)).Dot(Vec3f(0, 0, 1));
+    float desRedAttRotAn;
+    if (desRedAttRotAn_cos >= 1.0f) desRedAttRotAn = 0;
+    else if (desRedAttRotAn_cos <= -1.0f) desRedAttRotAn = float(M_PI);
+    else desRedAttRotAn = acosf(desRedAttRotAn_cos);
+    float n = desRedAttRotAx.GetNorm2();
+    if (n < 1e-12f) desRedAttRotAx = Vec3f(0, 0, 0);
+    else desRedAttRotAx = desRedAttRotAx / n;
+    float k3 = (1.0f / tc_z);
+    float k12 = (1.0f / tc_xy);
+    return -k3 * desRotVec - (k12 - k3) * desRedAttRotAn * desRedAttRotAx;
+  }
+
+  void Run(Vec3d const curPos, Vec3d const curVel, Rotationd const curAtt, Vec3d const desPos, Vec3d const desVel,
+           Vec3d const desAcc, double const desiredYawAngle, Vec3d &outCmdAngVel, double &outCmdThrust) const {
+    Vec3f const e3(0, 0, 1);
+    Vec3f const cmdAcc = (Vec3f(desPos) - Vec3f(curPos)) * natFreq * natFreq +
+                         (Vec3f(desVel) - Vec3f(curVel)) * 2 * natFreq * damping + Vec3f(desAcc);
+    Vec3f cmdProperAcc = cmdAcc + Vec3f(0, 0, 9.81f);
+    if (cmdProperAcc.GetNorm2() > maxProperAcc) cmdProperAcc *= maxProperAcc / cmdProperAcc.GetNorm2();
+    if (cmdProperAcc.z < minVerticalProperAcceleration) cmdProperAcc.z = minVerticalProperAcceleration;
+    float const normCmdProperAcc = cmdProperAcc.GetNorm2();
+    Vec3f const cmdThrustDir = cmdProperAcc / normCmdProperAcc;
+    outCmdThrust = normCmdProperAcc * (Rotationf(curAtt) * Vec3f(0, 0, 1)).Dot(cmdThrustDir);
+    if (outCmdThrust < minProperAcc) outCmdThrust = minProperAcc;
+    Rotationf cmdAtt;
+    const float cosAngle = cmdThrustDir.Dot(e3);
+    float angle;
+    if (cosAngle >= (1 - 1e-12f)) angle = 0;
+    else if (cosAngle <= -(1 - 1e-12f)) angle = float(M_PI);
+    else angle = acosf(cosAngle);
+    Vec3f rotAx = e3.Cross(cmdThrustDir);
+    const float n = rotAx.GetNorm2();
+    if (n < 1e-6f) cmdAtt = Rotationf::Identity();
+    else cmdAtt = Rotationf::FromRotationVector(rotAx * (angle / n));
+    Rotationf cmdAttYawed = cmdAtt * Rotationf::FromRotationVector(Vec3f(0, 0, float(desiredYawAngle)));
+    outCmdAngVel = Vec3d(GetDesiredAngularVelocity(cmdAttYawed, Rotationf(curAtt)));
+  }
+};
+
+void die(afe_engine *e, int rc, const char *what) {
+  if (rc == AFE_OK) return;
+  std::fprintf(stderr, "rappids_headless: %s failed: %s (%s)\n", what, afe_status_string(rc), e ? afe_last_error(e) : "");
+  std::exit(1);
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  int64_t nVehicles = 1, logVehicle = 0;
+  double endTime = 8.0;                  // main.cpp:142
+  uint64_t dt_us_arg = 0;
+  int precision = AFE_F32, seeds = AFE_SEED_REFERENCE, digits = 6;
+  std::string outPath = "simulation.csv";
+  for (int a = 1; a < argc; a++) {
+    const std::string k = argv[a];
+    const char *v = a + 1 < argc ? argv[a + 1] : "";
+    if (k == "--vehicles") { nVehicles = atoll(v); a++; }
+    else if (k == "--seconds") { endTime = atof(v); a++; }
+    else if (k == "--dt-us") { dt_us_arg = (uint64_t)atoll(v); a++; }
+    else if (k == "--precision") { precision = std::strcmp(v, "f64") ? AFE_F32 : AFE_F64; a++; }
+    else if (k == "--seeds") { seeds = std::strcmp(v, "decorrelated") ? AFE_SEED_REFERENCE : AFE_SEED_DECORRELATED; a++; }
+    else if (k == "--log-vehicle") { logVehicle = atoll(v); a++; }
+    else if (k == "--digits") { digits = atoi(v); a++; }
+    else if (k == "--out") { outPath = v; a++; }
+    else { std::fprintf(stderr, "rappids_headless: unknown option %s\n", k.c_str()); return 2; }
+  }
+  if (nVehicles < 1 || logVehicle < 0 || logVehicle >= nVehicles || digits < 1) return 2;
+
+  // Basic timing, main.cpp:139-144
+  const double dt = dt_us_arg ? dt_us_arg * 1e-6 : 1.0 / 500.0;
+  ManualTimer simTimer;
+  // the vehicle(s): id 1 -> QC_TYPE_CF_MINIQUAD (main.cpp:146-164,211-218)
+  uint8_t vehicleId = 1;
+  afe_vehicle_params vehConsts;
+  die(0, afe_params_from_type(afe_type_from_id(vehicleId), &vehConsts), "afe_params_from_type");
+  afe_rates_logic_params logicConsts;
+  die(0, afe_rates_logic_params_from_type(afe_type_from_id(vehicleId), &logicConsts), "afe_rates_logic_params_from_type");
+  double const periodMocapSystem = 1.0 / 200.0;        // :174
+  double const periodOffboardMainLoop = 1.0 / 100.0;   // :175
+  double const periodTelemetryLoop = 1.0 / 100.0;      // :176
+  double const periodOnboardLogic = 1.0 / 500.0;       // :177
+  double const timeDelayOffboardControlLoopTrue = 0.03;   // :178
+
+  afe_engine *quad = 0;
+  die(0, afe_create(&quad, nVehicles, precision, -1, 0), "afe_create");
+  die(quad, afe_set_type_table(quad, &vehConsts, 1), "afe_set_type_table");
+  die(quad, afe_set_logic_period(quad, periodOnboardLogic), "afe_set_logic_period");
+  die(quad, afe_set_imu_noise(quad, 1, 0.1, 0.2, seeds), "afe_set_imu_noise");       // Quadcopter_T.cpp:5-6
+  die(quad, afe_set_rates_logic(quad, &logicConsts, 1), "afe_set_rates_logic");
+  // quad->SetPosition(initErrPos); quad->SetAttitude(initErrAtt): origin, identity (:279-280) = the engine's initial state
+
+  HoverController ctrl;
+  Vec3d desiredPosition(0, 0, 3.5);   // :240
+  Vec3d desiredVelocity(0, 0, 0);
+  double desYawAngleDeg = 0;
+
+  std::ofstream logfile(outPath.c_str());
+  if (!logfile) { std::fprintf(stderr, "rappids_headless: cannot open %s\n", outPath.c_str()); return 1; }
+  logfile << std::setprecision(digits);
+  logfile << "t,posx,posy,posz,velx,vely,velz,attY,attP,attR,angvelx,angvely,angvelz,m1,m2,m3,m4,"
+             "estposx,estposy,estposz,estvelx,estvely,estvelz,esty,estp,estr,estangx,estangy,estangz,"
+             "desposx,desposy,desposz,desvelx,desvely,desvelz,panic,r1,r2,r3,r4\n";      // :266-270
+  std::printf("Starting simulation\n");
+
+  Timer t(&simTimer);
+  Timer integrationTimer(&simTimer);       // SimulationObject::_integrationTimer
+  typedef std::vector<agrifly::RawRadioMessage> RadioBatch;   // one uplink packet per vehicle
+  agrifly::DelayLine<RadioBatch> cmdRadioChannel(&simTimer, timeDelayOffboardControlLoopTrue);   // :282
+  Timer timerPrint(&simTimer), timerMocap(&simTimer), timerOffboardMainLoop(&simTimer), timerTelemetryLoop(&simTimer);
+  float lastRadioCommand[4] = {0, 0, 0, 0};
+  std::vector<double> pos(3 * nVehicles), vel(3 * nVehicles), att(4 * nVehicles), angVel(3 * nVehicles);
+  std::vector<float> cmds(4 * nVehicles), gyro(3 * nVehicles), acc(3 * nVehicles);
+  const int64_t N = nVehicles, L = logVehicle;
+
+  while (t.GetSeconds<double>() < endTime) {                                  // :330
+    {   // quad->Run(), Quadcopter_T.cpp:85-91: dt from the integration timer, nothing on the first call
+      const uint64_t run_us = integrationTimer.GetMicroSeconds();
+      if ((double)((double)run_us * 1e-6) >= 1e-6) {
+        integrationTimer.Reset();
+        die(quad, afe_step(quad, run_us, 1), "afe_step");
+      }
+    }
+    simTimer.AdvanceMicroSeconds(uint64_t(dt * 1e6));                          // :392
+
+    if (timerPrint.GetSeconds<double>() >= 1) {                                // :446-449
+      timerPrint.AdjustTimeBySeconds(-1);
+      std::printf("Current sim time = %.1fs\n", t.GetSeconds<double>());
+    }
+    if (timerMocap.GetSeconds<double>() > periodMocapSystem)                   // :451-457 (estimator stubbed)
+      timerMocap.AdjustTimeBySeconds(-periodMocapSystem);
+    if (timerTelemetryLoop.GetSeconds<double>() > periodTelemetryLoop)         // :459-466 (no consumer)
+      timerTelemetryLoop.AdjustTimeBySeconds(-periodTelemetryLoop);
+
+    if (timerOffboardMainLoop.GetSeconds<double>() > periodOffboardMainLoop) { // :471
+      timerOffboardMainLoop.AdjustTimeBySeconds(-periodOffboardMainLoop);      // :476
+      die(quad, afe_get_state(quad, 0, N, pos.data(), vel.data(), att.data(), angVel.data(), 0), "afe_get_state");
+      RadioBatch batch((size_t)N);
+      for (int64_t i = 0; i < N; i++) {                                        // :611-638 for every vehicle
+        Vec3d cmdAngVel;
+        double cmdThrust;
+        ctrl.Run(Vec3d(pos[i], pos[N + i], pos[2 * N + i]), Vec3d(vel[i], vel[N + i], vel[2 * N + i]),
+                 Rotationd(att[i], att[N + i], att[2 * N + i], att[3 * N + i]), desiredPosition, Vec3d(0, 0, 0),
+                 Vec3d(0, 0, 0), desYawAngleDeg * M_PI / 180.0, cmdAngVel, cmdThrust);
+        batch[(size_t)i] = agrifly::MakeRatesCommand(0, float(cmdThrust), Vec3f(cmdAngVel));   // CreateRatesCommand
+        if (i == L) {
+          lastRadioCommand[0] = cmdThrust;                                     // :643-646
+          lastRadioCommand[1] = cmdAngVel.x;
+          lastRadioCommand[2] = cmdAngVel.y;
+          lastRadioCommand[3] = cmdAngVel.z;
+        }
+      }
+      // telemetry of the logged vehicle, :659-664
+      die(quad, afe_get_motor_cmds(quad, 0, N, cmds.data()), "afe_get_motor_cmds");
+      die(quad, afe_get_imu(quad, 0, N, gyro.data(), acc.data()), "afe_get_imu");
+      afe_telemetry_packet tp, dataPacket;
+      std::memset(&tp, 0, sizeof(tp));
+      std::memset(&dataPacket, 0, sizeof(dataPacket));
+      tp.type = 0;
+      for (int k = 0; k < 3; k++) { tp.accel[k] = acc[k * N + L]; tp.gyro[k] = gyro[k * N + L]; tp.position[k] = float(pos[k * N + L]); }
+      for (int m = 0; m < 4; m++) tp.motor_forces[m] = float(vehConsts.prop_thrust_from_speed_sqr) * cmds[m * N + L] * cmds[m * N + L];
+      uint8_t wire[AFE_TELEMETRY_PACKET_SIZE];
+      afe_telemetry_encode(&tp, wire);
+      afe_telemetry_decode(wire, &dataPacket);
+
+      cmdRadioChannel.AddMessage(batch);                                       // :673
+
+      // the log row, :676-733
+      const Vec3d p(pos[L], pos[N + L], pos[2 * N + L]), v(vel[L], vel[N + L], vel[2 * N + L]);
+      const Vec3d w(angVel[L], angVel[N + L], angVel[2 * N + L]);
+      const Rotationd q(att[L], att[N + L], att[2 * N + L], att[3 * N + L]);
+      logfile << t.GetSeconds<double>() << ",";
+      logfile << toCSV(p, digits);
+      logfile << toCSV(v, digits);
+      logfile << toCSV(q.ToEulerYPR(), digits);
+      logfile << toCSV(w, digits);
+      for (int m = 0; m < 4; m++) logfile << dataPacket.motor_forces[m] << ",";
+      // estimator state (stub: the truth, narrowed to float like EstimatedState)
+      logfile << toCSV(Vec3f(p), digits);
+      logfile << toCSV(Vec3f(v), digits);
+      logfile << toCSV(Rotationf(q).ToEulerYPR(), digits);
+      logfile << toCSV(Vec3f(w), digits);
+      logfile << toCSV(desiredPosition, digits);
+      logfile << toCSV(desiredVelocity, digits);
+      logfile << int(dataPacket.panic_reason) << ",";
+      for (int i = 0; i < 4; i++) logfile << double(lastRadioCommand[i]) << ",";
+      logfile << "\n";
+    }
+
+    if (cmdRadioChannel.HaveNewMessage()) {                                    // :737-739
+      const RadioBatch msg = cmdRadioChannel.GetMessage();
+      die(quad, afe_set_commands_from_radio(quad, 0, N, msg[0].raw), "afe_set_commands_from_radio");
+    }
+  }
+  die(quad, afe_sync(quad), "afe_sync");
+  uint64_t ticks = 0, now = 0;
+  afe_logic_ticks(quad, &ticks);
+  afe_time_us(quad, &now);
+  std::printf("Done. %lld vehicle(s), engine clock %.6f s, %llu logic ticks\n", (long long)N, now * 1e-6, (unsigned long long)ticks);
+  logfile.close();
+  afe_destroy(quad);
+  return 0;
+}

@@ -1,0 +1,137 @@
+"""the headless Rappids_Simulator loop (agri-fly_amd/cli/rappids_headless.cpp, plain C++
+over the C ABI) flies BASELINE config 1 -- one CF_MINIQUAD from the ground to a 3.5 m hover, dt = 1 ms,
+500 Hz onboard logic on the device, 100 Hz offboard loop, 16-bit radio, 30 ms delay -- and writes
+simulation.csv with the reference's columns (Simulator/Rappids_Simulator/main.cpp:266-270,676-733).
+
+The log is checked three ways: its format against the reference's header and writing rules; its flight
+against the ORACLE loop replaying the logged radio commands through the same quantisation, delay and gate
+order (tests/closed_loop.py's loop: the program's clocking, gating, uplink and stepping are then the only
+things under test); and its controller column against the independent numpy restatement of
+QuadcopterController::Run in tests/offboard_stub.py.  Needs an MI355X."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.offboard_stub import OffboardHover, radio_quantise
+from tests.scenarios import MEASUREMENTS, afa
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "agri-fly_amd", "bin", "rappids_headless")
+HEADER = ("t,posx,posy,posz,velx,vely,velz,attY,attP,attR,angvelx,angvely,angvelz,m1,m2,m3,m4,"
+          "estposx,estposy,estposz,estvelx,estvely,estvelz,esty,estp,estr,estangx,estangy,estangz,"
+          "desposx,desposy,desposz,desvelx,desvely,desvelz,panic,r1,r2,r3,r4")
+
+
+def _run(tmp_path, *args):
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "agri-fly_amd", "csrc"), "cli"])
+    out = str(tmp_path / "simulation.csv")
+    txt = subprocess.check_output([EXE, "--out", out] + [str(a) for a in args]).decode()
+    lines = open(out).read().split("\n")
+    assert lines[0] == HEADER and lines[-1] == ""
+    rows = []
+    for l in lines[1:-1]:
+        cells = l.split(",")
+        assert len(cells) == 41 and cells[-1] == ""        # every value is followed by a comma, as in the reference
+        rows.append([float(c) for c in cells[:-1]])
+    return np.array(rows), txt
+
+
+def _ypr(q):
+    """Rotation.hpp:163-176"""
+    y = np.arctan2(2 * q[1] * q[2] + 2 * q[0] * q[3], q[1] * q[1] + q[0] * q[0] - q[3] * q[3] - q[2] * q[2])
+    p = -np.arcsin(2 * q[1] * q[3] - 2 * q[0] * q[2])
+    r = np.arctan2(2 * q[2] * q[3] + 2 * q[0] * q[1], q[3] * q[3] - q[2] * q[2] - q[1] * q[1] + q[0] * q[0])
+    return np.array([y, p, r])
+
+
+def _replay(ora, rows, seconds, dt_us=1000, period=1 / 500):
+    """the oracle through the loop of main.cpp:330,391-392,471-476,673,737-739 with the LOGGED commands"""
+    b = ora.Batch(1, [ora.params_from_type(5)])
+    cl = ora.ClosedLoopBatch(b, [ora.logic_params_from_type(5, period)], period)
+    n_runs = int(round(seconds * 1e6 / dt_us))
+    dts, ticks = ora.clock_ticks(dt_us * 1e-6, period, n_runs)
+    now, gate_reset, queue, k, out = 0, 0, [], 0, []
+    for it in range(n_runs):
+        if dts[it] > 0:
+            cl.step(dts[it], [ticks[it]])
+        now += dt_us
+        if (now - gate_reset) * 1e-6 > 0.01:                         # timerOffboardMainLoop, strict >
+            gate_reset += 10000
+            row = rows[k]
+            k += 1
+            assert row[0] == pytest.approx(now * 1e-6, abs=1e-12)
+            out.append(np.concatenate([b.pos[:, 0], b.vel[:, 0], _ypr(b.att[:, 0]), b.ang_vel[:, 0]]))
+            queue.append((now + 30000, radio_quantise(np.float32([row[36]]), 35),
+                          radio_quantise(np.float32(row[37:40]).reshape(3, 1), 35)))
+        if queue and now >= queue[0][0]:
+            _, th, w = queue.pop(0)
+            cl.set_rates_cmd(th, w)
+    assert k == len(rows)
+    return np.array(out), b
+
+
+@pytest.mark.parametrize("precision,seconds", [("f64", 10.0), ("f32", 3.0)])
+def test_config1_hover_log_against_the_oracle_loop(ora, tmp_path, precision, seconds):
+    rows, txt = _run(tmp_path, "--dt-us", 1000, "--seconds", seconds, "--precision", precision, "--digits", 17)
+    assert "Starting simulation" in txt and "Done." in txt
+    assert len(rows) == int(round(seconds * 100)) - 1              # gates at 11, 21, ... ms
+    assert rows[0, 0] == pytest.approx(0.011) and rows[1, 0] == pytest.approx(0.021)    # strict '>' gate: 11 ms, 21 ms, ...
+    want, b = _replay(ora, rows, seconds)
+    got = rows[:, 1:13]
+    err = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
+    worst = err.max(0)
+    MEASUREMENTS["headless_config1_vs_oracle_replay[%s]" % precision] = {
+        "seconds": seconds, "rows": len(rows), "worst_rel_err": dict(zip(HEADER.split(",")[1:13], worst.tolist()))}
+    if precision == "f64":
+        assert worst.max() <= 1e-10, worst
+    else:
+        # fp32 engine vs double oracle on the SAME command sequence: attitude and position are open loop
+        # here (no controller correcting the oracle), so rounding differences integrate: 1e-3 over 3 s
+        assert worst[:6].max() <= 2e-3 and worst[6:9].max() <= 2e-3 and worst[9:].max() <= 5e-2, worst
+    # the flight itself: off the ground, settled at the 3.5 m set-point by 10 s
+    assert rows[-1, 3] > (3.4 if seconds >= 10 else 1.0) and abs(rows[-1, 1]) < 0.05 and abs(rows[-1, 2]) < 0.05
+    # columns that are functions of others in the same row
+    np.testing.assert_array_equal(rows[:, 17:20], rows[:, 1:4].astype(np.float32))      # est pos = truth narrowed to float (stub)
+    np.testing.assert_array_equal(rows[:, 29:35], np.tile([0, 0, 3.5, 0, 0, 0], (len(rows), 1)))
+    np.testing.assert_array_equal(rows[:, 35], 0)                                       # panic
+    assert np.all((rows[:, 13:17] >= 0) & (rows[:, 13:17] <= 10))                       # telemetry force range
+    assert rows[-1, 13:17].sum() == pytest.approx(0.142 * 9.81, rel=0.05)               # hover: the four forces carry the weight
+    # the controller column against the independent numpy restatement, on the logged states
+    stub = OffboardHover(1)
+    for r in rows[:: max(1, len(rows) // 50)]:
+        q = _quat_from_ypr(r[7:10])
+        th, w = stub.controller(r[1:4].reshape(3, 1), r[4:7].reshape(3, 1), q.reshape(4, 1))
+        assert th[0] == pytest.approx(r[36], rel=2e-5, abs=2e-5)
+        np.testing.assert_allclose(w[:, 0], r[37:40], rtol=2e-4, atol=2e-4)
+
+
+def _quat_from_ypr(ypr):
+    y, p, r = ypr
+    cy, sy, cp, sp, cr, sr = np.cos(y / 2), np.sin(y / 2), np.cos(p / 2), np.sin(p / 2), np.cos(r / 2), np.sin(r / 2)
+    return np.array([cy * cp * cr + sy * sp * sr, cy * cp * sr - sy * sp * cr, cy * sp * cr + sy * cp * sr,
+                     sy * cp * cr - cy * sp * sr])
+
+
+def test_reference_defaults_and_an_ensemble(tmp_path):
+    """no options = the reference's own run: dt = 1/500 s, 8 s, 6 significant digits; and the same
+    program flying 4096 vehicles with per-vehicle noise streams"""
+    rows, txt = _run(tmp_path)
+    assert len(rows) == 799                                        # gates at 12, 22, ..., 7992 ms with dt = 2 ms
+    assert rows[0, 0] == pytest.approx(0.012)
+    assert "Current sim time = 7.0s" in txt
+    assert abs(rows[-1, 3] - 3.5) < 0.1
+    for cell in open(str(tmp_path / "simulation.csv")).read().split("\n")[400].split(",")[:-1]:
+        mantissa = cell.lstrip("-").split("e")[0].replace(".", "").lstrip("0")
+        assert len(mantissa) <= 6, cell                            # ofstream's default precision, like the reference's log
+    a, _ = _run(tmp_path, "--vehicles", 4096, "--seconds", 1.0, "--dt-us", 1000, "--seeds", "decorrelated", "--log-vehicle", 7,
+                "--digits", 17)
+    b, _ = _run(tmp_path, "--vehicles", 4096, "--seconds", 1.0, "--dt-us", 1000, "--seeds", "decorrelated", "--log-vehicle", 4000,
+                "--digits", 17)
+    assert a.shape == b.shape and np.isfinite(a).all() and np.isfinite(b).all()
+    assert not np.array_equal(a[:, 10:13], b[:, 10:13])            # different noise streams, different body rates
+    assert abs(a[-1, 3] - b[-1, 3]) < 0.05                         # same climb
