@@ -889,25 +889,35 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
   return AFE_OK;
 }
 
-extern "C" int afe_selftest_normals(afe_engine *e, const uint32_t *seeds, int64_t n, double *normals6, uint32_t *state_after) {
+namespace {
+int selftest_normals_any(afe_engine *e, const uint32_t *seeds, int64_t n, void *normals6, size_t elem_bytes, uint32_t *state_after) {
   if (!e || !seeds || n <= 0 || !normals6 || !state_after) return fail(e, AFE_ERR_INVALID_ARG, "bad selftest arguments");
   for (int64_t k = 0; k < n; k++)
     if (seeds[k] == 0 || seeds[k] >= 2147483647u) return fail(e, AFE_ERR_INVALID_ARG, "minstd_rand0 state must be in [1, 2^31-2]");
   AFE_HIP(e, hipSetDevice(e->device));
   uint32_t *d_seed = nullptr, *d_state = nullptr;
-  double *d_out = nullptr;
+  void *d_out = nullptr;
   AFE_HIP(e, hipMalloc((void **)&d_seed, (size_t)n * 4));
   AFE_HIP(e, hipMalloc((void **)&d_state, (size_t)n * 4));
-  AFE_HIP(e, hipMalloc((void **)&d_out, (size_t)n * 48));
+  AFE_HIP(e, hipMalloc((void **)&d_out, (size_t)n * 6 * elem_bytes));
   int rc = AFE_OK;
   if (hipMemcpy(d_seed, seeds, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
-      launch_normals_selftest(d_seed, n, d_out, d_state, e->stream) != 0 ||
+      (elem_bytes == 8 ? launch_normals_selftest(d_seed, n, (double *)d_out, d_state, e->stream)
+                       : launch_normals_selftest_f32(d_seed, n, (float *)d_out, d_state, e->stream)) != 0 ||
       hipStreamSynchronize(e->stream) != hipSuccess ||
-      hipMemcpy(normals6, d_out, (size_t)n * 48, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(normals6, d_out, (size_t)n * 6 * elem_bytes, hipMemcpyDeviceToHost) != hipSuccess ||
       hipMemcpy(state_after, d_state, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
     rc = fail(e, AFE_ERR_HIP, "normals selftest failed");
   (void)hipFree(d_seed); (void)hipFree(d_state); (void)hipFree(d_out);
   return rc;
+}
+}  // namespace
+
+extern "C" int afe_selftest_normals(afe_engine *e, const uint32_t *seeds, int64_t n, double *normals6, uint32_t *state_after) {
+  return selftest_normals_any(e, seeds, n, normals6, 8, state_after);
+}
+extern "C" int afe_selftest_normals_f32(afe_engine *e, const uint32_t *seeds, int64_t n, float *normals6, uint32_t *state_after) {
+  return selftest_normals_any(e, seeds, n, normals6, 4, state_after);
 }
 
 extern "C" int afe_pack_positions(afe_engine *e, float *device_xyz) {

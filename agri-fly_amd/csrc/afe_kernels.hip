@@ -69,6 +69,15 @@ __device__ __forceinline__ uint32_t minstd_next(uint32_t &s) {
   return r;
 }
 
+// x * k mod (2^31 - 1) for x, k in [1, 2^31 - 2]: the product is below 2^62, hi + lo below 2^32 - 1,
+// and the result is never 0 (the modulus is prime), so one conditional subtraction finishes it
+__device__ __forceinline__ uint32_t minstd_mul(uint32_t x, uint32_t k) {
+  const uint64_t p = (uint64_t)x * k;
+  uint32_t r = (uint32_t)(p & 0x7fffffffu) + (uint32_t)(p >> 31);
+  if (r >= 2147483647u) r -= 2147483647u;
+  return r;
+}
+
 __device__ __forceinline__ double canonical53(uint32_t &s) {
 #pragma clang fp contract(off)
   // generate_canonical<double,53>: two engine calls, R = 2147483646; the
@@ -132,36 +141,125 @@ __device__ __forceinline__ double polar_multiplier(double r2) {
   return L * g;
 }
 
-// Six N(0,1) draws = three Marsaglia polar pairs, in libstdc++'s order: pair k
-// yields d[2k] = y*mult (returned by the first operator() call) and d[2k+1] =
-// x*mult (the cached value returned by the second call).  Lanes with different
-// engine words reject different candidates; one merged acceptance loop (each
-// lane keeps drawing until it holds three accepted candidates) costs
-// max-over-lanes of the SUM of three geometric counts instead of three times
-// the max of one, and keeps the multiplier out of the divergent loop.  Accepted
-// candidates enter a three-deep shift register (one predicated block per
-// iteration); slot 2 ends up holding the first pair.
-__device__ __forceinline__ void six_normals(uint32_t &s, double d[6]) {
+// The same multiplier for the fp32 engine, whose noise samples are floats anyway (the reference narrows
+// them too: Vec3f(float(n(g)), ...), Quadcopter_T.cpp:167-169): same range reduction, with f = m - 1 still
+// taken exactly in double so that nothing cancels near r2 = 1 (where the multiplier and the sample go to
+// zero), everything after it in fp32 with the hardware reciprocal / square root.  Relative error of the
+// result ~3e-7 (a few float ulp) for every r2 in (0, 1]; ~1/3 of the cycles of the double version.
+__device__ __forceinline__ float polar_multiplier_f32(double r2) {
 #pragma clang fp contract(off)
-  double ax0 = 0, ay0 = 0, ar0 = 1, ax1 = 0, ay1 = 0, ar1 = 1, ax2 = 0, ay2 = 0, ar2 = 1;
+  double m = __builtin_amdgcn_frexp_mant(r2);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(r2);
+  if (m < 0.70710678118654752) { m = m + m; e -= 1; }
+  const float f = (float)(m - 1.0);            // the difference is exact; only its narrowing rounds
+  const float sq = f * __builtin_amdgcn_rcpf(2.0f + f);
+  const float z = sq * sq;                      // <= 0.0295
+  float p = 1.0f / 9.0f;
+  p = __builtin_fmaf(p, z, 1.0f / 7.0f);
+  p = __builtin_fmaf(p, z, 1.0f / 5.0f);
+  p = __builtin_fmaf(p, z, 1.0f / 3.0f);
+  const float two_s = sq + sq;
+  const float lnm = __builtin_fmaf(two_s * z, p, two_s);
+  const float ln_r2 = __builtin_fmaf((float)e, 0.693147182f, lnm);
+  const float L = -2.0f * ln_r2;               // >= 0; == 0 only for r2 == 1
+  if (!(L > 0.0f)) return 0.0f;
+  return __builtin_amdgcn_sqrtf(L * __builtin_amdgcn_rcpf((float)r2));
+}
+
+// One polar candidate from the four engine words it consumes: x, y in (-1, 1) and r2 = x^2 + y^2,
+// with libstdc++'s roundings (bits/random.tcc normal_distribution::operator()).
+__device__ __forceinline__ void polar_candidate(uint32_t &s, double &x, double &y, double &r2) {
+#pragma clang fp contract(off)
+  x = 2.0 * canonical53(s) - 1.0;
+  y = 2.0 * canonical53(s) - 1.0;
+  r2 = x * x + y * y;
+}
+
+// Six N(0,1) draws = three Marsaglia polar pairs, in libstdc++'s order: pair k yields d[2k] = y*mult
+// (returned by the first operator() call) and d[2k+1] = x*mult (the cached value returned by the
+// second call).  Lanes with different engine words reject different candidates, so the acceptance
+// loop is divergent: a wave runs it max-over-lanes of (the sum of three geometric counts) ~ 8 times
+// for 3.8 useful candidates per lane.  Two things keep that loop cheap:
+//   * one merged loop for the three pairs (not three loops: max of a sum, not a sum of maxima);
+//   * the loop only DECIDES.  Accept / reject is r2 in (0, 1]; x and y are 2 c - 1 with c = (lo + hi R) / R^2,
+//     so the high engine word alone gives c to 5e-10 and an fp32 evaluation of x^2 + y^2 from the two
+//     high words is within 2e-6 of r2.  Outside a +-1e-5 band around 1 (and above 1e-5) that settles
+//     the question without any double-precision work; inside the band (probability 1.6e-5 per candidate)
+//     the exact libstdc++ arithmetic decides.  The loop keeps just the engine word each accepted
+//     candidate started from (three dwords), and the exact x, y, r2 of the three accepted candidates are
+//     evaluated once, after the loop, by all lanes together -- the divergent part of the work is
+//     integer and fp32 only.
+__device__ __forceinline__ void three_accepted(uint32_t &s, uint32_t &st0, uint32_t &st1, uint32_t &st2) {
+#pragma clang fp contract(off)
+  st0 = s; st1 = s; st2 = s;   // engine word before the 1st / 2nd / 3rd accepted candidate
   int got = 0;
   while (got < 3) {
-    const double x = 2.0 * canonical53(s) - 1.0;
-    const double y = 2.0 * canonical53(s) - 1.0;
-    const double r2 = x * x + y * y;
-    if (!(r2 > 1.0 || r2 == 0.0)) {
-      ax2 = ax1; ay2 = ay1; ar2 = ar1;
-      ax1 = ax0; ay1 = ay0; ar1 = ar0;
-      ax0 = x; ay0 = y; ar0 = r2;
-      got++;
+    const uint32_t before = s;
+    // of the four words a candidate consumes the decision needs only the 2nd and the 4th (the high
+    // halves of the two uniforms), and the 4th is also the engine word afterwards: x_{n+2} = a^2 x_n and
+    // x_{n+4} = a^4 x_n (mod 2^31 - 1), two independent multiplications instead of four chained ones
+    const uint32_t hx = minstd_mul(before, 282475249u);    // 16807^2
+    const uint32_t hy = minstd_mul(before, 984943658u);    // 16807^4 mod (2^31 - 1)
+    s = hy;
+    // c ~ (h - 1) / R: x~ = 2 c~ - 1, |x~ - x| < 4e-7; |r2~ - r2| < 2e-6
+    const float kInvR = 1.0f / 2147483646.0f;
+    const float xf = __builtin_fmaf((float)(hx - 1u), 2.0f * kInvR, -1.0f);
+    const float yf = __builtin_fmaf((float)(hy - 1u), 2.0f * kInvR, -1.0f);
+    const float r2f = __builtin_fmaf(xf, xf, yf * yf);
+    bool accept = r2f < 1.0f - 1e-5f && r2f > 1e-5f;
+    const bool unsure = !accept && !(r2f > 1.0f + 1e-5f);   // too close to call in fp32
+    if (__ballot(unsure)) {   // wave-uniform on purpose: a real branch around the double-precision test, taken ~1e-3 of the time
+      if (unsure) {
+        uint32_t t = before;
+        asm volatile("" : "+v"(t));   // pins the double-precision test inside the branch (the compiler would otherwise run it speculatively every iteration)
+        double x, y, r2;
+        polar_candidate(t, x, y, r2);
+        accept = !(r2 > 1.0 || r2 == 0.0);
+      }
     }
+    // straight-line bookkeeping (selects, no branches): slot `got` takes the word if accepted
+    const int slot = accept ? got : 3;
+    st0 = slot == 0 ? before : st0;
+    st1 = slot == 1 ? before : st1;
+    st2 = slot == 2 ? before : st2;
+    got += accept ? 1 : 0;
   }
-  const double m0 = polar_multiplier(ar2);
-  const double m1 = polar_multiplier(ar1);
-  const double m2 = polar_multiplier(ar0);
-  d[0] = ay2 * m0; d[1] = ax2 * m0;
-  d[2] = ay1 * m1; d[3] = ax1 * m1;
-  d[4] = ay0 * m2; d[5] = ax0 * m2;
+}
+
+// double precision throughout: the fp64 engine and the generator self-test (libstdc++'s values to 4e-15)
+__device__ __forceinline__ void six_normals(uint32_t &s, double d[6]) {
+#pragma clang fp contract(off)
+  uint32_t st0, st1, st2;
+  three_accepted(s, st0, st1, st2);
+  double x0, y0, r0, x1, y1, r1, x2, y2, r2;
+  polar_candidate(st0, x0, y0, r0);
+  polar_candidate(st1, x1, y1, r1);
+  polar_candidate(st2, x2, y2, r2);
+  const double m0 = polar_multiplier(r0);
+  const double m1 = polar_multiplier(r1);
+  const double m2 = polar_multiplier(r2);
+  d[0] = y0 * m0; d[1] = x0 * m0;
+  d[2] = y1 * m1; d[3] = x1 * m1;
+  d[4] = y2 * m2; d[5] = x2 * m2;
+}
+
+// the fp32 engine's draws: the same engine words, the same accepted candidates, their x, y, r2 with
+// libstdc++'s double roundings -- and the multiplier and the final product in float, which is what the
+// sample is narrowed to in any case (each value within ~4e-7 relative of float(libstdc++'s double))
+__device__ __forceinline__ void six_normals(uint32_t &s, float d[6]) {
+#pragma clang fp contract(off)
+  uint32_t st0, st1, st2;
+  three_accepted(s, st0, st1, st2);
+  double x0, y0, r0, x1, y1, r1, x2, y2, r2;
+  polar_candidate(st0, x0, y0, r0);
+  polar_candidate(st1, x1, y1, r1);
+  polar_candidate(st2, x2, y2, r2);
+  const float m0 = polar_multiplier_f32(r0);
+  const float m1 = polar_multiplier_f32(r1);
+  const float m2 = polar_multiplier_f32(r2);
+  d[0] = (float)y0 * m0; d[1] = (float)x0 * m0;
+  d[2] = (float)y1 * m1; d[3] = (float)x1 * m1;
+  d[4] = (float)y2 * m2; d[5] = (float)x2 * m2;
 }
 
 // ---------------------------------------------------------------------------
@@ -219,6 +317,9 @@ __device__ __forceinline__ void rotvec_to_quat(float rx, float ry, float rz,
     d3 = sc * rz;
   }
 }
+
+template <typename R> struct NormalOf { typedef double type; };
+template <> struct NormalOf<float> { typedef float type; };
 
 __device__ __forceinline__ float quat_inv_norm(float n2) { return __builtin_amdgcn_rsqf(n2); }
 __device__ __forceinline__ double quat_inv_norm(double n2) { return 1.0 / sqrt(n2); }
@@ -378,7 +479,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
       // state loads issued above are still in flight.  g++ evaluates the ctor
       // arguments right to left (Quadcopter_T.cpp:167-169,176-178): z <- draw 1,
       // y <- 2, x <- 3.
-      double d[6];
+      typename NormalOf<R>::type d[6];   // double in the fp64 engine, float in the fp32 engine
       six_normals(rng, d);
       ng[0] = v.sigma_gyro * (float)d[2]; ng[1] = v.sigma_gyro * (float)d[1]; ng[2] = v.sigma_gyro * (float)d[0];
       na[0] = v.sigma_acc * (float)d[5]; na[1] = v.sigma_acc * (float)d[4]; na[2] = v.sigma_acc * (float)d[3];
@@ -530,7 +631,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #define AFE_LB_WAVES 1
 #endif
 #ifndef AFE_BLOCK
-#define AFE_BLOCK 256   // threads per workgroup of the homogeneous-ensemble step kernel
+#define AFE_BLOCK 64    // threads per workgroup of the homogeneous-ensemble step kernel: one wave (measured: 64 < 128 < 256 < 512 in launch time)
 #endif
 
 // homogeneous ensemble: the one parameter record rides in the kernel arguments
@@ -678,6 +779,24 @@ afe_normals_kernel(const uint32_t *seeds, int64_t n, double *out, uint32_t *stat
   six_normals(s, d);
   for (int k = 0; k < 6; k++) out[6 * i + k] = d[k];
   state_out[i] = s;
+}
+
+__global__ void __launch_bounds__(256)
+afe_normals_f32_kernel(const uint32_t *seeds, int64_t n, float *out, uint32_t *state_out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s = seeds[i];
+  float d[6];
+  six_normals(s, d);
+  for (int k = 0; k < 6; k++) out[6 * i + k] = d[k];
+  state_out[i] = s;
+}
+
+int launch_normals_selftest_f32(const uint32_t *seeds, int64_t n, float *out, uint32_t *state_out, void *stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(afe_normals_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, seeds, n, out, state_out);
+  return (int)hipGetLastError();
 }
 
 int launch_normals_selftest(const uint32_t *seeds, int64_t n, double *out, uint32_t *state_out, void *stream) {

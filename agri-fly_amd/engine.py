@@ -29,7 +29,7 @@ ABI_FUNCTIONS = [
     "afe_logic_ticks", "afe_get_imu", "afe_plan_ticks", "afe_get_device_view",
     "afe_algorithmic_bytes_per_step", "afe_event_create", "afe_event_destroy",
     "afe_event_record", "afe_event_elapsed_ms", "afe_pack_positions",
-    "afe_nearest_neighbour", "afe_selftest_normals",
+    "afe_nearest_neighbour", "afe_selftest_normals", "afe_selftest_normals_f32",
     "afe_rates_logic_params_from_type", "afe_set_rates_logic", "afe_set_rates_commands",
     "afe_get_motor_cmds", "afe_checkpoint_size", "afe_save_checkpoint", "afe_load_checkpoint",
     "afe_radio_create_rates_command", "afe_radio_create_position_command",
@@ -229,6 +229,7 @@ def library():
         "afe_pack_positions": [eng, vp],
         "afe_nearest_neighbour": [eng, vp, i64, vp, vp],
         "afe_selftest_normals": [eng, vp, i64, vp, vp],
+        "afe_selftest_normals_f32": [eng, vp, i64, vp, vp],
         "afe_rates_logic_params_from_type": [ci, C.POINTER(RatesLogicParams)],
         "afe_set_rates_logic": [eng, C.POINTER(RatesLogicParams), ci],
         "afe_set_rates_commands": [eng, i64, i64, vp, vp],
@@ -770,12 +771,14 @@ class Ensemble:
     def destroy_event(self, ev):
         self._L.afe_event_destroy(ev)
 
-    def selftest_normals(self, seeds):
-        """(normals[n, 6] float64, state_after[n] uint32) from the device generator"""
+    def selftest_normals(self, seeds, dtype=np.float64):
+        """(normals[n, 6], state_after[n] uint32) from the device generator: float64 = the AFE_F64
+        engine's (libstdc++'s doubles), float32 = the AFE_F32 engine's (float multiplier)"""
         s = np.ascontiguousarray(seeds, dtype=np.uint32)
-        out = np.empty((s.size, 6), np.float64)
+        out = np.empty((s.size, 6), dtype)
         st = np.empty(s.size, np.uint32)
-        self._ck(self._L.afe_selftest_normals(self._h, s.ctypes.data, s.size, out.ctypes.data, st.ctypes.data))
+        fn = self._L.afe_selftest_normals if dtype == np.float64 else self._L.afe_selftest_normals_f32
+        self._ck(fn(self._h, s.ctypes.data, s.size, out.ctypes.data, st.ctypes.data))
         return out, st
 
     # -- shared-world exchange and queries ------------------------------------

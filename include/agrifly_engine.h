@@ -120,7 +120,11 @@ int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count,
 int afe_set_logic_period(afe_engine *e, double seconds);
 /* IMU noise (Quadcopter_T.cpp:5-6,165-180).  The reference hard-codes
  * sigma_gyro = 0.1, sigma_acc = 0.2 and seed 1; these are the defaults.
- * enabled = 0 switches the six draws off (the stream does not advance). */
+ * enabled = 0 switches the six draws off (the stream does not advance).
+ * The std::minstd_rand0 words and the polar method's accept / reject decisions
+ * are libstdc++'s bit for bit in both precisions; the six normal values are
+ * libstdc++'s doubles (to 4e-15) in the AFE_F64 engine and float evaluations of
+ * the same expression (~4e-7 relative) in the AFE_F32 engine. */
 int afe_set_imu_noise(afe_engine *e, int enabled, double sigma_gyro,
                       double sigma_acc, int seed_policy);
 
@@ -463,6 +467,12 @@ int afe_algorithmic_bytes_per_step(const afe_engine *e, int imu_tick, double *by
  * physics step.  Replaces nothing in the reference. */
 int afe_selftest_normals(afe_engine *e, const uint32_t *seeds, int64_t n,
                          double *normals6, uint32_t *state_after);
+/* The same for the AFE_F32 engine's generator: identical engine words and accepted
+ * candidates; the polar multiplier and the final product are evaluated in float (the
+ * sample is narrowed to float in the reference as well, Quadcopter_T.cpp:167-169),
+ * each value within a few float ulp of float(libstdc++'s double). */
+int afe_selftest_normals_f32(afe_engine *e, const uint32_t *seeds, int64_t n,
+                             float *normals6, uint32_t *state_after);
 
 /* ---- HIP-event timing on the engine's stream (for bench.py) ------------- */
 int afe_event_create(void **event);

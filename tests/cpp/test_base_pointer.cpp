@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "agrifly/Quadcopter_T.hpp"
@@ -47,6 +48,14 @@ struct TapLogic {
 };
 
 typedef agrifly::Quadcopter_T<TapLogic> Quad;
+
+// a radio's position is a default-constructed (NaN) Vec3d until the first logic tick hands it the vehicle's
+static std::string num(double v) {
+  char buf[40];
+  if (!std::isfinite(v)) return "null";
+  std::snprintf(buf, sizeof(buf), "%.17g", v);
+  return buf;
+}
 
 static std::shared_ptr<Quad> make(BaseTimer *t, uint8_t id, int precision, double period) {
   afe_vehicle_params c;
@@ -112,11 +121,11 @@ int main(int argc, char **argv) {
     }
     std::printf("\"gyro\": [%.9g, %.9g, %.9g], \"acc\": [%.9g, %.9g, %.9g], \"runs\": %d, \"n_radio\": %d, \"radio_type\": %d, "
                 "\"telemetry\": [%d, %d, %d], \"n_uwb\": [%d, %d], \"uwb_range\": %.9g, \"uwb_responder\": %d, "
-                "\"radio_pos\": [%.17g, %.17g, %.17g]}%s\n",
+                "\"radio_pos\": [%s, %s, %s]}%s\n",
                 g.x, g.y, g.z, a.x, a.y, a.z, q1->Logic().runs, q1->Logic().n_radio, q1->Logic().last_radio_type, t1.type, t2.type,
                 t1.packetNumber, q1->Logic().n_uwb, q2->Logic().n_uwb, q1->Logic().uwb_range, q1->Logic().uwb_responder,
-                vehicles[1]->GetRadio()->GetPosition().x, vehicles[1]->GetRadio()->GetPosition().y,
-                vehicles[1]->GetRadio()->GetPosition().z, s + 1 < runs ? "," : "");
+                num(vehicles[1]->GetRadio()->GetPosition().x).c_str(), num(vehicles[1]->GetRadio()->GetPosition().y).c_str(),
+                num(vehicles[1]->GetRadio()->GetPosition().z).c_str(), s + 1 < runs ? "," : "");
   }
   std::printf("]}\n");
   return 0;

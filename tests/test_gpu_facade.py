@@ -107,8 +107,9 @@ def test_facade_through_the_simulationobject6dof_base_pointer(ora, precision):
         assert base[s]["runs"] == direct[s]["runs"]
         assert base[s]["telemetry"] == [0, 1, base[s]["runs"] % 256]
         assert base[s]["n_radio"] == (1 if s >= 1 else 0) and base[s]["radio_type"] == (5 if s >= 1 else 0)
-    # SetVelocity(0) on vehicle 1 after Run #3: the next step starts from rest (only gravity / thrust / drag act)
-    assert np.linalg.norm(base[2]["vel1"]) > 2.0 and np.linalg.norm(base[3]["vel1"]) < 0.05
+    # SetVelocity(0) on vehicle 1 after Run #3: the base's getter shows it at once (same trace row), and the next
+    # step starts from rest (only gravity / thrust / drag act)
+    assert np.linalg.norm(base[1]["vel1"]) > 2.0 and base[2]["vel1"] == [0, 0, 0] and np.linalg.norm(base[3]["vel1"]) < 0.05
     # UWB: request seen at t = 2 ms, completed at t = 4 ms (0.0015 s period), delivered to the logic on the next tick
     assert [b["n_uwb"][0] for b in base] == [0, 0, 0, 0, 0, 1, 1, 1]
     assert [b["n_uwb"][1] for b in base][-1] == 1                    # everyone "hears" the measurement

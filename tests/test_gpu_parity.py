@@ -197,7 +197,7 @@ def test_seed_policies():
         b.rng[:] = 1001 + np.arange(n)
         b.step(1e-3, 1, ticks=[1])
         np.testing.assert_array_equal(e.get_rng_state(), b.rng)
-        np.testing.assert_allclose(gyro, b.gyro, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(gyro, b.gyro, rtol=0, atol=3e-7)   # 0.1 * (a few float ulp of a |n| <= 5 draw)
 
 
 def test_partial_ranges_and_errors():
@@ -365,6 +365,20 @@ def test_device_normals_match_libstdcxx_known_answers(golden_dir):
         same = (got[:2000].astype(np.float32) == ref.astype(np.float32)).mean()
         assert same == 1.0
         assert np.isfinite(got).all() and abs(got.mean()) < 5e-3 and abs(got.std() - 1) < 5e-3
+        # The fp32 engine's generator: the same engine words and accepted candidates (state identical), the
+        # multiplier and the product in float.  Every value within a few float ulp of float(libstdc++'s double),
+        # all the way down to the smallest multipliers (r2 -> 1) and up to the tails (r2 -> 0).
+        got32, state32 = e.selftest_normals(many, dtype=np.float32)
+        np.testing.assert_array_equal(state32, state)
+        want32 = got.astype(np.float32)
+        rel = np.abs(got32.astype(np.float64) - got) / np.abs(got)
+        from tests.scenarios import MEASUREMENTS
+        MEASUREMENTS["fp32_engine_normals_vs_libstdcxx_double"] = {
+            "draws": int(got.size), "worst_rel_err": float(rel.max()), "mean_rel_err": float(rel.mean()),
+            "fraction_identical_to_narrowed_double": float((got32 == want32).mean()),
+            "smallest_abs_value": float(np.abs(got).min()), "largest_abs_value": float(np.abs(got).max())}
+        assert rel.max() < 6e-7, rel.max()
+        assert np.abs(got).min() < 1e-4 and np.abs(got).max() > 4.5      # the sample does reach both ends
 
 
 def test_checkpoint_resume_is_bitwise():

@@ -25,10 +25,11 @@ n = %(n)d
 p = afa.params_from_type(5)
 data = afa.scenarios.gust_ensemble(n, p, seed=4)
 res = {}
-for name, period, fext in (("off", 1000.0, True), ("on", 0.0005, True), ("mix", 0.002, True), ("off_nofext", 1000.0, False)):
+for name, period, fext in (("off", 1000.0, True), ("on", 0.0005, True), ("mix", 0.002, True), ("off_nofext", 1000.0, False),
+                           ("on_nonoise", 0.0005, True)):
     e = afa.Ensemble(n)
     e.set_type_table([p]); e.set_logic_period(period)
-    e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+    e.set_imu_noise(name != "on_nonoise", 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
     e.set_state(data.pos, data.vel, data.att, data.ang_vel, data.motor_speed)
     e.set_motor_cmds(data.motor_cmd)
     if fext: e.set_external_force(data.ext_force)
@@ -70,8 +71,8 @@ def main():
     for lib in a.libs:
         if lib in best:
             r = best[lib]
-            print("%-40s off %.2f us  on %.2f us  mix %.2f us  off_nofext %.2f us" %
-                  (os.path.basename(lib), r["off"], r["on"], r["mix"], r["off_nofext"]))
+            print("%-40s off %.2f us  on %.2f us  mix %.2f us  off_nofext %.2f us  on_nonoise %.2f us" %
+                  (os.path.basename(lib), r["off"], r["on"], r["mix"], r["off_nofext"], r["on_nonoise"]))
 
 
 if __name__ == "__main__":
