@@ -240,11 +240,21 @@ __global__ void afe_camera_pose_kernel(PoseArgs a) {
   o[11] = r0 - r1 - r2 + r3;
 }
 
+// One triangle as the kernel wants it (96 B, fetched by scalar loads -- the leaf being visited is the
+// same for the whole wave): vertex 0 and the two edges ALREADY in double, e = double(v_k) - double(v_0)
+// exactly as the ray / triangle test forms them (so every lane is spared 9 conversions and 6
+// subtractions per test), and the triangle's own box in fp32, inflated like the node boxes.
+struct TriRec {
+  double v0[3], e1[3], e2[3];
+  float lo[3], hi[3];
+};
+
 struct RenderArgs {
   const BvhNode *nodes;
-  const float4 *tris;       // 3 float4 per triangle: v0, v1, v2 (w unused)
+  const TriRec *tris;       // leaf order
   const double *poses;
   uint16_t *out;
+  unsigned long long *counters;   // counting build only: see afe_render_depth_stats
   int64_t n_views, n_blocks, blocks_per_xcd;
   int width, height, tiles_x, tiles_per_view;
   double focal, cx, cy, depth_scale;
@@ -258,7 +268,8 @@ struct RenderArgs {
 // therefore the fp64 hit distance, cannot depend on it.
 // (oi = o * inv is precomputed per ray, so a slab costs two FMAs; where that turns a zero direction
 // component into a NaN the fminf / fmaxf below ignore it, which again can only let a box through.)
-__device__ __forceinline__ float box_entry(const BvhNode &n, const float oi[3], const float inv[3], float best) {
+template <class BoxT>
+__device__ __forceinline__ float box_entry(const BoxT &n, const float oi[3], const float inv[3], float best) {
   float tmin = 0.0f, tmax = best;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -270,13 +281,11 @@ __device__ __forceinline__ float box_entry(const BvhNode &n, const float oi[3], 
   return tmin * 0.99999f <= tmax * 1.00001f ? tmin * 0.99999f : INFINITY;
 }
 
-__device__ __forceinline__ double ray_triangle(const double o[3], const double d[3], const float4 a, const float4 b,
-                                               const float4 c) {
+__device__ __forceinline__ double ray_triangle(const double o[3], const double d[3], const TriRec &T) {
 #pragma clang fp contract(off)
-  // Moeller-Trumbore, two-sided; operation order is part of the contract (see file header)
-  const double v0[3] = {(double)a.x, (double)a.y, (double)a.z};
-  const double e1[3] = {(double)b.x - v0[0], (double)b.y - v0[1], (double)b.z - v0[2]};
-  const double e2[3] = {(double)c.x - v0[0], (double)c.y - v0[1], (double)c.z - v0[2]};
+  // Moeller-Trumbore, two-sided; operation order is part of the contract (see file header).  v0, e1, e2
+  // are the doubles the checker forms from the float vertices (afe_scene_create computes them once).
+  const double *v0 = T.v0, *e1 = T.e1, *e2 = T.e2;
   const double p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
   const double det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
   if (fabs(det) < 1e-12) return INFINITY;
@@ -291,6 +300,7 @@ __device__ __forceinline__ double ray_triangle(const double o[3], const double d
   return t > 0.0 ? t : INFINITY;
 }
 
+template <bool COUNT>
 __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(RenderArgs a) {
 #pragma clang fp contract(off)
   __shared__ int32_t stack_node[kStack];     // one stack for the wave
@@ -331,18 +341,27 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   int sp = 0;
   int node = 0;
   bool mine = in_image, fresh = true;      // fresh: `mine` has to be established by a box test (root, popped nodes)
+  unsigned c_nodes = 0, c_tri_wave_box = 0, c_tri_wave_mt = 0, c_tri_lane_box = 0, c_tri_lane_mt = 0;   // COUNT only
   for (;;) {
     const BvhNode n = a.nodes[node];
+    if (COUNT) c_nodes += 1;
     if (fresh) mine = in_image && box_entry(n, of, inv, best_f) < INFINITY;
     int next = -1;
     if (__ballot(mine)) {
       if (n.b > 0) {
         for (int k = 0; k < n.b; k++) {
-          const float4 *t = a.tris + 3 * (int64_t)(n.a + k);
-          const float4 t0 = t[0], t1 = t[1], t2 = t[2];
-          if (mine) {
-            const double th = ray_triangle(o, d, t0, t1, t2);
-            if (th < best) { best = th; best_f = __double2float_ru(th); }
+          const TriRec &T = a.tris[n.a + k];
+          // the triangle's own (inflated) box first, in fp32: a ray that misses it, or enters it no nearer
+          // than its best hit so far, cannot gain anything from this triangle -- and when that holds for
+          // all 64 rays of the tile the double-precision test is skipped altogether
+          const bool reach = mine && box_entry(T, of, inv, best_f) < INFINITY;
+          if (COUNT) { c_tri_lane_box += mine ? 1 : 0; c_tri_wave_box += 1; }
+          if (__ballot(reach)) {
+            if (COUNT) { c_tri_wave_mt += 1; c_tri_lane_mt += reach ? 1 : 0; }
+            if (reach) {
+              const double th = ray_triangle(o, d, T);
+              if (th < best) { best = th; best_f = __double2float_ru(th); }
+            }
           }
         }
       } else {
@@ -373,6 +392,24 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
     if (c < (double)a.max_count) count = (uint16_t)c;
   }
   if (in_image) a.out[(view * a.height + py) * (int64_t)a.width + px] = count;
+  if (COUNT) {
+    // per wave: nodes visited, triangle box tests, triangle double-precision tests; per lane: the same two
+    // for the rays that took part, and the rays themselves
+    unsigned lane_box = c_tri_lane_box, lane_mt = c_tri_lane_mt, rays = in_image ? 1u : 0u;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      lane_box += __shfl_xor(lane_box, sft); lane_mt += __shfl_xor(lane_mt, sft); rays += __shfl_xor(rays, sft);
+    }
+    if (lane == 0) {
+      atomicAdd(&a.counters[0], (unsigned long long)c_nodes);
+      atomicAdd(&a.counters[1], (unsigned long long)c_tri_wave_box);
+      atomicAdd(&a.counters[2], (unsigned long long)c_tri_wave_mt);
+      atomicAdd(&a.counters[3], (unsigned long long)lane_box);
+      atomicAdd(&a.counters[4], (unsigned long long)lane_mt);
+      atomicAdd(&a.counters[5], (unsigned long long)rays);
+      atomicAdd(&a.counters[6], 1ull);
+    }
+  }
 }
 
 }  // namespace afe
@@ -388,7 +425,7 @@ struct afe_scene {
   int depth = 0;
   double bounds[6] = {0, 0, 0, 0, 0, 0};
   BvhNode *nodes = nullptr;
-  float4 *tris = nullptr;
+  TriRec *tris = nullptr;
 };
 
 namespace {
@@ -421,9 +458,9 @@ bool camera_ok(const afe_camera *c) {
 
 // poses (device, [count][12]) -> images; out_dev: device buffer of count*h*w uint16
 int launch_render(const afe_scene *s, const afe_camera *cam, int64_t count, const double *poses, uint16_t *out_dev,
-                  hipStream_t stream, float *kernel_ms) {
+                  hipStream_t stream, float *kernel_ms, unsigned long long *dev_counters = nullptr) {
   RenderArgs r;
-  r.nodes = s->nodes; r.tris = s->tris;
+  r.nodes = s->nodes; r.tris = s->tris; r.counters = dev_counters;
   r.width = cam->width; r.height = cam->height;
   r.tiles_x = (cam->width + kTileW - 1) / kTileW;
   r.tiles_per_view = r.tiles_x * ((cam->height + kTileH - 1) / kTileH);
@@ -447,7 +484,8 @@ int launch_render(const afe_scene *s, const afe_camera *cam, int64_t count, cons
     r.n_blocks = nv * r.tiles_per_view;
     r.blocks_per_xcd = (r.n_blocks + 7) / 8;
     const int64_t grid = r.blocks_per_xcd * 8;
-    hipLaunchKernelGGL(afe_render_depth_kernel, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
+    if (dev_counters) hipLaunchKernelGGL(afe_render_depth_kernel<true>, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
+    else hipLaunchKernelGGL(afe_render_depth_kernel<false>, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
     rc = hipGetLastError() == hipSuccess ? AFE_OK : AFE_ERR_HIP;
   }
   if (kernel_ms) {
@@ -511,11 +549,23 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
     b.build(n_tri);
     if (b.max_depth > kStack) return AFE_ERR_OUT_OF_RANGE;
   }
-  // triangles in leaf order, padded to three float4
-  std::vector<float> packed(12 * (size_t)n_tri, 0.0f);
+  // triangles in leaf order: vertex 0 and the edges in double (the checker's own expressions,
+  // oracle: e = (double)v_k - (double)v_0), and the triangle's box inflated like a node's
+  std::vector<TriRec> packed((size_t)n_tri);
   for (int64_t i = 0; i < n_tri; i++) {
     const float *src = triangles + 9 * (int64_t)b.order[(size_t)i];
-    for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) packed[12 * (size_t)i + 4 * v + k] = src[3 * v + k];
+    TriRec &T = packed[(size_t)i];
+    Box tb; tb.reset();
+    for (int v = 0; v < 3; v++) tb.grow(src + 3 * v);
+    BvhNode inflated;
+    b.set_bounds(inflated, tb);
+    for (int k = 0; k < 3; k++) {
+      T.v0[k] = (double)src[k];
+      T.e1[k] = (double)src[3 + k] - T.v0[k];
+      T.e2[k] = (double)src[6 + k] - T.v0[k];
+      T.lo[k] = inflated.lo[k];
+      T.hi[k] = inflated.hi[k];
+    }
   }
   afe_scene *s = new afe_scene();
   s->device = dev;
@@ -525,9 +575,9 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
   Box all = b.range_box(0, n_tri);
   for (int k = 0; k < 3; k++) { s->bounds[k] = all.lo[k]; s->bounds[3 + k] = all.hi[k]; }
   if (hipMalloc((void **)&s->nodes, b.nodes.size() * sizeof(BvhNode)) != hipSuccess ||
-      hipMalloc((void **)&s->tris, packed.size() * sizeof(float)) != hipSuccess ||
+      hipMalloc((void **)&s->tris, packed.size() * sizeof(TriRec)) != hipSuccess ||
       hipMemcpy(s->nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(s->tris, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(s->tris, packed.data(), packed.size() * sizeof(TriRec), hipMemcpyHostToDevice) != hipSuccess) {
     afe_scene_destroy(s);
     return AFE_ERR_HIP;
   }
@@ -612,6 +662,33 @@ extern "C" int afe_render_depth(afe_scene *s, const afe_camera *cam, int64_t n_v
   if (rc != AFE_OK) return rc;
   if (kernel_ms) *kernel_ms = ms;
   if (hipMemcpy(depth_out, d_out.p, (size_t)n_views * px * 2, hipMemcpyDeviceToHost) != hipSuccess) return AFE_ERR_HIP;
+  return AFE_OK;
+}
+
+// The counting build of the same kernel over explicit poses: what the traversal did, for the roofline
+// accounting of bench.py.  stats: [0] nodes visited (per wave), [1] triangle box tests (per wave),
+// [2] triangle double-precision tests actually executed (per wave), [3] triangle box tests (per ray),
+// [4] double-precision tests (per ray), [5] rays, [6] waves (8 x 8 tiles), [7] 0.
+extern "C" int afe_render_depth_stats(afe_scene *s, const afe_camera *cam, int64_t n_views, const double *pos,
+                                      const double *att, const double mount[4], uint64_t stats[8], float *kernel_ms) {
+  if (!s || !camera_ok(cam) || n_views <= 0 || !pos || !att || !stats) return AFE_ERR_INVALID_ARG;
+  if (hipSetDevice(s->device) != hipSuccess) return AFE_ERR_HIP;
+  const size_t px = (size_t)cam->width * cam->height;
+  DevBuf d_pos, d_att, d_pose, d_out, d_cnt;
+  if (!d_pos.upload(pos, (size_t)n_views * 24) || !d_att.upload(att, (size_t)n_views * 32) ||
+      !d_pose.alloc((size_t)n_views * 96) || !d_out.alloc((size_t)n_views * px * 2) || !d_cnt.alloc(64))
+    return AFE_ERR_HIP;
+  if (hipMemset(d_cnt.p, 0, 64) != hipSuccess) return AFE_ERR_HIP;
+  int rc = launch_poses(d_pos.p, d_att.p, n_views, 0, n_views, 8, mount, (double *)d_pose.p, nullptr);
+  if (rc != AFE_OK) return rc;
+  float ms = 0;
+  rc = launch_render(s, cam, n_views, (const double *)d_pose.p, (uint16_t *)d_out.p, nullptr, &ms,
+                     (unsigned long long *)d_cnt.p);
+  if (rc != AFE_OK) return rc;
+  if (kernel_ms) *kernel_ms = ms;
+  unsigned long long host[8];
+  if (hipMemcpy(host, d_cnt.p, 64, hipMemcpyDeviceToHost) != hipSuccess) return AFE_ERR_HIP;
+  for (int k = 0; k < 8; k++) stats[k] = host[k];
   return AFE_OK;
 }
 

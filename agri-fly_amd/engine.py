@@ -37,7 +37,7 @@ ABI_FUNCTIONS = [
     "afe_telemetry_encode", "afe_telemetry_decode", "afe_set_commands_from_radio",
     "afe_set_max_fused_steps", "afe_planner_default_config", "afe_planner_samples", "afe_rappids_plan",
     "afe_rappids_plan_device", "afe_camera_default", "afe_camera_default_mount", "afe_scene_create",
-    "afe_scene_destroy", "afe_scene_info", "afe_render_depth", "afe_render_depth_engine",
+    "afe_scene_destroy", "afe_scene_info", "afe_render_depth", "afe_render_depth_engine", "afe_render_depth_stats",
     "afe_device_alloc", "afe_device_free", "afe_device_download", "afe_scene_check_hierarchy",
     "afe_comm_unique_id", "afe_comm_create", "afe_comm_info", "afe_comm_destroy", "afe_comm_last_error",
     "afe_gather_positions", "afe_group_create", "afe_group_destroy", "afe_group_size", "afe_group_shard",
@@ -256,6 +256,7 @@ def library():
         "afe_scene_check_hierarchy": [vp, i64, C.POINTER(i64), C.POINTER(ci), C.POINTER(ci)],
         "afe_render_depth": [vp, C.POINTER(Camera), i64, vp, vp, vp, vp, C.POINTER(C.c_float)],
         "afe_render_depth_engine": [eng, vp, C.POINTER(Camera), i64, i64, vp, vp, ci, C.POINTER(C.c_float)],
+        "afe_render_depth_stats": [vp, C.POINTER(Camera), i64, vp, vp, vp, vp, C.POINTER(C.c_float)],
         "afe_device_alloc": [ci, u64, C.POINTER(vp)],
         "afe_device_free": [vp],
         "afe_device_download": [vp, vp, u64],
@@ -483,6 +484,22 @@ class Scene:
         if rc:
             raise AfeError(rc, library().afe_status_string(rc).decode())
         return out, ms.value
+
+    def render_stats(self, cam, pos, att, mount=None):
+        """traversal counters of one batch (counting build): dict + kernel_ms"""
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        q = np.ascontiguousarray(att, dtype=np.float64)
+        n = p.shape[1]
+        m = None if mount is None else np.ascontiguousarray(mount, dtype=np.float64)
+        st = np.zeros(8, np.uint64)
+        ms = C.c_float(0)
+        rc = library().afe_render_depth_stats(self._h, C.byref(cam), n, p.ctypes.data, q.ctypes.data,
+                                              None if m is None else m.ctypes.data, st.ctypes.data, C.byref(ms))
+        if rc:
+            raise AfeError(rc, library().afe_status_string(rc).decode())
+        keys = ("nodes_per_wave", "tri_box_tests_per_wave", "tri_fp64_tests_per_wave", "tri_box_tests_per_ray",
+                "tri_fp64_tests_per_ray", "rays", "waves")
+        return dict(zip(keys, (int(x) for x in st[:7]))), ms.value
 
     def render_engine(self, ensemble, cam, mount=None, first=0, count=None, out=None):
         """Depth images of vehicles [first, first+count) from the engine's device state.

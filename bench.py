@@ -229,12 +229,40 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
     bl.close()
     el.close()
     info = scene.info()
+    # ---- what bounds the two perception kernels (counting build / output counters) ----
+    st, _ = scene.render_stats(cam, pos, att, mount)
+    rays, waves = st["rays"], st["waves"]
+    FP64_PEAK_TFLOPS = 78.6            # MI355X fp64 vector peak (spec), MI355X_MICROARCH.md
+    mt_flops = 45.0                    # one Moeller-Trumbore evaluation to the end: 27 mul + 18 add/sub (+ 1 division)
+    ray_flops = 9 * 2 + 6 + 4          # direction = R (u, v, 1), final floor(z / scale)
+    fp64_flops = st["tri_fp64_tests_per_ray"] * mt_flops + rays * ray_flops
+    node_bytes = st["nodes_per_wave"] * 64.0 + st["tri_box_tests_per_wave"] * 96.0   # scalar loads, served by L2
+    render_roofline = {
+        "bound": "dependent BVH node fetches + fp32 box tests per wave (latency / VALU issue), not HBM and not fp64 throughput",
+        "per_ray": {"triangle_box_tests": st["tri_box_tests_per_ray"] / rays, "fp64_triangle_tests": st["tri_fp64_tests_per_ray"] / rays},
+        "per_wave_of_64_rays": {"nodes_visited": st["nodes_per_wave"] / waves, "triangle_box_tests": st["tri_box_tests_per_wave"] / waves,
+                                "fp64_triangle_tests_executed": st["tri_fp64_tests_per_wave"] / waves},
+        "fp64_TFLOPs_achieved": fp64_flops / (ms_render * 1e-3) / 1e12, "fp64_peak_TFLOPs": FP64_PEAK_TFLOPS,
+        "fp64_frac": fp64_flops / (ms_render * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+        "tree_bytes_GBs": node_bytes / (ms_render * 1e-3) / 1e9,
+        "hbm_bytes_GBs": rays * 2.0 / (ms_render * 1e-3) / 1e9, "hbm_frac": rays * 2.0 / (ms_render * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    plans = afa.plans_as_array(out)
+    px_bytes = 240 * 320 * 2
+    # per pyramid the search kernel sweeps the image twice (the two bit images) and once more over the grown
+    # rectangle; plus the candidate kernel's and the transpose's passes over the inputs
+    plan_bytes = float(plans["n_pyramids"].sum()) * 2.0 * px_bytes + n_views * 2.0 * px_bytes + n_planners * n_candidates * 9.0
+    planner_roofline = {
+        "bound": "dependent LDS / cache round trips of the sequential pyramid search (VALUBusy 34 %, profiles/r01_d_perception_pmc.json)",
+        "pyramids_per_plan": float(plans["n_pyramids"].mean()), "collision_checks_per_plan": float(plans["n_collision_checks"].mean()),
+        "algorithmic_bytes": plan_bytes, "achieved_GBs": plan_bytes / (ms_plan * 1e-3) / 1e9,
+        "hbm_frac": plan_bytes / (ms_plan * 1e-3) / 1e9 / HBM_PEAK_GBS}
     return {"closed_perception_loop_frame": frame,
             "depth_camera": {"views": n_views, "image": "320x240", "triangles": int(info["n_tri"]),
-                             "kernel_ms": ms_render, "rays_per_s": n_views * 76800 / (ms_render * 1e-3)},
+                             "kernel_ms": ms_render, "rays_per_s": n_views * 76800 / (ms_render * 1e-3),
+                             "roofline": render_roofline},
             "rappids_planner": {"planners": n_planners, "candidates": n_candidates, "distinct_images": n_views,
                                 "kernel_ms": ms_plan, "plans_per_s": n_planners / (ms_plan * 1e-3),
-                                "fraction_found": found},
+                                "fraction_found": found, "roofline": planner_roofline},
             "note": "images rendered from engine state and planned on without leaving HBM; results are "
                     "bit-identical to the CPU checkers in tests/test_gpu_render.py / test_gpu_planner.py"}
 
@@ -482,8 +510,9 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": n_local * bytes_step,
-                "kernel": "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, LOGIC=0, SINGLE=1> -- the timed region "
-                          "alternates NOISE=0 (no logic tick) and NOISE=1 (tick: IMU + six Gaussian draws) launches",
+                "kernel": "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, LOGIC=0, SINGLE=1>, 64-lane workgroups -- the timed region "
+                          "alternates NOISE=0 (no logic tick) and NOISE=1 (tick: IMU + six Gaussian draws) launches; "
+                          "the NOISE=1 launch is the dominant kernel (per_kernel.on_tick, profiles/r02*_summary.json)",
                 "kernel_us": t_kernel * 1e6,
                 "algorithmic_bytes_per_vehicle_step": bytes_step,
                 "imu_tick_fraction": tick_frac,

@@ -357,6 +357,13 @@ int afe_scene_info(const afe_scene *s, int64_t *n_tri, int64_t *n_nodes, int *de
 int afe_render_depth(afe_scene *s, const afe_camera *cam, int64_t n_views, const double *pos, const double *att,
                      const double mount[4], uint16_t *depth_out, float *kernel_ms);
 
+/* What the traversal did for such a batch (a counting build of the same kernel; the images are
+ * discarded): stats[0] BVH nodes visited and [1] triangle box tests / [2] double-precision
+ * ray-triangle tests executed, per wave of 64 rays; [3], [4] the same two per participating ray;
+ * [5] rays; [6] waves.  bench.py prices the depth camera against the fp64 vector peak with these. */
+int afe_render_depth_stats(afe_scene *s, const afe_camera *cam, int64_t n_views, const double *pos, const double *att,
+                           const double mount[4], uint64_t stats[8], float *kernel_ms);
+
 /* The same, with the poses read on the device from the engine's state slabs
  * (vehicles [first, first+count)), replacing client.simGetImages() for every
  * vehicle at once.  depth_out is a DEVICE pointer when out_is_device != 0
