@@ -337,6 +337,10 @@ struct Shrink {
 // the oracle on rendered orchard images, now tests/test_gpu_planner.py::test_campaign_...).  Keeping
 // the wave-cooperative pieces as separate functions gives the structurizer small, reducible bodies;
 // it costs nothing measurable and the campaign is the regression test.
+// Round 2 re-test: the bit image is now bracketed by workgroup barriers (build_mask), which rules out the
+// one cross-lane ordering this file relied on implicitly -- and with the helpers inlined again the campaign
+// still fails (plan 79 of 640: one candidate reported collision-free that is not).  So the barriers stay
+// because they are right, and `noinline` stays because it is needed.
 // ---- wave-cooperative pixel scans ------------------------------------------------
 // One wave runs one planner: everything outside the scans below is computed redundantly
 // (and therefore convergently) by all 64 lanes; inside a scan lane l looks at pixel
