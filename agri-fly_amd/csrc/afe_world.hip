@@ -347,6 +347,10 @@ struct afe_world {
   int64_t cap_self = 0;
   float *self_scratch = nullptr;
   GridDesc grid = {};
+  int64_t grid_n_all = -1;      // ensemble size the grid shape was chosen for
+  float grid_cell_arg = 0;      // and the caller's cell size then
+  int refresh_every = 1;        // re-shape the grid every this many queries (1: always)
+  int since_refresh = 0;
   uint32_t last_leftover = 0;
   std::string err;
 };
@@ -491,23 +495,34 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   W_HIP(w, hipSetDevice(w->device));
   int rc = ensure_capacity(w, n_all, 0);
   if (rc) return rc;
-  // 1. bounds and spread of the finite positions (one small read-back: the grid shape is a host decision)
+  // 1. bounds and spread of the finite positions (one small read-back: the grid shape is a host decision).
+  // The shape may be kept for a few queries: the query is exact for ANY grid (positions outside it clamp
+  // into its boundary cells), a stale shape only costs speed, and without the read-back the whole query is
+  // asynchronous on the stream (afe_set_neighbour_grid_refresh).
   static const uint32_t zero2[2] = {0, 0};
   W_HIP(w, hipMemcpyAsync(w->lohi + 6, zero2, sizeof(zero2), hipMemcpyHostToDevice, st));   // leftover counter
-  hipLaunchKernelGGL(world_bounds_kernel, dim3(AFE_WORLD_BOUNDS_BLOCKS), dim3(256), 0, st, all_xyz, n_all, w->bounds_part);
-  static thread_local BoundsPartial host_part[AFE_WORLD_BOUNDS_BLOCKS];
-  W_HIP(w, hipMemcpyAsync(host_part, w->bounds_part, sizeof(host_part), hipMemcpyDeviceToHost, st));
-  W_HIP(w, hipStreamSynchronize(st));
-  int lohi[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-  double stats[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int b = 0; b < AFE_WORLD_BOUNDS_BLOCKS; b++) {
-    for (int c = 0; c < 3; c++) { lohi[c] = std::min(lohi[c], host_part[b].lo[c]); lohi[3 + c] = std::max(lohi[3 + c], host_part[b].hi[c]); }
-    for (int c = 0; c < 7; c++) stats[c] += host_part[b].m[c];
+  const bool reshape = w->grid_n_all != n_all || w->grid_cell_arg != cell_size || w->since_refresh + 1 >= w->refresh_every;
+  if (reshape) {
+    hipLaunchKernelGGL(world_bounds_kernel, dim3(AFE_WORLD_BOUNDS_BLOCKS), dim3(256), 0, st, all_xyz, n_all, w->bounds_part);
+    static thread_local BoundsPartial host_part[AFE_WORLD_BOUNDS_BLOCKS];
+    W_HIP(w, hipMemcpyAsync(host_part, w->bounds_part, sizeof(host_part), hipMemcpyDeviceToHost, st));
+    W_HIP(w, hipStreamSynchronize(st));
+    int lohi[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    double stats[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < AFE_WORLD_BOUNDS_BLOCKS; b++) {
+      for (int c = 0; c < 3; c++) { lohi[c] = std::min(lohi[c], host_part[b].lo[c]); lohi[3 + c] = std::max(lohi[3 + c], host_part[b].hi[c]); }
+      for (int c = 0; c < 7; c++) stats[c] += host_part[b].m[c];
+    }
+    float lo[3], hi[3];
+    for (int c = 0; c < 3; c++) { lo[c] = unordered(lohi[c]); hi[c] = unordered(lohi[3 + c]); }
+    if (lohi[0] == 0x7fffffff) { for (int c = 0; c < 3; c++) lo[c] = hi[c] = 0.0f; }   // no finite position at all
+    choose_grid(lo, hi, stats, n_all, cell_size, w->grid);
+    w->grid_n_all = n_all;
+    w->grid_cell_arg = cell_size;
+    w->since_refresh = 0;
+  } else {
+    w->since_refresh++;
   }
-  float lo[3], hi[3];
-  for (int c = 0; c < 3; c++) { lo[c] = unordered(lohi[c]); hi[c] = unordered(lohi[3 + c]); }
-  if (lohi[0] == 0x7fffffff) { for (int c = 0; c < 3; c++) lo[c] = hi[c] = 0.0f; }   // no finite position at all
-  choose_grid(lo, hi, stats, n_all, cell_size, w->grid);
   const GridDesc g = w->grid;
   const int64_t m = g.n_cells + 2;   // cells, the dead bin, and the end sentinel
   if ((rc = ensure_capacity(w, n_all, m))) return rc;
@@ -527,6 +542,12 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   hipLaunchKernelGGL(world_brute_kernel, dim3(1024), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global, dist2_out,
                      index_out);
   W_HIP(w, hipGetLastError());
+  return AFE_OK;
+}
+
+int afe::world_set_refresh(afe_world *w, int every_n_queries) {
+  if (!w || every_n_queries < 1) return AFE_ERR_INVALID_ARG;
+  w->refresh_every = every_n_queries;
   return AFE_OK;
 }
 

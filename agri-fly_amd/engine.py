@@ -42,7 +42,7 @@ ABI_FUNCTIONS = [
     "afe_comm_unique_id", "afe_comm_create", "afe_comm_info", "afe_comm_destroy", "afe_comm_last_error",
     "afe_gather_positions", "afe_group_create", "afe_group_destroy", "afe_group_size", "afe_group_shard",
     "afe_group_step", "afe_group_sync", "afe_group_gather_positions", "afe_group_last_error",
-    "afe_nearest_neighbour_grid", "afe_neighbour_grid_info", "afe_nearest_neighbour_bruteforce",
+    "afe_nearest_neighbour_grid", "afe_neighbour_grid_info", "afe_set_neighbour_grid_refresh", "afe_nearest_neighbour_bruteforce",
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
 ]
 
@@ -278,6 +278,7 @@ def library():
         "afe_nearest_neighbour_grid": [eng, vp, i64, C.c_float, vp, vp],
         "afe_neighbour_grid_info": [eng, vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64)],
         "afe_nearest_neighbour_bruteforce": [eng, vp, i64, vp, i64, vp, vp],
+        "afe_set_neighbour_grid_refresh": [eng, ci],
         "afe_uwb_create": [C.POINTER(vp)],
         "afe_uwb_set_noise": [vp, C.c_double, C.c_double, C.c_double],
         "afe_uwb_draw": [vp, i64, vp, vp],
@@ -819,6 +820,9 @@ class Ensemble:
         self._ck(self._L.afe_nearest_neighbour_bruteforce(self._h, C.c_void_p(int(all_xyz_ptr)), int(n_all),
                                                           C.c_void_p(int(queries_ptr)), int(n_queries),
                                                           C.c_void_p(int(dist2_ptr)), C.c_void_p(int(index_ptr))))
+
+    def set_neighbour_grid_refresh(self, every_n_queries):
+        self._ck(self._L.afe_set_neighbour_grid_refresh(self._h, int(every_n_queries)))
 
     def neighbour_grid_info(self):
         dims = (C.c_int * 3)()

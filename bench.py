@@ -347,6 +347,8 @@ def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, ba
     res = rng.integers(0, n_all, 1024).astype(np.int32)
     torch.cuda.synchronize()
 
+    e.set_neighbour_grid_refresh(16)     # re-shape the grid (one read-back) every 16th query; exact either way
+
     def query(with_uwb=True):
         e.gather_positions(comm, xyz.data_ptr())
         e.nearest_neighbour(xyz.data_ptr(), n_all, d2.data_ptr(), idx.data_ptr())
@@ -396,6 +398,7 @@ def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, ba
         "vehicles_gathered": n_all,
         "allgather_bytes_per_rank": 12 * n_local,
         "query_cadence": "every 10 steps of 1 ms (100 Hz simulated time)",
+        "neighbour_grid_reshaped_every_n_queries": 16,
         "query_ms": parts["allgather_ms"] + parts["nearest_neighbour_ms"],
         "vsteps_per_s_with_queries": n_all * k / t_with,
         "vsteps_per_s_physics_only": n_all * k / t_without,
@@ -425,6 +428,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-shared-world", action="store_true")
+    ap.add_argument("--watchdog", type=int, default=240, help="seconds the shared-world part may take before the line is printed without it")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -559,14 +563,34 @@ def main():
                                  "ticks); fused50 = 50 steps per launch, state in registers (open-loop commands)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(afa)
+    # The headline is measured.  What follows (the shared-world exchange: a second communicator, collectives at
+    # query cadence) must never cost the line already in hand: if it has not finished within the watchdog's
+    # time -- a rank stuck in a collective, whatever the cause -- rank 0 prints the line with the failure
+    # recorded and every rank leaves.
+    import threading
+
+    def bail():
+        if rank == 0:
+            out["shared_world"] = {"error": "did not finish within %d s; headline and roofline above are unaffected" % args.watchdog}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    dog = threading.Timer(args.watchdog, bail)
+    dog.daemon = True
+    dog.start()
     if not args.no_shared_world:
-        sw = shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, barrier)   # collective: every rank
+        try:
+            sw = shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, barrier)   # collective: every rank
+        except Exception as ex:                      # the other ranks may be waiting for this one: the watchdog frees them
+            sw = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            sys.stderr.write("bench.py rank %d: shared_world failed: %s\n" % (rank, sw["error"]))
         if rank == 0:
             out["shared_world"] = sw
     e.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    dog.cancel()
     if rank == 0:
         print(json.dumps(out))
 

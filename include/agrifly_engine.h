@@ -553,6 +553,11 @@ int afe_nearest_neighbour(afe_engine *e, const float *all_xyz, int64_t n_all,
                           float *dist2_out, int32_t *index_out);
 int afe_nearest_neighbour_grid(afe_engine *e, const float *all_xyz, int64_t n_all, float cell_size,
                                float *dist2_out, int32_t *index_out);
+/* How often the grid is re-shaped from the ensemble's current bounds and spread: every
+ * `every_n_queries` queries (default 1).  Re-shaping needs one 6 KB read-back, i.e. it synchronises
+ * the stream; in between, queries are fully asynchronous.  Results do not depend on it (the query is
+ * exact for any grid; vehicles that have left the grid's core are clamped into its boundary cells). */
+int afe_set_neighbour_grid_refresh(afe_engine *e, int every_n_queries);
 /* shape of the grid the last query used, and how many of its queries fell through to brute force
  * (isolated vehicles; reading that count synchronises the device).  Any pointer may be NULL. */
 int afe_neighbour_grid_info(const afe_engine *e, int dims[3], float *cell_size, int64_t *n_cells, int64_t *n_bruteforce);

@@ -109,6 +109,37 @@ def test_grid_equals_the_definition_on_awkward_worlds(name, cell_size, ora):
     np.testing.assert_array_equal(d2, ref_d)
 
 
+def test_a_stale_grid_shape_is_still_exact(ora):
+    """afe_set_neighbour_grid_refresh: between two re-shapes the query runs without its read-back (fully
+    asynchronous) on the OLD grid.  The ensemble meanwhile spreads to three times its size, drifts out of the
+    old box altogether and collapses into clusters: every answer must still be the definition's."""
+    import torch
+    n = 5000
+    rng = np.random.default_rng(33)
+    base = rng.uniform(-10, 10, (3, n))
+    worlds = [base, base * 3.0, base + np.array([[80.0], [-60.0], [15.0]]),
+              np.concatenate([np.array(c, float)[:, None] + rng.normal(0, 0.2, (3, n // 2)) for c in ((200, 0, 0), (-150, 90, 5))], axis=1),
+              base * 0.01]
+    with afa.Ensemble(n) as e:
+        e.set_type_table([afa.params_from_type(5)])
+        e.set_neighbour_grid_refresh(1000)
+        shape = None
+        for k, w in enumerate(worlds):
+            pos = w.astype(np.float32)
+            t = torch.from_numpy(np.ascontiguousarray(pos)).cuda()
+            d2, idx = _nn(e, t, n)
+            info = e.neighbour_grid_info()
+            if shape is None:
+                shape = (info["dims"], info["cell_size"])
+            assert (info["dims"], info["cell_size"]) == shape          # the first query's grid, never re-shaped
+            ref_d, ref_i = ora.nearest_neighbour(pos)
+            np.testing.assert_array_equal(idx, ref_i, err_msg="world %d" % k)
+            np.testing.assert_array_equal(d2, ref_d)
+        e.set_neighbour_grid_refresh(1)
+        _nn(e, t, n)
+        assert e.neighbour_grid_info()["cell_size"] != shape[1]         # re-shaped for the collapsed ensemble
+
+
 def test_full_size_neighbour_query_is_exact_and_under_a_millisecond():
     """config-4 size on one GPU: 2^20 vehicles queried against 2^20; the grid result equals the
     brute-force definition (run on the GPU for a 4096-vehicle subsample plus the extremes) bit for
