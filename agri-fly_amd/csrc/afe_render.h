@@ -11,7 +11,7 @@ struct BvhNode {
   float lo[3];
   int32_t a;   // leaf: first triangle (leaf order); inner: left child, right child = a + 1
   float hi[3];
-  int32_t b;   // leaf: triangle count (> 0); inner: 0
+  int32_t b;   // leaf: triangle count (> 0); inner: minus the node's depth (root = -1)
 };
 
 // implemented in afe_engine.cpp: the stream the engine launches on and its device

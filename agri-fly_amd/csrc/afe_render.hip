@@ -178,7 +178,7 @@ struct Builder {
       nodes.push_back(BvhNode());
       nodes.push_back(BvhNode());
       nodes[(size_t)w.node].a = left;
-      nodes[(size_t)w.node].b = 0;
+      nodes[(size_t)w.node].b = -w.depth;   // inner node: b <= 0; the depth rides along for the counting build
       todo.push_back({left, w.first, mid - w.first, w.depth + 1});
       todo.push_back({left + 1, mid, w.first + w.count - mid, w.depth + 1});
     }
@@ -341,10 +341,10 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   int sp = 0;
   int node = 0;
   bool mine = in_image, fresh = true;      // fresh: `mine` has to be established by a box test (root, popped nodes)
-  unsigned c_nodes = 0, c_tri_wave_box = 0, c_tri_wave_mt = 0, c_tri_lane_box = 0, c_tri_lane_mt = 0;   // COUNT only
+  unsigned c_top = 0, c_nodes = 0, c_tri_wave_box = 0, c_tri_wave_mt = 0, c_tri_lane_box = 0, c_tri_lane_mt = 0;   // COUNT only
   for (;;) {
     const BvhNode n = a.nodes[node];
-    if (COUNT) c_nodes += 1;
+    if (COUNT) { c_nodes += 1; if (n.b <= 0 && n.b >= -8) c_top += 1; }
     if (fresh) mine = in_image && box_entry(n, of, inv, best_f) < INFINITY;
     int next = -1;
     if (__ballot(mine)) {
@@ -408,6 +408,7 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
       atomicAdd(&a.counters[4], (unsigned long long)lane_mt);
       atomicAdd(&a.counters[5], (unsigned long long)rays);
       atomicAdd(&a.counters[6], 1ull);
+      atomicAdd(&a.counters[7], (unsigned long long)c_top);
     }
   }
 }
@@ -668,7 +669,7 @@ extern "C" int afe_render_depth(afe_scene *s, const afe_camera *cam, int64_t n_v
 // The counting build of the same kernel over explicit poses: what the traversal did, for the roofline
 // accounting of bench.py.  stats: [0] nodes visited (per wave), [1] triangle box tests (per wave),
 // [2] triangle double-precision tests actually executed (per wave), [3] triangle box tests (per ray),
-// [4] double-precision tests (per ray), [5] rays, [6] waves (8 x 8 tiles), [7] 0.
+// [4] double-precision tests (per ray), [5] rays, [6] waves (8 x 8 tiles), [7] visits of inner nodes of depth <= 8 (per wave).
 extern "C" int afe_render_depth_stats(afe_scene *s, const afe_camera *cam, int64_t n_views, const double *pos,
                                       const double *att, const double mount[4], uint64_t stats[8], float *kernel_ms) {
   if (!s || !camera_ok(cam) || n_views <= 0 || !pos || !att || !stats) return AFE_ERR_INVALID_ARG;
