@@ -56,8 +56,10 @@ struct Builder {
   std::vector<float> centroid;   // n x 3
   std::vector<int32_t> order;    // permutation being partitioned
   std::vector<BvhNode> nodes;
+  std::vector<uint8_t> node_axis;   // inner nodes: the axis the children were separated along (left = lower side)
   int max_depth = 0;
   bool median_only = false;
+  int split_axis = 0;               // set by split()
 
   static constexpr int kBins = 16;
 #ifndef AFE_BVH_LEAF
@@ -89,6 +91,7 @@ struct Builder {
     float ext = -1;
     for (int k = 0; k < 3; k++) if (cb.hi[k] - cb.lo[k] > ext) { ext = cb.hi[k] - cb.lo[k]; axis = k; }
     auto median = [&]() -> int64_t {
+      split_axis = axis;
       const int64_t mid = first + count / 2;
       std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
                        [&](int32_t a, int32_t b) {
@@ -141,6 +144,7 @@ struct Builder {
     });
     const int64_t mid = it - order.begin();
     if (mid == first || mid == first + count) return median();
+    split_axis = best_axis;
     return mid;
   }
 
@@ -158,6 +162,7 @@ struct Builder {
     nodes.clear();
     nodes.reserve((size_t)(2 * n + 2));
     nodes.push_back(BvhNode());
+    node_axis.assign(1, 0);
     struct Work { int32_t node; int64_t first, count; int depth; };
     std::vector<Work> todo;
     todo.push_back({0, 0, n, 1});
@@ -177,11 +182,48 @@ struct Builder {
       const int32_t left = (int32_t)nodes.size();
       nodes.push_back(BvhNode());
       nodes.push_back(BvhNode());
+      node_axis.push_back(0);
+      node_axis.push_back(0);
+      node_axis[(size_t)w.node] = (uint8_t)split_axis;
       nodes[(size_t)w.node].a = left;
       nodes[(size_t)w.node].b = -w.depth;   // inner node: b <= 0; the depth rides along for the counting build
       todo.push_back({left, w.first, mid - w.first, w.depth + 1});
       todo.push_back({left + 1, mid, w.first + w.count - mid, w.depth + 1});
     }
+  }
+
+  // The kernel's form of the tree: one PairNode per inner node (afe_render.h).  A mesh small enough to be
+  // a single leaf gets one record naming that leaf twice (testing a triangle twice changes no minimum).
+  std::vector<PairNode> pairs() const {
+    std::vector<int32_t> pair_of(nodes.size(), -1);
+    int32_t n_pairs = 0;
+    for (size_t k = 0; k < nodes.size(); k++) if (nodes[k].b <= 0) pair_of[k] = n_pairs++;
+    std::vector<PairNode> out((size_t)std::max(n_pairs, 1));
+    auto child = [&](const BvhNode &c, size_t index, float box[6], int32_t &ref, uint32_t &count) {
+      for (int k = 0; k < 3; k++) { box[2 * k] = c.lo[k]; box[2 * k + 1] = c.hi[k]; }
+      if (c.b > 0) { ref = c.a; count = (uint32_t)c.b; }
+      else { ref = pair_of[index]; count = 0; }
+    };
+    if (n_pairs == 0) {
+      PairNode &p = out[0];
+      uint32_t cl = 0, cr = 0;
+      child(nodes[0], 0, p.box_l, p.left, cl);
+      child(nodes[0], 0, p.box_r, p.right, cr);
+      p.meta = (cl << 8) | (cr << 16) | (1u << 24);
+      p.pad = 0;
+      return out;
+    }
+    for (size_t k = 0; k < nodes.size(); k++) {
+      if (nodes[k].b > 0) continue;
+      PairNode &p = out[(size_t)pair_of[k]];
+      const size_t l = (size_t)nodes[k].a;
+      uint32_t cl = 0, cr = 0;
+      child(nodes[l], l, p.box_l, p.left, cl);
+      child(nodes[l + 1], l + 1, p.box_r, p.right, cr);
+      p.meta = (uint32_t)node_axis[k] | (cl << 8) | (cr << 16) | ((uint32_t)std::min(-nodes[k].b, 255) << 24);
+      p.pad = 0;
+    }
+    return out;
   }
 };
 
@@ -246,11 +288,11 @@ __global__ void afe_camera_pose_kernel(PoseArgs a) {
 // subtractions per test), and the triangle's own box in fp32, inflated like the node boxes.
 struct TriRec {
   double v0[3], e1[3], e2[3];
-  float lo[3], hi[3];
+  float box[6];   // {lo, hi} per axis
 };
 
 struct RenderArgs {
-  const BvhNode *nodes;
+  const PairNode *pairs;
   const TriRec *tris;       // leaf order
   const double *poses;
   uint16_t *out;
@@ -261,24 +303,26 @@ struct RenderArgs {
   int max_count;
 };
 
-// Slab test against one node's box in fp32; returns a lower bound of the entry distance or +inf.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
+// Slab test against one box in fp32: can the ray be inside it anywhere in [0, best]?
 // The builder inflates every box by 3e-4 m + 4e-6 |coordinate| -- two orders of magnitude more than
-// what rounding the ray to fp32 can move it -- and the comparisons below carry a relative slack of
+// what rounding the ray to fp32 can move it -- and the comparison below carries a relative slack of
 // 1e-5, so the test only ever errs towards visiting a box: which triangles a ray reaches, and
 // therefore the fp64 hit distance, cannot depend on it.
-// (oi = o * inv is precomputed per ray, so a slab costs two FMAs; where that turns a zero direction
-// component into a NaN the fminf / fmaxf below ignore it, which again can only let a box through.)
-template <class BoxT>
-__device__ __forceinline__ float box_entry(const BoxT &n, const float oi[3], const float inv[3], float best) {
-  float tmin = 0.0f, tmax = best;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const float t0 = __builtin_fmaf(n.lo[k], inv[k], -oi[k]);
-    const float t1 = __builtin_fmaf(n.hi[k], inv[k], -oi[k]);
-    tmin = fmaxf(tmin, fminf(t0, t1));
-    tmax = fminf(tmax, fmaxf(t0, t1));
-  }
-  return tmin * 0.99999f <= tmax * 1.00001f ? tmin * 0.99999f : INFINITY;
+// oi = o * inv is precomputed per ray and a box arrives as three {lo, hi} pairs in scalar registers, so a
+// slab is ONE packed FMA (v_pk_fma_f32: both faces at once).  Where a zero direction component has
+// turned oi into a NaN the fminf / fmaxf ignore it, which again can only let a box through.
+__device__ __forceinline__ bool box_reached(f32x2 bx, f32x2 by, f32x2 bz, const float oi[3], const float inv[3],
+                                            float best) {
+  const f32x2 tx = __builtin_elementwise_fma(bx, (f32x2){inv[0], inv[0]}, (f32x2){-oi[0], -oi[0]});
+  const f32x2 ty = __builtin_elementwise_fma(by, (f32x2){inv[1], inv[1]}, (f32x2){-oi[1], -oi[1]});
+  const f32x2 tz = __builtin_elementwise_fma(bz, (f32x2){inv[2], inv[2]}, (f32x2){-oi[2], -oi[2]});
+  float tmin = fmaxf(0.0f, fminf(tx.x, tx.y)), tmax = fminf(best, fmaxf(tx.x, tx.y));
+  tmin = fmaxf(tmin, fminf(ty.x, ty.y)); tmax = fminf(tmax, fmaxf(ty.x, ty.y));
+  tmin = fmaxf(tmin, fminf(tz.x, tz.y)); tmax = fminf(tmax, fmaxf(tz.x, tz.y));
+  return tmin * 0.99999f <= tmax * 1.00001f;
 }
 
 __device__ __forceinline__ double ray_triangle(const double o[3], const double d[3], const TriRec &T) {
@@ -300,11 +344,104 @@ __device__ __forceinline__ double ray_triangle(const double o[3], const double d
   return t > 0.0 ? t : INFINITY;
 }
 
+struct RayState {
+  double o[3], d[3];
+  float inv[3], oi[3];
+  double best;
+  float best_f;
+};
+
+struct WalkCounters { unsigned top = 0, nodes = 0, tri_wave_box = 0, tri_wave_mt = 0, tri_lane_box = 0, tri_lane_mt = 0; };
+
+__device__ __forceinline__ float as_float(uint32_t u) { return __builtin_bit_cast(float, u); }
+// v_writelane_b32 (this compiler has the read side as a builtin, the write side only as the intrinsic)
+extern "C" __device__ int afe_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+// the triangles of one leaf, for the lanes in mask m (wave-uniform): the triangle's own (inflated) box
+// first, in fp32 -- a ray that misses it, or enters it no nearer than its best hit so far, cannot gain
+// anything from this triangle, and when that holds for all 64 rays of the tile the double-precision
+// test is skipped altogether
+template <bool COUNT>
+__device__ __forceinline__ void leaf_triangles(const RenderArgs &a, RayState &ray, int32_t first, unsigned count,
+                                               uint64_t m, WalkCounters &cnt) {
+#pragma clang fp contract(off)
+  for (unsigned k = 0; k < count; k++) {
+    const TriRec &T = a.tris[first + (int32_t)k];
+    const bool in_box = box_reached((f32x2){T.box[0], T.box[1]}, (f32x2){T.box[2], T.box[3]},
+                                    (f32x2){T.box[4], T.box[5]}, ray.oi, ray.inv, ray.best_f);
+    const uint64_t reach = __ballot(in_box) & m;
+    if (COUNT) { cnt.tri_lane_box += __builtin_amdgcn_inverse_ballot_w64(m) ? 1 : 0; cnt.tri_wave_box += 1; }
+    if (reach) {
+      const bool me = __builtin_amdgcn_inverse_ballot_w64(reach);
+      if (COUNT) { cnt.tri_wave_mt += 1; cnt.tri_lane_mt += me ? 1 : 0; }
+      if (me) {
+        const double th = ray_triangle(ray.o, ray.d, T);
+        if (th < ray.best) { ray.best = th; ray.best_f = __double2float_ru(th); }
+      }
+    }
+  }
+}
+
+// The 64 rays of a tile walk the tree TOGETHER: one node index and one stack for the wave (so node
+// records and triangles arrive by scalar loads, once per wave instead of once per lane).  A visit
+// is one 64-byte scalar load (a PairNode: the boxes of both children); every lane tests its own ray
+// against both, and a child is entered if the ray of any lane still in the node reaches it.  The child
+// on the side the rays come from (split axis x direction sign: a scalar decision) goes first; a leaf
+// child's triangles are tested there and then, an inner child is descended into, and when both are
+// inner the farther one is pushed together with the mask of the lanes that reached it.  Lane sets
+// are 64-bit masks in scalar registers throughout (ballots), the stack lives in three vector
+// registers (entry k in lane k: v_writelane / v_readlane, no LDS, nothing to wait for).  The mask of a
+// popped entry may be stale (the ray's best hit may have come nearer since) -- that only costs box
+// tests.  The closest hit is a minimum over the triangles each ray reaches, each value computed in
+// double exactly as the checker does, so the result does not depend on the order.
+template <bool COUNT>
+__device__ __forceinline__ void walk(const RenderArgs &a, RayState &ray, bool in_image, unsigned neg,
+                                     WalkCounters &cnt) {
+  int sp = 0;
+  int st_node = 0, st_lo = 0, st_hi = 0;
+  int cur = 0;
+  uint64_t act = __ballot(in_image);
+  for (;;) {
+    const u32x16 R = *reinterpret_cast<const u32x16 *>(a.pairs + cur);
+    const uint32_t meta = R[14];
+    if (COUNT) { cnt.nodes += 1; if ((meta >> 24) <= 8u) cnt.top += 1; }
+    const bool bl = box_reached((f32x2){as_float(R[0]), as_float(R[1])}, (f32x2){as_float(R[2]), as_float(R[3])},
+                                (f32x2){as_float(R[4]), as_float(R[5])}, ray.oi, ray.inv, ray.best_f);
+    const bool br = box_reached((f32x2){as_float(R[6]), as_float(R[7])}, (f32x2){as_float(R[8]), as_float(R[9])},
+                                (f32x2){as_float(R[10]), as_float(R[11])}, ray.oi, ray.inv, ray.best_f);
+    const uint64_t ml = __ballot(bl) & act, mr = __ballot(br) & act;
+    // nearer side first: the left child holds the lower centroids along the split axis
+    const bool right_first = (neg >> (meta & 3u)) & 1u;
+    const uint64_t m1 = right_first ? mr : ml, m2 = right_first ? ml : mr;
+    const int32_t ref1 = (int32_t)(right_first ? R[13] : R[12]), ref2 = (int32_t)(right_first ? R[12] : R[13]);
+    const unsigned c1 = (right_first ? (meta >> 16) : (meta >> 8)) & 255u;
+    const unsigned c2 = (right_first ? (meta >> 8) : (meta >> 16)) & 255u;
+    if (m1 && c1) leaf_triangles<COUNT>(a, ray, ref1, c1, m1, cnt);
+    if (m2 && c2) leaf_triangles<COUNT>(a, ray, ref2, c2, m2, cnt);
+    const bool inner1 = m1 && !c1, inner2 = m2 && !c2;
+    if (inner1) {
+      if (inner2) {
+        const int lo = (int)(uint32_t)m2, hi = (int)(uint32_t)(m2 >> 32);
+        st_node = afe_writelane(ref2, sp, st_node);
+        st_lo = afe_writelane(lo, sp, st_lo);
+        st_hi = afe_writelane(hi, sp, st_hi);
+        sp++;
+      }
+      cur = ref1; act = m1;
+      continue;
+    }
+    if (inner2) { cur = ref2; act = m2; continue; }
+    if (sp == 0) break;
+    --sp;
+    cur = __builtin_amdgcn_readlane(st_node, sp);
+    act = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(st_lo, sp) |
+          ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(st_hi, sp) << 32);
+  }
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(RenderArgs a) {
 #pragma clang fp contract(off)
-  __shared__ int32_t stack_node[kStack];     // one stack for the wave
-
   // XCD-aware order: hardware block b runs on XCD b % 8; give each XCD a contiguous run
   // of logical blocks (= consecutive tiles of consecutive views) so that its L2 keeps the
   // part of the tree those views look at
@@ -319,72 +456,31 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   const bool in_image = px < a.width && py < a.height;   // lanes outside still take part in the wave's votes
 
   const double *pose = a.poses + 12 * view;
-  const double o[3] = {pose[0], pose[1], pose[2]};
+  RayState ray;
+  for (int k = 0; k < 3; k++) ray.o[k] = pose[k];
   const double u = (px - a.cx) / a.focal;
   const double v = (py - a.cy) / a.focal;
-  const double d[3] = {pose[3] * u + pose[4] * v + pose[5], pose[6] * u + pose[7] * v + pose[8],
-                       pose[9] * u + pose[10] * v + pose[11]};
-  const float inv[3] = {1.0f / (float)d[0], 1.0f / (float)d[1], 1.0f / (float)d[2]};
-  const float of[3] = {(float)o[0] * inv[0], (float)o[1] * inv[1], (float)o[2] * inv[2]};   // o * inv, see box_entry
-
-  double best = INFINITY;
+  for (int k = 0; k < 3; k++) ray.d[k] = pose[3 + 3 * k] * u + pose[4 + 3 * k] * v + pose[5 + 3 * k];
+  for (int k = 0; k < 3; k++) {
+    ray.inv[k] = 1.0f / (float)ray.d[k];
+    ray.oi[k] = (float)ray.o[k] * ray.inv[k];   // o * inv, see box_reached
+  }
+  ray.best = INFINITY;
   // pruning bound of the fp32 box tests: the best hit so far, rounded up.  A hit at or beyond
   // max_count * depth_scale saturates to max_count exactly like a miss, so nothing farther than
   // that needs to be found at all.
-  float best_f = __double2float_ru((double)a.max_count * a.depth_scale * 1.000001);
-  // The 64 rays of a tile walk the tree TOGETHER: one node index for the wave (so nodes and
-  // triangles arrive by scalar loads, once per wave instead of once per lane), every lane tests
-  // its own ray against the boxes, a child is entered if any lane's ray enters it, the nearer
-  // child by majority vote.  `mine` says whether this lane's ray is inside the node being visited;
-  // lanes that are not skip its triangles.  The closest hit is still a minimum over the triangles
-  // each ray reaches, so the result does not depend on the order.
-  int sp = 0;
-  int node = 0;
-  bool mine = in_image, fresh = true;      // fresh: `mine` has to be established by a box test (root, popped nodes)
-  unsigned c_top = 0, c_nodes = 0, c_tri_wave_box = 0, c_tri_wave_mt = 0, c_tri_lane_box = 0, c_tri_lane_mt = 0;   // COUNT only
-  for (;;) {
-    const BvhNode n = a.nodes[node];
-    if (COUNT) { c_nodes += 1; if (n.b <= 0 && n.b >= -8) c_top += 1; }
-    if (fresh) mine = in_image && box_entry(n, of, inv, best_f) < INFINITY;
-    int next = -1;
-    if (__ballot(mine)) {
-      if (n.b > 0) {
-        for (int k = 0; k < n.b; k++) {
-          const TriRec &T = a.tris[n.a + k];
-          // the triangle's own (inflated) box first, in fp32: a ray that misses it, or enters it no nearer
-          // than its best hit so far, cannot gain anything from this triangle -- and when that holds for
-          // all 64 rays of the tile the double-precision test is skipped altogether
-          const bool reach = mine && box_entry(T, of, inv, best_f) < INFINITY;
-          if (COUNT) { c_tri_lane_box += mine ? 1 : 0; c_tri_wave_box += 1; }
-          if (__ballot(reach)) {
-            if (COUNT) { c_tri_wave_mt += 1; c_tri_lane_mt += reach ? 1 : 0; }
-            if (reach) {
-              const double th = ray_triangle(o, d, T);
-              if (th < best) { best = th; best_f = __double2float_ru(th); }
-            }
-          }
-        }
-      } else {
-        const BvhNode l = a.nodes[n.a], r = a.nodes[n.a + 1];
-        const float tl = mine ? box_entry(l, of, inv, best_f) : INFINITY;
-        const float tr = mine ? box_entry(r, of, inv, best_f) : INFINITY;
-        const bool hl = tl < INFINITY, hr = tr < INFINITY;
-        const uint64_t ml = __ballot(hl), mr = __ballot(hr);
-        if (ml | mr) {
-          const int votes_l = __popcll(__ballot(hl && (!hr || tl <= tr)));
-          const int votes_r = __popcll(__ballot(hr && (!hl || tr < tl)));
-          const bool left_first = mr == 0 || (ml != 0 && votes_l >= votes_r);
-          if (ml && mr) { stack_node[sp] = left_first ? n.a + 1 : n.a; sp++; }
-          next = left_first ? n.a : n.a + 1;
-          mine = left_first ? hl : hr;
-        }
-      }
-    }
-    if (next >= 0) { node = next; fresh = false; continue; }
-    if (sp == 0) break;
-    node = __builtin_amdgcn_readfirstlane(stack_node[--sp]);
-    fresh = true;
-  }
+  ray.best_f = __double2float_ru((double)a.max_count * a.depth_scale * 1.000001);
+
+  // bit k of `neg`: direction component k is negative for the tile's rays (for some of them, where a
+  // tile straddles a coordinate plane through the camera -- it only orders the visits)
+  unsigned neg = 0;
+  for (int k = 0; k < 3; k++) neg |= __ballot(ray.inv[k] < 0.0f) ? (1u << k) : 0u;
+
+  WalkCounters cnt;
+  walk<COUNT>(a, ray, in_image, neg, cnt);
+  const double best = ray.best;
+  const unsigned c_top = cnt.top, c_nodes = cnt.nodes, c_tri_wave_box = cnt.tri_wave_box, c_tri_wave_mt = cnt.tri_wave_mt,
+                 c_tri_lane_box = cnt.tri_lane_box, c_tri_lane_mt = cnt.tri_lane_mt;
 
   uint16_t count = (uint16_t)a.max_count;
   if (best < INFINITY) {
@@ -425,7 +521,7 @@ struct afe_scene {
   int64_t n_tri = 0, n_nodes = 0;
   int depth = 0;
   double bounds[6] = {0, 0, 0, 0, 0, 0};
-  BvhNode *nodes = nullptr;
+  PairNode *pairs = nullptr;
   TriRec *tris = nullptr;
 };
 
@@ -461,7 +557,7 @@ bool camera_ok(const afe_camera *c) {
 int launch_render(const afe_scene *s, const afe_camera *cam, int64_t count, const double *poses, uint16_t *out_dev,
                   hipStream_t stream, float *kernel_ms, unsigned long long *dev_counters = nullptr) {
   RenderArgs r;
-  r.nodes = s->nodes; r.tris = s->tris; r.counters = dev_counters;
+  r.pairs = s->pairs; r.tris = s->tris; r.counters = dev_counters;
   r.width = cam->width; r.height = cam->height;
   r.tiles_x = (cam->width + kTileW - 1) / kTileW;
   r.tiles_per_view = r.tiles_x * ((cam->height + kTileH - 1) / kTileH);
@@ -564,8 +660,8 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
       T.v0[k] = (double)src[k];
       T.e1[k] = (double)src[3 + k] - T.v0[k];
       T.e2[k] = (double)src[6 + k] - T.v0[k];
-      T.lo[k] = inflated.lo[k];
-      T.hi[k] = inflated.hi[k];
+      T.box[2 * k] = inflated.lo[k];
+      T.box[2 * k + 1] = inflated.hi[k];
     }
   }
   afe_scene *s = new afe_scene();
@@ -575,9 +671,10 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
   s->depth = b.max_depth;
   Box all = b.range_box(0, n_tri);
   for (int k = 0; k < 3; k++) { s->bounds[k] = all.lo[k]; s->bounds[3 + k] = all.hi[k]; }
-  if (hipMalloc((void **)&s->nodes, b.nodes.size() * sizeof(BvhNode)) != hipSuccess ||
+  const std::vector<PairNode> pairs = b.pairs();
+  if (hipMalloc((void **)&s->pairs, pairs.size() * sizeof(PairNode)) != hipSuccess ||
       hipMalloc((void **)&s->tris, packed.size() * sizeof(TriRec)) != hipSuccess ||
-      hipMemcpy(s->nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(s->pairs, pairs.data(), pairs.size() * sizeof(PairNode), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(s->tris, packed.data(), packed.size() * sizeof(TriRec), hipMemcpyHostToDevice) != hipSuccess) {
     afe_scene_destroy(s);
     return AFE_ERR_HIP;
@@ -633,7 +730,7 @@ extern "C" int afe_scene_check_hierarchy(const float *triangles, int64_t n_tri, 
 
 extern "C" void afe_scene_destroy(afe_scene *s) {
   if (!s) return;
-  if (s->nodes) (void)hipFree(s->nodes);
+  if (s->pairs) (void)hipFree(s->pairs);
   if (s->tris) (void)hipFree(s->tris);
   delete s;
 }
