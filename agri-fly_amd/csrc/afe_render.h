@@ -20,7 +20,7 @@ struct BvhNode {
 struct PairNode {
   float box_l[6];           // left child's box (inflated, see Builder::set_bounds): {lo, hi} per axis
   float box_r[6];           // right child's box
-  int32_t left, right;      // inner child: index of its PairNode; leaf child: first triangle (leaf order)
+  uint32_t left, right;     // inner child: byte offset of its PairNode in the array; leaf child: first triangle (leaf order)
   uint32_t meta;            // bits 0-1 split axis (left = lower side), 8-15 / 16-23 triangle count of the
                             // left / right child (0 = inner), 24-31 depth of this node (root = 1)
   uint32_t pad;

@@ -192,17 +192,29 @@ struct Builder {
     }
   }
 
-  // The kernel's form of the tree: one PairNode per inner node (afe_render.h).  A mesh small enough to be
-  // a single leaf gets one record naming that leaf twice (testing a triangle twice changes no minimum).
-  std::vector<PairNode> pairs() const {
+  // The kernel's form of the tree: one PairNode per inner node (afe_render.h), child references as byte
+  // offsets into the array.  A mesh small enough to be a single leaf gets one record naming that leaf
+  // twice (testing a triangle twice changes no minimum).
+  //
+  // `octant` (bit k = axis k mirrored): the same tree in coordinates mirrored about the origin along
+  // those axes -- box {lo, hi} becomes {-hi, -lo} -- with the children of a node split along a mirrored
+  // axis exchanged.  For rays whose direction is negative exactly along those axes, mirrored, every
+  // component is positive: the near face of every slab is `lo`, and the child holding the lower
+  // centroids (stored first) is the one the rays meet first.  (-hi)(-inv) is hi * inv bit for bit, so
+  // the slab distances are the ones the unmirrored test computes.
+  std::vector<PairNode> pairs(unsigned octant = 0) const {
     std::vector<int32_t> pair_of(nodes.size(), -1);
     int32_t n_pairs = 0;
     for (size_t k = 0; k < nodes.size(); k++) if (nodes[k].b <= 0) pair_of[k] = n_pairs++;
     std::vector<PairNode> out((size_t)std::max(n_pairs, 1));
-    auto child = [&](const BvhNode &c, size_t index, float box[6], int32_t &ref, uint32_t &count) {
-      for (int k = 0; k < 3; k++) { box[2 * k] = c.lo[k]; box[2 * k + 1] = c.hi[k]; }
-      if (c.b > 0) { ref = c.a; count = (uint32_t)c.b; }
-      else { ref = pair_of[index]; count = 0; }
+    auto child = [&](const BvhNode &c, size_t index, float box[6], uint32_t &ref, uint32_t &count) {
+      for (int k = 0; k < 3; k++) {
+        const bool mirrored = (octant >> k) & 1u;
+        box[2 * k] = mirrored ? -c.hi[k] : c.lo[k];
+        box[2 * k + 1] = mirrored ? -c.lo[k] : c.hi[k];
+      }
+      if (c.b > 0) { ref = (uint32_t)c.a; count = (uint32_t)c.b; }
+      else { ref = (uint32_t)pair_of[index] * (uint32_t)sizeof(PairNode); count = 0; }
     };
     if (n_pairs == 0) {
       PairNode &p = out[0];
@@ -216,11 +228,13 @@ struct Builder {
     for (size_t k = 0; k < nodes.size(); k++) {
       if (nodes[k].b > 0) continue;
       PairNode &p = out[(size_t)pair_of[k]];
-      const size_t l = (size_t)nodes[k].a;
+      const unsigned axis = node_axis[k];
+      const bool exchange = (octant >> axis) & 1u;
+      const size_t l = (size_t)nodes[k].a + (exchange ? 1 : 0), r = (size_t)nodes[k].a + (exchange ? 0 : 1);
       uint32_t cl = 0, cr = 0;
       child(nodes[l], l, p.box_l, p.left, cl);
-      child(nodes[l + 1], l + 1, p.box_r, p.right, cr);
-      p.meta = (uint32_t)node_axis[k] | (cl << 8) | (cr << 16) | ((uint32_t)std::min(-nodes[k].b, 255) << 24);
+      child(nodes[r], r, p.box_r, p.right, cr);
+      p.meta = axis | (cl << 8) | (cr << 16) | ((uint32_t)std::min(-nodes[k].b, 255) << 24);
       p.pad = 0;
     }
     return out;
@@ -292,7 +306,8 @@ struct TriRec {
 };
 
 struct RenderArgs {
-  const PairNode *pairs;
+  const PairNode *pairs;    // eight copies of n_pairs records: [0] as built, [c] mirrored along the axes in c
+  int64_t n_pairs;
   const TriRec *tris;       // leaf order
   const double *poses;
   uint16_t *out;
@@ -357,16 +372,40 @@ __device__ __forceinline__ float as_float(uint32_t u) { return __builtin_bit_cas
 // v_writelane_b32 (this compiler has the read side as a builtin, the write side only as the intrinsic)
 extern "C" __device__ int afe_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
+// What a lane keeps of its ray for the box tests.  ORDERED (all 64 rays of the tile agree on the sign of
+// every direction component; the wave then walks the copy of the tree mirrored into the all-positive
+// octant): per axis {|inv| (1 - 1e-5), |inv| (1 + 1e-5)} and the same two factors on -o * inv, so that one
+// packed FMA on a {lo, hi} pair yields the near distance already slackened downwards and the far
+// distance upwards, and the test is max3 / min3 and one comparison.  Otherwise {inv, inv}, {-oi, -oi}.
+struct BoxRay { f32x2 scale[3], shift[3]; };
+
+template <bool ORDERED>
+__device__ __forceinline__ bool node_box_reached(f32x2 bx, f32x2 by, f32x2 bz, const BoxRay &r, float best) {
+  const f32x2 tx = __builtin_elementwise_fma(bx, r.scale[0], r.shift[0]);
+  const f32x2 ty = __builtin_elementwise_fma(by, r.scale[1], r.shift[1]);
+  const f32x2 tz = __builtin_elementwise_fma(bz, r.scale[2], r.shift[2]);
+  if (ORDERED) {
+    // a NaN (zero direction component) is ignored by fmaxf / fminf: that can only let a box through
+    const float tmin = fmaxf(fmaxf(fmaxf(0.0f, tx.x), ty.x), tz.x);
+    const float tmax = fminf(fminf(fminf(best, tx.y), ty.y), tz.y);
+    return tmin <= tmax;
+  }
+  float tmin = fmaxf(0.0f, fminf(tx.x, tx.y)), tmax = fminf(best, fmaxf(tx.x, tx.y));
+  tmin = fmaxf(tmin, fminf(ty.x, ty.y)); tmax = fminf(tmax, fmaxf(ty.x, ty.y));
+  tmin = fmaxf(tmin, fminf(tz.x, tz.y)); tmax = fminf(tmax, fmaxf(tz.x, tz.y));
+  return tmin * 0.99999f <= tmax * 1.00001f;
+}
+
 // the triangles of one leaf, for the lanes in mask m (wave-uniform): the triangle's own (inflated) box
 // first, in fp32 -- a ray that misses it, or enters it no nearer than its best hit so far, cannot gain
 // anything from this triangle, and when that holds for all 64 rays of the tile the double-precision
 // test is skipped altogether
 template <bool COUNT>
-__device__ __forceinline__ void leaf_triangles(const RenderArgs &a, RayState &ray, int32_t first, unsigned count,
+__device__ __forceinline__ void leaf_triangles(const RenderArgs &a, RayState &ray, uint32_t first, unsigned count,
                                                uint64_t m, WalkCounters &cnt) {
 #pragma clang fp contract(off)
   for (unsigned k = 0; k < count; k++) {
-    const TriRec &T = a.tris[first + (int32_t)k];
+    const TriRec &T = a.tris[first + k];
     const bool in_box = box_reached((f32x2){T.box[0], T.box[1]}, (f32x2){T.box[2], T.box[3]},
                                     (f32x2){T.box[4], T.box[5]}, ray.oi, ray.inv, ray.best_f);
     const uint64_t reach = __ballot(in_box) & m;
@@ -386,34 +425,35 @@ __device__ __forceinline__ void leaf_triangles(const RenderArgs &a, RayState &ra
 // records and triangles arrive by scalar loads, once per wave instead of once per lane).  A visit
 // is one 64-byte scalar load (a PairNode: the boxes of both children); every lane tests its own ray
 // against both, and a child is entered if the ray of any lane still in the node reaches it.  The child
-// on the side the rays come from (split axis x direction sign: a scalar decision) goes first; a leaf
-// child's triangles are tested there and then, an inner child is descended into, and when both are
-// inner the farther one is pushed together with the mask of the lanes that reached it.  Lane sets
-// are 64-bit masks in scalar registers throughout (ballots), the stack lives in three vector
-// registers (entry k in lane k: v_writelane / v_readlane, no LDS, nothing to wait for).  The mask of a
-// popped entry may be stale (the ray's best hit may have come nearer since) -- that only costs box
-// tests.  The closest hit is a minimum over the triangles each ray reaches, each value computed in
-// double exactly as the checker does, so the result does not depend on the order.
-template <bool COUNT>
-__device__ __forceinline__ void walk(const RenderArgs &a, RayState &ray, bool in_image, unsigned neg,
-                                     WalkCounters &cnt) {
+// on the side the rays come from goes first -- in the mirrored copies (ORDERED) that is simply the one
+// stored first, otherwise split axis x direction sign, a scalar decision; a leaf child's triangles are
+// tested there and then, an inner child is descended into, and when both are inner the farther one
+// is pushed together with the mask of the lanes that reached it.  Lane sets are 64-bit masks in
+// scalar registers throughout (ballots), the stack lives in three vector registers (entry k in lane
+// k: v_writelane / v_readlane, no LDS, nothing to wait for).  The mask of a popped entry may be stale
+// (the ray's best hit may have come nearer since) -- that only costs box tests.  The closest hit is a
+// minimum over the triangles each ray reaches, each value computed in double exactly as the checker
+// does, so the result does not depend on the order.
+template <bool COUNT, bool ORDERED>
+__device__ __forceinline__ void walk(const RenderArgs &a, const PairNode *tree, RayState &ray, const BoxRay &br,
+                                     bool in_image, unsigned neg, WalkCounters &cnt) {
   int sp = 0;
   int st_node = 0, st_lo = 0, st_hi = 0;
-  int cur = 0;
+  uint32_t cur = 0;   // byte offset of the PairNode
   uint64_t act = __ballot(in_image);
   for (;;) {
-    const u32x16 R = *reinterpret_cast<const u32x16 *>(a.pairs + cur);
+    const u32x16 R = *reinterpret_cast<const u32x16 *>(reinterpret_cast<const char *>(tree) + cur);
     const uint32_t meta = R[14];
     if (COUNT) { cnt.nodes += 1; if ((meta >> 24) <= 8u) cnt.top += 1; }
-    const bool bl = box_reached((f32x2){as_float(R[0]), as_float(R[1])}, (f32x2){as_float(R[2]), as_float(R[3])},
-                                (f32x2){as_float(R[4]), as_float(R[5])}, ray.oi, ray.inv, ray.best_f);
-    const bool br = box_reached((f32x2){as_float(R[6]), as_float(R[7])}, (f32x2){as_float(R[8]), as_float(R[9])},
-                                (f32x2){as_float(R[10]), as_float(R[11])}, ray.oi, ray.inv, ray.best_f);
-    const uint64_t ml = __ballot(bl) & act, mr = __ballot(br) & act;
+    const bool bl = node_box_reached<ORDERED>((f32x2){as_float(R[0]), as_float(R[1])}, (f32x2){as_float(R[2]), as_float(R[3])},
+                                              (f32x2){as_float(R[4]), as_float(R[5])}, br, ray.best_f);
+    const bool bR = node_box_reached<ORDERED>((f32x2){as_float(R[6]), as_float(R[7])}, (f32x2){as_float(R[8]), as_float(R[9])},
+                                              (f32x2){as_float(R[10]), as_float(R[11])}, br, ray.best_f);
+    const uint64_t ml = __ballot(bl) & act, mr = __ballot(bR) & act;
     // nearer side first: the left child holds the lower centroids along the split axis
-    const bool right_first = (neg >> (meta & 3u)) & 1u;
+    const bool right_first = !ORDERED && ((neg >> (meta & 3u)) & 1u);
     const uint64_t m1 = right_first ? mr : ml, m2 = right_first ? ml : mr;
-    const int32_t ref1 = (int32_t)(right_first ? R[13] : R[12]), ref2 = (int32_t)(right_first ? R[12] : R[13]);
+    const uint32_t ref1 = right_first ? R[13] : R[12], ref2 = right_first ? R[12] : R[13];
     const unsigned c1 = (right_first ? (meta >> 16) : (meta >> 8)) & 255u;
     const unsigned c2 = (right_first ? (meta >> 8) : (meta >> 16)) & 255u;
     if (m1 && c1) leaf_triangles<COUNT>(a, ray, ref1, c1, m1, cnt);
@@ -421,10 +461,9 @@ __device__ __forceinline__ void walk(const RenderArgs &a, RayState &ray, bool in
     const bool inner1 = m1 && !c1, inner2 = m2 && !c2;
     if (inner1) {
       if (inner2) {
-        const int lo = (int)(uint32_t)m2, hi = (int)(uint32_t)(m2 >> 32);
-        st_node = afe_writelane(ref2, sp, st_node);
-        st_lo = afe_writelane(lo, sp, st_lo);
-        st_hi = afe_writelane(hi, sp, st_hi);
+        st_node = afe_writelane((int)ref2, sp, st_node);
+        st_lo = afe_writelane((int)(uint32_t)m2, sp, st_lo);
+        st_hi = afe_writelane((int)(uint32_t)(m2 >> 32), sp, st_hi);
         sp++;
       }
       cur = ref1; act = m1;
@@ -433,7 +472,7 @@ __device__ __forceinline__ void walk(const RenderArgs &a, RayState &ray, bool in
     if (inner2) { cur = ref2; act = m2; continue; }
     if (sp == 0) break;
     --sp;
-    cur = __builtin_amdgcn_readlane(st_node, sp);
+    cur = (uint32_t)__builtin_amdgcn_readlane(st_node, sp);
     act = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(st_lo, sp) |
           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(st_hi, sp) << 32);
   }
@@ -471,13 +510,32 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   // that needs to be found at all.
   ray.best_f = __double2float_ru((double)a.max_count * a.depth_scale * 1.000001);
 
-  // bit k of `neg`: direction component k is negative for the tile's rays (for some of them, where a
-  // tile straddles a coordinate plane through the camera -- it only orders the visits)
+  // bit k of `neg`: direction component k is negative; `ordered`: all 64 rays of the tile agree on all
+  // three signs (every tile that does not straddle a coordinate plane through the camera) -- the wave
+  // then walks the copy of the tree mirrored into the octant where all of them are positive
   unsigned neg = 0;
-  for (int k = 0; k < 3; k++) neg |= __ballot(ray.inv[k] < 0.0f) ? (1u << k) : 0u;
-
+  bool ordered = true;
+  for (int k = 0; k < 3; k++) {
+    const uint64_t n = __ballot(ray.inv[k] < 0.0f);
+    neg |= n ? (1u << k) : 0u;
+    ordered = ordered && (n == 0 || n == ~0ull);
+  }
   WalkCounters cnt;
-  walk<COUNT>(a, ray, in_image, neg, cnt);
+  BoxRay br;
+  if (ordered) {
+    for (int k = 0; k < 3; k++) {
+      const float ai = fabsf(ray.inv[k]);      // mirrored axis: -inv, and (-o)(-inv) = o * inv
+      br.scale[k] = (f32x2){ai * 0.99999f, ai * 1.00001f};
+      br.shift[k] = (f32x2){-ray.oi[k] * 0.99999f, -ray.oi[k] * 1.00001f};
+    }
+    walk<COUNT, true>(a, a.pairs + (int64_t)neg * a.n_pairs, ray, br, in_image, neg, cnt);
+  } else {
+    for (int k = 0; k < 3; k++) {
+      br.scale[k] = (f32x2){ray.inv[k], ray.inv[k]};
+      br.shift[k] = (f32x2){-ray.oi[k], -ray.oi[k]};
+    }
+    walk<COUNT, false>(a, a.pairs, ray, br, in_image, neg, cnt);
+  }
   const double best = ray.best;
   const unsigned c_top = cnt.top, c_nodes = cnt.nodes, c_tri_wave_box = cnt.tri_wave_box, c_tri_wave_mt = cnt.tri_wave_mt,
                  c_tri_lane_box = cnt.tri_lane_box, c_tri_lane_mt = cnt.tri_lane_mt;
@@ -521,7 +579,8 @@ struct afe_scene {
   int64_t n_tri = 0, n_nodes = 0;
   int depth = 0;
   double bounds[6] = {0, 0, 0, 0, 0, 0};
-  PairNode *pairs = nullptr;
+  PairNode *pairs = nullptr;   // 8 x n_pairs (Builder::pairs)
+  int64_t n_pairs = 0;
   TriRec *tris = nullptr;
 };
 
@@ -557,7 +616,7 @@ bool camera_ok(const afe_camera *c) {
 int launch_render(const afe_scene *s, const afe_camera *cam, int64_t count, const double *poses, uint16_t *out_dev,
                   hipStream_t stream, float *kernel_ms, unsigned long long *dev_counters = nullptr) {
   RenderArgs r;
-  r.pairs = s->pairs; r.tris = s->tris; r.counters = dev_counters;
+  r.pairs = s->pairs; r.n_pairs = s->n_pairs; r.tris = s->tris; r.counters = dev_counters;
   r.width = cam->width; r.height = cam->height;
   r.tiles_x = (cam->width + kTileW - 1) / kTileW;
   r.tiles_per_view = r.tiles_x * ((cam->height + kTileH - 1) / kTileH);
@@ -671,7 +730,13 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
   s->depth = b.max_depth;
   Box all = b.range_box(0, n_tri);
   for (int k = 0; k < 3; k++) { s->bounds[k] = all.lo[k]; s->bounds[3 + k] = all.hi[k]; }
-  const std::vector<PairNode> pairs = b.pairs();
+  std::vector<PairNode> pairs = b.pairs(0);
+  s->n_pairs = (int64_t)pairs.size();
+  if (pairs.size() * sizeof(PairNode) > 0xffffffffull) { delete s; return AFE_ERR_OUT_OF_RANGE; }   // 32-bit child offsets
+  for (unsigned octant = 1; octant < 8; octant++) {
+    const std::vector<PairNode> mirrored = b.pairs(octant);
+    pairs.insert(pairs.end(), mirrored.begin(), mirrored.end());
+  }
   if (hipMalloc((void **)&s->pairs, pairs.size() * sizeof(PairNode)) != hipSuccess ||
       hipMalloc((void **)&s->tris, packed.size() * sizeof(TriRec)) != hipSuccess ||
       hipMemcpy(s->pairs, pairs.data(), pairs.size() * sizeof(PairNode), hipMemcpyHostToDevice) != hipSuccess ||

@@ -1,5 +1,5 @@
-import importlib, sys, numpy as np
-sys.path.insert(0, '.')
+import importlib, os, sys, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 afa = importlib.import_module("agri-fly_amd")
 n = 1 << 20
