@@ -9,9 +9,14 @@
 //
 // MI355X mapping
 //   * one wave (64 lanes) per 8x8 pixel tile of one view, and the 64 rays walk the tree together:
-//     one node index and one stack per wave, nodes (32 bytes, sibling pairs adjacent) and
-//     triangles (48 bytes padded) fetched by scalar loads once per wave; box tests in fp32
-//     against conservatively inflated boxes, triangle tests in fp64;
+//     one node index and one stack per wave (the stack in vector registers, one entry per lane);
+//     a visit is ONE 64-byte scalar load carrying the boxes of both children (PairNode), triangles
+//     (96 bytes: double edges + their own box) arrive by scalar loads too; box tests in fp32 against
+//     conservatively inflated boxes, a slab = one packed FMA; triangle tests in fp64;
+//   * eight copies of the tree, mirrored into each direction octant: a tile whose rays agree on
+//     the direction signs (all but those on a coordinate plane through the camera) walks the copy in
+//     which every component is positive -- near face = lo, nearer child = the one stored first,
+//     9 vector instructions per box;
 //   * the BVH and the triangles stay in HBM and are served from L2 / Infinity Cache; the block
 //     index is remapped so that each XCD (own L2) renders a contiguous range of views;
 //   * poses are prepared by a small kernel straight from the engine's state slabs, so a

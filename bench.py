@@ -238,7 +238,7 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
     fp64_flops = st["tri_fp64_tests_per_ray"] * mt_flops + rays * ray_flops
     node_bytes = st["nodes_per_wave"] * 64.0 + st["tri_box_tests_per_wave"] * 96.0   # scalar loads, served by L2
     render_roofline = {
-        "bound": "dependent BVH node fetches + fp32 box tests per wave (latency / VALU issue), not HBM and not fp64 throughput",
+        "bound": "vector-instruction issue (SQ_ACTIVE_INST_VALU x 4 / SIMD = 92 % of busy cycles, scalar unit 81 %: profiles/r02d_render_pmc.json), not HBM and not fp64 throughput",
         "per_ray": {"triangle_box_tests": st["tri_box_tests_per_ray"] / rays, "fp64_triangle_tests": st["tri_fp64_tests_per_ray"] / rays},
         "per_wave_of_64_rays": {"nodes_visited": st["nodes_per_wave"] / waves, "triangle_box_tests": st["tri_box_tests_per_wave"] / waves,
                                 "fp64_triangle_tests_executed": st["tri_fp64_tests_per_wave"] / waves},
