@@ -29,7 +29,7 @@ namespace {
 
 // -DAFE_PLANNER_PROFILE: per-phase cycle totals (s_memtime), printed by launch_rappids; development only
 #ifdef AFE_PLANNER_PROFILE
-__device__ unsigned long long g_prof[8];
+__device__ unsigned long long g_prof[10];   // [8]: the longest planner (cycles)
 #define PL_T0(var) const unsigned long long var = __builtin_readcyclecounter()
 #define PL_T1(var, slot) do { if (threadIdx.x == 0) atomicAdd(&g_prof[slot], __builtin_readcyclecounter() - var); } while (0)
 #define PL_COUNT(slot, n) do { if (threadIdx.x == 0) atomicAdd(&g_prof[slot], (unsigned long long)(n)); } while (0)
@@ -1233,6 +1233,9 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
     out->n_pyramids = nPyr;
   }
   PL_T1(t_all, 0);
+#ifdef AFE_PLANNER_PROFILE
+  if (threadIdx.x == 0) atomicMax(&g_prof[8], __builtin_readcyclecounter() - t_all);
+#endif
 }
 
 // images [n][H][W] -> images_t [n][W][H] through 32x32 LDS tiles
@@ -1265,7 +1268,7 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   }
   const unsigned mask_bytes = (unsigned)(((cfg.width + 63) >> 6) * cfg.height) * (unsigned)sizeof(uint64_t);
 #ifdef AFE_PLANNER_PROFILE
-  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero));
 #endif
   const int64_t n_cand = b.n * b.n_candidates;
@@ -1273,12 +1276,12 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
                      cfg, b);
   hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, b);
 #ifdef AFE_PLANNER_PROFILE
-  unsigned long long prof[8];
+  unsigned long long prof[10];
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_prof), sizeof(prof));
   fprintf(stderr, "planner profile (cycles per planner): total %.0f | collision_free %.0f | inflate: mask1 %.0f expansion(all) %.0f "
-          "sides+mask2 %.0f corners %.0f | completed pyramids/planner %.2f ringloop %.0f\n", (double)prof[0] / b.n, (double)prof[6] / b.n,
-          (double)prof[1] / b.n, (double)prof[2] / b.n, (double)prof[3] / b.n, (double)prof[4] / b.n, (double)prof[5] / b.n, (double)prof[7] / b.n);
+          "sides+mask2 %.0f corners %.0f | completed pyramids/planner %.2f ringloop %.0f | longest planner %.0f\n", (double)prof[0] / b.n, (double)prof[6] / b.n,
+          (double)prof[1] / b.n, (double)prof[2] / b.n, (double)prof[3] / b.n, (double)prof[4] / b.n, (double)prof[5] / b.n, (double)prof[7] / b.n, (double)prof[8]);
 #endif
   return (int)hipGetLastError();
 }

@@ -16,6 +16,17 @@ def main():
     m, n_img = 256, 16
     rng = np.random.default_rng(9)
     images = np.stack([afa.scenarios.synthetic_depth_image(seed=300 + k, n_trunks=3 + k % 6) for k in range(n_img)])
+    if len(sys.argv) > 2 and sys.argv[2] == "orchard":
+        # the bench's cluttered case: views rendered from random poses inside the procedural orchard
+        n_img = 512
+        scene = afa.Scene(afa.scenarios.orchard_mesh(rows=32, cols=32, seed=1))
+        cam = afa.camera_default(320, 240)
+        r4 = np.random.default_rng(4)
+        pos = np.stack([r4.uniform(-5, 90, n_img), r4.uniform(-5, 120, n_img), r4.uniform(0.8, 2.5, n_img)])
+        yaw = r4.uniform(-np.pi, np.pi, n_img)
+        att = np.stack([np.cos(yaw / 2), 0 * yaw, 0 * yaw, np.sin(yaw / 2)])
+        images, _ = scene.render(cam, pos, att, afa.camera_default_mount())
+        images = np.asarray(images).reshape(n_img, 240, 320)
     cfg = afa.planner_default_config(320, 240, 10.0 / 256.0, 160.0, 0.116, 0.174, 0.5)
     cfg.cost_type = 1
     cfg.cost_vec[2] = 120.0
