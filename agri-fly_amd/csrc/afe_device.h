@@ -81,12 +81,15 @@ struct StepView {
 
 struct LaunchFlags {
   bool ext_force, ext_torque, noise, logic;
+  // heterogeneous ensemble whose type index is constant over every aligned run of 64 vehicles (fleets
+  // laid out type by type): each wave then reads its one record by scalar loads -- no LDS table
+  bool wave_uniform_types = false;
 };
 
 // kernel launchers (afe_kernels.hip); stream is a hipStream_t
 // `uniform` != nullptr: every vehicle uses this one record, passed by value in
 // the kernel-argument segment (scalar registers); otherwise v.table is staged
-// into LDS and indexed per lane by v.type.
+// into LDS and indexed per lane by v.type (or, LaunchFlags::wave_uniform_types, read per wave by scalar loads).
 int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, const DevParams<float> *uniform,
                     const DevLogic *uniform_logic, void *stream);
 int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> *uniform,

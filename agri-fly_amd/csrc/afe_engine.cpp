@@ -36,6 +36,8 @@ struct afe_engine {
   std::vector<DevParams<float>> table_f32;   // host copies of the device table
   std::vector<DevParams<double>> table_f64;
   bool types_uniform = true;  // every vehicle uses record 0 (kernel-argument fast path)
+  std::vector<uint8_t> type_host;   // host mirror of the type slab (zeros until afe_set_vehicle_types / a checkpoint)
+  bool types_wave_uniform = true;   // the type index is constant over every aligned run of 64 vehicles
   float *pack_scratch = nullptr;  // 3*n floats, lazily allocated
   afe_world *world = nullptr;     // shared-world query scratch (uniform grid), lazily created
   // on-device rates logic (allocated by afe_set_rates_logic)
@@ -395,6 +397,20 @@ extern "C" int afe_set_type_table(afe_engine *e, const afe_vehicle_params *table
   return AFE_OK;
 }
 
+// what the step launcher may assume about the type slab: all on record 0 (parameters ride in the kernel
+// arguments), or at least one type per wave (scalar loads of the wave's record), or neither (LDS table)
+static void refresh_type_flags(afe_engine *e) {
+  if (e->type_host.size() != (size_t)e->n) e->type_host.assign((size_t)e->n, 0);
+  bool all_zero = true, per_wave = true;
+  for (int64_t k = 0; k < e->n; k++) {
+    const uint8_t t = e->type_host[(size_t)k];
+    all_zero = all_zero && t == 0;
+    per_wave = per_wave && t == e->type_host[(size_t)(k & ~int64_t(63))];
+  }
+  e->types_uniform = all_zero;
+  e->types_wave_uniform = per_wave;
+}
+
 extern "C" int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count, const uint8_t *type_index) {
   int rc = check_range(e, first, count);
   if (rc) return rc;
@@ -407,11 +423,9 @@ extern "C" int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count
   AFE_HIP(e, hipSetDevice(e->device));
   AFE_HIP(e, hipMemcpyAsync(e->type + first, type_index, (size_t)count, hipMemcpyHostToDevice, e->stream));
   AFE_HIP(e, hipStreamSynchronize(e->stream));
-  // the kernel-argument fast path needs every vehicle on record 0
-  bool all_zero = true;
-  for (int64_t k = 0; k < count; k++) all_zero = all_zero && (type_index[k] == 0);
-  if (!all_zero) e->types_uniform = false;
-  else if (first == 0 && count == e->n) e->types_uniform = true;
+  if (e->type_host.size() != (size_t)e->n) e->type_host.assign((size_t)e->n, 0);
+  std::memcpy(e->type_host.data() + first, type_index, (size_t)count);
+  refresh_type_flags(e);
   return AFE_OK;
 }
 
@@ -611,6 +625,7 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     // launches without a logic tick draw no noise: use the lean instantiation
     f.noise = e->noise && mask != 0;
     f.logic = e->logic_on && mask != 0;
+    f.wave_uniform_types = !e->types_uniform && e->types_wave_uniform;
     const DevLogic *ulogic = (e->logic_on && e->types_uniform) ? &e->logic_table[0] : nullptr;
     int lrc;
     if (e->precision == AFE_F64) {
@@ -875,12 +890,10 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
     std::vector<uint8_t> types((size_t)e->n);
     const char *type_in_ckp = (const char *)host_buffer + sizeof(h) + ((const char *)e->type - (const char *)e->arena);
     std::memcpy(types.data(), type_in_ckp, (size_t)e->n);
-    bool all_zero = true;
-    for (size_t k = 0; k < types.size(); k++) {
+    for (size_t k = 0; k < types.size(); k++)
       if (types[k] >= e->table.size()) return fail(e, AFE_ERR_INVALID_ARG, "checkpoint holds a type index outside the type table");
-      all_zero = all_zero && types[k] == 0;
-    }
-    e->types_uniform = all_zero;
+    e->type_host = types;
+    refresh_type_flags(e);
   }
   // the arena also holds the device copy of the type table for the checkpoint's dt: rebuild on next step
   e->table_dirty = true;

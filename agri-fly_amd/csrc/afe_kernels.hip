@@ -668,6 +668,22 @@ afe_step_kernel_table(const StepView<R> v) {
   run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false>(v, P, G, i);
 }
 
+// heterogeneous ensemble, but every wave (aligned run of 64 vehicles) is of one type -- the host checked
+// the type slab (afe_engine.cpp refresh_type_flags): the wave's record is copied out of the global table by
+// scalar loads before anything is stored, and from there on the kernel is the homogeneous one (parameters
+// in scalar registers, one-wave workgroups, no LDS)
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC>
+__global__ void __launch_bounds__(AFE_BLOCK, AFE_LB_WAVES)
+afe_step_kernel_wave_types(const StepView<R> v) {
+  const int64_t i = (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;
+  if (i >= v.n) return;
+  const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)v.type[i]);
+  const DevParams<R> P = v.table[t];
+  DevLogic G = {};
+  if (LOGIC) G = v.logic_table[t];
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false>(v, P, G, i);
+}
+
 template <typename R>
 static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevParams<R> *uniform,
                        const DevLogic *uniform_logic, hipStream_t st) {
@@ -683,6 +699,8 @@ static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevPara
       hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
     else if (uniform)                                                                                      \
       hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, false>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
+    else if (f.wave_uniform_types && AFE_BLOCK == 64)                                                      \
+      hipLaunchKernelGGL((afe_step_kernel_wave_types<R, FE, TE, NO, LO>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v); \
     else {                                                                                                 \
       /* a large type table (up to 256 records: 83 KB fp32 / 124 KB fp64 with the logic records) needs   \
          more than the default 64 KB of dynamic LDS; gfx950 has 160 KB per CU */                          \

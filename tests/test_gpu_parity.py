@@ -562,6 +562,74 @@ def test_largest_type_table():
             assert np.isfinite(e.get_state()["att"]).all()
 
 
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+def test_fleet_laid_out_type_by_type_equals_the_shuffled_fleet_bitwise(precision):
+    """A heterogeneous ensemble whose type is constant over every aligned run of 64 vehicles takes the
+    scalar-load kernel (one record per wave) instead of the LDS table.  Same vehicles, two layouts --
+    shuffled (LDS table) and type by type -- must give the same bits per vehicle, IMU, noise (reference seed
+    policy: every vehicle the same stream) and on-device logic included; a partial type update that breaks
+    the layout must fall back, a checkpoint taken in one layout must resume in a fresh engine."""
+    n, T = 4096 + 37, 4                      # a ragged tail: the last wave is partial
+    ens = random_ensemble(n, seed=81, type_ids=(5, 1, 2, 4))
+    d = ens.data
+    d.pos[2] += 20
+    rng = np.random.default_rng(5)
+    by_type = (np.arange(n) // 64 % T).astype(np.uint8)                               # one type per aligned run of 64
+    perm = rng.permutation(n)                                                         # shuffled[k] = sorted[perm[k]]
+    table = [afa.params_from_type(t) for t in d.type_ids]
+    ltable = [afa.rates_logic_params_from_type(t) for t in d.type_ids]
+    cmd = np.minimum(d.motor_cmd, 900.0)
+
+    def fly(order, types, break_at=None, checkpoint=False):
+        with afa.Ensemble(n, precision=precision) as e:
+            e.set_type_table(table)
+            e.set_vehicle_types(types[order])
+            if break_at is not None:
+                e.set_vehicle_types(np.array([(types[order][break_at] + 1) % T], np.uint8), first=break_at)
+            e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_REFERENCE)
+            e.set_state(d.pos[:, order], d.vel[:, order], d.att[:, order], d.ang_vel[:, order], d.motor_speed[:, order])
+            e.set_motor_cmds(cmd[:, order])
+            e.set_external_force(d.ext_force[:, order])
+            e.set_external_torque(d.ext_torque[:, order])
+            e.set_rates_logic(ltable)
+            e.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
+            e.step(1000, 7)
+            if checkpoint:
+                blob = e.save_checkpoint()
+                with afa.Ensemble(n, precision=precision) as f:
+                    f.set_type_table(table)
+                    f.set_rates_logic(ltable)
+                    f.load_checkpoint(blob)
+                    f.step(1000, 6)
+                    st, imu, rs = f.get_state(), f.get_imu(), f.get_rng_state()
+            else:
+                e.step(1000, 6)
+                st, imu, rs = e.get_state(), e.get_imu(), e.get_rng_state()
+        return st, imu, rs
+
+    ident = np.arange(n)
+    a_st, a_imu, a_rng = fly(ident, by_type)                      # type by type: scalar-load kernel
+    b_st, b_imu, b_rng = fly(perm, by_type)                       # the same vehicles shuffled: LDS table
+    for k in a_st:
+        assert np.array_equal(a_st[k][..., perm], b_st[k]), k
+    assert np.array_equal(a_imu[0][:, perm], b_imu[0]) and np.array_equal(a_imu[1][:, perm], b_imu[1])
+    assert np.array_equal(a_rng[perm], b_rng)
+    # one vehicle re-typed in the middle of a run: the layout no longer holds, the LDS table takes over
+    k0 = 1000
+    c_st, _, _ = fly(ident, by_type, break_at=k0)
+    retyped = by_type.copy()
+    retyped[k0] = (retyped[k0] + 1) % T
+    r_st, _, _ = fly(perm, retyped)
+    for k in c_st:
+        assert np.array_equal(c_st[k][..., perm], r_st[k]), k
+    assert not np.array_equal(c_st["vel"][:, k0], a_st["vel"][:, k0])
+    # checkpoint mid-flight, resume in a fresh engine (which re-derives the layout from the restored slab)
+    s_st, s_imu, s_rng = fly(ident, by_type, checkpoint=True)
+    for k in a_st:
+        assert np.array_equal(a_st[k], s_st[k]), k
+    assert np.array_equal(a_imu[0], s_imu[0]) and np.array_equal(a_rng, s_rng)
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 257, 1000])
 def test_ragged_sizes(n):
     """ensemble sizes that are not a multiple of the wave / workgroup / slab granule"""

@@ -25,8 +25,12 @@ def run(types, nt, logic=False, period=0.002):
     e.close()
     return us, bts
 rng = np.random.default_rng(0)
-for name, types, nt in (("uniform (kernel-arg params)", None, 1), ("4 types, LDS table", rng.integers(0, 4, n).astype(np.uint8), 4),
-                        ("64 types", rng.integers(0, 64, n).astype(np.uint8), 64), ("256 types", rng.integers(0, 256, n).astype(np.uint8), 256)):
+def runs(nt):     # fleets laid out type by type: one type per aligned run of 64 vehicles
+    return (np.arange(n) * nt // n).astype(np.uint8)
+for name, types, nt in (("uniform (kernel-arg params)", None, 1), ("4 types, random (LDS table)", rng.integers(0, 4, n).astype(np.uint8), 4),
+                        ("4 types, type by type", runs(4), 4),
+                        ("64 types, random", rng.integers(0, 64, n).astype(np.uint8), 64), ("64 types, type by type", runs(64), 64),
+                        ("256 types, random", rng.integers(0, 256, n).astype(np.uint8), 256), ("256 types, type by type", runs(256), 256)):
     for logic in (False, True):
         us, bts = run(types, nt, logic)
         print("%-28s logic=%d  %.2f us/step  %.0f B/veh  %.0f GB/s" % (name, logic, us, bts, n * bts / us / 1e3))
