@@ -110,8 +110,13 @@ int afe_abi_version(void);
 int afe_set_stream(afe_engine *e, void *hip_stream);
 
 /* ---- configuration ------------------------------------------------------ */
-/* Table of up to 256 parameter records, staged into LDS by the step kernel;
- * vehicle i uses table[type_index[i]].  Replaces the per-object ctor args. */
+/* Table of up to 256 parameter records; vehicle i uses table[type_index[i]].
+ * Replaces the per-object ctor args.  How the step kernel gets at a record:
+ * all vehicles on record 0 -> kernel arguments; the type index constant over
+ * every aligned run of 64 vehicles (a fleet laid out type by type) -> one
+ * scalar-loaded record per wave, as fast as the homogeneous case whatever the
+ * table size; types mixed within a run of 64 -> the table is staged into LDS
+ * per workgroup (slower as the table grows).  Results are the same bits. */
 int afe_set_type_table(afe_engine *e, const afe_vehicle_params *table, int n_types);
 int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count,
                           const uint8_t *type_index);
