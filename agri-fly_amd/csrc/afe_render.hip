@@ -754,7 +754,8 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
 }
 
 // Pure host: build the hierarchy for a mesh and verify it (every triangle in exactly one leaf, every
-// leaf's and inner node's box containing what hangs below it); no GPU needed.
+// leaf's and inner node's box containing what hangs below it; then the eight mirrored PairNode arrays the
+// kernel walks); no GPU needed.
 extern "C" int afe_scene_check_hierarchy(const float *triangles, int64_t n_tri, int64_t *n_nodes, int *depth,
                                          int *max_leaf) {
   if (!triangles || n_tri <= 0 || n_tri > 0x3fffffff) return AFE_ERR_INVALID_ARG;
@@ -792,6 +793,57 @@ extern "C" int afe_scene_check_hierarchy(const float *triangles, int64_t n_tri, 
     }
   }
   for (int64_t i = 0; i < n_tri; i++) if (seen[(size_t)i] != 1) return AFE_ERR_OUT_OF_RANGE;
+  // the kernel's form, all eight mirrored copies: walked from the root every copy reaches every triangle
+  // exactly once (a single-leaf mesh: twice, by construction), child references stay inside the array and
+  // point forward, every child box is the builder's box mirrored, and across a split along a mirrored axis
+  // the children are exchanged (so that the first child is always the one on the lower mirrored side)
+  const std::vector<PairNode> plain = b.pairs(0);
+  const bool single_leaf = b.nodes[0].b > 0;
+  for (unsigned octant = 0; octant < 8; octant++) {
+    const std::vector<PairNode> pr = b.pairs(octant);
+    if (pr.size() != plain.size()) return AFE_ERR_OUT_OF_RANGE;
+    std::vector<int> hits((size_t)n_tri, 0);
+    std::vector<uint32_t> todo(1, 0u);
+    size_t visited = 0;
+    while (!todo.empty()) {
+      const uint32_t off = todo.back();
+      todo.pop_back();
+      if (off % sizeof(PairNode) || off / sizeof(PairNode) >= pr.size() || ++visited > pr.size()) return AFE_ERR_OUT_OF_RANGE;
+      const PairNode &p = pr[off / sizeof(PairNode)], &q = plain[off / sizeof(PairNode)];
+      const unsigned axis = p.meta & 3u;
+      if (axis > 2 || axis != (q.meta & 3u) || (p.meta >> 24) != (q.meta >> 24)) return AFE_ERR_OUT_OF_RANGE;
+      const bool exchanged = (octant >> axis) & 1u;
+      const unsigned pl = (p.meta >> 8) & 255u, prc = (p.meta >> 16) & 255u, ql = (q.meta >> 8) & 255u, qr = (q.meta >> 16) & 255u;
+      if (pl != (exchanged ? qr : ql) || prc != (exchanged ? ql : qr)) return AFE_ERR_OUT_OF_RANGE;
+      for (int c = 0; c < 2; c++) {
+        const float *box = c ? p.box_r : p.box_l;
+        const float *orig = (c != 0) != exchanged ? q.box_r : q.box_l;   // the unmirrored copy's same child
+        for (int k = 0; k < 3; k++) {
+          const bool m = (octant >> k) & 1u;
+          if (box[2 * k] != (m ? -orig[2 * k + 1] : orig[2 * k]) || box[2 * k + 1] != (m ? -orig[2 * k] : orig[2 * k + 1]) ||
+              !(box[2 * k] < box[2 * k + 1]))
+            return AFE_ERR_OUT_OF_RANGE;
+        }
+        const uint32_t ref = c ? p.right : p.left, count = (p.meta >> (c ? 16 : 8)) & 255u;
+        if (count == 0) {
+          if (ref <= off) return AFE_ERR_OUT_OF_RANGE;
+          todo.push_back(ref);
+        } else {
+          if ((int64_t)ref + count > n_tri) return AFE_ERR_OUT_OF_RANGE;
+          for (uint32_t t = 0; t < count; t++) {
+            hits[(size_t)ref + t]++;
+            const float *tri = triangles + 9 * (int64_t)b.order[(size_t)ref + t];
+            for (int v = 0; v < 3; v++)
+              for (int k = 0; k < 3; k++) {
+                const float cm = ((octant >> k) & 1u) ? -tri[3 * v + k] : tri[3 * v + k];
+                if (!(cm > box[2 * k] && cm < box[2 * k + 1])) return AFE_ERR_OUT_OF_RANGE;
+              }
+          }
+        }
+      }
+    }
+    for (int64_t i = 0; i < n_tri; i++) if (hits[(size_t)i] != (single_leaf ? 2 : 1)) return AFE_ERR_OUT_OF_RANGE;
+  }
   if (n_nodes) *n_nodes = (int64_t)b.nodes.size();
   if (depth) *depth = b.max_depth;
   if (max_leaf) *max_leaf = worst_leaf;

@@ -499,8 +499,7 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   // The shape may be kept for a few queries: the query is exact for ANY grid (positions outside it clamp
   // into its boundary cells), a stale shape only costs speed, and without the read-back the whole query is
   // asynchronous on the stream (afe_set_neighbour_grid_refresh).
-  static const uint32_t zero2[2] = {0, 0};
-  W_HIP(w, hipMemcpyAsync(w->lohi + 6, zero2, sizeof(zero2), hipMemcpyHostToDevice, st));   // leftover counter
+  W_HIP(w, hipMemsetAsync(w->lohi + 6, 0, 8, st));   // leftover counter (a device-side fill: a copy from pageable host memory would make the host wait for the stream)
   const bool reshape = w->grid_n_all != n_all || w->grid_cell_arg != cell_size || w->since_refresh + 1 >= w->refresh_every;
   if (reshape) {
     hipLaunchKernelGGL(world_bounds_kernel, dim3(AFE_WORLD_BOUNDS_BLOCKS), dim3(256), 0, st, all_xyz, n_all, w->bounds_part);

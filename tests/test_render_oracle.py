@@ -85,7 +85,8 @@ def test_orchard_mesh_shape_and_regression(ora, scen, golden_dir):
 def test_bvh_builder_invariants_on_the_host(afa, scen):
     """afe_scene_check_hierarchy builds the hierarchy the GPU traverses and verifies it without a GPU:
     every triangle in exactly one leaf, boxes containing what hangs below them, depth within the
-    traversal stack -- for the orchard, for coincident / degenerate triangles (median-split fallback)
+    traversal stack, and the eight octant-mirrored pair-node arrays the kernel walks (each reaches every
+    triangle once, boxes mirrored exactly, children exchanged across mirrored split axes) -- for the orchard, for coincident / degenerate triangles (median-split fallback)
     and for a single triangle."""
     tris = scen.orchard_mesh(rows=6, cols=8, seed=3)
     n_nodes, depth, max_leaf = afa.scene_check_hierarchy(tris)

@@ -1,0 +1,24 @@
+"""Times the shared-world neighbour query on the bench's world (2^20 vehicles) for kernel / host-path A/B work:
+   AGRIFLY_ENGINE_LIB=<variant.so> python tools/world_probe.py"""
+import importlib, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+afa = importlib.import_module("agri-fly_amd")
+import bench
+n = 1 << 20
+e = bench.build_shard(afa, n, 0, n, 0)
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20): e.step(1000, 1)
+xyz = torch.empty((3, n), dtype=torch.float32, device="cuda")
+d2 = torch.empty(n, dtype=torch.float32, device="cuda"); idx = torch.empty(n, dtype=torch.int32, device="cuda")
+e.pack_positions(xyz.data_ptr())
+for refresh in (1, 16):
+    e.set_neighbour_grid_refresh(refresh)
+    for _ in range(3): e.nearest_neighbour(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr())
+    e.sync()
+    a, b = e.event(), e.event(); e.record(a); t0 = time.perf_counter()
+    for _ in range(32): e.nearest_neighbour(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr())
+    t_submit = time.perf_counter() - t0
+    e.record(b); ms = e.elapsed_ms(a, b) / 32
+    print("refresh every %2d queries: %.3f ms per query on the stream, %.3f ms of host time to submit one" % (refresh, ms, t_submit / 32 * 1e3))
+print(e.neighbour_grid_info())
