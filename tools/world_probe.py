@@ -22,3 +22,11 @@ for refresh in (1, 16):
     e.record(b); ms = e.elapsed_ms(a, b) / 32
     print("refresh every %2d queries: %.3f ms per query on the stream, %.3f ms of host time to submit one" % (refresh, ms, t_submit / 32 * 1e3))
 print(e.neighbour_grid_info())
+e.set_neighbour_grid_refresh(16)
+for cs in (6.0, 8.0, 10.0, 11.0, 12.0, 14.0, 17.0):
+    for _ in range(3): e.nearest_neighbour(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr(), cell_size=cs)
+    e.sync()
+    a, b = e.event(), e.event(); e.record(a)
+    for _ in range(32): e.nearest_neighbour(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr(), cell_size=cs)
+    e.record(b); ms = e.elapsed_ms(a, b) / 32
+    print("cell %.1f m: %.3f ms per query  %s" % (cs, ms, e.neighbour_grid_info()))
