@@ -461,7 +461,9 @@ typedef struct afe_device_view {
   float *motor_cmd;                              /* 4 components */
   float *gyro, *acc;                             /* 3,3 components */
   uint32_t *rng;
-  uint8_t *type_index;
+  uint8_t *type_index;   /* READ ONLY: the engine chooses its step kernel from a host mirror of this
+                          * slab (afe_set_vehicle_types keeps both in step); writing it through this
+                          * pointer desynchronises them */
 } afe_device_view;
 int afe_get_device_view(afe_engine *e, afe_device_view *out);
 
