@@ -321,6 +321,7 @@ struct RenderArgs {
   int width, height, tiles_x, tiles_per_view;
   double focal, cx, cy, depth_scale;
   int max_count;
+  int plain_walk_only;      // afe_scene_set_walk(1)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -332,8 +333,8 @@ typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 // 1e-5, so the test only ever errs towards visiting a box: which triangles a ray reaches, and
 // therefore the fp64 hit distance, cannot depend on it.
 // oi = o * inv is precomputed per ray and a box arrives as three {lo, hi} pairs in scalar registers, so a
-// slab is ONE packed FMA (v_pk_fma_f32: both faces at once).  Where a zero direction component has
-// turned oi into a NaN the fminf / fmaxf ignore it, which again can only let a box through.
+// slab is ONE packed FMA (v_pk_fma_f32: both faces at once).  |inv| is capped at 1e18 (kernel), so every
+// distance here is finite.
 __device__ __forceinline__ bool box_reached(f32x2 bx, f32x2 by, f32x2 bz, const float oi[3], const float inv[3],
                                             float best) {
   const f32x2 tx = __builtin_elementwise_fma(bx, (f32x2){inv[0], inv[0]}, (f32x2){-oi[0], -oi[0]});
@@ -390,7 +391,6 @@ __device__ __forceinline__ bool node_box_reached(f32x2 bx, f32x2 by, f32x2 bz, c
   const f32x2 ty = __builtin_elementwise_fma(by, r.scale[1], r.shift[1]);
   const f32x2 tz = __builtin_elementwise_fma(bz, r.scale[2], r.shift[2]);
   if (ORDERED) {
-    // a NaN (zero direction component) is ignored by fmaxf / fminf: that can only let a box through
     const float tmin = fmaxf(fmaxf(fmaxf(0.0f, tx.x), ty.x), tz.x);
     const float tmax = fminf(fminf(fminf(best, tx.y), ty.y), tz.y);
     return tmin <= tmax;
@@ -506,7 +506,12 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   const double v = (py - a.cy) / a.focal;
   for (int k = 0; k < 3; k++) ray.d[k] = pose[3 + 3 * k] * u + pose[4 + 3 * k] * v + pose[5 + 3 * k];
   for (int k = 0; k < 3; k++) {
-    ray.inv[k] = 1.0f / (float)ray.d[k];
+    // |1/d| is capped: a direction component of exactly zero (a pixel on the principal axis of an
+    // axis-aligned camera) would make it infinite and the slab distances inf - inf = NaN -- and NaNs are NOT
+    // harmless in the min / max chains below (fmaxf(-inf, NaN) = -inf shuts a box the ray is inside of).
+    // 1e18 instead stands for a component of 1e-18: over the 10 m range that moves the ray by 1e-17 m, and
+    // every slab distance stays finite for coordinates up to 1e20 m.
+    ray.inv[k] = fminf(fmaxf(1.0f / (float)ray.d[k], -1e18f), 1e18f);
     ray.oi[k] = (float)ray.o[k] * ray.inv[k];   // o * inv, see box_reached
   }
   ray.best = INFINITY;
@@ -525,6 +530,7 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
     neg |= n ? (1u << k) : 0u;
     ordered = ordered && (n == 0 || n == ~0ull);
   }
+  ordered = ordered && !a.plain_walk_only;
   WalkCounters cnt;
   BoxRay br;
   if (ordered) {
@@ -584,6 +590,7 @@ struct afe_scene {
   int64_t n_tri = 0, n_nodes = 0;
   int depth = 0;
   double bounds[6] = {0, 0, 0, 0, 0, 0};
+  int plain_walk_only = 0;
   PairNode *pairs = nullptr;   // 8 x n_pairs (Builder::pairs)
   int64_t n_pairs = 0;
   TriRec *tris = nullptr;
@@ -627,6 +634,7 @@ int launch_render(const afe_scene *s, const afe_camera *cam, int64_t count, cons
   r.tiles_per_view = r.tiles_x * ((cam->height + kTileH - 1) / kTileH);
   r.focal = cam->focal_length; r.cx = cam->cx; r.cy = cam->cy; r.depth_scale = cam->depth_scale;
   r.max_count = cam->max_count;
+  r.plain_walk_only = s->plain_walk_only;
   // A launch may not exceed 2^32 threads in all (HIP truncates the product silently): 65 536 views of
   // 320 x 240 are 78.6 M tiles x 64 lanes = 5.0e9.  Views go out in runs that stay below 2^31 threads.
   const int64_t max_blocks = (int64_t(1) << 31) / (kTileW * kTileH);
@@ -855,6 +863,12 @@ extern "C" void afe_scene_destroy(afe_scene *s) {
   if (s->pairs) (void)hipFree(s->pairs);
   if (s->tris) (void)hipFree(s->tris);
   delete s;
+}
+
+extern "C" int afe_scene_set_walk(afe_scene *s, int mode) {
+  if (!s || (mode != 0 && mode != 1)) return AFE_ERR_INVALID_ARG;
+  s->plain_walk_only = mode;
+  return AFE_OK;
 }
 
 extern "C" int afe_scene_info(const afe_scene *s, int64_t *n_tri, int64_t *n_nodes, int *depth, double bounds[6]) {

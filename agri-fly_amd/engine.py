@@ -37,7 +37,7 @@ ABI_FUNCTIONS = [
     "afe_telemetry_encode", "afe_telemetry_decode", "afe_set_commands_from_radio",
     "afe_set_max_fused_steps", "afe_planner_default_config", "afe_planner_samples", "afe_rappids_plan",
     "afe_rappids_plan_device", "afe_camera_default", "afe_camera_default_mount", "afe_scene_create",
-    "afe_scene_destroy", "afe_scene_info", "afe_render_depth", "afe_render_depth_engine", "afe_render_depth_stats",
+    "afe_scene_destroy", "afe_scene_info", "afe_scene_set_walk", "afe_render_depth", "afe_render_depth_engine", "afe_render_depth_stats",
     "afe_device_alloc", "afe_device_free", "afe_device_download", "afe_scene_check_hierarchy",
     "afe_comm_unique_id", "afe_comm_create", "afe_comm_info", "afe_comm_destroy", "afe_comm_last_error",
     "afe_gather_positions", "afe_group_create", "afe_group_destroy", "afe_group_size", "afe_group_shard",
@@ -257,6 +257,7 @@ def library():
         "afe_render_depth": [vp, C.POINTER(Camera), i64, vp, vp, vp, vp, C.POINTER(C.c_float)],
         "afe_render_depth_engine": [eng, vp, C.POINTER(Camera), i64, i64, vp, vp, ci, C.POINTER(C.c_float)],
         "afe_render_depth_stats": [vp, C.POINTER(Camera), i64, vp, vp, vp, vp, C.POINTER(C.c_float)],
+        "afe_scene_set_walk": [vp, C.c_int],
         "afe_device_alloc": [ci, u64, C.POINTER(vp)],
         "afe_device_free": [vp],
         "afe_device_download": [vp, vp, u64],
@@ -485,6 +486,13 @@ class Scene:
         if rc:
             raise AfeError(rc, library().afe_status_string(rc).decode())
         return out, ms.value
+
+    def set_walk(self, plain_only):
+        """False (default): ordered walk of the octant-mirrored trees where a tile allows it; True: the plain
+        walk everywhere.  Same images -- a cross-check."""
+        rc = library().afe_scene_set_walk(self._h, 1 if plain_only else 0)
+        if rc:
+            raise AfeError(rc, library().afe_status_string(rc).decode())
 
     def render_stats(self, cam, pos, att, mount=None):
         """traversal counters of one batch (counting build): dict + kernel_ms"""

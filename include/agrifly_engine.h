@@ -362,6 +362,12 @@ int afe_scene_info(const afe_scene *s, int64_t *n_tri, int64_t *n_nodes, int *de
 int afe_render_depth(afe_scene *s, const afe_camera *cam, int64_t n_views, const double *pos, const double *att,
                      const double mount[4], uint16_t *depth_out, float *kernel_ms);
 
+/* Which form of the traversal the renders of this scene use: 0 (default) -- tiles whose 64 rays agree on
+ * the direction signs walk the octant-mirrored copy of the tree (ordered box tests), the others the plain
+ * copy; 1 -- every tile takes the plain, sign-agnostic walk.  The images are the same bits either way
+ * (tests/test_gpu_render.py renders thousands of views both ways): a cross-check, not a tuning knob. */
+int afe_scene_set_walk(afe_scene *s, int mode);
+
 /* What the traversal did for such a batch (a counting build of the same kernel; the images are
  * discarded): stats[0] BVH nodes visited and [1] triangle box tests / [2] double-precision
  * ray-triangle tests executed, per wave of 64 rays; [3], [4] the same two per participating ray;

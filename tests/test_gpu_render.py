@@ -6,7 +6,7 @@ on the device.  Needs an MI355X."""
 import numpy as np
 import pytest
 
-from tests.scenarios import afa
+from tests.scenarios import MEASUREMENTS, afa
 
 pytestmark = pytest.mark.gpu
 
@@ -187,3 +187,51 @@ def test_config5_shape_throughput():
     sky, _ = scene.render(cam, np.array([[10.0], [10.0], [30.0]]), up, mount)
     assert np.all(sky == 255)
     assert 0.2 < np.mean(imgs < 255) < 0.99
+
+
+def test_ordered_and_plain_walk_give_the_same_images_on_thousands_of_views():
+    """Two formulations of the traversal -- the ordered walk of the octant-mirrored trees (near face = lo, nearer
+    child stored first, slack folded into the ray factors) and the plain sign-agnostic walk of the unmirrored
+    tree (per-lane min / max, explicit slack) -- must agree on every pixel: 4 096 views from anywhere in and
+    above the orchard, every attitude (all eight direction octants, tiles straddling the coordinate planes,
+    views straight down and straight up), 3.1e8 rays.  Each is separately compared with the brute-force checker
+    on a few views elsewhere in this file; this is the wide net for a box test that culls what it must not."""
+    tris = scen.orchard_mesh(rows=16, cols=16, seed=11)
+    scene = afa.Scene(tris)
+    cam = afa.camera_default(320, 240)
+    mount = afa.camera_default_mount()
+    rng = np.random.default_rng(21)
+    n = 4096
+    pos = np.stack([rng.uniform(-10, 60, n), rng.uniform(-10, 60, n), rng.uniform(0.3, 9.0, n)])
+    q = rng.normal(size=(4, n))
+    q /= np.linalg.norm(q, axis=0)
+    # a share of exactly axis-aligned attitudes: direction components that are exactly zero (inf / NaN slabs)
+    k = n // 8
+    yaw = rng.integers(0, 4, k) * (np.pi / 2)
+    q[:, :k] = np.stack([np.cos(yaw / 2), 0 * yaw, 0 * yaw, np.sin(yaw / 2)])
+    pos[:, :k] = np.round(pos[:, :k])          # and origins on whole metres (o * inv = 0 * inf)
+    ident = np.array([1.0, 0.0, 0.0, 0.0])
+    for m in (mount, ident):
+        scene.set_walk(False)
+        a, ms_a = scene.render(cam, pos, q, m)
+        scene.set_walk(True)
+        b, ms_b = scene.render(cam, pos, q, m)
+        scene.set_walk(False)
+        assert np.array_equal(a, b)
+        assert a.min() < 255 and (a == 255).any()
+    MEASUREMENTS["render_walks_4096_views"] = {"ordered_ms": ms_a, "plain_ms": ms_b, "rays": n * 76800}
+    # and the checker on the class of views that once broke BOTH walks: an axis-aligned camera on whole-metre
+    # coordinates has pixels whose ray direction has a component of exactly zero -- 1/d infinite, slab
+    # distances inf - inf = NaN, and a min / max chain that took -inf from the other face shut boxes the ray
+    # was inside of (found by this test; |1/d| is capped in the kernel now)
+    from oracle import oracle_py as ora
+    oc = _ocam(ora, cam)
+    for v in (0, 1, 6, 20, 21):
+        for m in (mount, ident):
+            want = ora.render_depth(oc, tris, pos[:, v], q[:, v], m)
+            for plain in (False, True):
+                scene.set_walk(plain)
+                got, _ = scene.render(cam, pos[:, v:v + 1], q[:, v:v + 1], m)
+                np.testing.assert_array_equal(got[0], want)
+    scene.set_walk(False)
+    scene.close()
