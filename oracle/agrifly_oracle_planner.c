@@ -22,6 +22,22 @@ static const float RF_PI = 3.141592653589793238463;
 static const float RF_EPS = 1e-12;
 #define RF_2PI ((float)(2 * RF_PI))
 
+/* Test hook (sensitivity analysis, tools/planner_campaign.py): the k-th acos / cos / pow result of the
+ * calling thread can be moved by a few ulps.  libm implementations differ by an ulp in these (glibc vs the
+ * device's math library); a planner outcome that flips under such a nudge is one no two platforms agree on.
+ * Off unless ora_planner_nudge() was called on this thread. */
+static _Thread_local long ora_nudge_at = -1, ora_nudge_seen = 0;
+static _Thread_local int ora_nudge_ulps = 0;
+void ora_planner_nudge(long call_index, int ulps) { ora_nudge_at = call_index; ora_nudge_ulps = ulps; ora_nudge_seen = 0; }
+long ora_planner_nudge_calls(void) { return ora_nudge_seen; }
+static double ora_tr(double v) {
+  if (ora_nudge_seen++ == ora_nudge_at) {
+    int k;
+    for (k = 0; k < abs(ora_nudge_ulps); k++) v = nextafter(v, ora_nudge_ulps > 0 ? INFINITY : -INFINITY);
+  }
+  return v;
+}
+
 unsigned ora_solve_cubic(double a, double b, double c, double *x) {
   /* :55-96 */
   double a2 = a * a;
@@ -34,15 +50,15 @@ unsigned ora_solve_cubic(double a, double b, double c, double *x) {
     double t = r / sqrt(q3);
     if (t < -1) t = -1;
     if (t > 1) t = 1;
-    t = acos(t);
+    t = ora_tr(acos(t));
     a /= 3;
     q = -2 * sqrt(q);
-    x[0] = q * cos(t / 3) - a;
-    x[1] = q * cos((t + (double)RF_2PI) / (double)3) - a;
-    x[2] = q * cos((t - (double)RF_2PI) / (double)3) - a;
+    x[0] = q * ora_tr(cos(t / 3)) - a;
+    x[1] = q * ora_tr(cos((t + (double)RF_2PI) / (double)3)) - a;
+    x[2] = q * ora_tr(cos((t - (double)RF_2PI) / (double)3)) - a;
     return 3;
   } else {
-    A = -pow(fabs(r) + sqrt(r2 - q3), 1. / 3);
+    A = -ora_tr(pow(fabs(r) + sqrt(r2 - q3), 1. / 3));
     if (r < 0) A = -A;
     B = (fabs(A) < (double)RF_EPS ? 0 : q / A);
     a /= 3;

@@ -86,6 +86,10 @@ void ora_planner_samples(uint32_t seed, int width, int height, int n, double (*s
 int ora_planner_sampled_collision(const ora_planner_config *cfg, const uint16_t *depth,
                                   const double coeffs[6][3], double tf, int n_samples);
 
+/* test hook: move the k-th acos / cos / pow result of the calling thread's next run by `ulps` (k < 0: off) */
+void ora_planner_nudge(long call_index, int ulps);
+long ora_planner_nudge_calls(void);
+
 #ifdef __cplusplus
 }
 #endif

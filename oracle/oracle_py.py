@@ -354,6 +354,10 @@ def planner_lib():
         L.ora_planner_run.argtypes = [C.POINTER(OraPlannerConfig), C.c_void_p, dp, dp, dp, C.c_void_p, C.c_int,
                                       C.POINTER(OraPlanResult), C.c_void_p]
         L.ora_planner_run.restype = None
+        L.ora_planner_nudge.argtypes = [C.c_long, C.c_int]
+        L.ora_planner_nudge.restype = None
+        L.ora_planner_nudge_calls.argtypes = []
+        L.ora_planner_nudge_calls.restype = C.c_long
         L.ora_planner_samples.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ora_planner_samples.restype = None
         L.ora_planner_sampled_collision.argtypes = [C.POINTER(OraPlannerConfig), C.c_void_p, C.c_void_p, C.c_double, C.c_int]
@@ -373,6 +377,16 @@ def planner_samples(seed, width, height, n):
     s = np.empty((n, 4))
     planner_lib().ora_planner_samples(int(seed), width, height, n, s.ctypes.data)
     return s
+
+
+def planner_nudge(call_index, ulps):
+    """sensitivity hook: move the call_index-th acos / cos / pow result of the next planner_run on THIS thread
+    by `ulps` (call_index < 0: off).  planner_nudge_calls() = how many such calls the last run made."""
+    planner_lib().ora_planner_nudge(int(call_index), int(ulps))
+
+
+def planner_nudge_calls():
+    return int(planner_lib().ora_planner_nudge_calls())
 
 
 def planner_run(cfg, depth, vel0, acc0, grav, samples):
