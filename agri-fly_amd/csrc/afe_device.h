@@ -23,6 +23,7 @@ struct alignas(16) DevParams {
   R kf;        // _thrustFromSpeedSqr
   R ktau;      // _torqueFromSpeedSqr
   R c_lag;     // exp(-dt/_timeConstant), or 0 when _timeConstant == 0
+  R omc_lag;   // 1 - c_lag evaluated in double (-expm1(-dt/tau)): the fp32 kernel's rotor-speed increment factor
   R Jm;        // Motor::_inertia
   R wmin;
   R wmax;

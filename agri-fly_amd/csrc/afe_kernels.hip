@@ -493,12 +493,25 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     for (int m = 0; m < 4; m++) {
       const R spin = (R)AFE_MOTOR_SPIN(m);
       const R old = ms[m];
-      R w = fm(c, old, (1 - c) * cmd[m]);                    // :60
-      if (w > P.wmax) w = P.wmax; else if (w < P.wmin) w = P.wmin;  // :62-66
+      R w, dw;
+      if (sizeof(R) == 8) {
+        w = fm(c, old, (1 - c) * cmd[m]);                    // :60
+        if (w > P.wmax) w = P.wmax; else if (w < P.wmin) w = P.wmin;  // :62-66
+        dw = w - old;
+      } else {
+        // fp32 storage: (c old + (1 - c) cmd) - old cancels down to the rounding of a ~1e3 rad/s speed (6e-5)
+        // and :78 divides that by dt -- at dt = 100 us, with J_m > 0, the rotor-acceleration torque then carries
+        // 0.6 rad/s^2 of noise per motor (found by tools/step_campaign.py: 1e-4 relative in ang_vel after 30
+        // steps).  The increment is formed directly instead, (1 - c)(cmd - old) with 1 - c from the host's
+        // double; tau_m = 0 (every shipped type) gives c = 0, 1 - c = 1 and the same bits as before.
+        w = fm(c, old, P.omc_lag * cmd[m]);
+        dw = P.omc_lag * (cmd[m] - old);
+        if (w > P.wmax) { w = P.wmax; dw = w - old; } else if (w < P.wmin) { w = P.wmin; dw = w - old; }
+      }
       ms[m] = w;
       const R thrust = P.kf * w * m_abs(w);                  // :70 (along +z)
       const R aero = -P.ktau * w * m_abs(w);                 // :73 (along spin*z)
-      const R ang_acc = div_dt(w - old, dt, v.inv_dt);       // :78
+      const R ang_acc = div_dt(dw, dt, v.inv_dt);            // :78
       // torque = aero*axis + p x (0,0,thrust) - ang_acc*J*axis   :71-79
       const R tz_m = (aero * spin) - (ang_acc * P.Jm) * spin;
       Fz = Fz + thrust;                                      // Quadcopter_T.cpp:102

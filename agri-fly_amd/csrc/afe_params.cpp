@@ -133,6 +133,7 @@ void to_device_params(const HostParams &h, double dt, DevParams<R> &d) {
   d.ktau = (R)h.ktau;
   // Motor.cpp:54-58, evaluated in double like the reference
   d.c_lag = (R)((h.tau_m == 0) ? 0.0 : std::exp(-dt / h.tau_m));
+  d.omc_lag = (R)((h.tau_m == 0) ? 1.0 : -std::expm1(-dt / h.tau_m));
   d.Jm = (R)h.Jm;
   d.wmin = (R)h.wmin;
   d.wmax = (R)h.wmax;

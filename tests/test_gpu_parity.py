@@ -697,3 +697,25 @@ def test_rotor_speeds_are_those_of_the_last_step_even_though_they_are_not_stored
     e.step(1000, 1)
     np.testing.assert_allclose(e.get_state(5, 9)["motor_speed"], want_b[:, 5:14], rtol=1e-7 if precision == afa.AFE_F32 else 0)
     e.close()
+
+
+def test_configuration_campaign():
+    """150 random configurations x both precisions (tools/step_campaign.py): random type tables (mass, full inertia
+    tensors, motor lag, rotor inertia, CoM error, drag, IMU mount), 1..6 types laid out at random / type by type /
+    all on record 0 -- the three ways a parameter record reaches the kernel --, dt from 100 us to 4 ms, five logic
+    periods, wrench arrays on or off, IMU noise on or off under either seed policy, fused or single-step
+    launches, sizes from 1 to 5000, random first_global_index.  fp64 engine <= 2e-11 everywhere (it is the same
+    arithmetic in the same order); fp32 engine <= 1e-5 with the reference's motor model (tau_m = J_m = 0, every
+    shipped type) and <= 5e-5 with a lagged rotor, whose fp32 speed state limits it; RNG words and tick counts
+    exact.  Vehicles the explicit integrator blows up in both (|w| dt > 0.5 rad per step) are not compared."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "step_campaign.py")
+    spec = importlib.util.spec_from_file_location("step_campaign", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    worst = mod.run_campaign(n_cfg=150, seed=7, verbose=False)
+    from tests.scenarios import MEASUREMENTS
+    MEASUREMENTS["step_configuration_campaign"] = worst
+    assert worst["f64"]["failures"] == 0 and worst["f32"]["failures"] == 0
+    assert worst["f32"]["vehicles_blown_up"] < 0.05 * worst["f32"]["vehicles"]
+    assert worst["f32"]["worst_reference_motor_model"] <= 1e-5
