@@ -719,3 +719,9 @@ def test_configuration_campaign():
     assert worst["f64"]["failures"] == 0 and worst["f32"]["failures"] == 0
     assert worst["f32"]["vehicles_blown_up"] < 0.05 * worst["f32"]["vehicles"]
     assert worst["f32"]["worst_reference_motor_model"] <= 1e-5
+    # the same with the loop closed on the device (onboard rates logic vs the oracle's restated logic): type mixes
+    # and layouts, dt, onboard period, noise, commands up to saturation, idle -> command -> partly re-commanded
+    logic = mod.run_logic_campaign(n_cfg=24, seed=7, verbose=False)
+    MEASUREMENTS["logic_configuration_campaign"] = logic
+    assert logic["f64"]["failures"] == 0 and logic["f32"]["failures"] == 0
+    assert logic["f64"]["motor_cmd"] <= 1e-9

@@ -162,8 +162,98 @@ def run_campaign(n_cfg=40, seed=1, verbose=True, only=None):
     return worst
 
 
+def run_logic_campaign(n_cfg=30, seed=1, verbose=True):
+    """The same idea with the loop closed on the device: onboard rates logic (KalmanFilter6DOF gyro path, low-pass,
+    rates controller, mixer) against the oracle's restated logic, over vehicle-type mixes and layouts, dt, onboard
+    period, noise, command magnitudes up to saturation, idle -> command -> partly re-commanded flights."""
+    master = np.random.default_rng(seed)
+    worst = {"f32": {"failures": 0}, "f64": {"failures": 0}}
+    for ci in range(n_cfg):
+        rng = np.random.default_rng(master.integers(1 << 31))
+        n = int(rng.choice([1, 65, 300, 513]))
+        ids = [int(t) for t in rng.permutation([5, 1, 2, 4])[:int(rng.integers(1, 5))]]
+        layout = str(rng.choice(["random", "by_type"]))
+        types = (rng.integers(0, len(ids), n) if layout == "random" else np.arange(n) // 64 % len(ids)).astype(np.uint8)
+        dt_us = int(rng.choice([250, 500, 1000, 2000]))
+        period = float(rng.choice([1 / 1000, 1 / 500, 1 / 250]))
+        noise = bool(rng.random() < 0.7)
+        policy = int(rng.choice([afa.AFE_SEED_REFERENCE, afa.AFE_SEED_DECORRELATED]))
+        fused = int(rng.choice([1, 3, 64]))
+        k0, k1, k2 = int(rng.integers(0, 8)), int(rng.integers(4, 30)), int(rng.integers(0, 25))
+        d = afa.scenarios.random_ensemble(n, int(rng.integers(1 << 30)), type_ids=tuple(ids), ground_fraction=0.0)
+        d.types = types
+        d.pos[2] += 30
+        d.ang_vel *= 0.3
+        hover = np.array([afa.params_from_type(t).hover_speed for t in ids])[types]
+        speed = hover * (1 + 0.05 * rng.uniform(-0.5, 0.5, (4, n)))
+        thrust = np.clip(9.81 + rng.normal(0, 3.0, n), 0, 25).astype(np.float32)
+        wdes = rng.normal(0, 2.0, (3, n)).astype(np.float32)
+        thrust_b = np.clip(9.81 + rng.normal(0, 1.0, n), 0, 25).astype(np.float32)
+        wdes_b = rng.normal(0, 0.5, (3, n)).astype(np.float32)
+        half = n // 2
+        steps = k0 + k1 + k2
+        ticks = afa.plan_ticks(period, 0, dt_us, steps)[0]
+        for precision, tag, tol in ((afa.AFE_F64, "f64", 1e-9), (afa.AFE_F32, "f32", 1e-5)):
+            with afa.Ensemble(n, precision=precision) as e:
+                e.set_type_table([afa.params_from_type(t) for t in ids])
+                e.set_vehicle_types(types)
+                e.set_logic_period(period)
+                e.set_imu_noise(noise, 0.1, 0.2, policy)
+                e.set_max_fused_steps(fused)
+                e.set_state(d.pos, d.vel, d.att, d.ang_vel, speed)
+                e.set_motor_cmds(np.zeros((4, n), np.float32))
+                e.set_external_force(d.ext_force)
+                e.set_rates_logic([afa.rates_logic_params_from_type(t) for t in ids])
+                rng0 = e.get_rng_state()
+                if k0:
+                    e.step(dt_us, k0)
+                e.set_rates_commands(thrust, wdes)
+                e.step(dt_us, k1)
+                if k2:
+                    if half:
+                        e.set_rates_commands(thrust_b[:half], wdes_b[:, :half], first=0, count=half)
+                    e.step(dt_us, k2)
+                st, cmds, rs = e.get_state(), e.get_motor_cmds(), e.get_rng_state()
+            olist = [ora.params_from_type(t) for t in ids]
+            for o in olist:
+                if not noise:
+                    o.sigma_gyro = o.sigma_acc = 0.0
+                else:
+                    o.sigma_gyro, o.sigma_acc = 0.1, 0.2
+            b = ora.Batch(n, olist, types)
+            b.pos[:], b.vel[:], b.att[:], b.ang_vel[:], b.motor_speed[:] = d.pos, d.vel, d.att, d.ang_vel, speed
+            b.ext_force[:] = d.ext_force
+            b.rng[:] = rng0
+            cl = ora.ClosedLoopBatch(b, [ora.logic_params_from_type(t, period) for t in ids], period)
+            cl.step(dt_us * 1e-6, ticks[:k0])
+            cl.set_rates_cmd(thrust, wdes)
+            cl.step(dt_us * 1e-6, ticks[k0:k0 + k1])
+            if k2:
+                if half:
+                    t2, w2 = thrust.copy(), wdes.copy()
+                    t2[:half], w2[:, :half] = thrust_b[:half], wdes_b[:, :half]
+                    cl.set_rates_cmd(t2, w2)
+                cl.step(dt_us * 1e-6, ticks[k0 + k1:])
+            errs = {k: rel_err_vec(st[k], getattr(b, k), FLOORS[k]) for k in ("pos", "vel", "att", "ang_vel", "motor_speed")}
+            errs["motor_cmd"] = rel_err_vec(cmds, b.motor_cmd, 1.0)
+            rng_ok = not noise or bool(np.array_equal(rs, b.rng))
+            bad = [k for k, v in errs.items() if not v <= (max(tol, 1e-6) if k == "motor_cmd" else tol)] + ([] if rng_ok else ["rng"])
+            for k, v in errs.items():
+                worst[tag][k] = max(worst[tag].get(k, 0.0), v)
+            worst[tag]["failures"] += 1 if bad else 0
+            if verbose or bad:
+                print("logic cfg %3d %s n=%4d types=%s/%-7s dt=%4dus period=%.4f steps=%d+%d+%d fused=%2d noise=%d/%d  worst %-11s %.2e %s"
+                      % (ci, tag, n, ids, layout, dt_us, period, k0, k1, k2, fused, noise, policy, max(errs, key=errs.get),
+                         max(errs.values()), ("FAIL " + ",".join(bad)) if bad else ""), flush=True)
+    return worst
+
+
 if __name__ == "__main__":
     w = run_campaign(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
                      only=int(sys.argv[3]) if len(sys.argv) > 3 else None)
     print(w)
+    if len(sys.argv) <= 3:
+        wl = run_logic_campaign(max(4, (int(sys.argv[1]) if len(sys.argv) > 1 else 40) // 4), int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+        print(wl)
+        w["f32"]["failures"] += wl["f32"]["failures"] + wl["f64"]["failures"]
     sys.exit(1 if w["f32"]["failures"] or w["f64"]["failures"] else 0)
