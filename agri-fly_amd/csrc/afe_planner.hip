@@ -29,7 +29,7 @@ namespace {
 
 // -DAFE_PLANNER_PROFILE: per-phase cycle totals (s_memtime), printed by launch_rappids; development only
 #ifdef AFE_PLANNER_PROFILE
-__device__ unsigned long long g_prof[10];   // [8]: the longest planner (cycles)
+__device__ unsigned long long g_prof[16];   // [8]: the longest planner (cycles); [9] scan chunks examined, [10] of them holding a marked pixel, [11] scan calls
 #define PL_T0(var) const unsigned long long var = __builtin_readcyclecounter()
 #define PL_T1(var, slot) do { if (threadIdx.x == 0) atomicAdd(&g_prof[slot], __builtin_readcyclecounter() - var); } while (0)
 #define PL_COUNT(slot, n) do { if (threadIdx.x == 0) atomicAdd(&g_prof[slot], (unsigned long long)(n)); } while (0)
@@ -607,6 +607,9 @@ __device__ __attribute__((noinline)) bool side_scan(const uint16_t *__restrict__
         vs[c] = mask_bit(mask, WW, xs[c], ys[c]);          // ignore < d < maxDepth, from the bit image
       }
     }
+#ifdef AFE_PLANNER_PROFILE
+    for (int c = 0; c < kScanBatch; c++) if (base0 + 64 * c < total) { PL_COUNT(9, 1); if (__ballot(vs[c])) PL_COUNT(10, 1); }
+#endif
 #pragma unroll
     for (int c = 0; c < kScanBatch; c++) {                  // depths only where a marked pixel needs one
       ds[c] = 1;
@@ -714,6 +717,9 @@ __device__ __attribute__((noinline)) bool corner_scan(const uint16_t *__restrict
         vs[c] = mask_bit(mask, WW, xs[c], ys[c]);
       }
     }
+#ifdef AFE_PLANNER_PROFILE
+    for (int c = 0; c < kScanBatch; c++) if (base0 + 64 * c < total) { PL_COUNT(9, 1); if (__ballot(vs[c])) PL_COUNT(10, 1); }
+#endif
 #pragma unroll
     for (int c = 0; c < kScanBatch; c++) {
       ds[c] = 1;
@@ -1268,7 +1274,7 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   }
   const unsigned mask_bytes = (unsigned)(((cfg.width + 63) >> 6) * cfg.height) * (unsigned)sizeof(uint64_t);
 #ifdef AFE_PLANNER_PROFILE
-  unsigned long long zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long zero[16] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero));
 #endif
   const int64_t n_cand = b.n * b.n_candidates;
@@ -1276,12 +1282,12 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
                      cfg, b);
   hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, b);
 #ifdef AFE_PLANNER_PROFILE
-  unsigned long long prof[10];
+  unsigned long long prof[16];
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_prof), sizeof(prof));
   fprintf(stderr, "planner profile (cycles per planner): total %.0f | collision_free %.0f | inflate: mask1 %.0f expansion(all) %.0f "
-          "sides+mask2 %.0f corners %.0f | completed pyramids/planner %.2f ringloop %.0f | longest planner %.0f\n", (double)prof[0] / b.n, (double)prof[6] / b.n,
-          (double)prof[1] / b.n, (double)prof[2] / b.n, (double)prof[3] / b.n, (double)prof[4] / b.n, (double)prof[5] / b.n, (double)prof[7] / b.n, (double)prof[8]);
+          "sides+mask2 %.0f corners %.0f | completed pyramids/planner %.2f ringloop %.0f | longest planner %.0f | scan chunks/planner %.0f, holding a marked pixel %.0f\n", (double)prof[0] / b.n, (double)prof[6] / b.n,
+          (double)prof[1] / b.n, (double)prof[2] / b.n, (double)prof[3] / b.n, (double)prof[4] / b.n, (double)prof[5] / b.n, (double)prof[7] / b.n, (double)prof[8], (double)prof[9] / b.n, (double)prof[10] / b.n);
 #endif
   return (int)hipGetLastError();
 }
