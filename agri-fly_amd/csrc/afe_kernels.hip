@@ -487,38 +487,50 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     // ---- 4 motors: Motor::Run, Motor.cpp:39-84 ----
     R Fz = 0;                       // totalForce_b (thrust axes are all +z)
     R Tx = 0, Ty = 0, Tz = 0;       // totalTorque_b
-    R Lm[4];                        // rotor angular momenta (about z)
+    R Lm[4] = {0, 0, 0, 0};         // rotor angular momenta (about z)
     const R c = P.c_lag;
+    // wave-uniform (kernel argument): every type has tau_m = 0 and J_m = 0 -- all shipped types.  The speed is
+    // then 0 old + 1 cmd = cmd exactly, and the rotor's inertial terms, J_m times something finite, are zeros
+    // that change no sum: they are not computed at all (12 fewer vector instructions per sub-step).
+    const bool lagged = !v.motor_stateless;
 #pragma unroll
     for (int m = 0; m < 4; m++) {
       const R spin = (R)AFE_MOTOR_SPIN(m);
-      const R old = ms[m];
-      R w, dw;
-      if (sizeof(R) == 8) {
-        w = fm(c, old, (1 - c) * cmd[m]);                    // :60
+      R w;
+      R rotor_tz = 0;                                        // (ang_acc * J) * spin, :78-79
+      if (!lagged) {
+        w = cmd[m];                                          // :60 with c = 0
         if (w > P.wmax) w = P.wmax; else if (w < P.wmin) w = P.wmin;  // :62-66
-        dw = w - old;
       } else {
-        // fp32 storage: (c old + (1 - c) cmd) - old cancels down to the rounding of a ~1e3 rad/s speed (6e-5)
-        // and :78 divides that by dt -- at dt = 100 us, with J_m > 0, the rotor-acceleration torque then carries
-        // 0.6 rad/s^2 of noise per motor (found by tools/step_campaign.py: 1e-4 relative in ang_vel after 30
-        // steps).  The increment is formed directly instead, (1 - c)(cmd - old) with 1 - c from the host's
-        // double; tau_m = 0 (every shipped type) gives c = 0, 1 - c = 1 and the same bits as before.
-        w = fm(c, old, P.omc_lag * cmd[m]);
-        dw = P.omc_lag * (cmd[m] - old);
-        if (w > P.wmax) { w = P.wmax; dw = w - old; } else if (w < P.wmin) { w = P.wmin; dw = w - old; }
+        const R old = ms[m];
+        R dw;
+        if (sizeof(R) == 8) {
+          w = fm(c, old, (1 - c) * cmd[m]);                  // :60
+          if (w > P.wmax) w = P.wmax; else if (w < P.wmin) w = P.wmin;  // :62-66
+          dw = w - old;
+        } else {
+          // fp32 storage: (c old + (1 - c) cmd) - old cancels down to the rounding of a ~1e3 rad/s speed (6e-5)
+          // and :78 divides that by dt -- at dt = 100 us, with J_m > 0, the rotor-acceleration torque then
+          // carries 0.6 rad/s^2 of noise per motor (found by tools/step_campaign.py: 1e-4 relative in ang_vel
+          // after 30 steps).  The increment is formed directly instead, (1 - c)(cmd - old) with 1 - c from the
+          // host's double.
+          w = fm(c, old, P.omc_lag * cmd[m]);
+          dw = P.omc_lag * (cmd[m] - old);
+          if (w > P.wmax) { w = P.wmax; dw = w - old; } else if (w < P.wmin) { w = P.wmin; dw = w - old; }
+        }
+        const R ang_acc = div_dt(dw, dt, v.inv_dt);          // :78
+        rotor_tz = (ang_acc * P.Jm) * spin;
+        Lm[m] = (w * P.Jm) * spin;                           // Motor.cpp:68
       }
       ms[m] = w;
       const R thrust = P.kf * w * m_abs(w);                  // :70 (along +z)
       const R aero = -P.ktau * w * m_abs(w);                 // :73 (along spin*z)
-      const R ang_acc = div_dt(dw, dt, v.inv_dt);            // :78
       // torque = aero*axis + p x (0,0,thrust) - ang_acc*J*axis   :71-79
-      const R tz_m = (aero * spin) - (ang_acc * P.Jm) * spin;
+      const R tz_m = lagged ? (aero * spin) - rotor_tz : aero * spin;
       Fz = Fz + thrust;                                      // Quadcopter_T.cpp:102
       Tx = fm(P.mpy[m], thrust, Tx);                         // Vec3.hpp:106-109
       Ty = fm(-P.mpx[m], thrust, Ty);                        // z*rx - x*rz, rx = 0
       Tz = Tz + tz_m;
-      Lm[m] = (w * P.Jm) * spin;                             // Motor.cpp:68
     }
 
     R Rm[9];
@@ -533,7 +545,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     // angular momentum and acceleration, Quadcopter_T.cpp:113-120
     R Lx, Ly, Lzz;
     mat_vec<R>(P.I, wx, wy, wz, Lx, Ly, Lzz);
-    Lzz = (((Lzz + Lm[0]) + Lm[1]) + Lm[2]) + Lm[3];
+    if (lagged) Lzz = (((Lzz + Lm[0]) + Lm[1]) + Lm[2]) + Lm[3];
     const R cx = fm(wy, Lzz, -(wz * Ly));   // _angVel.Cross(angMomentum)
     const R cy = fm(wz, Lx, -(wx * Lzz));
     const R cz = fm(wx, Ly, -(wy * Lx));
