@@ -257,6 +257,8 @@ int materialize_motor(afe_engine *e) {
   return AFE_OK;
 }
 
+size_t logic_arena_bytes(const afe_engine *e);
+
 template <typename R>
 void fill_view(const afe_engine *e, StepView<R> &v) {
   v.lpf = e->lpf; v.rates_cmd = e->rates_cmd; v.have_cmd = e->have_cmd; v.imu_init = e->imu_init;
@@ -272,6 +274,11 @@ void fill_view(const afe_engine *e, StepView<R> &v) {
   v.motor_write = !motor_lazy(e);
   v.sigma_gyro = (float)e->sigma_gyro;  // float(_stdDevRateGyroNoise), Quadcopter_T.cpp:170
   v.sigma_acc = (float)e->sigma_acc;
+  // one buffer resource spans the arena (pos is its first slab), another the logic arena (lpf first)
+  const size_t lbytes = logic_arena_bytes(e);
+  const bool fits = e->arena_bytes < 0xffff0000ull && lbytes < 0xffff0000ull;
+  v.buf_bytes = fits ? (uint32_t)e->arena_bytes : 0u;
+  v.logic_buf_bytes = fits ? (uint32_t)lbytes : 0u;
 }
 
 }  // namespace

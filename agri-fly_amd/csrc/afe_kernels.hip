@@ -404,7 +404,21 @@ __device__ __forceinline__ void rates_logic_tick(const DevLogic &G, LogicRegs &s
 // The vehicle step.  P is either the kernel-argument copy of the single
 // parameter record of a homogeneous ensemble (scalar registers: costs no
 // VGPRs) or this lane's record in the LDS-staged type table.
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE>
+// slab access through a buffer resource: address = resource base + 32-bit per-lane offset + scalar offset
+// (buffer_load_dword v, voff, s[rsrc:4], soff offen)
+template <typename T>
+__device__ __forceinline__ T buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+template <typename T>
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, T val) {
+  if constexpr (sizeof(T) == 8)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0)), val), r, (int)voff, (int)soff, 0);
+  else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), r, (int)voff, (int)soff, 0);
+}
+
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE, bool BUF>
 __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParams<R> &P, const DevLogic &G,
                                             const int64_t i) {
   // No implicit FMA contraction: every rounding is the one the source spells
@@ -413,14 +427,29 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   // order is the reference's (which is built without FMA on x86-64).
 #pragma clang fp contract(off)
   constexpr bool RENORM = (sizeof(R) == 4);  // fp32 storage renormalises the quaternion
-  // Addressing: every slab component is a wave-uniform base (scalar registers)
-  // plus ONE 32-bit per-lane byte offset, i.e. the saddr + voffset form of
-  // global_load/store; no 64-bit per-lane address is ever formed or kept live.
+  // Addressing: every slab component is wave-uniform (scalar registers) plus ONE 32-bit per-lane byte offset;
+  // no 64-bit per-lane address is ever formed or kept live.
+  //   BUF: one buffer resource spans the engine's arena from its first slab (`pos`), a second one the logic
+  //   arena (from `lpf`); a component is the resource + a scalar byte offset + the lane offset --
+  //   buffer_load_dword v, voff, s[rsrc:4], soff offen.  No vector instruction and no vector register goes
+  //   into an address (left to global_load, the compiler formed 34 64-bit lane addresses and kept 26 registers
+  //   of them alive from the loads to the stores: 88 -> 6x VGPRs).  Lanes past the arena read 0 / write nothing.
+  //   !BUF (an arena beyond 4 GiB): global_load / global_store on scalar base + 32-bit lane offset.
   const int64_t S = v.stride;
   const uint32_t off = (uint32_t)i * (uint32_t)sizeof(R);  // engine caps n so this cannot wrap
   const uint32_t off4 = (uint32_t)i * 4u;
-#define AFE_LD(T, base, comp, o) (*reinterpret_cast<const T *>(reinterpret_cast<const char *>((base) + (comp) * S) + (o)))
-#define AFE_ST(T, base, comp, o, val) (*reinterpret_cast<T *>(reinterpret_cast<char *>((base) + (comp) * S) + (o)) = (val))
+  // (built unconditionally: without BUF nothing uses them and they fold away)
+  const __amdgpu_buffer_rsrc_t rs_main = __builtin_amdgcn_make_buffer_rsrc((void *)v.pos, 0, (int)v.buf_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_logic = __builtin_amdgcn_make_buffer_rsrc((void *)v.lpf, 0, (int)v.logic_buf_bytes, 0x00020000);
+#define AFE_SOFF(first, base, comp) ((uint32_t)(reinterpret_cast<const char *>((base) + (comp) * S) - reinterpret_cast<const char *>(first)))
+#define AFE_LD(T, base, comp, o) (BUF ? buf_ld<T>(rs_main, (o), AFE_SOFF(v.pos, base, comp)) \
+                                      : *reinterpret_cast<const T *>(reinterpret_cast<const char *>((base) + (comp) * S) + (o)))
+#define AFE_ST(T, base, comp, o, val) do { if (BUF) buf_st<T>(rs_main, (o), AFE_SOFF(v.pos, base, comp), (val)); \
+                                           else *reinterpret_cast<T *>(reinterpret_cast<char *>((base) + (comp) * S) + (o)) = (val); } while (0)
+#define AFE_LDL(T, base, comp, o) (BUF ? buf_ld<T>(rs_logic, (o), AFE_SOFF(v.lpf, base, comp)) \
+                                       : *reinterpret_cast<const T *>(reinterpret_cast<const char *>((base) + (comp) * S) + (o)))
+#define AFE_STL(T, base, comp, o, val) do { if (BUF) buf_st<T>(rs_logic, (o), AFE_SOFF(v.lpf, base, comp), (val)); \
+                                            else *reinterpret_cast<T *>(reinterpret_cast<char *>((base) + (comp) * S) + (o)) = (val); } while (0)
 
   // ---- issue every load up front (independent, coalesced) ----
   // The engine word goes first: loads return in order, so the Gaussian draws of
@@ -445,13 +474,13 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   if (LOGIC && v.tick_mask) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      lg.xm0[k] = AFE_LD(float, v.lpf, k, off4);
-      lg.xm1[k] = AFE_LD(float, v.lpf, 3 + k, off4);
-      lg.ym0[k] = AFE_LD(float, v.lpf, 6 + k, off4);
-      lg.ym1[k] = AFE_LD(float, v.lpf, 9 + k, off4);
-      lg.wdes[k] = AFE_LD(float, v.rates_cmd, 1 + k, off4);
+      lg.xm0[k] = AFE_LDL(float, v.lpf, k, off4);
+      lg.xm1[k] = AFE_LDL(float, v.lpf, 3 + k, off4);
+      lg.ym0[k] = AFE_LDL(float, v.lpf, 6 + k, off4);
+      lg.ym1[k] = AFE_LDL(float, v.lpf, 9 + k, off4);
+      lg.wdes[k] = AFE_LDL(float, v.rates_cmd, 1 + k, off4);
     }
-    lg.thrust_norm = AFE_LD(float, v.rates_cmd, 0, off4);
+    lg.thrust_norm = AFE_LDL(float, v.rates_cmd, 0, off4);
     lg.imu_init = v.imu_init[(uint32_t)i];
     lg.have_cmd = v.have_cmd[(uint32_t)i];
   }
@@ -638,10 +667,10 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     if (LOGIC) {
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        AFE_ST(float, v.lpf, k, off4, lg.xm0[k]);
-        AFE_ST(float, v.lpf, 3 + k, off4, lg.xm1[k]);
-        AFE_ST(float, v.lpf, 6 + k, off4, lg.ym0[k]);
-        AFE_ST(float, v.lpf, 9 + k, off4, lg.ym1[k]);
+        AFE_STL(float, v.lpf, k, off4, lg.xm0[k]);
+        AFE_STL(float, v.lpf, 3 + k, off4, lg.xm1[k]);
+        AFE_STL(float, v.lpf, 6 + k, off4, lg.ym0[k]);
+        AFE_STL(float, v.lpf, 9 + k, off4, lg.ym1[k]);
       }
       v.imu_init[(uint32_t)i] = lg.imu_init;
 #pragma unroll
@@ -650,6 +679,9 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   }
 #undef AFE_LD
 #undef AFE_ST
+#undef AFE_LDL
+#undef AFE_STL
+#undef AFE_SOFF
 }
 
 #ifndef AFE_LB_WAVES
@@ -660,16 +692,16 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #endif
 
 // homogeneous ensemble: the one parameter record rides in the kernel arguments
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE>
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE, bool BUF>
 __global__ void __launch_bounds__(AFE_BLOCK, AFE_LB_WAVES)
 afe_step_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G) {
   const int64_t i = (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;
   if (i >= v.n) return;
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE>(v, P, G, i);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE, BUF>(v, P, G, i);
 }
 
 // heterogeneous ensemble: type tables staged into LDS, one record per lane
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC>
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool BUF>
 __global__ void __launch_bounds__(256)
 afe_step_kernel_table(const StepView<R> v) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -690,14 +722,14 @@ afe_step_kernel_table(const StepView<R> v) {
   const unsigned t = v.type[(uint32_t)i];
   const DevParams<R> &P = reinterpret_cast<const DevParams<R> *>(lds_raw)[t];
   const DevLogic &G = reinterpret_cast<const DevLogic *>(lds_raw + (size_t)words_p * 4)[LOGIC ? t : 0];
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false>(v, P, G, i);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false, BUF>(v, P, G, i);
 }
 
 // heterogeneous ensemble, but every wave (aligned run of 64 vehicles) is of one type -- the host checked
 // the type slab (afe_engine.cpp refresh_type_flags): the wave's record is copied out of the global table by
 // scalar loads before anything is stored, and from there on the kernel is the homogeneous one (parameters
 // in scalar registers, one-wave workgroups, no LDS)
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC>
+template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool BUF>
 __global__ void __launch_bounds__(AFE_BLOCK, AFE_LB_WAVES)
 afe_step_kernel_wave_types(const StepView<R> v) {
   const int64_t i = (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;
@@ -706,7 +738,7 @@ afe_step_kernel_wave_types(const StepView<R> v) {
   const DevParams<R> P = v.table[t];
   DevLogic G = {};
   if (LOGIC) G = v.logic_table[t];
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false>(v, P, G, i);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false, BUF>(v, P, G, i);
 }
 
 template <typename R>
@@ -718,24 +750,26 @@ static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevPara
   const size_t lds = (size_t)v.n_types * (sizeof(DevParams<R>) + (f.logic ? sizeof(DevLogic) : 0));
   DevLogic no_logic = {};
   const DevLogic &G = uniform_logic ? *uniform_logic : no_logic;
-#define AFE_LAUNCH(FE, TE, NO, LO)                                                                         \
+#define AFE_LAUNCH_B(FE, TE, NO, LO, BU)                                                                   \
   do {                                                                                                     \
     if (uniform && v.n_steps == 1)                                                                         \
-      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
+      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true, BU>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
     else if (uniform)                                                                                      \
-      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, false>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
+      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, false, BU>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
     else if (f.wave_uniform_types && AFE_BLOCK == 64)                                                      \
-      hipLaunchKernelGGL((afe_step_kernel_wave_types<R, FE, TE, NO, LO>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v); \
+      hipLaunchKernelGGL((afe_step_kernel_wave_types<R, FE, TE, NO, LO, BU>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v); \
     else {                                                                                                 \
       /* a large type table (up to 256 records: 83 KB fp32 / 124 KB fp64 with the logic records) needs   \
          more than the default 64 KB of dynamic LDS; gfx950 has 160 KB per CU */                          \
       if (lds > 65536 &&                                                                                   \
-          hipFuncSetAttribute(reinterpret_cast<const void *>(&afe_step_kernel_table<R, FE, TE, NO, LO>),  \
+          hipFuncSetAttribute(reinterpret_cast<const void *>(&afe_step_kernel_table<R, FE, TE, NO, LO, BU>), \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)         \
         return (int)hipErrorInvalidValue;                                                                  \
-      hipLaunchKernelGGL((afe_step_kernel_table<R, FE, TE, NO, LO>), dim3(grid), dim3(256), lds, st, v);   \
+      hipLaunchKernelGGL((afe_step_kernel_table<R, FE, TE, NO, LO, BU>), dim3(grid), dim3(256), lds, st, v); \
     }                                                                                                      \
   } while (0)
+  /* buffer addressing whenever the arenas fit 32-bit offsets (StepView::buf_bytes) */
+#define AFE_LAUNCH(FE, TE, NO, LO) do { if (v.buf_bytes) AFE_LAUNCH_B(FE, TE, NO, LO, true); else AFE_LAUNCH_B(FE, TE, NO, LO, false); } while (0)
 #define AFE_SEL_LO(FE, TE, NO) do { if (f.logic) AFE_LAUNCH(FE, TE, NO, true); else AFE_LAUNCH(FE, TE, NO, false); } while (0)
 #define AFE_SEL_NO(FE, TE) do { if (f.noise) AFE_SEL_LO(FE, TE, true); else AFE_SEL_LO(FE, TE, false); } while (0)
 #define AFE_SEL_TE(FE) do { if (f.ext_torque) AFE_SEL_NO(FE, true); else AFE_SEL_NO(FE, false); } while (0)
@@ -744,6 +778,7 @@ static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevPara
 #undef AFE_SEL_NO
 #undef AFE_SEL_LO
 #undef AFE_LAUNCH
+#undef AFE_LAUNCH_B
   return (int)hipGetLastError();
 }
 

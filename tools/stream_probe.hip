@@ -34,6 +34,34 @@ __global__ void __launch_bounds__(256) planar(const float *__restrict__ in, floa
   }
 }
 
+// planar through ONE buffer resource: address = rsrc base + per-lane 32-bit offset + scalar component offset
+// (buffer_load_dword v, voff, s[rsrc], soff offen): no per-lane address arithmetic at all
+__global__ void __launch_bounds__(64) planar_buffer(float *base, long S, long n) {
+  const unsigned i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(NR * S * 4), 0x00020000);
+  const unsigned off = i * 4u;
+  const int S4 = (int)S * 4;
+  float v[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, k * S4, 0));
+  float acc = 0;
+  for (int k = NW; k < NR; k++) acc += v[k];
+#pragma unroll
+  for (int k = 0; k < NW; k++) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k] * 1.0001f + acc), r, off, k * S4, 0);
+}
+__global__ void __launch_bounds__(64) planar64(const float *__restrict__ in, float *__restrict__ out, long S, long n) {
+  const long i = (long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float v[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) v[k] = in[k * S + i];
+  float acc = 0;
+  for (int k = NW; k < NR; k++) acc += v[k];
+#pragma unroll
+  for (int k = 0; k < NW; k++) out[k * S + i] = v[k] * 1.0001f + acc;
+}
+
 // tiled: 64-vehicle tile = NR rows of 64 floats; comp k of vehicle i at base[(i/64)*NR*64 + k*64 + i%64]
 __global__ void __launch_bounds__(256) tiled(const float *__restrict__ in, float *__restrict__ out, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -90,6 +118,24 @@ int main(int argc, char **argv) {
     if (variant < 5) printf("%-28s %.2f us/launch  %.0f GB/s\n", names[variant], best * 10, bytes / (best * 1e-5) / 1e9);
     else if (variant >= 11) printf("planar dwordx%d pad 256        %.2f us/launch  %.0f GB/s\n", 1 << (variant - 11), best * 10, bytes / (best * 1e-5) / 1e9);
     else printf("planar dword pad %-10ld  %.2f us/launch  %.0f GB/s\n", pads[variant], best * 10, bytes / (best * 1e-5) / 1e9);
+  }
+  // one-wave workgroups like the engine: global addressing vs one buffer resource (stride n + 256)
+  S = n + 256;
+  for (int variant = 0; variant < 2; variant++) {
+    float best = 1e9;
+    for (int rep = 0; rep < 5; rep++) {
+      hipEventRecord(e0);
+      for (int it = 0; it < (n > (1 << 21) ? 20 : 100); it++) {
+        if (variant == 0) planar64<<<(n + 63) / 64, 64>>>(a, a, S, n);
+        else planar_buffer<<<(n + 63) / 64, 64>>>(a, S, n);
+      }
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      ms *= (n > (1 << 21) ? 5.0f : 1.0f);
+      if (ms < best) best = ms;
+    }
+    printf("%-28s %.2f us/launch  %.0f GB/s\n", variant ? "64-lane groups, buffer rsrc" : "64-lane groups, global", best * 10, bytes / (best * 1e-5) / 1e9);
   }
   return 0;
 }
