@@ -36,6 +36,7 @@ struct afe_engine {
   std::vector<DevParams<float>> table_f32;   // host copies of the device table
   std::vector<DevParams<double>> table_f64;
   bool types_uniform = true;  // every vehicle uses record 0 (kernel-argument fast path)
+  bool force_global_addressing = false;   // afe_set_addressing(1): the kernels of arenas beyond 4 GiB, on any arena
   std::vector<uint8_t> type_host;   // host mirror of the type slab (zeros until afe_set_vehicle_types / a checkpoint)
   bool types_wave_uniform = true;   // the type index is constant over every aligned run of 64 vehicles
   float *pack_scratch = nullptr;  // 3*n floats, lazily allocated
@@ -276,7 +277,7 @@ void fill_view(const afe_engine *e, StepView<R> &v) {
   v.sigma_acc = (float)e->sigma_acc;
   // one buffer resource spans the arena (pos is its first slab), another the logic arena (lpf first)
   const size_t lbytes = logic_arena_bytes(e);
-  const bool fits = e->arena_bytes < 0xffff0000ull && lbytes < 0xffff0000ull;
+  const bool fits = !e->force_global_addressing && e->arena_bytes < 0xffff0000ull && lbytes < 0xffff0000ull;
   v.buf_bytes = fits ? (uint32_t)e->arena_bytes : 0u;
   v.logic_buf_bytes = fits ? (uint32_t)lbytes : 0u;
 }
@@ -650,6 +651,12 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     if (motor_lazy(e)) e->motor_stale = true;
     done += chunk;
   }
+  return AFE_OK;
+}
+
+extern "C" int afe_set_addressing(afe_engine *e, int mode) {
+  if (!e || (mode != 0 && mode != 1)) return fail(e, AFE_ERR_INVALID_ARG, "addressing mode must be 0 (automatic) or 1 (global)");
+  e->force_global_addressing = mode == 1;
   return AFE_OK;
 }
 

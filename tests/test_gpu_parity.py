@@ -725,3 +725,42 @@ def test_configuration_campaign():
     MEASUREMENTS["logic_configuration_campaign"] = logic
     assert logic["f64"]["failures"] == 0 and logic["f32"]["failures"] == 0
     assert logic["f64"]["motor_cmd"] <= 1e-9
+
+
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+@pytest.mark.parametrize("layout", ["record0", "by_type", "random"])
+def test_buffer_and_global_addressing_are_bitwise_equal(precision, layout):
+    """The step kernels reach the slabs through buffer resources; ensembles whose arena exceeds 4 GiB (> ~19 M
+    vehicles) run the same kernels instantiated with global addresses.  afe_set_addressing(1) forces the latter
+    at any size: state, IMU, commands, filter-driven behaviour and RNG words must be the same bits -- homogeneous
+    (kernel-argument record), one-type-per-wave and LDS-table kernels, single and fused launches, noise, wrench,
+    on-device logic, a ragged last wave."""
+    n = 4096 + 21
+    ens = random_ensemble(n, seed=91, type_ids=(5, 1, 2, 4))
+    d = ens.data
+    d.pos[2] += 20
+    if layout == "record0":
+        d.types[:] = 0
+    elif layout == "by_type":
+        d.types[:] = np.arange(n) // 64 % 4
+
+    def fly(force_global):
+        with ens.to_engine(precision) as e:
+            e.set_addressing(force_global)
+            e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+            e.set_rates_logic([afa.rates_logic_params_from_type(t) for t in d.type_ids])
+            e.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
+            e.step(1000, 1)
+            e.step(1000, 9)
+            e.set_rates_logic(None)                      # and without the logic: the open-loop instantiations
+            e.set_motor_cmds(np.minimum(d.motor_cmd, 900.0))
+            e.step(1000, 1)
+            e.step(1000, 6)
+            return e.get_state(), e.get_imu(), e.get_rng_state(), e.get_motor_cmds()
+
+    a, b = fly(False), fly(True)
+    for k in a[0]:
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert np.isfinite(a[0]["pos"]).all()
