@@ -322,6 +322,7 @@ struct RenderArgs {
   double focal, cx, cy, depth_scale;
   int max_count;
   int plain_walk_only;      // afe_scene_set_walk(1)
+  const double *uv;         // pixel-ray table: u(px) = (px - cx) / focal for px < tiles_x * 8, then v(py) likewise
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -483,6 +484,12 @@ __device__ __forceinline__ void walk(const RenderArgs &a, const PairNode *tree, 
   }
 }
 
+__global__ void __launch_bounds__(256) afe_pixel_ray_table_kernel(double *uv, int nx, int ny, double cx, double cy, double focal) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nx) uv[i] = (i - cx) / focal;
+  else if (i < nx + ny) uv[i] = ((i - nx) - cy) / focal;
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(RenderArgs a) {
 #pragma clang fp contract(off)
@@ -502,8 +509,10 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   const double *pose = a.poses + 12 * view;
   RayState ray;
   for (int k = 0; k < 3; k++) ray.o[k] = pose[k];
-  const double u = (px - a.cx) / a.focal;
-  const double v = (py - a.cy) / a.focal;
+  // (px - cx) / focal and (py - cy) / focal: the contract's own double-precision divisions, done once per camera
+  // by afe_pixel_ray_table_kernel instead of twice per ray (55 of the ~1 000 vector instructions of a wave)
+  const double u = a.uv[px];
+  const double v = a.uv[a.tiles_x * kTileW + py];
   for (int k = 0; k < 3; k++) ray.d[k] = pose[3 + 3 * k] * u + pose[4 + 3 * k] * v + pose[5 + 3 * k];
   for (int k = 0; k < 3; k++) {
     // |1/d| is capped: a direction component of exactly zero (a pixel on the principal axis of an
@@ -594,6 +603,10 @@ struct afe_scene {
   PairNode *pairs = nullptr;   // 8 x n_pairs (Builder::pairs)
   int64_t n_pairs = 0;
   TriRec *tris = nullptr;
+  // pixel-ray tables, one per camera geometry this scene has been rendered with (kept until the scene goes:
+  // a launch still in flight on some stream may be reading one)
+  struct RayTable { int width, height; double cx, cy, focal; double *uv; };
+  std::vector<RayTable> ray_tables;
 };
 
 namespace {
@@ -625,9 +638,26 @@ bool camera_ok(const afe_camera *c) {
 }
 
 // poses (device, [count][12]) -> images; out_dev: device buffer of count*h*w uint16
-int launch_render(const afe_scene *s, const afe_camera *cam, int64_t count, const double *poses, uint16_t *out_dev,
+int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const double *poses, uint16_t *out_dev,
                   hipStream_t stream, float *kernel_ms, unsigned long long *dev_counters = nullptr) {
   RenderArgs r;
+  {
+    const int nx = ((cam->width + kTileW - 1) / kTileW) * kTileW, ny = ((cam->height + kTileH - 1) / kTileH) * kTileH;
+    const double *uv = nullptr;
+    for (const afe_scene::RayTable &t : s->ray_tables)
+      if (t.width == cam->width && t.height == cam->height && t.cx == cam->cx && t.cy == cam->cy && t.focal == cam->focal_length) uv = t.uv;
+    if (!uv) {
+      double *fresh = nullptr;
+      if (hipMalloc((void **)&fresh, (size_t)(nx + ny) * sizeof(double)) != hipSuccess) return AFE_ERR_HIP;
+      hipLaunchKernelGGL(afe_pixel_ray_table_kernel, dim3((unsigned)((nx + ny + 255) / 256)), dim3(256), 0, stream, fresh, nx, ny,
+                         cam->cx, cam->cy, cam->focal_length);
+      // other streams may use the table from now on: make it complete before it is published
+      if (hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(fresh); return AFE_ERR_HIP; }
+      s->ray_tables.push_back({cam->width, cam->height, cam->cx, cam->cy, cam->focal_length, fresh});
+      uv = fresh;
+    }
+    r.uv = uv;
+  }
   r.pairs = s->pairs; r.n_pairs = s->n_pairs; r.tris = s->tris; r.counters = dev_counters;
   r.width = cam->width; r.height = cam->height;
   r.tiles_x = (cam->width + kTileW - 1) / kTileW;
@@ -860,6 +890,7 @@ extern "C" int afe_scene_check_hierarchy(const float *triangles, int64_t n_tri, 
 
 extern "C" void afe_scene_destroy(afe_scene *s) {
   if (!s) return;
+  for (const afe_scene::RayTable &t : s->ray_tables) (void)hipFree(t.uv);
   if (s->pairs) (void)hipFree(s->pairs);
   if (s->tris) (void)hipFree(s->tris);
   delete s;
