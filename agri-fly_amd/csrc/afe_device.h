@@ -80,7 +80,7 @@ struct StepView {
   const DevLogic *logic_table;
   // Buffer addressing (afe_kernels.hip run_vehicle): bytes of the engine's arena reachable from `pos`, its first
   // slab -- every slab up to `type` lies inside -- and of the logic arena from `lpf`; 0 when an arena does not
-  // fit 32-bit offsets (> 4 GiB: ensembles beyond ~19 M vehicles), which selects the global-address kernels.
+  // fit 32-bit offsets (> 4 GiB: ensembles beyond ~31 M fp32 vehicles), which selects the global-address kernels.
   uint32_t buf_bytes;
   uint32_t logic_buf_bytes;
 };

@@ -415,7 +415,7 @@ int afe_rappids_plan_device(int device, const afe_planner_config *cfg, int64_t n
  * dt_us may be fused before its Run() is due (>= 1). */
 int afe_step(afe_engine *e, uint64_t dt_us, int n_steps);
 /* How the step kernels address the state slabs: 0 (default) -- through buffer resources spanning the engine's
- * arenas whenever those fit 32-bit offsets (up to ~19 M vehicles), otherwise by global addresses; 1 -- always by
+ * arenas whenever those fit 32-bit offsets (up to ~31 M fp32 vehicles), otherwise by global addresses; 1 -- always by
  * global addresses.  Same results bit for bit; mode 1 exists so that the kernels very large ensembles run are
  * testable at any size. */
 int afe_set_addressing(afe_engine *e, int mode);

@@ -199,3 +199,54 @@ def test_config3_65536_vehicles_planner_in_the_loop(ora):
     print("\nconfig 3 in loop: %d vehicles, %d frames, render %.0f ms + plan %.0f ms per frame, found %.3f..%.3f"
           % (n, len(frames), np.mean([f["render_ms"] for f in frames]), np.mean([f["plan_ms"] for f in frames]),
              min(f["found"] for f in frames), max(f["found"] for f in frames)))
+
+
+@pytest.mark.parametrize("n,addressing", [(30_000_000, "buffer resources, offsets up to 4.1e9"),
+                                          (40_000_000, "global addresses: the arena exceeds 4 GiB")])
+def test_tens_of_millions_of_vehicles_address_their_slabs_correctly(n, addressing):
+    """Sized for 288 GB: 3e7 vehicles are a 4.1 GB arena -- buffer-resource offsets right up to the 32-bit limit --
+    and 4e7 a 5.5 GB one, beyond it, which takes the global-address instantiations for real (not via
+    afe_set_addressing).  Three windows of 4 096 vehicles -- the first, the middle, the very last -- get random
+    states, commands and gusts, everybody else rests at the origin; after 6 noisy steps the windows must match
+    the oracle (seeded per global index) and a resting vehicle next to each window must still rest."""
+    from oracle import oracle_py as ora
+    from tests.scenarios import FLOORS, rel_err_vec
+    w = 4096
+    windows = [0, (n // 2) // 64 * 64 + 17, n - w]
+    p = afa.params_from_type(5)
+    with afa.Ensemble(n, first_global_index=5) as e:
+        e.set_type_table([p])
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+        e.set_logic_period(1 / 500)
+        data = []
+        for k, first in enumerate(windows):
+            d = afa.scenarios.random_ensemble(w, 700 + k, type_ids=(5,), ground_fraction=0.0)
+            d.pos[2] += 30
+            cmd = np.minimum(d.motor_cmd, 900.0)
+            e.set_state(d.pos, d.vel, d.att, d.ang_vel, d.motor_speed, first=first, count=w)
+            e.set_motor_cmds(cmd, first=first, count=w)
+            e.set_external_force(d.ext_force, first=first, count=w)
+            data.append((d, cmd))
+        steps = 6
+        e.step(1000, steps)
+        ticks = afa.plan_ticks(1 / 500, 0, 1000, steps)[0]
+        for (d, cmd), first in zip(data, windows):
+            st = e.get_state(first=first, count=w)
+            gyro, acc = e.get_imu(first=first, count=w)
+            b = ora.Batch(w, [ora.params_from_type(5)])
+            b.pos[:], b.vel[:], b.att[:], b.ang_vel[:], b.motor_speed[:] = d.pos, d.vel, d.att, d.ang_vel, d.motor_speed
+            b.motor_cmd[:] = cmd
+            b.ext_force[:] = d.ext_force
+            b.rng[:] = 5 + first + 1 + np.arange(w)
+            b.step(1e-3, steps, ticks=ticks)
+            for f in ("pos", "vel", "att", "ang_vel"):
+                assert rel_err_vec(st[f], getattr(b, f), FLOORS[f]) <= 1e-5, (first, f)
+            assert rel_err_vec(gyro, b.gyro, FLOORS["gyro"]) <= 1e-5 and rel_err_vec(acc, b.acc, FLOORS["acc"]) <= 1e-5
+            assert np.array_equal(e.get_rng_state(first=first, count=w), b.rng)
+        # bystanders: at rest at the origin with zero commands they fall freely for 6 ms, all alike
+        rest = [e.get_state(first=f, count=1) for f in (w, windows[1] - 1, n - w - 1)]
+        for r in rest[1:]:
+            for f in r:
+                assert np.array_equal(r[f], rest[0][f]), f
+        assert abs(rest[0]["vel"][2, 0] + 9.81 * 0.006) < 1e-3 or rest[0]["pos"][2, 0] == 0.0
+    MEASUREMENTS["large_ensemble_%d" % n] = {"vehicles": n, "addressing": addressing}
