@@ -23,6 +23,25 @@ import numpy as np
 
 F = np.float32
 
+# glibc's float transcendentals for small batches: numpy's own float32 routines differ from sinf / cosf / asinf /
+# acosf by an ulp now and then, and one ulp in a command flips a 16-bit radio code every few seconds of flight --
+# enough to part from a run of the reference by 1e-5 m (tests/test_reference_anchors.py wants them identical)
+import ctypes as _C
+import ctypes.util as _Cu
+
+_libm = _C.CDLL(_Cu.find_library("m") or "libm.so.6")
+for _n in ("sinf", "cosf", "asinf", "acosf"):
+    getattr(_libm, _n).restype = _C.c_float
+    getattr(_libm, _n).argtypes = [_C.c_float]
+
+
+def _tr(name, np_fn, x):
+    x = np.asarray(x, F)
+    if x.size > 64:
+        return np_fn(x).astype(F)
+    f = getattr(_libm, name)
+    return np.array([f(float(v)) for v in x.reshape(-1)], F).reshape(x.shape)
+
 
 def _quat_mul(a, b):
     """Rotation.hpp:124-131 (this = a, r1 = b), float32, arrays [4, n]"""
@@ -59,8 +78,8 @@ def _from_rotvec(r):
     theta = np.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]).astype(F)
     small = theta < F(4.84813681e-6)
     th = np.where(small, F(1), theta)
-    s = np.sin(th * F(0.5)).astype(F)
-    q = np.stack([np.cos(th * F(0.5)).astype(F), s * (r[0] / th), s * (r[1] / th), s * (r[2] / th)]).astype(F)
+    s = _tr("sinf", np.sin, th * F(0.5))
+    q = np.stack([_tr("cosf", np.cos, th * F(0.5)), s * (r[0] / th), s * (r[1] / th), s * (r[2] / th)]).astype(F)
     q[:, small] = np.array([[1], [0], [0], [0]], F)
     return q
 
@@ -70,7 +89,7 @@ def _to_rotvec(q):
     sgn = np.where(q[0] > 0, F(1), F(-1))
     n = (q[1:4] * sgn).astype(F)
     norm = np.sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]).astype(F)
-    angle = (np.arcsin(np.minimum(norm, F(1))) * F(2)).astype(F)
+    angle = (_tr("asinf", np.arcsin, np.minimum(norm, F(1))) * F(2)).astype(F)
     small = angle < F(4.84813681e-6)
     out = (n * (angle / np.where(norm == 0, F(1), norm))).astype(F)
     out[:, small] = 0
@@ -121,7 +140,7 @@ class OffboardHover:
         thrust = np.maximum(norm * (body_z * tdir).sum(0).astype(F), F(-1)).astype(F)
         cosang = tdir[2]
         angle = np.where(cosang >= F(1 - 1e-12), F(0),
-                         np.where(cosang <= F(-(1 - 1e-12)), F(np.pi), np.arccos(np.clip(cosang, -1, 1)))).astype(F)
+                         np.where(cosang <= F(-(1 - 1e-12)), F(np.pi), _tr("acosf", np.arccos, np.clip(cosang, -1, 1)))).astype(F)
         rot_ax = np.stack([-tdir[1], tdir[0], np.zeros(self.n, F)]).astype(F)   # e3 x tdir
         nrm = np.sqrt((rot_ax * rot_ax).sum(0)).astype(F)
         tiny = nrm < F(1e-6)
@@ -135,7 +154,7 @@ class OffboardHover:
         red_ax = np.stack([z_in_err[1], -z_in_err[0], np.zeros(self.n, F)]).astype(F)   # (.) x e3
         cos_red = z_in_err[2]
         red_an = np.where(cos_red >= F(1), F(0), np.where(cos_red <= F(-1), F(np.pi),
-                                                            np.arccos(np.clip(cos_red, -1, 1)))).astype(F)
+                                                            _tr("acosf", np.arccos, np.clip(cos_red, -1, 1)))).astype(F)
         nn = np.sqrt((red_ax * red_ax).sum(0)).astype(F)
         red_ax = np.where(nn < F(1e-12), F(0), red_ax / np.where(nn < F(1e-12), F(1), nn)).astype(F)
         k3, k12 = F(1) / self.tc_z, F(1) / self.tc_xy
