@@ -9,16 +9,19 @@
 // What is stubbed, and says so in the log header comment line when --verbose:
 //   * AirSim / Unity (:183-184,300-321,331-389,397-438): absent; with --scene orchard the depth image
 //     comes from the engine's own depth camera and the RAPPIDS planner runs on the GPU (afe_rappids_plan).
-//   * MocapStateEstimator (:221-224,451-457,468-469): the estimate handed to the controller is the
-//     TRUE state sampled at the offboard tick (caller-side GNC is out of scope, SURVEY section 2 row 10;
-//     inside the agri-fly tree the reference's estimator and controller drop in here unchanged).
-//   * QuadcopterController::Run (:625-627): restated below (float, QuadcopterController.cpp:11-74)
-//     because the tree's Offboard/ sources are not part of this repository.
+//   * MocapStateEstimator (:221-224,451-457,468-469,647-649) and QuadcopterController::Run (:625-627): the tree's
+//     Offboard/ sources are not part of this repository, so both are restated -- cli/mocap_estimator.hpp
+//     (200 Hz truth pose in, prediction 30 ms ahead out, driven by the commands in flight) and HoverController
+//     below (float, QuadcopterController.cpp:11-74); inside the agri-fly tree the reference's own classes drop
+//     into the same calls.  --estimator truth hands the controller the true state instead.
 //   * telemetry (:459-466,659-664): m1..m4 are the commanded motor forces k_f cmd^2 put through the
 //     reference's telemetry quantisation (afe_telemetry_encode / _decode); panic is always 0.
 //
 //   rappids_headless [--vehicles N] [--seconds T] [--dt-us 2000] [--precision f32|f64]
 //                    [--seeds reference|decorrelated] [--log-vehicle i] [--digits D] [--out simulation.csv]
+//                    [--estimator mocap|truth] [--print-seconds]
+// --print-seconds: the logged vehicle's true state on stdout after every whole second of Run() calls
+//   ("t=1.000 pos=x y z vel=... q=... f0=..."), the line format SURVEY.md Appendix B quotes for the reference.
 // Defaults are the reference's own: 1 vehicle, dt = 1/500 s, 8 s, 6 significant digits (ofstream default).
 #include <cmath>
 #include <cstdio>
@@ -31,6 +34,7 @@
 #include <vector>
 
 #include "agrifly/Wire.hpp"
+#include "mocap_estimator.hpp"
 
 namespace {
 
@@ -108,6 +112,7 @@ int main(int argc, char **argv) {
   uint64_t dt_us_arg = 0;
   int precision = AFE_F32, seeds = AFE_SEED_REFERENCE, digits = 6;
   std::string outPath = "simulation.csv";
+  bool useMocapEstimator = true, printSeconds = false;
   for (int a = 1; a < argc; a++) {
     const std::string k = argv[a];
     const char *v = a + 1 < argc ? argv[a + 1] : "";
@@ -119,6 +124,8 @@ int main(int argc, char **argv) {
     else if (k == "--log-vehicle") { logVehicle = atoll(v); a++; }
     else if (k == "--digits") { digits = atoi(v); a++; }
     else if (k == "--out") { outPath = v; a++; }
+    else if (k == "--estimator") { useMocapEstimator = std::strcmp(v, "truth") != 0; a++; }
+    else if (k == "--print-seconds") { printSeconds = true; }
     else { std::fprintf(stderr, "rappids_headless: unknown option %s\n", k.c_str()); return 2; }
   }
   if (nVehicles < 1 || logVehicle < 0 || logVehicle >= nVehicles || digits < 1) return 2;
@@ -146,6 +153,9 @@ int main(int argc, char **argv) {
   die(quad, afe_set_rates_logic(quad, &logicConsts, 1), "afe_set_rates_logic");
   // quad->SetPosition(initErrPos); quad->SetAttitude(initErrAtt): origin, identity (:279-280) = the engine's initial state
 
+  std::vector<agrifly_cli::MocapEstimator> est;                              // :221-224, one per vehicle
+  for (int64_t i = 0; i < nVehicles; i++) est.push_back(agrifly_cli::MocapEstimator(&simTimer, timeDelayOffboardControlLoopTrue));
+  double const timeDelayOffboardControlLoopEstimate = 0.03;                  // :179
   HoverController ctrl;
   Vec3d desiredPosition(0, 0, 3.5);   // :240
   Vec3d desiredVelocity(0, 0, 0);
@@ -169,6 +179,11 @@ int main(int argc, char **argv) {
   std::vector<float> cmds(4 * nVehicles), gyro(3 * nVehicles), acc(3 * nVehicles);
   const int64_t N = nVehicles, L = logVehicle;
 
+  long steps = 0;
+  const long stepsPerSecond = (long)(1.0 / dt);
+  double p1[3], v1[3], q1[4], w1[3], m1[4];
+  agrifly_cli::Estimate estLogged;
+  estLogged.att = Rotationd::Identity();
   while (t.GetSeconds<double>() < endTime) {                                  // :330
     {   // quad->Run(), Quadcopter_T.cpp:85-91: dt from the integration timer, nothing on the first call
       const uint64_t run_us = integrationTimer.GetMicroSeconds();
@@ -183,8 +198,21 @@ int main(int argc, char **argv) {
       timerPrint.AdjustTimeBySeconds(-1);
       std::printf("Current sim time = %.1fs\n", t.GetSeconds<double>());
     }
-    if (timerMocap.GetSeconds<double>() > periodMocapSystem)                   // :451-457 (estimator stubbed)
+    steps++;
+    if (printSeconds && steps % stepsPerSecond == 0) {
+      die(quad, afe_get_state(quad, L, 1, p1, v1, q1, w1, m1), "afe_get_state");
+      std::printf("t=%.3f pos=%.9g %.9g %.9g vel=%.6g %.6g %.6g q=%.9g %.6g %.6g %.6g w=%.4g %.4g %.4g f0=%.6g\n",
+                  t.GetSeconds<double>(), p1[0], p1[1], p1[2], v1[0], v1[1], v1[2], q1[0], q1[1], q1[2], q1[3], w1[0], w1[1], w1[2],
+                  vehConsts.prop_thrust_from_speed_sqr * m1[0] * std::fabs(m1[0]));
+    }
+    if (timerMocap.GetSeconds<double>() > periodMocapSystem) {                 // :451-457
       timerMocap.AdjustTimeBySeconds(-periodMocapSystem);
+      if (useMocapEstimator) {
+        die(quad, afe_get_state(quad, 0, N, pos.data(), vel.data(), att.data(), angVel.data(), 0), "afe_get_state");
+        for (int64_t i = 0; i < N; i++)
+          est[(size_t)i].Measure(Vec3d(pos[i], pos[N + i], pos[2 * N + i]), Rotationd(att[i], att[N + i], att[2 * N + i], att[3 * N + i]));
+      }
+    }
     if (timerTelemetryLoop.GetSeconds<double>() > periodTelemetryLoop)         // :459-466 (no consumer)
       timerTelemetryLoop.AdjustTimeBySeconds(-periodTelemetryLoop);
 
@@ -195,9 +223,18 @@ int main(int argc, char **argv) {
       for (int64_t i = 0; i < N; i++) {                                        // :611-638 for every vehicle
         Vec3d cmdAngVel;
         double cmdThrust;
-        ctrl.Run(Vec3d(pos[i], pos[N + i], pos[2 * N + i]), Vec3d(vel[i], vel[N + i], vel[2 * N + i]),
-                 Rotationd(att[i], att[N + i], att[2 * N + i], att[3 * N + i]), desiredPosition, Vec3d(0, 0, 0),
+        agrifly_cli::Estimate estState;                                        // :468-469
+        if (useMocapEstimator) estState = est[(size_t)i].Predict(timeDelayOffboardControlLoopEstimate);
+        else {
+          estState.pos = Vec3d(pos[i], pos[N + i], pos[2 * N + i]); estState.vel = Vec3d(vel[i], vel[N + i], vel[2 * N + i]);
+          estState.att = Rotationd(att[i], att[N + i], att[2 * N + i], att[3 * N + i]);
+          estState.angVel = Vec3d(angVel[i], angVel[N + i], angVel[2 * N + i]);
+        }
+        ctrl.Run(estState.pos, estState.vel, estState.att, desiredPosition, Vec3d(0, 0, 0),
                  Vec3d(0, 0, 0), desYawAngleDeg * M_PI / 180.0, cmdAngVel, cmdThrust);
+        if (useMocapEstimator)                                                 // :647-649
+          est[(size_t)i].Announce(cmdAngVel, (estState.att * Vec3d(0, 0, 1) * cmdThrust - Vec3d(0, 0, 9.81)));
+        if (i == L) estLogged = useMocapEstimator ? est[(size_t)i].Predict(0) : estState;   // :699-704
         batch[(size_t)i] = agrifly::MakeRatesCommand(0, float(cmdThrust), Vec3f(cmdAngVel));   // CreateRatesCommand
         if (i == L) {
           lastRadioCommand[0] = cmdThrust;                                     // :643-646
@@ -231,11 +268,11 @@ int main(int argc, char **argv) {
       logfile << toCSV(q.ToEulerYPR(), digits);
       logfile << toCSV(w, digits);
       for (int m = 0; m < 4; m++) logfile << dataPacket.motor_forces[m] << ",";
-      // estimator state (stub: the truth, narrowed to float like EstimatedState)
-      logfile << toCSV(Vec3f(p), digits);
-      logfile << toCSV(Vec3f(v), digits);
-      logfile << toCSV(Rotationf(q).ToEulerYPR(), digits);
-      logfile << toCSV(Vec3f(w), digits);
+      // estimator state, :694-716: GetPrediction(0), narrowed to float
+      logfile << toCSV(Vec3f(estLogged.pos), digits);
+      logfile << toCSV(Vec3f(estLogged.vel), digits);
+      logfile << toCSV(Rotationf(estLogged.att).ToEulerYPR(), digits);
+      logfile << toCSV(Vec3f(estLogged.angVel), digits);
       logfile << toCSV(desiredPosition, digits);
       logfile << toCSV(desiredVelocity, digits);
       logfile << int(dataPacket.panic_reason) << ",";
