@@ -38,6 +38,8 @@ struct afe_engine {
   bool types_uniform = true;  // every vehicle uses record 0 (kernel-argument fast path)
   bool force_global_addressing = false;   // afe_set_addressing(1): the kernels of arenas beyond 4 GiB, on any arena
   std::vector<uint8_t> type_host;   // host mirror of the type slab (zeros until afe_set_vehicle_types / a checkpoint)
+  std::vector<uint8_t> run_nonzero, run_mixed;   // per aligned run of 64 vehicles: count off record 0 (<= 64), mixed types?
+  int64_t n_nonzero = 0, n_mixed_runs = 0;
   bool types_wave_uniform = true;   // the type index is constant over every aligned run of 64 vehicles
   float *pack_scratch = nullptr;  // 3*n floats, lazily allocated
   afe_world *world = nullptr;     // shared-world query scratch (uniform grid), lazily created
@@ -407,16 +409,34 @@ extern "C" int afe_set_type_table(afe_engine *e, const afe_vehicle_params *table
 
 // what the step launcher may assume about the type slab: all on record 0 (parameters ride in the kernel
 // arguments), or at least one type per wave (scalar loads of the wave's record), or neither (LDS table)
-static void refresh_type_flags(afe_engine *e) {
-  if (e->type_host.size() != (size_t)e->n) e->type_host.assign((size_t)e->n, 0);
-  bool all_zero = true, per_wave = true;
-  for (int64_t k = 0; k < e->n; k++) {
-    const uint8_t t = e->type_host[(size_t)k];
-    all_zero = all_zero && t == 0;
-    per_wave = per_wave && t == e->type_host[(size_t)(k & ~int64_t(63))];
+// Kept incrementally -- per aligned run of 64 vehicles: how many are off record 0 and whether the run is
+// mixed -- so that a caller who sets the types one vehicle at a time pays for the runs it touches, not for
+// the ensemble (first = 0, count = n: everything).
+static void refresh_type_flags(afe_engine *e, int64_t first = 0, int64_t count = -1) {
+  const int64_t n = e->n, n_runs = (n + 63) / 64;
+  if (e->type_host.size() != (size_t)n) e->type_host.assign((size_t)n, 0);
+  if (e->run_nonzero.size() != (size_t)n_runs) {
+    e->run_nonzero.assign((size_t)n_runs, 0);
+    e->run_mixed.assign((size_t)n_runs, 0);
+    e->n_nonzero = e->n_mixed_runs = 0;
+    first = 0; count = n;
   }
-  e->types_uniform = all_zero;
-  e->types_wave_uniform = per_wave;
+  if (count < 0) count = n - first;
+  if (count == 0) return;
+  for (int64_t r = first / 64; r <= (first + count - 1) / 64; r++) {
+    const int64_t a = r * 64, b = std::min(n, a + 64);
+    int nonzero = 0, mixed = 0;
+    for (int64_t k = a; k < b; k++) {
+      nonzero += e->type_host[(size_t)k] != 0;
+      mixed |= e->type_host[(size_t)k] != e->type_host[(size_t)a];
+    }
+    e->n_nonzero += nonzero - (int)e->run_nonzero[(size_t)r];
+    e->n_mixed_runs += mixed - (int)e->run_mixed[(size_t)r];
+    e->run_nonzero[(size_t)r] = (uint8_t)nonzero;
+    e->run_mixed[(size_t)r] = (uint8_t)mixed;
+  }
+  e->types_uniform = e->n_nonzero == 0;
+  e->types_wave_uniform = e->n_mixed_runs == 0;
 }
 
 extern "C" int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count, const uint8_t *type_index) {
@@ -433,7 +453,7 @@ extern "C" int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count
   AFE_HIP(e, hipStreamSynchronize(e->stream));
   if (e->type_host.size() != (size_t)e->n) e->type_host.assign((size_t)e->n, 0);
   std::memcpy(e->type_host.data() + first, type_index, (size_t)count);
-  refresh_type_flags(e);
+  refresh_type_flags(e, first, count);
   return AFE_OK;
 }
 
@@ -907,6 +927,7 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
     for (size_t k = 0; k < types.size(); k++)
       if (types[k] >= e->table.size()) return fail(e, AFE_ERR_INVALID_ARG, "checkpoint holds a type index outside the type table");
     e->type_host = types;
+    e->run_nonzero.clear();          // re-derive everything from the restored slab
     refresh_type_flags(e);
   }
   // the arena also holds the device copy of the type table for the checkpoint's dt: rebuild on next step

@@ -580,10 +580,15 @@ def test_fleet_laid_out_type_by_type_equals_the_shuffled_fleet_bitwise(precision
     ltable = [afa.rates_logic_params_from_type(t) for t in d.type_ids]
     cmd = np.minimum(d.motor_cmd, 900.0)
 
-    def fly(order, types, break_at=None, checkpoint=False):
+    def fly(order, types, break_at=None, checkpoint=False, piecemeal=False):
         with afa.Ensemble(n, precision=precision) as e:
             e.set_type_table(table)
-            e.set_vehicle_types(types[order])
+            if piecemeal:        # ragged pieces, out of order: the engine keeps its view of the layout incrementally
+                pieces = [(a, min(n, a + 37)) for a in range(0, n, 37)]
+                for a, b in pieces[::2] + pieces[1::2]:
+                    e.set_vehicle_types(types[order][a:b], first=a)
+            else:
+                e.set_vehicle_types(types[order])
             if break_at is not None:
                 e.set_vehicle_types(np.array([(types[order][break_at] + 1) % T], np.uint8), first=break_at)
             e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_REFERENCE)
@@ -623,6 +628,11 @@ def test_fleet_laid_out_type_by_type_equals_the_shuffled_fleet_bitwise(precision
     for k in c_st:
         assert np.array_equal(c_st[k][..., perm], r_st[k]), k
     assert not np.array_equal(c_st["vel"][:, k0], a_st["vel"][:, k0])
+    # the same fleet typed in 37-vehicle pieces, even pieces first: same kernel choice, same bits
+    p_st, _, p_rng = fly(ident, by_type, piecemeal=True)
+    for k in a_st:
+        assert np.array_equal(a_st[k], p_st[k]), k
+    assert np.array_equal(a_rng, p_rng)
     # checkpoint mid-flight, resume in a fresh engine (which re-derives the layout from the restored slab)
     s_st, s_imu, s_rng = fly(ident, by_type, checkpoint=True)
     for k in a_st:
