@@ -674,6 +674,16 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   return AFE_OK;
 }
 
+extern "C" int afe_step_kernel_info(const afe_engine *e, int *record_path, int *addressing) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  if (record_path) *record_path = e->types_uniform ? 0 : (e->types_wave_uniform ? 1 : 2);
+  if (addressing) {
+    const bool fits = !e->force_global_addressing && e->arena_bytes < 0xffff0000ull && logic_arena_bytes(e) < 0xffff0000ull;
+    *addressing = fits ? 0 : 1;
+  }
+  return AFE_OK;
+}
+
 extern "C" int afe_set_addressing(afe_engine *e, int mode) {
   if (!e || (mode != 0 && mode != 1)) return fail(e, AFE_ERR_INVALID_ARG, "addressing mode must be 0 (automatic) or 1 (global)");
   e->force_global_addressing = mode == 1;

@@ -35,7 +35,7 @@ ABI_FUNCTIONS = [
     "afe_radio_create_rates_command", "afe_radio_create_position_command",
     "afe_radio_create_acceleration_command", "afe_radio_create_simple_command", "afe_radio_decode",
     "afe_telemetry_encode", "afe_telemetry_decode", "afe_set_commands_from_radio",
-    "afe_set_max_fused_steps", "afe_set_addressing", "afe_planner_default_config", "afe_planner_samples", "afe_rappids_plan",
+    "afe_set_max_fused_steps", "afe_set_addressing", "afe_step_kernel_info", "afe_planner_default_config", "afe_planner_samples", "afe_rappids_plan",
     "afe_rappids_plan_device", "afe_camera_default", "afe_camera_default_mount", "afe_scene_create",
     "afe_scene_destroy", "afe_scene_info", "afe_scene_set_walk", "afe_render_depth", "afe_render_depth_engine", "afe_render_depth_stats",
     "afe_device_alloc", "afe_device_free", "afe_device_download", "afe_scene_check_hierarchy",
@@ -244,6 +244,7 @@ def library():
         "afe_set_commands_from_radio": [eng, i64, i64, vp],
         "afe_set_max_fused_steps": [eng, ci],
         "afe_set_addressing": [eng, ci],
+        "afe_step_kernel_info": [eng, C.POINTER(ci), C.POINTER(ci)],
         "afe_planner_default_config": [C.POINTER(PlannerConfig), ci, ci] + [C.c_double] * 5,
         "afe_planner_samples": [C.c_uint32, ci, ci, ci, vp],
         "afe_rappids_plan": [ci, C.POINTER(PlannerConfig), i64, vp, i64, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp,
@@ -728,6 +729,12 @@ class Ensemble:
     def set_addressing(self, force_global):
         """False (default): buffer resources when the arenas fit 32-bit offsets; True: global addresses always"""
         self._ck(self._L.afe_set_addressing(self._h, 1 if force_global else 0))
+
+    def step_kernel_info(self):
+        """(record path, addressing): ("kernel arguments" | "per-wave scalar loads" | "LDS table", "buffer" | "global")"""
+        a, b = C.c_int(0), C.c_int(0)
+        self._ck(self._L.afe_step_kernel_info(self._h, C.byref(a), C.byref(b)))
+        return ("kernel arguments", "per-wave scalar loads", "LDS table")[a.value], ("buffer", "global")[b.value]
 
     def set_max_fused_steps(self, k):
         self._ck(self._L.afe_set_max_fused_steps(self._h, int(k)))

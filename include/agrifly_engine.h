@@ -419,6 +419,10 @@ int afe_step(afe_engine *e, uint64_t dt_us, int n_steps);
  * global addresses.  Same results bit for bit; mode 1 exists so that the kernels very large ensembles run are
  * testable at any size. */
 int afe_set_addressing(afe_engine *e, int mode);
+/* Which step kernel the next afe_step will launch: record_path 0 = parameters in the kernel arguments (all
+ * vehicles on record 0), 1 = one scalar-loaded record per wave (type constant over every aligned run of 64),
+ * 2 = type table in LDS; addressing 0 = buffer resources, 1 = global addresses.  Either pointer may be NULL. */
+int afe_step_kernel_info(const afe_engine *e, int *record_path, int *addressing);
 
 /* How many sub-steps afe_step may fuse into one kernel launch (1..64, default
  * 64).  1 = one launch per step (state goes through HBM every step: the

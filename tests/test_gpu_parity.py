@@ -592,6 +592,7 @@ def test_fleet_laid_out_type_by_type_equals_the_shuffled_fleet_bitwise(precision
             if break_at is not None:
                 e.set_vehicle_types(np.array([(types[order][break_at] + 1) % T], np.uint8), first=break_at)
             e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_REFERENCE)
+            paths.append(e.step_kernel_info()[0])
             e.set_state(d.pos[:, order], d.vel[:, order], d.att[:, order], d.ang_vel[:, order], d.motor_speed[:, order])
             e.set_motor_cmds(cmd[:, order])
             e.set_external_force(d.ext_force[:, order])
@@ -613,6 +614,7 @@ def test_fleet_laid_out_type_by_type_equals_the_shuffled_fleet_bitwise(precision
         return st, imu, rs
 
     ident = np.arange(n)
+    paths = []
     a_st, a_imu, a_rng = fly(ident, by_type)                      # type by type: scalar-load kernel
     b_st, b_imu, b_rng = fly(perm, by_type)                       # the same vehicles shuffled: LDS table
     for k in a_st:
@@ -633,6 +635,7 @@ def test_fleet_laid_out_type_by_type_equals_the_shuffled_fleet_bitwise(precision
     for k in a_st:
         assert np.array_equal(a_st[k], p_st[k]), k
     assert np.array_equal(a_rng, p_rng)
+    assert paths == ["per-wave scalar loads", "LDS table", "LDS table", "LDS table", "per-wave scalar loads"], paths
     # checkpoint mid-flight, resume in a fresh engine (which re-derives the layout from the restored slab)
     s_st, s_imu, s_rng = fly(ident, by_type, checkpoint=True)
     for k in a_st:
@@ -769,6 +772,11 @@ def test_buffer_and_global_addressing_are_bitwise_equal(precision, layout):
             return e.get_state(), e.get_imu(), e.get_rng_state(), e.get_motor_cmds()
 
     a, b = fly(False), fly(True)
+    with ens.to_engine(precision) as e:
+        want = {"record0": "kernel arguments", "by_type": "per-wave scalar loads", "random": "LDS table"}[layout]
+        assert e.step_kernel_info() == (want, "buffer")
+        e.set_addressing(True)
+        assert e.step_kernel_info() == (want, "global")
     for k in a[0]:
         assert np.array_equal(a[0][k], b[0][k]), k
     assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
