@@ -218,6 +218,7 @@ def test_tens_of_millions_of_vehicles_address_their_slabs_correctly(n, addressin
         e.set_type_table([p])
         e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
         e.set_logic_period(1 / 500)
+        assert e.step_kernel_info() == ("kernel arguments", "buffer" if n == 30_000_000 else "global")
         data = []
         for k, first in enumerate(windows):
             d = afa.scenarios.random_ensemble(w, 700 + k, type_ids=(5,), ground_fraction=0.0)
