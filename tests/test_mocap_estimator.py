@@ -1,0 +1,77 @@
+"""The headless program's C++ estimator (agri-fly_amd/cli/mocap_estimator.hpp) against the test side's Python
+restatement (tests/offboard_reference.py) on a synthetic flight -- irregular measurement times, commands announced
+through the 30 ms pipe, a jump that the 6-sigma gate rejects ten times before the forced reset -- compared BIT FOR
+BIT, and the C++ side built with AddressSanitizer + UBSan.  (Both restate Offboard::MocapStateEstimator; flown around
+the engine they reproduce the reference's config-1 positions, tests/test_gpu_headless.py.)  CPU only."""
+import math
+import os
+import subprocess
+
+from tests.offboard_reference import Clock, MocapStateEstimator, q_from_rotvec, q_mul
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+DRIVER = r'''
+#include <cstdio>
+#include "mocap_estimator.hpp"
+static Vec3d path(double t, bool jumped) { return Vec3d(0.3 * t + (jumped ? 4.0 : 0.0), 0.1 * t * t, 1.0 + 0.5 * t); }
+int main() {
+  ManualTimer clock;
+  agrifly_cli::MocapEstimator est(&clock, 0.03);
+  Rotationd att = Rotationd::Identity();
+  unsigned long long now = 0;
+  for (int it = 0; it < 1500; it++) {
+    const unsigned long long step = 700 + 37 * (unsigned long long)(it % 11);      // irregular loop period, microseconds
+    clock.AdvanceMicroSeconds(step);
+    now += step;
+    const double t = now * 1e-6;
+    att = att * Rotationd::FromRotationVector(Vec3d(0.2, -0.1, 0.4) * (step * 1e-6));
+    if (it % 5 == 0) est.Measure(path(t, it >= 900), att);
+    if (it % 9 == 0) est.Announce(Vec3d(0.2, -0.1, 0.4 + 0.001 * it), Vec3d(0.0, 0.2, 0.01 * (it % 7)));
+    if (it % 3 == 0) {
+      const agrifly_cli::Estimate e = est.Predict(0.03);
+      std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %u\n", e.pos.x, e.pos.y, e.pos.z,
+                  e.vel.x, e.vel.y, e.vel.z, e.att[0], e.att[1], e.att[2], e.att[3], e.angVel.x, e.angVel.y, e.angVel.z, est.Rejected());
+    }
+  }
+  return 0;
+}
+'''
+
+
+def _python_side():
+    clock = Clock()
+    est = MocapStateEstimator(clock, 0.03)
+    att = (1.0, 0.0, 0.0, 0.0)
+    rows = []
+    for it in range(1500):
+        step = 700 + 37 * (it % 11)
+        clock.us += step
+        t = clock.us * 1e-6
+        att = q_mul(att, q_from_rotvec(tuple(c * (step * 1e-6) for c in (0.2, -0.1, 0.4))))
+        if it % 5 == 0:
+            est.update((0.3 * t + (4.0 if it >= 900 else 0.0), 0.1 * t * t, 1.0 + 0.5 * t), att)
+        if it % 9 == 0:
+            est.set_predicted((0.2, -0.1, 0.4 + 0.001 * it), (0.0, 0.2, 0.01 * (it % 7)))
+        if it % 3 == 0:
+            p, v, q, w = est.prediction(0.03)
+            rows.append(tuple(p) + tuple(v) + tuple(q) + tuple(w) + (est.n_rejected,))
+    return rows
+
+
+def test_cpp_estimator_equals_the_python_restatement_bit_for_bit(tmp_path):
+    src = tmp_path / "driver.cpp"
+    src.write_text(DRIVER)
+    exe = tmp_path / "driver"
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "agri-fly_amd", "cli"),
+                           str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    cpp = [tuple(float(x) for x in line.split()) for line in out.stdout.strip().split("\n")]
+    py = _python_side()
+    assert len(cpp) == len(py) == 500
+    for k, (a, b) in enumerate(zip(cpp, py)):
+        assert all((x == y) or (math.isnan(x) and math.isnan(y)) for x, y in zip(a, b)), (k, a, b)
+    assert py[-1][-1] == 10                    # the jump: ten rejections, then the reset took it
+    assert abs(py[-1][0] - (0.3 * 1.3 + 4.0)) < 0.5
