@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "agrifly/Wire.hpp"
+#include "hover_controller.hpp"
 #include "mocap_estimator.hpp"
 
 namespace {
@@ -44,59 +45,6 @@ std::string toCSV(const Vec3<Real> v, int digits) {   // main.cpp:55-60
   ss << std::setprecision(digits) << v.x << "," << v.y << "," << v.z << ",";
   return ss.str();
 }
-
-// Offboard::QuadcopterController::Run, QuadcopterController.cpp:11-74, with the position controller
-// of Logic/QuadcopterPositionController.hpp:22-28 and the attitude controller of
-// Logic/QuadcopterAttitudeController.hpp:35-68 -- float, like the reference.
-struct HoverController {
-  float natFreq, damping, tc_xy, tc_z;
-  float minVerticalProperAcceleration, maxProperAcc, minProperAcc;
-  HoverController() : natFreq(2.0f), damping(0.7f), tc_xy(0.08f), tc_z(0.4f),   // QuadcopterConstants.hpp:214-226
-                      minVerticalProperAcceleration(0.5f * 9.81f), maxProperAcc(20), minProperAcc(-1) {}
-
-  Vec3f GetDesiredAngularVelocity(const Rotationf desAttitude, const Rotationf estAttitude) const {
-    Rotationf errAtt = (desAttitude.Inverse() * estAttitude);
-    const Vec3f desRotVec = errAtt.ToRotationVector();
-    Vec3f desRedAttRotAx = Vec3f(errAtt.Inverse() * Vec3f(0, 0, 1)).Cross(Vec3f(0, 0, 1));
-    float desRedAttRotAn_cos = Vec3f(errAtt.Inverse() * Vec3f(0, 0, 1)).Dot(Vec3f(0, 0, 1));
-    float desRedAttRotAn;
-    if (desRedAttRotAn_cos >= 1.0f) desRedAttRotAn = 0;
-    else if (desRedAttRotAn_cos <= -1.0f) desRedAttRotAn = float(M_PI);
-    else desRedAttRotAn = acosf(desRedAttRotAn_cos);
-    float n = desRedAttRotAx.GetNorm2();
-    if (n < 1e-12f) desRedAttRotAx = Vec3f(0, 0, 0);
-    else desRedAttRotAx = desRedAttRotAx / n;
-    float k3 = (1.0f / tc_z);
-    float k12 = (1.0f / tc_xy);
-    return -k3 * desRotVec - (k12 - k3) * desRedAttRotAn * desRedAttRotAx;
-  }
-
-  void Run(Vec3d const curPos, Vec3d const curVel, Rotationd const curAtt, Vec3d const desPos, Vec3d const desVel,
-           Vec3d const desAcc, double const desiredYawAngle, Vec3d &outCmdAngVel, double &outCmdThrust) const {
-    Vec3f const e3(0, 0, 1);
-    Vec3f const cmdAcc = (Vec3f(desPos) - Vec3f(curPos)) * natFreq * natFreq +
-                         (Vec3f(desVel) - Vec3f(curVel)) * 2 * natFreq * damping + Vec3f(desAcc);
-    Vec3f cmdProperAcc = cmdAcc + Vec3f(0, 0, 9.81f);
-    if (cmdProperAcc.GetNorm2() > maxProperAcc) cmdProperAcc *= maxProperAcc / cmdProperAcc.GetNorm2();
-    if (cmdProperAcc.z < minVerticalProperAcceleration) cmdProperAcc.z = minVerticalProperAcceleration;
-    float const normCmdProperAcc = cmdProperAcc.GetNorm2();
-    Vec3f const cmdThrustDir = cmdProperAcc / normCmdProperAcc;
-    outCmdThrust = normCmdProperAcc * (Rotationf(curAtt) * Vec3f(0, 0, 1)).Dot(cmdThrustDir);
-    if (outCmdThrust < minProperAcc) outCmdThrust = minProperAcc;
-    Rotationf cmdAtt;
-    const float cosAngle = cmdThrustDir.Dot(e3);
-    float angle;
-    if (cosAngle >= (1 - 1e-12f)) angle = 0;
-    else if (cosAngle <= -(1 - 1e-12f)) angle = float(M_PI);
-    else angle = acosf(cosAngle);
-    Vec3f rotAx = e3.Cross(cmdThrustDir);
-    const float n = rotAx.GetNorm2();
-    if (n < 1e-6f) cmdAtt = Rotationf::Identity();
-    else cmdAtt = Rotationf::FromRotationVector(rotAx * (angle / n));
-    Rotationf cmdAttYawed = cmdAtt * Rotationf::FromRotationVector(Vec3f(0, 0, float(desiredYawAngle)));
-    outCmdAngVel = Vec3d(GetDesiredAngularVelocity(cmdAttYawed, Rotationf(curAtt)));
-  }
-};
 
 void die(afe_engine *e, int rc, const char *what) {
   if (rc == AFE_OK) return;
@@ -156,7 +104,7 @@ int main(int argc, char **argv) {
   std::vector<agrifly_cli::MocapEstimator> est;                              // :221-224, one per vehicle
   for (int64_t i = 0; i < nVehicles; i++) est.push_back(agrifly_cli::MocapEstimator(&simTimer, timeDelayOffboardControlLoopTrue));
   double const timeDelayOffboardControlLoopEstimate = 0.03;                  // :179
-  HoverController ctrl;
+  agrifly_cli::HoverController ctrl;
   Vec3d desiredPosition(0, 0, 3.5);   // :240
   Vec3d desiredVelocity(0, 0, 0);
   double desYawAngleDeg = 0;

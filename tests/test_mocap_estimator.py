@@ -75,3 +75,55 @@ def test_cpp_estimator_equals_the_python_restatement_bit_for_bit(tmp_path):
         assert all((x == y) or (math.isnan(x) and math.isnan(y)) for x, y in zip(a, b)), (k, a, b)
     assert py[-1][-1] == 10                    # the jump: ten rejections, then the reset took it
     assert abs(py[-1][0] - (0.3 * 1.3 + 4.0)) < 0.5
+
+
+CONTROLLER_DRIVER = r'''
+#include <cstdio>
+#include <cstdlib>
+#include "hover_controller.hpp"
+int main(int argc, char **argv) {
+  agrifly_cli::HoverController ctrl;
+  double in[10];
+  while (std::scanf("%lf %lf %lf %lf %lf %lf %lf %lf %lf %lf", in, in + 1, in + 2, in + 3, in + 4, in + 5, in + 6, in + 7, in + 8, in + 9) == 10) {
+    Vec3d w; double thr;
+    ctrl.Run(Vec3d(in[0], in[1], in[2]), Vec3d(in[3], in[4], in[5]), Rotationd(in[6], in[7], in[8], in[9]), Vec3d(0, 0, 3.5),
+             Vec3d(0, 0, 0), Vec3d(0, 0, 0), 0.0, w, thr);
+    std::printf("%.9g %.9g %.9g %.9g\n", thr, w.x, w.y, w.z);
+  }
+  return 0;
+}
+'''
+
+
+def test_cpp_controller_equals_the_numpy_restatement_bit_for_bit(tmp_path):
+    """agri-fly_amd/cli/hover_controller.hpp against tests/offboard_stub.py (both restate QuadcopterController::Run in
+    float): 2 000 random states from hover-like to violently tilted and far away (thrust saturation, the tilt limit,
+    the small-angle branches), every float of every answer equal."""
+    import numpy as np
+    from tests.offboard_stub import OffboardHover
+    src = tmp_path / "ctrl.cpp"
+    src.write_text(CONTROLLER_DRIVER)
+    exe = tmp_path / "ctrl"
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "agri-fly_amd", "cli"),
+                           str(src), "-o", str(exe)])
+    rng = np.random.default_rng(12)
+    n = 2000
+    scale = np.where(np.arange(n) % 4 == 0, 30.0, 1.0)
+    pos = rng.normal(0, 2.0, (3, n)) * scale + np.array([[0], [0], [3.5]])
+    vel = rng.normal(0, 1.0, (3, n)) * scale
+    q = rng.normal(size=(4, n)) * np.array([[1.0], [0.3], [0.3], [0.3]])
+    q[:, ::7] = np.array([[1.0], [0.0], [0.0], [0.0]]) + rng.normal(0, 1e-4, (4, len(q[0, ::7])))
+    q /= np.linalg.norm(q, axis=0)
+    pos[:, 5], vel[:, 5], q[:, 5] = [0, 0, 3.5], [0, 0, 0], [1, 0, 0, 0]           # exactly at the set point, level
+    text = "".join(" ".join("%.17g" % x for x in np.concatenate([pos[:, i], vel[:, i], q[:, i]])) + "\n" for i in range(n))
+    out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    cpp = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().split("\n")], np.float32)
+    stub = OffboardHover(1)
+    mism = 0
+    for i in range(n):
+        th, w = stub.controller(pos[:, i].reshape(3, 1), vel[:, i].reshape(3, 1), q[:, i].reshape(4, 1))
+        got = np.array([th[0], w[0, 0], w[1, 0], w[2, 0]], np.float32)
+        mism += not np.array_equal(got, cpp[i])
+    assert mism == 0
