@@ -1,5 +1,15 @@
 // hover_controller.hpp -- the caller-side position / attitude controller of the Rappids_Simulator loop, restated for
-// the headless program (see mocap_estimator.hpp for why restated); float, like the reference.
+// the headless program (see mocap_estimator.hpp for why restated).
+//
+// What it restates, in float like the sources and in their operation order:
+//   * a PD law on position gives the acceleration to ask for (Logic/QuadcopterPositionController.hpp:22-28);
+//     gravity is added, the result limited to 20 m/s^2 and to a vertical part of at least g / 2, and split into a
+//     thrust magnitude -- projected on where the vehicle's z axis points now -- and a thrust direction
+//     (Offboard/QuadcopterController.cpp:19-45);
+//   * the attitude that tilts e3 onto that direction by the shortest rotation, then the commanded yaw (:47-70);
+//   * body rates that close the attitude error with time constant tc_z about the full error rotation plus
+//     (1/tc_xy - 1/tc_z) on the reduced, tilt-only part (Logic/QuadcopterAttitudeController.hpp:35-68).
+// tests/test_mocap_estimator.py holds every output float against the numpy restatement of tests/offboard_stub.py.
 #pragma once
 #include <cmath>
 
@@ -7,56 +17,50 @@
 
 namespace agrifly_cli {
 
-// Offboard::QuadcopterController::Run, QuadcopterController.cpp:11-74, with the position controller
-// of Logic/QuadcopterPositionController.hpp:22-28 and the attitude controller of
-// Logic/QuadcopterAttitudeController.hpp:35-68 -- float, like the reference.
 struct HoverController {
-  float natFreq, damping, tc_xy, tc_z;
-  float minVerticalProperAcceleration, maxProperAcc, minProperAcc;
-  HoverController() : natFreq(2.0f), damping(0.7f), tc_xy(0.08f), tc_z(0.4f),   // QuadcopterConstants.hpp:214-226
-                      minVerticalProperAcceleration(0.5f * 9.81f), maxProperAcc(20), minProperAcc(-1) {}
+  // CF_MINIQUAD tuning (Logic/QuadcopterConstants.hpp:214-226) and the limits of QuadcopterController.cpp:5-9
+  float wn = 2.0f, zeta = 0.7f, tcTilt = 0.08f, tcYaw = 0.4f;
+  float leastVertical = 0.5f * 9.81f, mostThrust = 20, leastThrust = -1;
 
-  Vec3f GetDesiredAngularVelocity(const Rotationf desAttitude, const Rotationf estAttitude) const {
-    Rotationf errAtt = (desAttitude.Inverse() * estAttitude);
-    const Vec3f desRotVec = errAtt.ToRotationVector();
-    Vec3f desRedAttRotAx = Vec3f(errAtt.Inverse() * Vec3f(0, 0, 1)).Cross(Vec3f(0, 0, 1));
-    float desRedAttRotAn_cos = Vec3f(errAtt.Inverse() * Vec3f(0, 0, 1)).Dot(Vec3f(0, 0, 1));
-    float desRedAttRotAn;
-    if (desRedAttRotAn_cos >= 1.0f) desRedAttRotAn = 0;
-    else if (desRedAttRotAn_cos <= -1.0f) desRedAttRotAn = float(M_PI);
-    else desRedAttRotAn = acosf(desRedAttRotAn_cos);
-    float n = desRedAttRotAx.GetNorm2();
-    if (n < 1e-12f) desRedAttRotAx = Vec3f(0, 0, 0);
-    else desRedAttRotAx = desRedAttRotAx / n;
-    float k3 = (1.0f / tc_z);
-    float k12 = (1.0f / tc_xy);
-    return -k3 * desRotVec - (k12 - k3) * desRedAttRotAn * desRedAttRotAx;
+  // angle between two unit vectors whose cosine is `c`, with the ends of acosf's domain pinned
+  static float AngleFromCosine(float c, float oneish) {
+    if (c >= oneish) return 0;
+    if (c <= -oneish) return float(M_PI);
+    return acosf(c);
   }
 
+  Vec3f RatesFor(const Rotationf &wanted, const Rotationf &have) const {
+    const Rotationf err = wanted.Inverse() * have;
+    const Vec3f whole = err.ToRotationVector();
+    const Vec3f upInErr = err.Inverse() * Vec3f(0, 0, 1);
+    Vec3f tiltAxis = upInErr.Cross(Vec3f(0, 0, 1));
+    const float tilt = AngleFromCosine(upInErr.Dot(Vec3f(0, 0, 1)), 1.0f);
+    const float len = tiltAxis.GetNorm2();
+    tiltAxis = len < 1e-12f ? Vec3f(0, 0, 0) : tiltAxis / len;
+    const float gYaw = 1.0f / tcYaw, gTilt = 1.0f / tcTilt;
+    return -gYaw * whole - (gTilt - gYaw) * tilt * tiltAxis;
+  }
+
+  // same argument list as Offboard::QuadcopterController::Run
   void Run(Vec3d const curPos, Vec3d const curVel, Rotationd const curAtt, Vec3d const desPos, Vec3d const desVel,
            Vec3d const desAcc, double const desiredYawAngle, Vec3d &outCmdAngVel, double &outCmdThrust) const {
-    Vec3f const e3(0, 0, 1);
-    Vec3f const cmdAcc = (Vec3f(desPos) - Vec3f(curPos)) * natFreq * natFreq +
-                         (Vec3f(desVel) - Vec3f(curVel)) * 2 * natFreq * damping + Vec3f(desAcc);
-    Vec3f cmdProperAcc = cmdAcc + Vec3f(0, 0, 9.81f);
-    if (cmdProperAcc.GetNorm2() > maxProperAcc) cmdProperAcc *= maxProperAcc / cmdProperAcc.GetNorm2();
-    if (cmdProperAcc.z < minVerticalProperAcceleration) cmdProperAcc.z = minVerticalProperAcceleration;
-    float const normCmdProperAcc = cmdProperAcc.GetNorm2();
-    Vec3f const cmdThrustDir = cmdProperAcc / normCmdProperAcc;
-    outCmdThrust = normCmdProperAcc * (Rotationf(curAtt) * Vec3f(0, 0, 1)).Dot(cmdThrustDir);
-    if (outCmdThrust < minProperAcc) outCmdThrust = minProperAcc;
-    Rotationf cmdAtt;
-    const float cosAngle = cmdThrustDir.Dot(e3);
-    float angle;
-    if (cosAngle >= (1 - 1e-12f)) angle = 0;
-    else if (cosAngle <= -(1 - 1e-12f)) angle = float(M_PI);
-    else angle = acosf(cosAngle);
-    Vec3f rotAx = e3.Cross(cmdThrustDir);
-    const float n = rotAx.GetNorm2();
-    if (n < 1e-6f) cmdAtt = Rotationf::Identity();
-    else cmdAtt = Rotationf::FromRotationVector(rotAx * (angle / n));
-    Rotationf cmdAttYawed = cmdAtt * Rotationf::FromRotationVector(Vec3f(0, 0, float(desiredYawAngle)));
-    outCmdAngVel = Vec3d(GetDesiredAngularVelocity(cmdAttYawed, Rotationf(curAtt)));
+    const Vec3f up(0, 0, 1);
+    const Rotationf attNow(curAtt);
+    Vec3f pull = (Vec3f(desPos) - Vec3f(curPos)) * wn * wn + (Vec3f(desVel) - Vec3f(curVel)) * 2 * wn * zeta + Vec3f(desAcc);
+    pull = pull + Vec3f(0, 0, 9.81f);
+    if (pull.GetNorm2() > mostThrust) pull *= mostThrust / pull.GetNorm2();
+    if (pull.z < leastVertical) pull.z = leastVertical;
+    const float size = pull.GetNorm2();
+    const Vec3f along = pull / size;
+    outCmdThrust = size * (attNow * up).Dot(along);
+    if (outCmdThrust < leastThrust) outCmdThrust = leastThrust;
+
+    const float turn = AngleFromCosine(along.Dot(up), 1 - 1e-12f);
+    const Vec3f axis = up.Cross(along);
+    const float axisLen = axis.GetNorm2();
+    const Rotationf tilted = axisLen < 1e-6f ? Rotationf::Identity() : Rotationf::FromRotationVector(axis * (turn / axisLen));
+    const Rotationf wanted = tilted * Rotationf::FromRotationVector(Vec3f(0, 0, float(desiredYawAngle)));
+    outCmdAngVel = Vec3d(RatesFor(wanted, attNow));
   }
 };
 
