@@ -361,3 +361,20 @@ def test_device_view_matches_host_getters():
         e.step(1000, 3)
         e.sync()
         np.testing.assert_array_equal(pos.cpu().numpy(), e.get_state(dtype=np.float32)["pos"])
+
+
+def test_wide_campaign_grid_equals_brute_force_on_every_query():
+    """tools/world_campaign.py: 150 random worlds -- boxes at three scales, flats, clusters, lines, duplicates,
+    lattices (all ties), two densities 1e5 apart, shells; 1 to 60 000 vehicles; non-finite positions and fly-aways;
+    cell sizes from 1 mm to 10 km; shards of the ensemble; grids shaped on a DIFFERENT world and kept -- the grid
+    query must return the brute-force kernel's distance bits and index for every single query."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "world_campaign.py")
+    spec = importlib.util.spec_from_file_location("world_campaign", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run_campaign(worlds=150, seed=3, verbose=False)
+    from tests.scenarios import MEASUREMENTS
+    MEASUREMENTS["neighbour_query_campaign"] = r
+    assert r["mismatching_worlds"] == 0 and r["queries"] > 100000
