@@ -529,13 +529,13 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
       R rotor_tz = 0;                                        // (ang_acc * J) * spin, :78-79
       if (!lagged) {
         w = cmd[m];                                          // :60 with c = 0
-        if (w > P.wmax) w = P.wmax; else if (w < P.wmin) w = P.wmin;  // :62-66
+        w = w > P.wmax ? P.wmax : (w < P.wmin ? P.wmin : w); // :62-66 (selects, not branches; a NaN stays a NaN)
       } else {
         const R old = ms[m];
         R dw;
         if (sizeof(R) == 8) {
           w = fm(c, old, (1 - c) * cmd[m]);                  // :60
-          if (w > P.wmax) w = P.wmax; else if (w < P.wmin) w = P.wmin;  // :62-66
+          w = w > P.wmax ? P.wmax : (w < P.wmin ? P.wmin : w);   // :62-66
           dw = w - old;
         } else {
           // fp32 storage: (c old + (1 - c) cmd) - old cancels down to the rounding of a ~1e3 rad/s speed (6e-5)
@@ -545,7 +545,9 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
           // host's double.
           w = fm(c, old, P.omc_lag * cmd[m]);
           dw = P.omc_lag * (cmd[m] - old);
-          if (w > P.wmax) { w = P.wmax; dw = w - old; } else if (w < P.wmin) { w = P.wmin; dw = w - old; }
+          const bool clamped = w > P.wmax || w < P.wmin;
+          w = w > P.wmax ? P.wmax : (w < P.wmin ? P.wmin : w);
+          dw = clamped ? w - old : dw;
         }
         const R ang_acc = div_dt(dw, dt, v.inv_dt);          // :78
         rotor_tz = (ang_acc * P.Jm) * spin;
