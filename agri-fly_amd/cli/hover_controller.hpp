@@ -19,7 +19,11 @@ namespace agrifly_cli {
 
 struct HoverController {
   // CF_MINIQUAD tuning (Logic/QuadcopterConstants.hpp:214-226) and the limits of QuadcopterController.cpp:5-9
-  float wn = 2.0f, zeta = 0.7f, tcTilt = 0.08f, tcYaw = 0.4f;
+  // The attitude time constants are DERIVED in the reference, in float: attControl_timeConst_xy = 0.04f * 2 and
+  // attControl_timeConst_z = (0.04f * 5) * 2 -- and 0.04f * 5 rounds to 0.199999988, so the yaw constant is
+  // 0.399999976, one ulp below 0.4f.  With the literal 0.4f every rate command is an ulp off and, a few seconds
+  // into a flight, one 16-bit radio code differs from the reference's.
+  float wn = 2.0f, zeta = 0.7f, tcTilt = 0.04f * 2, tcYaw = (0.04f * 5) * 2;
   float leastVertical = 0.5f * 9.81f, mostThrust = 20, leastThrust = -1;
 
   // angle between two unit vectors whose cosine is `c`, with the ends of acosf's domain pinned

@@ -15,8 +15,9 @@
  *     below restate the reference source line by line (citations given) in
  *     the same operation order, in double, no FMA contraction.  Informational
  *     (tests/test_reference_anchors.py): flown in the reference's config-1
- *     loop they reproduce, to all nine printed digits, the position SURVEY.md
- *     Appendix B records for the unmodified reference after 1 s of flight.
+ *     loop they reproduce, to all nine printed digits, the positions SURVEY.md
+ *     Appendix B records for the unmodified reference after 1 s and after
+ *     10 s of flight (10 000 steps).
  *   - clock / logic-gate cadence (a6): pinned against the reference's own
  *     Timer/ManualTimer headers, which compile stand-alone (oracle/_ref/
  *     timer_probe, fixture tests/golden/timer_cadence.json).

@@ -25,7 +25,8 @@ F = np.float32
 
 # glibc's float transcendentals for small batches: numpy's own float32 routines differ from sinf / cosf / asinf /
 # acosf by an ulp now and then, and one ulp in a command flips a 16-bit radio code every few seconds of flight --
-# enough to part from a run of the reference by 1e-5 m (tests/test_reference_anchors.py wants them identical)
+# enough to part from a run of the reference by 1e-5 m (tests/test_reference_anchors.py wants them identical, and
+# over 10 s of config 1 they are)
 import ctypes as _C
 import ctypes.util as _Cu
 
@@ -110,9 +111,10 @@ def radio_quantise(val, limit):
 
 class OffboardHover:
     """QuadcopterController with the MINIQUAD tuning (QuadcopterConstants.hpp:
-    34-39,214-224; main.cpp:225-229), desired position (0, 0, 3.5) (main.cpp:240)."""
+    34-39,214-224; main.cpp:225-229), desired position (0, 0, 3.5) (main.cpp:240).
+    The attitude time constants are derived in float there: 0.04f * 2 and (0.04f * 5) * 2 = 0.399999976 (not 0.4f)."""
 
-    def __init__(self, n, des_pos=(0.0, 0.0, 3.5), nat_freq=2.0, damping=0.7, tc_xy=0.08, tc_z=0.4,
+    def __init__(self, n, des_pos=(0.0, 0.0, 3.5), nat_freq=2.0, damping=0.7, tc_xy=F(0.04) * F(2), tc_z=(F(0.04) * F(5)) * F(2),
                  period_offboard=1.0 / 100.0, delay=0.03):
         self.n = n
         self.des_pos = np.tile(np.asarray(des_pos, F).reshape(3, 1), (1, n))
