@@ -15,6 +15,15 @@ struct PlannerPyramid {   // RectangularPyramidPlanner::Pyramid (Pyramid.hpp:24-
   double normal[4][3];
 };
 
+// the monotonic sections of one candidate (GetMonotonicSections, DepthImagePlanner.cpp:303-354): they depend on
+// nothing but the candidate, so afe_rappids_candidates_kernel forms them for every admissible candidate, one lane
+// each, and the search kernel's wave reads them instead of all 64 lanes repeating the quartic
+struct CandSections {
+  double t[5][2];                // [t0, t1] of each section, in the order IsCollisionFree pops them (last first)
+  int32_t n;                     // <= 5 (a quartic has at most four roots inside (0, tf))
+  uint32_t increasing;           // bit k: section k moves away from the camera
+};
+
 struct PlannerBatch {
   int64_t n;
   const uint16_t *images;        // [n_images][height][width]
@@ -28,6 +37,7 @@ struct PlannerBatch {
   int n_candidates;
   double *cand_cost;             // [n][n_candidates] scratch: cost of every candidate
   uint8_t *cand_bits;            // [n][n_candidates] scratch: input-feasible / velocity-admissible bits
+  CandSections *cand_sections;   // [n][n_candidates] scratch, filled for the admissible candidates
   PlannerPyramid *pyramids;      // [n][max_pyramids] scratch
   int max_pyramids;
   PlanOutput *out;               // [n]

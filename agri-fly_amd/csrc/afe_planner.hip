@@ -29,14 +29,22 @@ namespace {
 
 // -DAFE_PLANNER_PROFILE: per-phase cycle totals (s_memtime), printed by launch_rappids; development only
 #ifdef AFE_PLANNER_PROFILE
-__device__ unsigned long long g_prof[16];   // [8]: the longest planner (cycles); [9] scan chunks examined, [10] of them holding a marked pixel, [11] scan calls
+__device__ unsigned long long g_prof[24];   // [8]: the longest planner (cycles); [9] scan chunks examined, [10] of them holding a marked pixel, [11] scan calls
 #define PL_T0(var) const unsigned long long var = __builtin_readcyclecounter()
-#define PL_T1(var, slot) do { if (threadIdx.x == 0) atomicAdd(&g_prof[slot], __builtin_readcyclecounter() - var); } while (0)
-#define PL_COUNT(slot, n) do { if (threadIdx.x == 0) atomicAdd(&g_prof[slot], (unsigned long long)(n)); } while (0)
+__device__ unsigned long long g_longest[24];   // the same slots, of the longest planner alone
+__shared__ unsigned long long s_mine[24];
+#define PL_T1(var, slot) do { if (threadIdx.x == 0) { const unsigned long long d_ = __builtin_readcyclecounter() - var; atomicAdd(&g_prof[slot], d_); s_mine[slot] += d_; } } while (0)
+#define PL_COUNT(slot, n) do { if (threadIdx.x == 0) { atomicAdd(&g_prof[slot], (unsigned long long)(n)); s_mine[slot] += (unsigned long long)(n); } } while (0)
+#ifndef AFE_PLANNER_PROFILE_SCANS   // the per-chunk counters sit in the innermost loops and slow the kernel several times
+#define PL_COUNT_SCAN(slot, n)
+#else
+#define PL_COUNT_SCAN(slot, n) PL_COUNT(slot, n)
+#endif
 #else
 #define PL_T0(var)
 #define PL_T1(var, slot)
 #define PL_COUNT(slot, n)
+#define PL_COUNT_SCAN(slot, n)
 #endif
 
 #define PL_MIN(a, b) (((b) < (a)) ? (b) : (a))  // std::min / std::max semantics
@@ -608,7 +616,7 @@ __device__ __attribute__((noinline)) bool side_scan(const uint16_t *__restrict__
       }
     }
 #ifdef AFE_PLANNER_PROFILE
-    for (int c = 0; c < kScanBatch; c++) if (base0 + 64 * c < total) { PL_COUNT(9, 1); if (__ballot(vs[c])) PL_COUNT(10, 1); }
+    for (int c = 0; c < kScanBatch; c++) if (base0 + 64 * c < total) { PL_COUNT_SCAN(9, 1); if (__ballot(vs[c])) PL_COUNT_SCAN(10, 1); }
 #endif
 #pragma unroll
     for (int c = 0; c < kScanBatch; c++) {                  // depths only where a marked pixel needs one
@@ -620,7 +628,15 @@ __device__ __attribute__((noinline)) bool side_scan(const uint16_t *__restrict__
       const int x = xs[c], y = ys[c];
       const uint16_t d = ds[c];
       const bool valid = vs[c];
-      if (!__ballot(valid)) continue;
+      {  // no marked pixel of the chunk acts under the edges as they stand: nothing moves, next chunk
+         // (before the integer division below, which most chunks of a cluttered image then never pay)
+        bool hit0;
+        if (SIDE == SIDE_RIGHT) hit0 = valid && num > (x - s.right) * (int)d;
+        else if (SIDE == SIDE_LEFT) hit0 = valid && (s.left - x) * (int)d < num;
+        else if (SIDE == SIDE_TOP) hit0 = valid && (s.top - y) * (int)d < num;
+        else hit0 = valid && num > (y - s.bottom) * (int)d;
+        if (!__ballot(hit0)) continue;
+      }
       int k = 0;
       if (valid) k = (int)(num / d);
       // the edge this pixel asks for, and whether granting it would cut the seed pixel off
@@ -718,7 +734,7 @@ __device__ __attribute__((noinline)) bool corner_scan(const uint16_t *__restrict
       }
     }
 #ifdef AFE_PLANNER_PROFILE
-    for (int c = 0; c < kScanBatch; c++) if (base0 + 64 * c < total) { PL_COUNT(9, 1); if (__ballot(vs[c])) PL_COUNT(10, 1); }
+    for (int c = 0; c < kScanBatch; c++) if (base0 + 64 * c < total) { PL_COUNT_SCAN(9, 1); if (__ballot(vs[c])) PL_COUNT_SCAN(10, 1); }
 #endif
 #pragma unroll
     for (int c = 0; c < kScanBatch; c++) {
@@ -731,8 +747,6 @@ __device__ __attribute__((noinline)) bool corner_scan(const uint16_t *__restrict
       const uint16_t d = ds[c];
       const bool valid = vs[c];
       if (!__ballot(valid)) continue;
-      int k = 0;
-      if (valid) k = (int)(num / d);
       uint64_t todo = ~0ull;
       for (;;) {
         const bool hx = RIGHT ? num > (x - s.right) * (int)d : (s.left - x) * (int)d < num;
@@ -740,7 +754,8 @@ __device__ __attribute__((noinline)) bool corner_scan(const uint16_t *__restrict
         const uint64_t b = __ballot(valid && hx && hy) & todo;
         if (!b) break;
         const int l = (int)__ffsll((unsigned long long)b) - 1;
-        const int xl = __builtin_amdgcn_readlane(x, l), yl = __builtin_amdgcn_readlane(y, l), kl = __builtin_amdgcn_readlane(k, l);
+        const int xl = __builtin_amdgcn_readlane(x, l), yl = __builtin_amdgcn_readlane(y, l);
+        const int kl = num / __builtin_amdgcn_readlane((int)d, l);   // only the acting pixel's quotient is needed
         const int xT = RIGHT ? xl - kl : xl + kl;          // rightTemp / leftTemp
         const int yT = TOP ? yl + kl : yl - kl;            // topTemp / bottomTemp
         const bool cutX = RIGHT ? x0 > xT - buf : x0 < xT + buf;
@@ -1020,10 +1035,8 @@ __device__ bool deepest_collision_time(const Poly &p, const Section &m, const Pl
   return m.increasing ? cand > m.t0 : cand < m.t1;
 }
 
-// GetMonotonicSections (DIP.cpp:303-354) + IsCollisionFree (:214-301)
-__device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restrict__ img,
-                               const uint16_t *__restrict__ imgT, uint64_t *mask_lds, int lane, const Poly &p,
-                               double tf, PlannerPyramid *pyr, int &nPyr, int maxPyr) {
+// GetMonotonicSections (DIP.cpp:303-354): a function of the candidate alone
+__device__ void monotonic_sections(const Poly &p, double tf, CandSections &out) {
 #pragma clang fp contract(off)
   double dc[5];
   for (int i = 0; i < 5; i++) dc[i] = (5 - i) * p.c[i][2];
@@ -1034,7 +1047,7 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
   if (fabs(dc[0]) > 1e-6) n = solve_quartic(dc[1] / dc[0], dc[2] / dc[0], dc[3] / dc[0], dc[4] / dc[0], roots + 2);
   else n = solve_cubic(dc[2] / dc[1], dc[3] / dc[1], dc[4] / dc[1], roots + 2);
   sort_small(roots, (int)n + 2);
-  Section sec[16];   // pending sections (a std::vector in the reference; 16 like the CPU checker)
+  Section sec[5];
   int ns = 0;
   for (unsigned i = 0; i < n + 1; i++) {
     if (roots[i] < 0) continue;
@@ -1049,6 +1062,27 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
     while (j > 0 && deepest(p, v) < deepest(p, sec[j - 1])) { sec[j] = sec[j - 1]; j--; }
     sec[j] = v;
   }
+  out.n = ns;
+  out.increasing = 0;
+  for (int i = 0; i < 5; i++) {
+    out.t[i][0] = i < ns ? sec[i].t0 : 0.0;
+    out.t[i][1] = i < ns ? sec[i].t1 : 0.0;
+    if (i < ns && sec[i].increasing) out.increasing |= 1u << i;
+  }
+}
+
+// IsCollisionFree (DIP.cpp:214-301) on the candidate's sections
+__device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restrict__ img,
+                               const uint16_t *__restrict__ imgT, uint64_t *mask_lds, int lane, const Poly &p,
+                               const CandSections &first, PlannerPyramid *pyr, int &nPyr, int maxPyr) {
+#pragma clang fp contract(off)
+  Section sec[16];   // pending sections (a std::vector in the reference; 16 like the CPU checker)
+  int ns = first.n;
+  for (int i = 0; i < 5; i++) {
+    sec[i].t0 = first.t[i][0];
+    sec[i].t1 = first.t[i][1];
+    sec[i].increasing = (first.increasing >> i) & 1u;
+  }
   while (ns > 0) {
     const Section m = sec[--ns];
     const double ts = m.increasing ? m.t0 : m.t1, te = m.increasing ? m.t1 : m.t0;
@@ -1059,6 +1093,7 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
     const double py = ey * cfg.focal_length / ez + cfg.cy;
     // FindContainingPyramid, DIP.cpp:356-380
     int at = -1;
+    PL_T0(t_find);
     {
       int first = 0;
       while (first < nPyr && pyr[first].depth < ez) first++;
@@ -1066,19 +1101,26 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
         if (pyr[q].left + cfg.pixel_buffer < px && px < pyr[q].right - cfg.pixel_buffer &&
             pyr[q].top + cfg.pixel_buffer < py && py < pyr[q].bottom - cfg.pixel_buffer) { at = q; break; }
     }
+    PL_T1(t_find, 17);
     if (at < 0) {
       if (nPyr >= maxPyr) return false;                        // _maxNumPyramids, :255-260
       PlannerPyramid fresh;
       if (!inflate_pyramid(cfg, img, imgT, mask_lds, lane, (int)px, (int)py, ez, fresh)) return false;
+      PL_T0(t_ins);
       int idx = 0;                                             // std::lower_bound + insert, :269-271
       while (idx < nPyr && pyr[idx].depth < fresh.depth) idx++;
       for (int q = nPyr; q > idx; q--) pyr[q] = pyr[q - 1];
       pyr[idx] = fresh;
       nPyr++;
       at = idx;
+      PL_T1(t_ins, 18);
     }
     double tcol;
-    if (deepest_collision_time(p, m, pyr[at], lane, tcol)) {
+    PL_T0(t_deep);
+    const bool hits = deepest_collision_time(p, m, pyr[at], lane, tcol);
+    PL_T1(t_deep, 19);
+    PL_COUNT(20, 1);
+    if (hits) {
       if (ns >= 16) return false;
       sec[ns++] = m.increasing ? make_section(p, m.t0, tcol) : make_section(p, tcol, m.t1);
     }
@@ -1124,6 +1166,18 @@ __device__ __forceinline__ double candidate_cost(const PlannerConfig &cfg, const
 
 enum { CAND_INPUT_FEASIBLE = 1, CAND_VELOCITY_OK = 2 };
 
+__device__ __forceinline__ void candidate_poly(const Cand &k, Poly &p) {   // RTG.hpp GetTrajectory
+#pragma clang fp contract(off)
+  for (int a = 0; a < 3; a++) {
+    p.c[0][a] = k.al[a] / 120;
+    p.c[1][a] = k.be[a] / 24;
+    p.c[2][a] = k.ga[a] / 6;
+    p.c[3][a] = c_acc(k, a, 0) / 2;
+    p.c[4][a] = c_vel(k, a, 0);
+    p.c[5][a] = c_pos(k, a, 0);
+  }
+}
+
 __global__ void __launch_bounds__(256) afe_rappids_candidates_kernel(const PlannerConfig cfg, const PlannerBatch b) {
 #pragma clang fp contract(off)
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1140,7 +1194,12 @@ __global__ void __launch_bounds__(256) afe_rappids_candidates_kernel(const Plann
   uint8_t bits = 0;
   if (input_feasible(k, cfg)) {
     bits |= CAND_INPUT_FEASIBLE;
-    if (velocity_feasible(k, cfg.max_velocity)) bits |= CAND_VELOCITY_OK;
+    if (velocity_feasible(k, cfg.max_velocity)) {
+      bits |= CAND_VELOCITY_OK;
+      Poly p;
+      candidate_poly(k, p);
+      monotonic_sections(p, k.tf, b.cand_sections[t]);
+    }
   }
   b.cand_bits[t] = bits;
 }
@@ -1152,6 +1211,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFE_PLA
 afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
 #pragma clang fp contract(off)
   const int64_t i = blockIdx.x;      // one wave per planner
+#ifdef AFE_PLANNER_PROFILE
+  if (threadIdx.x < 24) s_mine[threadIdx.x] = 0;
+  __syncthreads();
+#endif
   PL_T0(t_all);
   const int lane = threadIdx.x;
   extern __shared__ uint64_t mask_lds[];   // one bit per pixel of this planner's image, see build_mask
@@ -1161,6 +1224,7 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
   const double *samples = b.samples + (int64_t)(b.sample_table ? b.sample_table[i] : 0) * b.n_candidates * 4;
   const double *cand_cost = b.cand_cost + i * b.n_candidates;
   const uint8_t *cand_bits = b.cand_bits + i * b.n_candidates;
+  const CandSections *__restrict__ cand_sections = b.cand_sections + i * b.n_candidates;
   PlannerPyramid *pyr = b.pyramids + i * b.max_pyramids;
   PlanOutput *out = b.out + i;
   int nPyr = 0;
@@ -1192,23 +1256,18 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
         if (bits & CAND_VELOCITY_OK) {
           result |= 4;
           n_velocity++;
+          PL_T0(t_regen);
           const double *sample = samples + 4 * (base + l);
           Cand k;
           double cost_vec[3], pf[3];
           load_planner_state(cfg, b, i, k, cost_vec);
           deproject(cfg, sample[0], sample[1], sample[2], pf);
           c_generate(k, pf, sample[3]);
-          Poly p;                    // RTG.hpp GetTrajectory
-          for (int a = 0; a < 3; a++) {
-            p.c[0][a] = k.al[a] / 120;
-            p.c[1][a] = k.be[a] / 24;
-            p.c[2][a] = k.ga[a] / 6;
-            p.c[3][a] = c_acc(k, a, 0) / 2;
-            p.c[4][a] = c_vel(k, a, 0);
-            p.c[5][a] = c_pos(k, a, 0);
-          }
+          Poly p;
+          candidate_poly(k, p);
+          PL_T1(t_regen, 21);
           PL_T0(t_cf);
-          const bool cfree = collision_free(cfg, img, imgT, mask_lds, lane, p, k.tf, pyr, nPyr, b.max_pyramids);
+          const bool cfree = collision_free(cfg, img, imgT, mask_lds, lane, p, cand_sections[base + l], pyr, nPyr, b.max_pyramids);
           PL_T1(t_cf, 6);
           if (cfree) {
             result |= 8;
@@ -1240,7 +1299,13 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
   }
   PL_T1(t_all, 0);
 #ifdef AFE_PLANNER_PROFILE
-  if (threadIdx.x == 0) atomicMax(&g_prof[8], __builtin_readcyclecounter() - t_all);
+  if (threadIdx.x == 0) {
+    const unsigned long long mine = __builtin_readcyclecounter() - t_all;
+    if (atomicMax(&g_prof[8], mine) < mine) {
+      for (int q = 0; q < 24; q++) g_longest[q] = s_mine[q];
+      g_longest[8] = mine; g_longest[12] = (unsigned long long)n_cost; g_longest[13] = (unsigned long long)n_velocity; g_longest[14] = (unsigned long long)nPyr; g_longest[15] = (unsigned long long)i;
+    }
+  }
 #endif
 }
 
@@ -1274,7 +1339,7 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   }
   const unsigned mask_bytes = (unsigned)(((cfg.width + 63) >> 6) * cfg.height) * (unsigned)sizeof(uint64_t);
 #ifdef AFE_PLANNER_PROFILE
-  unsigned long long zero[16] = {0};
+  unsigned long long zero[24] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero));
 #endif
   const int64_t n_cand = b.n * b.n_candidates;
@@ -1282,12 +1347,19 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
                      cfg, b);
   hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, b);
 #ifdef AFE_PLANNER_PROFILE
-  unsigned long long prof[16];
+  unsigned long long prof[24];
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_prof), sizeof(prof));
   fprintf(stderr, "planner profile (cycles per planner): total %.0f | collision_free %.0f | inflate: mask1 %.0f expansion(all) %.0f "
           "sides+mask2 %.0f corners %.0f | completed pyramids/planner %.2f ringloop %.0f | longest planner %.0f | scan chunks/planner %.0f, holding a marked pixel %.0f\n", (double)prof[0] / b.n, (double)prof[6] / b.n,
           (double)prof[1] / b.n, (double)prof[2] / b.n, (double)prof[3] / b.n, (double)prof[4] / b.n, (double)prof[5] / b.n, (double)prof[7] / b.n, (double)prof[8], (double)prof[9] / b.n, (double)prof[10] / b.n);
+  fprintf(stderr, "  per planner: regenerate %.0f | sections %.0f | find pyramid %.0f | insert %.0f | section quartics %.0f (%.1f of them)\n",
+          (double)prof[21] / b.n, (double)prof[16] / b.n, (double)prof[17] / b.n, (double)prof[18] / b.n, (double)prof[19] / b.n, (double)prof[20] / b.n);
+  (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_longest), sizeof(prof));
+  fprintf(stderr, "  longest: regenerate %llu | sections %llu | find pyramid %llu | insert %llu | section quartics %llu (%llu of them)\n",
+          prof[21], prof[16], prof[17], prof[18], prof[19], prof[20]);
+  fprintf(stderr, "  longest planner #%llu: total %llu | collision_free %llu | mask1 %llu expansion(all) %llu sides+mask2 %llu corners %llu | pyramids inflated %llu "
+          "(kept %llu) | cost checks %llu, collision checks %llu | scan chunks %llu\n", prof[15], prof[8], prof[6], prof[1], prof[2], prof[3], prof[4], prof[5], prof[14], prof[12], prof[13], prof[9]);
 #endif
   return (int)hipGetLastError();
 }

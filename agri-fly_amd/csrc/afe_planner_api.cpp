@@ -88,7 +88,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   if (hipSetDevice(device) != hipSuccess) return AFE_ERR_HIP;
 
   const size_t px = (size_t)cfg->width * cfg->height;
-  DevBuf d_img, d_imgT, d_cc, d_cb, d_idx, d_v, d_a, d_g, d_c, d_s, d_t, d_pyr, d_out, d_flags;
+  DevBuf d_img, d_imgT, d_cc, d_cb, d_cs, d_idx, d_v, d_a, d_g, d_c, d_s, d_t, d_pyr, d_out, d_flags;
   if ((!depth_on_device && !d_img.upload(depth_images, (size_t)n_images * px * 2)) || !d_v.upload(vel0, (size_t)n * 24) ||
       !d_a.upload(acc0, (size_t)n * 24) || !d_g.upload(grav, (size_t)n * 24) ||
       !d_s.upload(samples, (size_t)n_tables * n_candidates * 32))
@@ -98,7 +98,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   if (sample_table && !d_t.upload(sample_table, (size_t)n * 4)) return AFE_ERR_HIP;
   if (!d_pyr.alloc((size_t)n * cfg->max_pyramids * sizeof(PlannerPyramid)) || !d_out.alloc((size_t)n * sizeof(PlanOutput)) ||
       !d_imgT.alloc((size_t)n_images * px * 2) || !d_cc.alloc((size_t)n * n_candidates * 8) ||
-      !d_cb.alloc((size_t)n * n_candidates))
+      !d_cb.alloc((size_t)n * n_candidates) || !d_cs.alloc((size_t)n * n_candidates * sizeof(CandSections)))
     return AFE_ERR_HIP;
   if (flags && !d_flags.alloc((size_t)n * n_candidates)) return AFE_ERR_HIP;
 
@@ -108,6 +108,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   b.images_t = (uint16_t *)d_imgT.p;
   b.cand_cost = (double *)d_cc.p;
   b.cand_bits = (uint8_t *)d_cb.p;
+  b.cand_sections = (CandSections *)d_cs.p;
   b.n_images = n_images;
   b.image_index = image_index ? (const int32_t *)d_idx.p : nullptr;
   b.vel0 = (const double *)d_v.p; b.acc0 = (const double *)d_a.p; b.grav = (const double *)d_g.p;
