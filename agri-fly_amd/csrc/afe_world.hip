@@ -3,7 +3,8 @@
 //
 //   * nearest neighbour of every local vehicle among the whole ensemble, by a uniform grid
 //     (cell list built by a counting sort on the device, 3x3x3 cell search, exact: rings are
-//     added until no unvisited cell can hold a closer point);
+//     added until no unvisited cell can hold a closer point; a shard asking for its block of a larger
+//     gathered ensemble sorts only its own surroundings, see GridDesc::filtered);
 //   * UWB-style ranging between requester / responder pairs, the batched form of
 //     Simulation::UWBNetwork::Run (Components/Components/Simulation/UWBNetwork.cpp:22-89).
 //
@@ -30,7 +31,15 @@ struct GridDesc {
   float inv_h, h;
   int n[3];          // cells per axis
   int64_t n_cells;   // n[0]*n[1]*n[2]; bin n_cells collects non-finite positions (never searched)
+  // shard-local grids (this shard queries for a block of the gathered ensemble): the grid is shaped on the
+  // shard's own vehicles, and vehicles of other shards farther than `keep` outside it never enter the sort
+  int filtered;
+  float keep_lo[3], keep_hi[3];
+  int64_t self_first, self_count;
 };
+#define AFE_WORLD_DROPPED 0xffffffffu
+#define AFE_WORLD_BRUTE_CHUNK 32768
+#define AFE_WORLD_KEY_NONE 0x7f7fc99effffffffull   // (3.4e38f, no index): what a brute-force scan that finds nobody keeps
 
 __device__ __forceinline__ int ordered(float f) {
   const int i = __float_as_int(f);
@@ -56,12 +65,14 @@ struct BoundsPartial {
   double m[7];
 };
 
-__global__ void __launch_bounds__(256) world_bounds_kernel(const float *__restrict__ xyz, int64_t n, BoundsPartial *__restrict__ part) {
+__global__ void __launch_bounds__(256) world_bounds_kernel(const float *__restrict__ xyz_all, int64_t stride, int64_t first, int64_t n,
+                                                           BoundsPartial *__restrict__ part) {
+  const float *__restrict__ xyz = xyz_all + first;   // planar [3][stride], the block [first, first + n) of it
   __shared__ BoundsPartial wave_part[4];
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   double m[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float x = xyz[i], y = xyz[n + i], z = xyz[2 * n + i];
+    const float x = xyz[i], y = xyz[stride + i], z = xyz[2 * stride + i];
     if (finite3(x, y, z)) {
       const int ox = ordered(x), oy = ordered(y), oz = ordered(z);
       lo[0] = min(lo[0], ox); hi[0] = max(hi[0], ox);
@@ -121,7 +132,15 @@ __global__ void __launch_bounds__(256) world_count_kernel(const float *__restric
   if (i >= n) return;
   const float x = xyz[i], y = xyz[n + i], z = xyz[2 * n + i];
   uint32_t c = (uint32_t)g.n_cells;
-  if (finite3(x, y, z)) {
+  const bool fin = finite3(x, y, z);
+  if (g.filtered && (uint64_t)(i - g.self_first) >= (uint64_t)g.self_count) {
+    // somebody else's vehicle: it matters only if it can be the nearest neighbour of a query the rings settle,
+    // i.e. if it lies within `keep` of the grid (world_query_kernel has the argument); NaN compares false: dropped
+    const bool near = x >= g.keep_lo[0] && x <= g.keep_hi[0] && y >= g.keep_lo[1] && y <= g.keep_hi[1] &&
+                      z >= g.keep_lo[2] && z <= g.keep_hi[2];
+    if (!(fin && near)) { cell[i] = AFE_WORLD_DROPPED; return; }
+  }
+  if (fin) {
     int cx, cy, cz;
     cell_of(g, x, y, z, cx, cy, cz);
     c = (uint32_t)(((int64_t)cz * g.n[1] + cy) * g.n[0] + cx);
@@ -195,7 +214,9 @@ __global__ void __launch_bounds__(256) world_scatter_kernel(const float *__restr
                                                             uint4 *__restrict__ sorted) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  sorted[starts[cell[i]] + slot[i]] = make_uint4(__float_as_uint(xyz[i]), __float_as_uint(xyz[n + i]), __float_as_uint(xyz[2 * n + i]), (uint32_t)i);
+  const uint32_t c = cell[i];
+  if (c == AFE_WORLD_DROPPED) return;
+  sorted[starts[c] + slot[i]] = make_uint4(__float_as_uint(xyz[i]), __float_as_uint(xyz[n + i]), __float_as_uint(xyz[2 * n + i]), (uint32_t)i);
 }
 
 // squared distance exactly as the brute-force definition rounds it (three products, two sums, fp32)
@@ -234,9 +255,9 @@ __device__ __forceinline__ void scan_range(const uint4 *__restrict__ sorted, uin
 __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restrict__ sorted, int64_t n_all, const uint32_t *__restrict__ starts,
                                                           GridDesc g, int64_t first_global, int64_t n_self, float *__restrict__ dist2_out,
                                                           int32_t *__restrict__ index_out, uint32_t *__restrict__ leftover_count,
-                                                          int32_t *__restrict__ leftover) {
+                                                          int32_t *__restrict__ leftover, uint64_t *__restrict__ leftover_keys) {
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (s >= n_all) return;
+  if (s >= n_all || s >= (int64_t)starts[g.n_cells + 1]) return;   // the end sentinel: how many points were sorted
   const uint4 qb = sorted[s];
   const float3 q = make_float3(__uint_as_float(qb.x), __uint_as_float(qb.y), __uint_as_float(qb.z));
   const int me = (int)qb.w;
@@ -249,7 +270,21 @@ __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restric
   cell_of(g, q.x, q.y, q.z, cx, cy, cz);
   const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
   bool done = false;
-  for (int r = 1; r <= AFE_WORLD_MAX_RING && !done; r++) {
+  // Filtered grids: vehicles of other shards outside the keep box (the grid and AFE_WORLD_MAX_RING + 1 cells around
+  // it) were never sorted.  Every one of them is at least `clear` -- the query's distance to the faces of the keep
+  // box -- away, so the rings may settle a query only with best < clear^2 (then no dropped vehicle can be the
+  // answer, nor tie with it).  Inside the grid clear >= (AFE_WORLD_MAX_RING + 1) h, more than any ring reaches, so
+  // nothing changes there; a fly-away clamped into a boundary cell settles only if its neighbour is nearer than
+  // the keep box's faces; and "the rings cover the whole grid" proves nothing about what was dropped.  Whatever
+  // the rings cannot settle goes to the brute force, which reads the whole gathered buffer.
+  float clear = 3.4e38f;   // no dropped vehicle is nearer to this query than `clear`
+  if (g.filtered) {
+#pragma clang fp contract(off)
+    clear = fminf(fminf(fminf(q.x - g.keep_lo[0], g.keep_hi[0] - q.x), fminf(q.y - g.keep_lo[1], g.keep_hi[1] - q.y)),
+                  fminf(q.z - g.keep_lo[2], g.keep_hi[2] - q.z));
+    clear = fmaxf(clear - 0.05f * g.h, 0.0f);   // roundings of the differences: far below a twentieth of a cell
+  }
+  for (int r = 1; r <= AFE_WORLD_MAX_RING && !done && clear > 0.0f; r++) {
     for (int dz = -r; dz <= r; dz++) {
       const int z = cz + dz;
       if (z < 0 || z >= nz) continue;
@@ -267,46 +302,70 @@ __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restric
         }
       }
     }
-    const float reach = ((float)r - 0.05f) * g.h;   // 0.05 h: slack for the fp32 cell coordinates (<= 65536 per axis)
+    const float reach = fminf(((float)r - 0.05f) * g.h, clear);   // 0.05 h: slack for the fp32 cell coordinates (<= 65536 per axis)
     const bool covers_all = cx - r <= 0 && cx + r >= nx - 1 && cy - r <= 0 && cy + r >= ny - 1 && cz - r <= 0 && cz + r >= nz - 1;
-    done = covers_all || best < reach * reach;
+    done = (covers_all && !g.filtered) || best < reach * reach;
+    if (covers_all) break;
   }
   if (done) { dist2_out[local] = best; index_out[local] = best_j; }
-  else leftover[atomicAdd(leftover_count, 1u)] = (int32_t)local;
+  else {
+    const uint32_t k = atomicAdd(leftover_count, 1u);
+    leftover[k] = (int32_t)local;
+    leftover_keys[k] = AFE_WORLD_KEY_NONE;
+  }
 }
 
-// brute force for listed queries, one workgroup per query: every thread strides over the ensemble,
-// then (distance, index) pairs are reduced keeping the lowest index among equals
-__global__ void __launch_bounds__(256) world_brute_kernel(const float *__restrict__ all_xyz, int64_t n_all, const int32_t *__restrict__ queries,
-                                                          const uint32_t *__restrict__ n_queries, int64_t first_global,
-                                                          float *__restrict__ dist2_out, int32_t *__restrict__ index_out) {
-  __shared__ float sd[4];
-  __shared__ int sj[4];
-  for (uint32_t qi = blockIdx.x; qi < *n_queries; qi += gridDim.x) {
-    const int64_t local = queries[qi];
-    const int me = (int)(first_global + local);
+// Brute force for listed queries.  The work is cut into (query, chunk of the ensemble) items that the whole launch
+// shares -- a single left-over query is then finished by a hundred workgroups in ~0.1 ms instead of by one in 12 ms
+// (8 x 2^20 positions) -- and an item's winner is merged into the query's 64-bit key with one atomic minimum:
+// key = distance bits (non-negative floats order like their bit patterns) << 32 | index, so the smaller distance
+// wins and among equal distances the lower index, which is the definition's tie-break.
+
+__global__ void __launch_bounds__(256) world_brute_init_kernel(uint64_t *__restrict__ keys, const uint32_t *__restrict__ n_queries) {
+  for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < *n_queries; k += gridDim.x * 256) keys[k] = AFE_WORLD_KEY_NONE;
+}
+
+__global__ void __launch_bounds__(256) world_brute_chunks_kernel(const float *__restrict__ all_xyz, int64_t n_all, const int32_t *__restrict__ queries,
+                                                                 const uint32_t *__restrict__ n_queries, int64_t first_global,
+                                                                 unsigned long long *__restrict__ keys) {
+  __shared__ unsigned long long wave_key[4];
+  const int64_t n_chunks = (n_all + AFE_WORLD_BRUTE_CHUNK - 1) / AFE_WORLD_BRUTE_CHUNK;
+  const int64_t items = (int64_t)*n_queries * n_chunks;
+  for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const int64_t qi = item / n_chunks, chunk = item - qi * n_chunks;
+    const int me = (int)(first_global + queries[qi]);
     const float x = all_xyz[me], y = all_xyz[n_all + me], z = all_xyz[2 * n_all + me];
     float best = 3.4e38f;
     int best_j = -1;
     if (finite3(x, y, z)) {
-      for (int64_t j = threadIdx.x; j < n_all; j += 256)
+      const int64_t j1 = min(n_all, (chunk + 1) * AFE_WORLD_BRUTE_CHUNK);
+      for (int64_t j = chunk * AFE_WORLD_BRUTE_CHUNK + threadIdx.x; j < j1; j += 256)
         consider(dist2(all_xyz[j], all_xyz[n_all + j], all_xyz[2 * n_all + j], x, y, z), (int)j, me, best, best_j);
     }
+    unsigned long long key = best_j >= 0 ? ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_j : AFE_WORLD_KEY_NONE;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
-      const float od = __shfl_xor(best, s);
-      const int oj = __shfl_xor(best_j, s);
-      if (oj >= 0 && (od < best || (od == best && (best_j < 0 || oj < best_j)))) { best = od; best_j = oj; }
+      const unsigned long long o = __shfl_xor(key, s);
+      key = o < key ? o : key;
     }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) { sd[threadIdx.x >> 6] = best; sj[threadIdx.x >> 6] = best_j; }
+    if ((threadIdx.x & 63) == 0) wave_key[threadIdx.x >> 6] = key;
     __syncthreads();
     if (threadIdx.x == 0) {
-      for (int w = 1; w < 4; w++)
-        if (sj[w] >= 0 && (sd[w] < best || (sd[w] == best && (best_j < 0 || sj[w] < best_j)))) { best = sd[w]; best_j = sj[w]; }
-      dist2_out[local] = best;
-      index_out[local] = best_j;
+      for (int w = 1; w < 4; w++) key = wave_key[w] < key ? wave_key[w] : key;
+      if (key != AFE_WORLD_KEY_NONE) atomicMin(&keys[qi], key);
     }
+  }
+}
+
+__global__ void __launch_bounds__(256) world_brute_finish_kernel(const int32_t *__restrict__ queries, const uint32_t *__restrict__ n_queries,
+                                                                 const uint64_t *__restrict__ keys, float *__restrict__ dist2_out,
+                                                                 int32_t *__restrict__ index_out) {
+  for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < *n_queries; k += gridDim.x * 256) {
+    const int64_t local = queries[k];
+    const uint64_t key = keys[k];
+    dist2_out[local] = __uint_as_float((uint32_t)(key >> 32));
+    index_out[local] = (int32_t)(uint32_t)key;   // 0xffffffff = -1: nobody
   }
 }
 
@@ -348,12 +407,14 @@ struct afe_world {
   uint32_t *cell = nullptr, *slot = nullptr;
   uint4 *sorted = nullptr;
   int32_t *leftover = nullptr;
+  uint64_t *leftover_keys = nullptr;   // per listed query: packed (distance, index) minimum of the brute force
   int *lohi = nullptr;         // 6 ints + leftover counter
   BoundsPartial *bounds_part = nullptr;   // one record per workgroup of the bounds kernel
   int64_t cap_self = 0;
   float *self_scratch = nullptr;
   GridDesc grid = {};
   int64_t grid_n_all = -1;      // ensemble size the grid shape was chosen for
+  int64_t grid_first = -1, grid_n_self = -1;   // and the block of it the queries were for
   float grid_cell_arg = 0;      // and the caller's cell size then
   int refresh_every = 1;        // re-shape the grid every this many queries (1: always)
   int since_refresh = 0;
@@ -379,7 +440,8 @@ void free_points(afe_world *w) {
   if (w->slot) (void)hipFree(w->slot);
   if (w->sorted) (void)hipFree(w->sorted);
   if (w->leftover) (void)hipFree(w->leftover);
-  w->cell = w->slot = nullptr; w->sorted = nullptr; w->leftover = nullptr;
+  if (w->leftover_keys) (void)hipFree(w->leftover_keys);
+  w->cell = w->slot = nullptr; w->sorted = nullptr; w->leftover = nullptr; w->leftover_keys = nullptr;
 }
 
 // The grid covers the CORE of the ensemble: the bounding box cut to mean +- 6 sigma per axis.  Points
@@ -437,6 +499,15 @@ void choose_grid(const float lo[3], const float hi[3], const double stats[7], in
   g.h = (float)h;
   g.inv_h = (float)(1.0 / h);
   for (int c = 0; c < 3; c++) g.min[c] = (float)rlo[c];
+  g.filtered = 0;
+  g.self_first = 0;
+  g.self_count = 0;
+  for (int c = 0; c < 3; c++) {   // what a filtered grid keeps of the other shards: the grid and a margin of
+    // AFE_WORLD_MAX_RING + 1 cells around it (one cell more than any ring reaches, for the fp32 roundings)
+    const double keep = (AFE_WORLD_MAX_RING + 1.0) * h;
+    g.keep_lo[c] = (float)(rlo[c] - keep);
+    g.keep_hi[c] = (float)(rlo[c] + (double)g.n[c] * h + keep);
+  }
 }
 
 int ensure_capacity(afe_world *w, int64_t n_all, int64_t n_cells_total) {
@@ -447,6 +518,7 @@ int ensure_capacity(afe_world *w, int64_t n_all, int64_t n_cells_total) {
     W_HIP(w, hipMalloc((void **)&w->slot, (size_t)cap * 4));
     W_HIP(w, hipMalloc((void **)&w->sorted, (size_t)cap * sizeof(uint4)));
     W_HIP(w, hipMalloc((void **)&w->leftover, (size_t)cap * 4));
+    W_HIP(w, hipMalloc((void **)&w->leftover_keys, (size_t)cap * 8));
     w->cap_points = cap;
   }
   if (n_cells_total > w->cap_cells) {
@@ -506,9 +578,15 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   // into its boundary cells), a stale shape only costs speed, and without the read-back the whole query is
   // asynchronous on the stream (afe_set_neighbour_grid_refresh).
   W_HIP(w, hipMemsetAsync(w->lohi + 6, 0, 8, st));   // leftover counter (a device-side fill: a copy from pageable host memory would make the host wait for the stream)
-  const bool reshape = w->grid_n_all != n_all || w->grid_cell_arg != cell_size || w->since_refresh + 1 >= w->refresh_every;
+  // A shard that queries for its own block of a larger gathered ensemble shapes the grid on ITS vehicles and sorts
+  // only what can matter to them (see GridDesc::filtered): the cost of a query then follows the shard, not the
+  // ensemble -- on 8 GPUs every rank would otherwise sort all 8 x 2^20 gathered positions for its 2^20 queries.
+  const bool sharded = n_self < n_all;
+  const bool reshape = w->grid_n_all != n_all || w->grid_first != first_global || w->grid_n_self != n_self ||
+                       w->grid_cell_arg != cell_size || w->since_refresh + 1 >= w->refresh_every;
   if (reshape) {
-    hipLaunchKernelGGL(world_bounds_kernel, dim3(AFE_WORLD_BOUNDS_BLOCKS), dim3(256), 0, st, all_xyz, n_all, w->bounds_part);
+    hipLaunchKernelGGL(world_bounds_kernel, dim3(AFE_WORLD_BOUNDS_BLOCKS), dim3(256), 0, st, all_xyz, n_all, sharded ? first_global : (int64_t)0,
+                       sharded ? n_self : n_all, w->bounds_part);
     static thread_local BoundsPartial host_part[AFE_WORLD_BOUNDS_BLOCKS];
     W_HIP(w, hipMemcpyAsync(host_part, w->bounds_part, sizeof(host_part), hipMemcpyDeviceToHost, st));
     W_HIP(w, hipStreamSynchronize(st));
@@ -521,8 +599,13 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
     float lo[3], hi[3];
     for (int c = 0; c < 3; c++) { lo[c] = unordered(lohi[c]); hi[c] = unordered(lohi[3 + c]); }
     if (lohi[0] == 0x7fffffff) { for (int c = 0; c < 3; c++) lo[c] = hi[c] = 0.0f; }   // no finite position at all
-    choose_grid(lo, hi, stats, n_all, cell_size, w->grid);
+    choose_grid(lo, hi, stats, sharded ? n_self : n_all, cell_size, w->grid);
+    w->grid.filtered = sharded ? 1 : 0;
+    w->grid.self_first = first_global;
+    w->grid.self_count = n_self;
     w->grid_n_all = n_all;
+    w->grid_first = first_global;
+    w->grid_n_self = n_self;
     w->grid_cell_arg = cell_size;
     w->since_refresh = 0;
   } else {
@@ -543,9 +626,10 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   // 3. queries in cell order; isolated vehicles finish in the brute-force kernel
   uint32_t *left_count = (uint32_t *)(w->lohi + 6);
   hipLaunchKernelGGL(world_query_kernel, dim3(pb), dim3(256), 0, st, w->sorted, n_all, w->counts, g, first_global, n_self, dist2_out,
-                     index_out, left_count, w->leftover);
-  hipLaunchKernelGGL(world_brute_kernel, dim3(1024), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global, dist2_out,
-                     index_out);
+                     index_out, left_count, w->leftover, w->leftover_keys);
+  hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(2048), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global,
+                     (unsigned long long *)w->leftover_keys);
+  hipLaunchKernelGGL(world_brute_finish_kernel, dim3(64), dim3(256), 0, st, w->leftover, left_count, w->leftover_keys, dist2_out, index_out);
   W_HIP(w, hipGetLastError());
   return AFE_OK;
 }
@@ -579,14 +663,16 @@ int afe::world_nearest_bruteforce(afe_world *w, void *hip_stream, const float *a
     return wfail(w, AFE_ERR_INVALID_ARG, "bad brute-force arguments");
   hipStream_t st = (hipStream_t)hip_stream;
   W_HIP(w, hipSetDevice(w->device));
-  int rc = ensure_capacity(w, 1, 0);
+  int rc = ensure_capacity(w, n_queries, 0);
   if (rc) return rc;
   const uint32_t nq = (uint32_t)n_queries;
   uint32_t *cnt = (uint32_t *)(w->lohi + 7);
   W_HIP(w, hipMemcpyAsync(cnt, &nq, 4, hipMemcpyHostToDevice, st));
   W_HIP(w, hipStreamSynchronize(st));   // nq lives on this stack frame
-  hipLaunchKernelGGL(world_brute_kernel, dim3((unsigned)std::min<int64_t>(n_queries, 4096)), dim3(256), 0, st, all_xyz, n_all, dev_queries, cnt,
-                     first_global, dist2_out, index_out);
+  hipLaunchKernelGGL(world_brute_init_kernel, dim3(64), dim3(256), 0, st, w->leftover_keys, cnt);
+  hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(2048), dim3(256), 0, st, all_xyz, n_all, dev_queries, cnt, first_global,
+                     (unsigned long long *)w->leftover_keys);
+  hipLaunchKernelGGL(world_brute_finish_kernel, dim3(64), dim3(256), 0, st, dev_queries, cnt, w->leftover_keys, dist2_out, index_out);
   W_HIP(w, hipGetLastError());
   return AFE_OK;
 }

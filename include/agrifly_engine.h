@@ -571,6 +571,9 @@ const char *afe_group_last_error(const afe_group *g);
  * Outputs are DEVICE buffers of n_vehicles entries.  Implementation: uniform
  * grid (counting sort by cell on the device, 3x3x3 search, further rings until
  * no unvisited cell can be closer, isolated vehicles by brute force) -- exact.
+ * An engine that is a shard (n_vehicles < n_all) shapes the grid on its own block
+ * of all_xyz and sorts only the other shards' vehicles near it; the cost of a query
+ * then follows the shard, not the gathered ensemble.  Results do not depend on it.
  * cell_size <= 0 (and afe_nearest_neighbour): chosen from the occupied box,
  * about two vehicles per cell. */
 int afe_nearest_neighbour(afe_engine *e, const float *all_xyz, int64_t n_all,

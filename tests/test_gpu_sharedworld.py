@@ -140,6 +140,117 @@ def test_a_stale_grid_shape_is_still_exact(ora):
         assert e.neighbour_grid_info()["cell_size"] != shape[1]         # re-shaped for the collapsed ensemble
 
 
+def _shard_query(world, first, n, cell_size=0.0, refresh=1, e=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(world.astype(np.float32))).cuda()
+    own = e or afa.Ensemble(n, first_global_index=first)
+    own.set_neighbour_grid_refresh(refresh)
+    d2, idx = _nn(own, t, world.shape[1], cell_size)
+    info = own.neighbour_grid_info()
+    if e is None:
+        own.close()
+    return d2, idx, info
+
+
+def test_a_shard_sorts_only_its_surroundings_and_still_gets_the_definition(ora):
+    """A shard that queries for its block of a gathered ensemble shapes the grid on its OWN vehicles and leaves the
+    other shards' vehicles that are far outside it out of the sort (afe_world.hip, GridDesc::filtered).  Worlds
+    built to catch what that could break: the nearest neighbour of a border vehicle is somebody else's, just
+    across the border; a neighbour sits exactly on the keep box's faces; some of the shard's own vehicles have
+    flown away -- into the other shards' territory, next to vehicles the sort has dropped, so only the brute
+    force can answer for them; other shards hold non-finite positions; and the shard's vehicles all coincide."""
+    rng = np.random.default_rng(71)
+    n_all, first, n = 24000, 9000, 3000
+    # eight strips of a 240 m x 30 m field, 3 000 vehicles each; ours is strip 3
+    x = np.concatenate([rng.uniform(30 * k, 30 * (k + 1), 3000) for k in range(8)])
+    world = np.stack([x, rng.uniform(0, 30, n_all), rng.uniform(0, 3, n_all)])
+    worlds = {"strips": world.copy()}
+    w = world.copy()                                    # five of ours far inside strips 0 and 7, one a kilometre out
+    w[0, first:first + 5] = [3.0, 7.5, 231.0, 236.5, 1200.0]
+    w[0, first + 5] = -500.0                            # and one with nobody near it at all
+    worlds["fly-aways"] = w
+    w = world.copy()                                    # other shards' vehicles: NaN, inf, and a far cluster
+    w[:, :40] = np.nan
+    w[1, 40:80] = np.inf
+    w[:, 20000:21000] += 5000.0
+    worlds["non-finite and far neighbours"] = w
+    w = world.copy()                                    # all of ours in one point; the others around it
+    w[:, first:first + n] = np.array([[105.0], [15.0], [1.5]])
+    worlds["coincident shard"] = w
+    for name, w in worlds.items():
+        for cell in (0.0, 0.5, 40.0):
+            d2, idx, info = _shard_query(w, first, n, cell)
+            ref_d, ref_i = ora.nearest_neighbour(w.astype(np.float32), first, n)
+            np.testing.assert_array_equal(idx, ref_i, err_msg="%s, cell %g, grid %r" % (name, cell, info))
+            np.testing.assert_array_equal(d2, ref_d)
+            if name == "fly-aways" and cell == 0.0:
+                assert info["n_bruteforce"] >= 2, info     # the two far outside the grid: rings over a filtered sort cannot settle them
+    # Other shards' vehicles as a wall `off` metres left of a SPARSE shard (20 m lattice: the wall is the left
+    # column's nearest neighbour): inside the rings' reach, between the reach and the keep box's face (kept, but only
+    # the brute force may answer), exactly on the face, a float beyond it (dropped), far beyond.  Cell sizes 1 m and
+    # 3 m: keep boxes of (AFE_WORLD_MAX_RING + 1) = 7 cells, i.e. 7 m and 21 m.
+    gx, gy = np.meshgrid(np.arange(0.0, 200.0, 20.0), np.arange(0.0, 200.0, 20.0), indexing="ij")
+    ours = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)])
+    f32 = np.float32
+    for cell in (1.0, 3.0):
+        for off in (0.4 * cell, 5.9 * cell, 6.999 * cell, 7.0 * cell, np.nextafter(f32(7.0 * cell), f32(1e9)), 7.5 * cell, 19.9, 25.0):
+            wall = np.stack([np.full(10, -float(off)), np.arange(0.0, 200.0, 20.0), np.zeros(10)])
+            w = np.concatenate([wall, ours, wall + np.array([[1000.0], [0.0], [0.0]])], axis=1)
+            d2, idx, info = _shard_query(w, 10, ours.shape[1], cell)
+            ref_d, ref_i = ora.nearest_neighbour(w.astype(np.float32), 10, ours.shape[1])
+            np.testing.assert_array_equal(idx, ref_i, err_msg="cell %g, wall at -%r, %r" % (cell, off, info))
+            np.testing.assert_array_equal(d2, ref_d)
+            assert (ref_i[:10] < 10).all() or off > 19.9          # the wall really is the left column's answer
+
+
+def test_a_stale_shard_grid_is_still_exact(ora):
+    """the filtered grid kept across queries while the shard moves out of it and the other shards move in"""
+    rng = np.random.default_rng(72)
+    n_all, first, n = 9000, 3000, 3000
+    base = np.stack([np.concatenate([rng.uniform(40 * k, 40 * (k + 1), 3000) for k in range(3)]), rng.uniform(0, 40, n_all),
+                     rng.uniform(0, 4, n_all)])
+    moved = base.copy(); moved[0, first:first + n] += 25.0        # half-way into the next shard's strip
+    gone = base.copy(); gone[0, first:first + n] -= 300.0          # out of everything that was kept
+    swapped = base.copy(); swapped[0] = base[0, ::-1]               # the others now sit where we were
+    with afa.Ensemble(n, first_global_index=first) as e:
+        shape = None
+        for k, w in enumerate([base, moved, swapped, gone, base * 0.02]):
+            d2, idx, info = _shard_query(w, first, n, refresh=1000, e=e)
+            shape = shape or (info["dims"], info["cell_size"])
+            assert (info["dims"], info["cell_size"]) == shape
+            ref_d, ref_i = ora.nearest_neighbour(w.astype(np.float32), first, n)
+            np.testing.assert_array_equal(idx, ref_i, err_msg="world %d, %r" % (k, info))
+            np.testing.assert_array_equal(d2, ref_d)
+
+
+def test_brute_force_finisher_alone(ora):
+    """afe_nearest_neighbour_bruteforce -- (query, chunk) items merged by a packed atomic minimum -- against the
+    definition: more positions than one chunk holds, ties (lattice: the lowest index must win), coincident
+    points, non-finite queries and non-finite candidates, many queries and a single one."""
+    import torch
+    rng = np.random.default_rng(73)
+    n_all, first, n = 70001, 20000, 30000
+    w = np.rint(rng.uniform(0, 40, (3, n_all))).astype(np.float32)      # integer coordinates: ties everywhere
+    w[:, 5] = np.nan
+    w[2, first + 7] = np.inf
+    w[:, first + 9] = w[:, 3]                                            # coincident with a lower and a higher index
+    w[:, 69000] = w[:, 3]
+    t = torch.from_numpy(w).cuda()
+    ref_d, ref_i = ora.nearest_neighbour(w, first, n)
+    with afa.Ensemble(n, first_global_index=first) as e:
+        for queries in (np.arange(n, dtype=np.int32), np.array([7], np.int32), np.array([9, 0, n - 1], np.int32)):
+            q = torch.from_numpy(queries).cuda()
+            d2 = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+            idx = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            e.nearest_neighbour_bruteforce(t.data_ptr(), n_all, q.data_ptr(), len(queries), d2.data_ptr(), idx.data_ptr())
+            e.sync()
+            np.testing.assert_array_equal(idx.cpu().numpy()[queries], ref_i[queries])
+            np.testing.assert_array_equal(d2.cpu().numpy()[queries], ref_d[queries])
+            untouched = np.setdiff1d(np.arange(n), queries)
+            assert (idx.cpu().numpy()[untouched] == -7).all()
+
+
 def test_full_size_neighbour_query_is_exact_and_under_a_millisecond():
     """config-4 size on one GPU: 2^20 vehicles queried against 2^20; the grid result equals the
     brute-force definition (run on the GPU for a 4096-vehicle subsample plus the extremes) bit for
