@@ -231,7 +231,11 @@ __device__ __forceinline__ void consider(float d, int j, int me, float &best, in
 }
 
 // candidates sorted[a .. b): four loads in flight per trip (the tail re-reads the last entry, which changes
-// no minimum) -- one dependent cache round trip per four candidates instead of one each
+// no minimum) -- one dependent cache round trip per four candidates instead of one each.  (Eight per trip, and the
+// nine rows' start offsets of ring 1 fetched together ahead of the scans, were measured and are slower: 0.45
+// against 0.40 ms on the smeared 2^20 world.  So are two cooperative forms in which a workgroup, or a single wave,
+// stages the nine cell stretches around a run of 32 cells in LDS with coalesced loads and the vehicles scan from
+// there: 0.57 and 0.42 ms -- lanes in cell order already share most of their cache lines.)
 __device__ __forceinline__ void scan_range(const uint4 *__restrict__ sorted, uint32_t a, uint32_t b, float x, float y, float z, int me,
                                            float &best, int &best_j) {
   for (uint32_t k = a; k < b; k += 4) {
@@ -245,6 +249,63 @@ __device__ __forceinline__ void scan_range(const uint4 *__restrict__ sorted, uin
 }
 
 #define AFE_WORLD_MAX_RING 6
+
+// Filtered grids: vehicles of other shards outside the keep box (the grid and AFE_WORLD_MAX_RING + 1 cells around
+// it) were never sorted.  Every one of them is at least `clear` -- the query's distance to the faces of the keep
+// box -- away, so the rings may settle a query only with best < clear^2 (then no dropped vehicle can be the
+// answer, nor tie with it).  Inside the grid clear >= (AFE_WORLD_MAX_RING + 1) h, more than any ring reaches, so
+// nothing changes there; a fly-away clamped into a boundary cell settles only if its neighbour is nearer than
+// the keep box's faces; and "the rings cover the whole grid" proves nothing about what was dropped.  Whatever
+// the rings cannot settle goes to the brute force, which reads the whole gathered buffer.
+__device__ __forceinline__ float clearance(const GridDesc &g, float x, float y, float z) {
+#pragma clang fp contract(off)
+  if (!g.filtered) return 3.4e38f;
+  const float c = fminf(fminf(fminf(x - g.keep_lo[0], g.keep_hi[0] - x), fminf(y - g.keep_lo[1], g.keep_hi[1] - y)),
+                        fminf(z - g.keep_lo[2], g.keep_hi[2] - z));
+  return fmaxf(c - 0.05f * g.h, 0.0f);   // roundings of the differences: far below a twentieth of a cell
+}
+
+// rings r_first, r_first + 1, ... around cell (cx, cy, cz) through the cache; true if the query is settled
+__device__ bool ring_search(const uint4 *__restrict__ sorted, const uint32_t *__restrict__ starts, const GridDesc &g, float qx, float qy,
+                            float qz, int me, int cx, int cy, int cz, float clear, int r_first, float &best, int &best_j) {
+  const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
+  bool done = false;
+  for (int r = r_first; r <= AFE_WORLD_MAX_RING && !done; r++) {
+    for (int dz = -r; dz <= r; dz++) {
+      const int z = cz + dz;
+      if (z < 0 || z >= nz) continue;
+      for (int dy = -r; dy <= r; dy++) {
+        const int y = cy + dy;
+        if (y < 0 || y >= ny) continue;
+        const int64_t row = ((int64_t)z * ny + y) * nx;
+        const bool shell_row = (dz == -r || dz == r || dy == -r || dy == r) || r == 1;
+        if (shell_row) {   // the whole x-run of the row is new: its cells are contiguous in the cell order
+          const int xa = max(cx - r, 0), xb = min(cx + r, nx - 1);
+          scan_range(sorted, starts[row + xa], starts[row + xb + 1], qx, qy, qz, me, best, best_j);
+        } else {           // interior row of a wider ring: only its two end cells are new
+          if (cx - r >= 0) scan_range(sorted, starts[row + cx - r], starts[row + cx - r + 1], qx, qy, qz, me, best, best_j);
+          if (cx + r < nx) scan_range(sorted, starts[row + cx + r], starts[row + cx + r + 1], qx, qy, qz, me, best, best_j);
+        }
+      }
+    }
+    const float reach = fminf(((float)r - 0.05f) * g.h, clear);   // 0.05 h: slack for the fp32 cell coordinates (<= 65536 per axis)
+    const bool covers_all = cx - r <= 0 && cx + r >= nx - 1 && cy - r <= 0 && cy + r >= ny - 1 && cz - r <= 0 && cz + r >= nz - 1;
+    done = (covers_all && !g.filtered) || best < reach * reach;
+    if (covers_all) break;
+  }
+  return done;
+}
+
+__device__ __forceinline__ void finish_query(bool done, int64_t local, float best, int best_j, float *__restrict__ dist2_out,
+                                             int32_t *__restrict__ index_out, uint32_t *__restrict__ leftover_count,
+                                             int32_t *__restrict__ leftover, uint64_t *__restrict__ leftover_keys) {
+  if (done) { dist2_out[local] = best; index_out[local] = best_j; }
+  else {
+    const uint32_t k = atomicAdd(leftover_count, 1u);
+    leftover[k] = (int32_t)local;
+    leftover_keys[k] = AFE_WORLD_KEY_NONE;
+  }
+}
 
 // One lane per point IN CELL ORDER (neighbouring lanes sit in the same or adjacent cells, so their
 // reads share cache lines); lanes whose point is not one of this shard's vehicles retire at once.
@@ -268,51 +329,10 @@ __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restric
   if (!finite3(q.x, q.y, q.z)) { dist2_out[local] = best; index_out[local] = best_j; return; }
   int cx, cy, cz;
   cell_of(g, q.x, q.y, q.z, cx, cy, cz);
-  const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
   bool done = false;
-  // Filtered grids: vehicles of other shards outside the keep box (the grid and AFE_WORLD_MAX_RING + 1 cells around
-  // it) were never sorted.  Every one of them is at least `clear` -- the query's distance to the faces of the keep
-  // box -- away, so the rings may settle a query only with best < clear^2 (then no dropped vehicle can be the
-  // answer, nor tie with it).  Inside the grid clear >= (AFE_WORLD_MAX_RING + 1) h, more than any ring reaches, so
-  // nothing changes there; a fly-away clamped into a boundary cell settles only if its neighbour is nearer than
-  // the keep box's faces; and "the rings cover the whole grid" proves nothing about what was dropped.  Whatever
-  // the rings cannot settle goes to the brute force, which reads the whole gathered buffer.
-  float clear = 3.4e38f;   // no dropped vehicle is nearer to this query than `clear`
-  if (g.filtered) {
-#pragma clang fp contract(off)
-    clear = fminf(fminf(fminf(q.x - g.keep_lo[0], g.keep_hi[0] - q.x), fminf(q.y - g.keep_lo[1], g.keep_hi[1] - q.y)),
-                  fminf(q.z - g.keep_lo[2], g.keep_hi[2] - q.z));
-    clear = fmaxf(clear - 0.05f * g.h, 0.0f);   // roundings of the differences: far below a twentieth of a cell
-  }
-  for (int r = 1; r <= AFE_WORLD_MAX_RING && !done && clear > 0.0f; r++) {
-    for (int dz = -r; dz <= r; dz++) {
-      const int z = cz + dz;
-      if (z < 0 || z >= nz) continue;
-      for (int dy = -r; dy <= r; dy++) {
-        const int y = cy + dy;
-        if (y < 0 || y >= ny) continue;
-        const int64_t row = ((int64_t)z * ny + y) * nx;
-        const bool shell_row = (dz == -r || dz == r || dy == -r || dy == r) || r == 1;
-        if (shell_row) {   // the whole x-run of the row is new: its cells are contiguous in the cell order
-          const int xa = max(cx - r, 0), xb = min(cx + r, nx - 1);
-          scan_range(sorted, starts[row + xa], starts[row + xb + 1], q.x, q.y, q.z, me, best, best_j);
-        } else {           // interior row of a wider ring: only its two end cells are new
-          if (cx - r >= 0) scan_range(sorted, starts[row + cx - r], starts[row + cx - r + 1], q.x, q.y, q.z, me, best, best_j);
-          if (cx + r < nx) scan_range(sorted, starts[row + cx + r], starts[row + cx + r + 1], q.x, q.y, q.z, me, best, best_j);
-        }
-      }
-    }
-    const float reach = fminf(((float)r - 0.05f) * g.h, clear);   // 0.05 h: slack for the fp32 cell coordinates (<= 65536 per axis)
-    const bool covers_all = cx - r <= 0 && cx + r >= nx - 1 && cy - r <= 0 && cy + r >= ny - 1 && cz - r <= 0 && cz + r >= nz - 1;
-    done = (covers_all && !g.filtered) || best < reach * reach;
-    if (covers_all) break;
-  }
-  if (done) { dist2_out[local] = best; index_out[local] = best_j; }
-  else {
-    const uint32_t k = atomicAdd(leftover_count, 1u);
-    leftover[k] = (int32_t)local;
-    leftover_keys[k] = AFE_WORLD_KEY_NONE;
-  }
+  const float clear = clearance(g, q.x, q.y, q.z);
+  if (clear > 0.0f) done = ring_search(sorted, starts, g, q.x, q.y, q.z, me, cx, cy, cz, clear, 1, best, best_j);
+  finish_query(done, local, best, best_j, dist2_out, index_out, leftover_count, leftover, leftover_keys);
 }
 
 // Brute force for listed queries.  The work is cut into (query, chunk of the ensemble) items that the whole launch
@@ -627,7 +647,7 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   uint32_t *left_count = (uint32_t *)(w->lohi + 6);
   hipLaunchKernelGGL(world_query_kernel, dim3(pb), dim3(256), 0, st, w->sorted, n_all, w->counts, g, first_global, n_self, dist2_out,
                      index_out, left_count, w->leftover, w->leftover_keys);
-  hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(2048), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global,
+  hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(1024), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global,
                      (unsigned long long *)w->leftover_keys);
   hipLaunchKernelGGL(world_brute_finish_kernel, dim3(64), dim3(256), 0, st, w->leftover, left_count, w->leftover_keys, dist2_out, index_out);
   W_HIP(w, hipGetLastError());
