@@ -252,7 +252,8 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
     # rectangle; plus the candidate kernel's and the transpose's passes over the inputs
     plan_bytes = float(plans["n_pyramids"].sum()) * 2.0 * px_bytes + n_views * 2.0 * px_bytes + n_planners * n_candidates * 9.0
     planner_roofline = {
-        "bound": "dependent LDS / cache round trips of the sequential pyramid search (VALUBusy 34 %, profiles/r01_d_perception_pmc.json)",
+        "bound": "the longest planner of the launch (one wave per planner, a sequential search: profiles/r02d_planner_pmc.json -- the shader "
+                 "engines are busy 57 % of the launch, the vector pipe issues in 64 % of their busy cycles), not HBM",
         "pyramids_per_plan": float(plans["n_pyramids"].mean()), "collision_checks_per_plan": float(plans["n_collision_checks"].mean()),
         "algorithmic_bytes": plan_bytes, "achieved_GBs": plan_bytes / (ms_plan * 1e-3) / 1e9,
         "hbm_frac": plan_bytes / (ms_plan * 1e-3) / 1e9 / HBM_PEAK_GBS}

@@ -30,3 +30,13 @@ for cs in (6.0, 8.0, 10.0, 11.0, 12.0, 14.0, 17.0):
     for _ in range(32): e.nearest_neighbour(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr(), cell_size=cs)
     e.record(b); ms = e.elapsed_ms(a, b) / 32
     print("cell %.1f m: %.3f ms per query  %s" % (cs, ms, e.neighbour_grid_info()))
+# host cost of submitting one query to an idle stream (no back-pressure from the queue)
+e.set_neighbour_grid_refresh(1 << 20)
+hs = []
+for _ in range(20):
+    e.sync()
+    t0 = time.perf_counter()
+    e.nearest_neighbour(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr())
+    hs.append(time.perf_counter() - t0)
+e.sync()
+print("host time to submit one query to an idle stream: median %.1f us" % (np.median(hs) * 1e6))
