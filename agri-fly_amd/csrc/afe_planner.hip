@@ -783,6 +783,7 @@ __device__ __attribute__((noinline)) bool inflate_pyramid(const PlannerConfig &c
                                 const uint16_t *__restrict__ imgT, uint64_t *mask, int lane, int x0, int y0,
                                 double minimumDepth, PlannerPyramid &out) {
 #pragma clang fp contract(off)
+  PL_COUNT(22, 1);
   const int W = c.width, H = c.height, buf = c.pixel_buffer;
   const int edgeOff = (int)(c.focal_length * c.true_vehicle_radius / c.min_checking_dist);
   if (x0 <= edgeOff + buf + 1 || x0 > W - edgeOff - buf - 1 || y0 <= edgeOff + buf + 1 || y0 > H - edgeOff - buf - 1)
@@ -797,16 +798,25 @@ __device__ __attribute__((noinline)) bool inflate_pyramid(const PlannerConfig &c
   else { R = PL_MIN(W - edgeOff - 1, x0 + initR); L = R - 2 * initR; }
   const uint16_t ignore = (uint16_t)(c.true_vehicle_radius / c.depth_scale);
   {  // :505-518, any pixel of [L,R) x [T,B) nearer than minDepthPix
+    // (the answer does not depend on the order the pixels are looked at: eight chunks of 64 are loaded together,
+    // one memory round trip per 512 pixels instead of eight -- a plan in a cluttered image asks this ~90 times)
     const int w = R - L, total = w * (B - T);
-    for (int base = 0; base < total; base += 64) {
-      const int i = base + lane;
-      bool bad = false;
-      if (i < total) {
-        const int o = i / w;
-        const uint16_t d = img[(T + o) * W + L + (i - o * w)];
-        bad = d <= minDepthPix && d > ignore;
+    const unsigned magic = div_magic(w);
+    for (int base = 0; base < total; base += 64 * kSweepBatch) {
+      uint16_t d[kSweepBatch];
+#pragma unroll
+      for (int u = 0; u < kSweepBatch; u++) {
+        const int i = base + 64 * u + lane;
+        d[u] = 0;                                        // 0 <= ignore: never "bad"
+        if (i < total) {
+          const int o = div_small(i, w, magic);
+          d[u] = img[(T + o) * W + L + (i - o * w)];
+        }
       }
-      if (__ballot(bad)) return false;
+      bool bad = false;
+#pragma unroll
+      for (int u = 0; u < kSweepBatch; u++) bad |= d[u] <= minDepthPix && d[u] > ignore;
+      if (__ballot(bad)) { PL_COUNT(23, 1); return false; }
     }
   }
   PL_T0(t_exp);
@@ -948,27 +958,27 @@ __device__ __attribute__((noinline)) bool inflate_pyramid(const PlannerConfig &c
   const int ny = B - T + 1, nx = R - L + 1;
   // right side :617-661 (columns R.. outward, rows T..B); left side :663-698
   if (mask_region_any(mask, WW, lane, R, W - 1, T, B) &&
-      !side_scan<SIDE_RIGHT>(imgT, H, 1, mask, WW, lane, (W - R) * ny, ny, R, T, 1, 0, 0, 1, num, buf, x0, y0, dmin, s)) return false;
+      !side_scan<SIDE_RIGHT>(imgT, H, 1, mask, WW, lane, (W - R) * ny, ny, R, T, 1, 0, 0, 1, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
   if (mask_region_any(mask, WW, lane, 0, L, T, B) &&
-      !side_scan<SIDE_LEFT>(imgT, H, 1, mask, WW, lane, (L + 1) * ny, ny, L, T, -1, 0, 0, 1, num, buf, x0, y0, dmin, s)) return false;
+      !side_scan<SIDE_LEFT>(imgT, H, 1, mask, WW, lane, (L + 1) * ny, ny, L, T, -1, 0, 0, 1, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
   if (s.left + buf > s.right - buf) return false;
   // top side :705-744 (rows T.. outward, columns L..R); bottom side :746-785
   if (mask_region_any(mask, WW, lane, L, R, 0, T) &&
-      !side_scan<SIDE_TOP>(img, 1, W, mask, WW, lane, (T + 1) * nx, nx, L, T, 0, -1, 1, 0, num, buf, x0, y0, dmin, s)) return false;
+      !side_scan<SIDE_TOP>(img, 1, W, mask, WW, lane, (T + 1) * nx, nx, L, T, 0, -1, 1, 0, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
   if (mask_region_any(mask, WW, lane, L, R, B, H - 1) &&
-      !side_scan<SIDE_BOTTOM>(img, 1, W, mask, WW, lane, (H - B) * nx, nx, L, B, 0, 1, 1, 0, num, buf, x0, y0, dmin, s)) return false;
+      !side_scan<SIDE_BOTTOM>(img, 1, W, mask, WW, lane, (H - B) * nx, nx, L, B, 0, 1, 1, 0, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
   if (s.top + buf > s.bottom - buf) return false;
   PL_T1(t_side, 3);
   PL_T0(t_corner);
   // corners :794-940
   if (mask_region_any(mask, WW, lane, R, W - 1, 0, T) &&
-      !corner_scan<CORNER_TR>(img, W, mask, WW, lane, T + 1, W - R, R, T, num, buf, x0, y0, dmin, s)) return false;
+      !corner_scan<CORNER_TR>(img, W, mask, WW, lane, T + 1, W - R, R, T, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
   if (mask_region_any(mask, WW, lane, R, W - 1, B, H - 1) &&
-      !corner_scan<CORNER_BR>(img, W, mask, WW, lane, H - B, W - R, R, B, num, buf, x0, y0, dmin, s)) return false;
+      !corner_scan<CORNER_BR>(img, W, mask, WW, lane, H - B, W - R, R, B, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
   if (mask_region_any(mask, WW, lane, 0, L, 0, T) &&
-      !corner_scan<CORNER_TL>(img, W, mask, WW, lane, T + 1, L + 1, L, T, num, buf, x0, y0, dmin, s)) return false;
+      !corner_scan<CORNER_TL>(img, W, mask, WW, lane, T + 1, L + 1, L, T, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
   if (mask_region_any(mask, WW, lane, 0, L, B, H - 1) &&
-      !corner_scan<CORNER_BL>(img, W, mask, WW, lane, H - B, L + 1, L, B, num, buf, x0, y0, dmin, s)) return false;
+      !corner_scan<CORNER_BL>(img, W, mask, WW, lane, H - B, L + 1, L, B, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
   PL_T1(t_corner, 4);
   PL_COUNT(5, 1);
   // :942-966
@@ -1353,7 +1363,8 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   fprintf(stderr, "planner profile (cycles per planner): total %.0f | collision_free %.0f | inflate: mask1 %.0f expansion(all) %.0f "
           "sides+mask2 %.0f corners %.0f | completed pyramids/planner %.2f ringloop %.0f | longest planner %.0f | scan chunks/planner %.0f, holding a marked pixel %.0f\n", (double)prof[0] / b.n, (double)prof[6] / b.n,
           (double)prof[1] / b.n, (double)prof[2] / b.n, (double)prof[3] / b.n, (double)prof[4] / b.n, (double)prof[5] / b.n, (double)prof[7] / b.n, (double)prof[8], (double)prof[9] / b.n, (double)prof[10] / b.n);
-  fprintf(stderr, "  per planner: regenerate %.0f | sections %.0f | find pyramid %.0f | insert %.0f | section quartics %.0f (%.1f of them)\n",
+  fprintf(stderr, "  per planner: inflate calls %.2f, refused at the seed rectangle %.2f, refused inside a scan %.2f\n", (double)prof[22] / b.n, (double)prof[23] / b.n, (double)prof[16] / b.n);
+  fprintf(stderr, "  per planner: regenerate %.0f | sections(unused) %.0f | find pyramid %.0f | insert %.0f | section quartics %.0f (%.1f of them)\n",
           (double)prof[21] / b.n, (double)prof[16] / b.n, (double)prof[17] / b.n, (double)prof[18] / b.n, (double)prof[19] / b.n, (double)prof[20] / b.n);
   (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_longest), sizeof(prof));
   fprintf(stderr, "  longest: regenerate %llu | sections %llu | find pyramid %llu | insert %llu | section quartics %llu (%llu of them)\n",
