@@ -308,6 +308,9 @@ __global__ void afe_camera_pose_kernel(PoseArgs a) {
 struct TriRec {
   double v0[3], e1[3], e2[3];
   float box[6];   // {lo, hi} per axis
+#ifdef AFE_RENDER_FP32_CEILING
+  float v0f[3], e1f[3], e2f[3];   // measurement build only, see ray_triangle
+#endif
 };
 
 struct RenderArgs {
@@ -349,6 +352,27 @@ __device__ __forceinline__ bool box_reached(f32x2 bx, f32x2 by, f32x2 bz, const 
 
 __device__ __forceinline__ double ray_triangle(const double o[3], const double d[3], const TriRec &T) {
 #pragma clang fp contract(off)
+#ifdef AFE_RENDER_FP32_CEILING
+  // MEASUREMENT BUILD ONLY (-DAFE_RENDER_FP32_CEILING): the whole test in fp32 with the hardware reciprocal and no
+  // double-precision re-test anywhere.  Images are no longer the checker's; the point is the time, which bounds
+  // from above what an fp32 filter with an fp64 re-test near decision boundaries could ever gain.
+  {
+    const float of[3] = {(float)o[0], (float)o[1], (float)o[2]}, df[3] = {(float)d[0], (float)d[1], (float)d[2]};
+    const float *v0 = T.v0f, *e1 = T.e1f, *e2 = T.e2f;
+    const float p[3] = {df[1] * e2[2] - df[2] * e2[1], df[2] * e2[0] - df[0] * e2[2], df[0] * e2[1] - df[1] * e2[0]};
+    const float det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+    if (fabsf(det) < 1e-12f) return INFINITY;
+    const float inv = __builtin_amdgcn_rcpf(det);
+    const float tv[3] = {of[0] - v0[0], of[1] - v0[1], of[2] - v0[2]};
+    const float u = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) * inv;
+    if (u < 0.0f || u > 1.0f) return INFINITY;
+    const float q[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+    const float v = (df[0] * q[0] + df[1] * q[1] + df[2] * q[2]) * inv;
+    if (v < 0.0f || u + v > 1.0f) return INFINITY;
+    const float t = (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]) * inv;
+    return t > 0.0f ? (double)t : INFINITY;
+  }
+#endif
   // Moeller-Trumbore, two-sided; operation order is part of the contract (see file header).  v0, e1, e2
   // are the doubles the checker forms from the float vertices (afe_scene_create computes them once).
   const double *v0 = T.v0, *e1 = T.e1, *e2 = T.e2;
@@ -764,6 +788,9 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
       T.e2[k] = (double)src[6 + k] - T.v0[k];
       T.box[2 * k] = inflated.lo[k];
       T.box[2 * k + 1] = inflated.hi[k];
+#ifdef AFE_RENDER_FP32_CEILING
+      T.v0f[k] = (float)T.v0[k]; T.e1f[k] = (float)T.e1[k]; T.e2f[k] = (float)T.e2[k];
+#endif
     }
   }
   afe_scene *s = new afe_scene();
