@@ -66,6 +66,27 @@ struct HoverController {
     const Rotationf wanted = tilted * Rotationf::FromRotationVector(Vec3f(0, 0, float(desiredYawAngle)));
     outCmdAngVel = Vec3d(RatesFor(wanted, attNow));
   }
+
+  // same argument list as Offboard::QuadcopterController::RunTracking (QuadcopterController.cpp:76-132): the
+  // reference trajectory's thrust and body rates are fed forward, the PD law only closes the position error
+  // (its acceleration feed-forward is deliberately zero there), and the attitude that points the thrust along
+  // refAcc + correction + g is tracked with the same rate law as in Run
+  void RunTracking(Vec3d const curPos, Vec3d const curVel, Rotationd const curAtt, Vec3d const refPos, Vec3d const refVel,
+                   Vec3d const refAcc, double const desiredYawAngle, double const refThrust, Vec3d const refAngVel,
+                   Vec3d &outCmdAngVel, double &outCmdThrust, Rotationf &outCmdAtt) const {
+    const Vec3f up(0, 0, 1);
+    const Rotationf attNow(curAtt);
+    const Vec3f correction = (Vec3f(refPos) - Vec3f(curPos)) * wn * wn + (Vec3f(refVel) - Vec3f(curVel)) * 2 * wn * zeta + Vec3f(0, 0, 0);
+    outCmdThrust = refThrust + correction.Dot(attNow * up);
+    const Vec3f proper = Vec3f(refAcc) + correction + Vec3f(0, 0, 9.81f);
+    const Vec3f along = proper / proper.GetNorm2();
+    const float turn = AngleFromCosine(along.Dot(up), 1 - 1e-12f);
+    const Vec3f axis = up.Cross(along);
+    const float axisLen = axis.GetNorm2();
+    const Rotationf tilted = axisLen < 1e-6f ? Rotationf::Identity() : Rotationf::FromRotationVector(axis * (turn / axisLen));
+    outCmdAtt = tilted * Rotationf::FromRotationVector(Vec3f(0, 0, float(desiredYawAngle)));
+    outCmdAngVel = refAngVel + Vec3d(RatesFor(outCmdAtt, attNow));
+  }
 };
 
 }  // namespace agrifly_cli

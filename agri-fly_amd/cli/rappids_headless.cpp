@@ -7,8 +7,13 @@
 // What runs on the GPU:     quad->Run() for every vehicle -- physics, motors, IMU synthesis and the
 //   rates-control slice of Onboard::QuadcopterLogic (afe_set_rates_logic) -- one launch per step.
 // What is stubbed, and says so in the log header comment line when --verbose:
-//   * AirSim / Unity (:183-184,300-321,331-389,397-438): absent; with --scene orchard the depth image
-//     comes from the engine's own depth camera and the RAPPIDS planner runs on the GPU (afe_rappids_plan).
+//   * AirSim / Unity (:183-184,300-321,331-389,397-438): absent.  With --scene <mesh> the depth image of every
+//     vehicle comes from the engine's own depth camera at the reference's 30 Hz (afe_render_depth_engine, poses
+//     read from the state slabs, images stay in HBM) and DepthImagePlanner runs on the GPU for all vehicles at once
+//     (afe_rappids_plan_device; a candidate count instead of the 50 ms wall-clock budget of :502): the flight
+//     branch of the loop, :478-608 -- plan on a ready image, keep the trajectory's frame, track it with
+//     RunTracking (:629-632), hover at (0, 0, 2) until the first plan (:553-556).  Without --scene only the
+//     take-off branch runs (hover at (0, 0, 3.5)), whatever the time.
 //   * MocapStateEstimator (:221-224,451-457,468-469,647-649) and QuadcopterController::Run (:625-627): the tree's
 //     Offboard/ sources are not part of this repository, so both are restated -- cli/mocap_estimator.hpp
 //     (200 Hz truth pose in, prediction 30 ms ahead out, driven by the commands in flight) and HoverController
@@ -20,6 +25,14 @@
 //   rappids_headless [--vehicles N] [--seconds T] [--dt-us 2000] [--precision f32|f64]
 //                    [--seeds reference|decorrelated] [--log-vehicle i] [--digits D] [--out simulation.csv]
 //                    [--estimator mocap|truth] [--print-seconds]
+//                    [--scene mesh.f32 [--goal x y z] [--start-flight T] [--candidates K] [--traj-log file]
+//                     [--hover z] [--line-up dy]]
+// --scene: n x 9 little-endian float32 (v0, v1, v2 per triangle), world frame = the simulation's (z up).
+// --goal: goalWorld (:241; default 120 0 3.5); --start-flight: startFlightTime (:141; default 5 s);
+// --candidates: candidates per plan (default 256); --hover z: fly at height z before and after take-off instead
+// of the reference's 3.5 m / 2 m; --line-up dy: vehicle i starts, hovers and aims dy * i metres further along y.
+// --traj-log: PlannedTrajectory.csv of the logged vehicle, the reference's columns (:534-551) followed by what the
+//   plan was made from (time, winning candidate, planner inputs, the pose its image was rendered at).
 // --print-seconds: the logged vehicle's true state on stdout after every whole second of Run() calls
 //   ("t=1.000 pos=x y z vel=... q=... f0=..."), the line format SURVEY.md Appendix B quotes for the reference.
 // Defaults are the reference's own: 1 vehicle, dt = 1/500 s, 8 s, 6 significant digits (ofstream default).
@@ -36,6 +49,7 @@
 #include "agrifly/Wire.hpp"
 #include "hover_controller.hpp"
 #include "mocap_estimator.hpp"
+#include "planned_trajectory.hpp"
 
 namespace {
 
@@ -61,6 +75,11 @@ int main(int argc, char **argv) {
   int precision = AFE_F32, seeds = AFE_SEED_REFERENCE, digits = 6;
   std::string outPath = "simulation.csv";
   bool useMocapEstimator = true, printSeconds = false;
+  std::string scenePath, trajLogPath;
+  double goalArg[3] = {120.0, 0.0, 3.5};   // main.cpp:241
+  double startFlightTime = 5.0;            // :141
+  double hoverArg = -1, lineUp = 0;
+  int nCandidates = 256;
   for (int a = 1; a < argc; a++) {
     const std::string k = argv[a];
     const char *v = a + 1 < argc ? argv[a + 1] : "";
@@ -74,9 +93,16 @@ int main(int argc, char **argv) {
     else if (k == "--out") { outPath = v; a++; }
     else if (k == "--estimator") { useMocapEstimator = std::strcmp(v, "truth") != 0; a++; }
     else if (k == "--print-seconds") { printSeconds = true; }
+    else if (k == "--scene") { scenePath = v; a++; }
+    else if (k == "--traj-log") { trajLogPath = v; a++; }
+    else if (k == "--goal" && a + 3 < argc) { for (int c = 0; c < 3; c++) goalArg[c] = atof(argv[a + 1 + c]); a += 3; }
+    else if (k == "--start-flight") { startFlightTime = atof(v); a++; }
+    else if (k == "--candidates") { nCandidates = atoi(v); a++; }
+    else if (k == "--hover") { hoverArg = atof(v); a++; }
+    else if (k == "--line-up") { lineUp = atof(v); a++; }
     else { std::fprintf(stderr, "rappids_headless: unknown option %s\n", k.c_str()); return 2; }
   }
-  if (nVehicles < 1 || logVehicle < 0 || logVehicle >= nVehicles || digits < 1) return 2;
+  if (nVehicles < 1 || logVehicle < 0 || logVehicle >= nVehicles || digits < 1 || nCandidates < 1) return 2;
 
   // Basic timing, main.cpp:139-144
   const double dt = dt_us_arg ? dt_us_arg * 1e-6 : 1.0 / 500.0;
@@ -101,13 +127,65 @@ int main(int argc, char **argv) {
   die(quad, afe_set_rates_logic(quad, &logicConsts, 1), "afe_set_rates_logic");
   // quad->SetPosition(initErrPos); quad->SetAttitude(initErrAtt): origin, identity (:279-280) = the engine's initial state
 
+  if (lineUp != 0) {   // vehicle i starts dy * i further along y (quad->SetPosition, :279)
+    std::vector<double> p0(3 * nVehicles, 0.0), zero3(3 * nVehicles, 0.0), q0(4 * nVehicles, 0.0);
+    for (int64_t i = 0; i < nVehicles; i++) { p0[nVehicles + i] = lineUp * (double)i; q0[i] = 1.0; }
+    die(quad, afe_set_state(quad, 0, nVehicles, p0.data(), zero3.data(), q0.data(), zero3.data(), 0), "afe_set_state");
+  }
+
+  // the depth camera and the planner, main.cpp:119-125,166-170 (only with --scene)
+  afe_scene *scene = 0;
+  afe_camera cam;
+  double depthCamAtt[4];
+  afe_planner_config planCfg;
+  void *depthImages = 0;                 // [nVehicles][240][320] uint16 in HBM
+  std::vector<double> candidateSamples;
+  die(0, afe_camera_default(&cam, 320, 240), "afe_camera_default");
+  die(0, afe_camera_default_mount(depthCamAtt), "afe_camera_default_mount");
+  const Rotationd camAtt(depthCamAtt[0], depthCamAtt[1], depthCamAtt[2], depthCamAtt[3]);
+  if (!scenePath.empty()) {
+    std::ifstream f(scenePath.c_str(), std::ios::binary | std::ios::ate);
+    if (!f) { std::fprintf(stderr, "rappids_headless: cannot open %s\n", scenePath.c_str()); return 1; }
+    const std::streamsize bytes = f.tellg();
+    if (bytes <= 0 || bytes % 36) { std::fprintf(stderr, "rappids_headless: %s is not n x 9 float32\n", scenePath.c_str()); return 1; }
+    std::vector<float> tris((size_t)bytes / 4);
+    f.seekg(0);
+    f.read((char *)tris.data(), bytes);
+    die(0, afe_scene_create(-1, tris.data(), (int64_t)(bytes / 36), &scene), "afe_scene_create");
+    // physicalVehicleRadius = 2 armLength, vehicleRadiusPlanning = 3 armLength, minCollisionDist 0.5 (:167-169)
+    die(0, afe_planner_default_config(&planCfg, cam.width, cam.height, cam.depth_scale, cam.focal_length, 2 * vehConsts.arm_length,
+                                      3 * vehConsts.arm_length, 0.5), "afe_planner_default_config");
+    planCfg.cost_type = 1;               // ExplorationCost::GetTrajCost with the goal in the camera frame (:93-107)
+    candidateSamples.resize((size_t)nCandidates * 4);
+    die(0, afe_planner_samples(0, cam.width, cam.height, nCandidates, candidateSamples.data()), "afe_planner_samples");
+    die(0, afe_device_alloc(-1, (uint64_t)nVehicles * cam.width * cam.height * 2, &depthImages), "afe_device_alloc");
+  }
+
   std::vector<agrifly_cli::MocapEstimator> est;                              // :221-224, one per vehicle
   for (int64_t i = 0; i < nVehicles; i++) est.push_back(agrifly_cli::MocapEstimator(&simTimer, timeDelayOffboardControlLoopTrue));
   double const timeDelayOffboardControlLoopEstimate = 0.03;                  // :179
   agrifly_cli::HoverController ctrl;
-  Vec3d desiredPosition(0, 0, 3.5);   // :240
+  Vec3d desiredPosition(0, 0, hoverArg > 0 ? hoverArg : 3.5);   // :240
   Vec3d desiredVelocity(0, 0, 0);
   double desYawAngleDeg = 0;
+  const Vec3d goalWorld(goalArg[0], goalArg[1], goalArg[2]);
+  const Vec3d noTrajectoryYet(0, 0, hoverArg > 0 ? hoverArg : 2.0);          // :553-556
+  // per vehicle: what main.cpp keeps in trajPlanned, _traj, trajAtt, trajOffset, trackTrajTime, previousThrust, imageReady
+  struct Flight {
+    bool planned, imageReady;
+    agrifly_cli::PlannedTrajectory traj;
+    Rotationd trajAtt;
+    Vec3d trajOffset;
+    double trajStart, previousThrust;
+    double imagePose[7];
+    Flight() : planned(false), imageReady(false), trajAtt(Rotationd::Identity()), trajOffset(0, 0, 0), trajStart(0), previousThrust(9.81) {}
+  };
+  std::vector<Flight> flight((size_t)nVehicles);
+  bool requestNewImage = true;                                               // :199
+  double const periodBetweenImages = 1 / 30.0;                               // :200-201
+  int plannedTrajCount = 0;
+  std::ofstream trajLog;
+  if (!trajLogPath.empty()) { trajLog.open(trajLogPath.c_str()); trajLog << std::setprecision(17); }
 
   std::ofstream logfile(outPath.c_str());
   if (!logfile) { std::fprintf(stderr, "rappids_headless: cannot open %s\n", outPath.c_str()); return 1; }
@@ -122,6 +200,7 @@ int main(int argc, char **argv) {
   typedef std::vector<agrifly::RawRadioMessage> RadioBatch;   // one uplink packet per vehicle
   agrifly::DelayLine<RadioBatch> cmdRadioChannel(&simTimer, timeDelayOffboardControlLoopTrue);   // :282
   Timer timerPrint(&simTimer), timerMocap(&simTimer), timerOffboardMainLoop(&simTimer), timerTelemetryLoop(&simTimer);
+  Timer timerRequestNewImage(&simTimer);
   float lastRadioCommand[4] = {0, 0, 0, 0};
   std::vector<double> pos(3 * nVehicles), vel(3 * nVehicles), att(4 * nVehicles), angVel(3 * nVehicles);
   std::vector<float> cmds(4 * nVehicles), gyro(3 * nVehicles), acc(3 * nVehicles);
@@ -132,7 +211,17 @@ int main(int argc, char **argv) {
   double p1[3], v1[3], q1[4], w1[3], m1[4];
   agrifly_cli::Estimate estLogged;
   estLogged.att = Rotationd::Identity();
+  Vec3d desiredPositionLogged(desiredPosition), desiredVelocityLogged(desiredVelocity);
   while (t.GetSeconds<double>() < endTime) {                                  // :330
+    if (scene && requestNewImage) {                                            // :331-389: one DepthVis image per vehicle
+      die(quad, afe_render_depth_engine(quad, scene, &cam, 0, nVehicles, depthCamAtt, depthImages, 1, 0), "afe_render_depth_engine");
+      double rp[3], rv[3], rq[4], rw[3];
+      die(quad, afe_get_state(quad, logVehicle, 1, rp, rv, rq, rw, 0), "afe_get_state");
+      for (int64_t i = 0; i < nVehicles; i++) flight[(size_t)i].imageReady = true;
+      for (int c = 0; c < 3; c++) flight[(size_t)logVehicle].imagePose[c] = rp[c];
+      for (int c = 0; c < 4; c++) flight[(size_t)logVehicle].imagePose[3 + c] = rq[c];
+      requestNewImage = false;
+    }
     {   // quad->Run(), Quadcopter_T.cpp:85-91: dt from the integration timer, nothing on the first call
       const uint64_t run_us = integrationTimer.GetMicroSeconds();
       if ((double)((double)run_us * 1e-6) >= 1e-6) {
@@ -142,6 +231,10 @@ int main(int argc, char **argv) {
     }
     simTimer.AdvanceMicroSeconds(uint64_t(dt * 1e6));                          // :392
 
+    if (timerRequestNewImage.GetSeconds<double>() > periodBetweenImages) {     // :440-444
+      requestNewImage = true;
+      timerRequestNewImage.AdjustTimeBySeconds(-periodBetweenImages);
+    }
     if (timerPrint.GetSeconds<double>() >= 1) {                                // :446-449
       timerPrint.AdjustTimeBySeconds(-1);
       std::printf("Current sim time = %.1fs\n", t.GetSeconds<double>());
@@ -168,18 +261,115 @@ int main(int argc, char **argv) {
       timerOffboardMainLoop.AdjustTimeBySeconds(-periodOffboardMainLoop);      // :476
       die(quad, afe_get_state(quad, 0, N, pos.data(), vel.data(), att.data(), angVel.data(), 0), "afe_get_state");
       RadioBatch batch((size_t)N);
-      for (int64_t i = 0; i < N; i++) {                                        // :611-638 for every vehicle
-        Vec3d cmdAngVel;
-        double cmdThrust;
-        agrifly_cli::Estimate estState;                                        // :468-469
+      std::vector<agrifly_cli::Estimate> estStates((size_t)N);                 // :468-469
+      for (int64_t i = 0; i < N; i++) {
+        agrifly_cli::Estimate &estState = estStates[(size_t)i];
         if (useMocapEstimator) estState = est[(size_t)i].Predict(timeDelayOffboardControlLoopEstimate);
         else {
           estState.pos = Vec3d(pos[i], pos[N + i], pos[2 * N + i]); estState.vel = Vec3d(vel[i], vel[N + i], vel[2 * N + i]);
           estState.att = Rotationd(att[i], att[N + i], att[2 * N + i], att[3 * N + i]);
           estState.angVel = Vec3d(angVel[i], angVel[N + i], angVel[2 * N + i]);
         }
-        ctrl.Run(estState.pos, estState.vel, estState.att, desiredPosition, Vec3d(0, 0, 0),
-                 Vec3d(0, 0, 0), desYawAngleDeg * M_PI / 180.0, cmdAngVel, cmdThrust);
+      }
+      const bool flying = scene && t.GetSeconds<double>() > startFlightTime;   // :478
+      if (flying) {                                                            // :479-552, every vehicle with a ready image at once
+        std::vector<int32_t> who;
+        for (int64_t i = 0; i < N; i++) if (flight[(size_t)i].imageReady) who.push_back((int32_t)i);
+        const int64_t n = (int64_t)who.size();
+        if (n > 0) {
+          std::vector<double> vel0(3 * n), acc0(3 * n), grav(3 * n), goalCam(3 * n);
+          for (int64_t k = 0; k < n; k++) {
+            const int64_t i = who[(size_t)k];
+            const agrifly_cli::Estimate &es = estStates[(size_t)i];
+            const Vec3d offset(0, lineUp * (double)i, 0);
+            const Rotationd toCam = camAtt.Inverse() * es.att.Inverse();
+            const Vec3d v = toCam * es.vel;                                    // :490-495
+            const Vec3d a = toCam * (Vec3d(0, 0, 1) * flight[(size_t)i].previousThrust - Vec3d(0, 0, 9.81));
+            const Vec3d g = toCam * Vec3d(0, 0, -9.81);
+            const Vec3d G = toCam * ((goalWorld + offset) - es.pos);           // ExplorationCost::GetTrajCost, :100-102
+            for (int c = 0; c < 3; c++) { vel0[c * n + k] = v[c]; acc0[c * n + k] = a[c]; grav[c * n + k] = g[c]; goalCam[c * n + k] = G[c]; }
+          }
+          std::vector<afe_plan_output> plans((size_t)n);
+          die(0, afe_rappids_plan_device(-1, &planCfg, n, depthImages, N, who.data(), vel0.data(), acc0.data(), grav.data(), goalCam.data(),
+                                         candidateSamples.data(), 1, 0, nCandidates, plans.data(), 0, 0), "afe_rappids_plan_device");
+          for (int64_t k = 0; k < n; k++) {
+            if (!plans[(size_t)k].found) continue;                             // the image stays ready: the next tick plans on it again
+            const int64_t i = who[(size_t)k];
+            Flight &fl = flight[(size_t)i];
+            const agrifly_cli::Estimate &es = estStates[(size_t)i];
+            for (int q = 0; q < 6; q++) for (int c = 0; c < 3; c++) fl.traj.c[q][c] = plans[(size_t)k].coeffs[q][c];
+            fl.traj.duration = plans[(size_t)k].tf;
+            fl.traj.gravity = Vec3d(grav[k], grav[n + k], grav[2 * n + k]);
+            fl.trajAtt = es.att * camAtt;                                      // :520
+            fl.trajOffset = es.pos;
+            fl.trajStart = t.GetSeconds<double>();                             // trackTrajTime.Reset()
+            fl.planned = true;
+            fl.imageReady = false;
+            if (i == L) {
+              plannedTrajCount++;
+              if (trajLog.is_open()) {                                         // :534-551
+                trajLog << plannedTrajCount << ",";
+                for (int q = 0; q < 6; q++) trajLog << fl.traj.c[q][0] << "," << fl.traj.c[q][1] << "," << fl.traj.c[q][2] << ",";
+                const Vec3d ypr = fl.trajAtt.ToEulerYPR();
+                trajLog << ypr.x << "," << ypr.y << "," << ypr.z << ",";
+                trajLog << fl.trajOffset.x << "," << fl.trajOffset.y << "," << fl.trajOffset.z << ",";
+                trajLog << 0.0 << "," << fl.traj.duration;
+                trajLog << "," << t.GetSeconds<double>() << "," << plans[(size_t)k].best_index;
+                for (int c = 0; c < 3; c++) trajLog << "," << vel0[c * n + k];
+                for (int c = 0; c < 3; c++) trajLog << "," << acc0[c * n + k];
+                for (int c = 0; c < 3; c++) trajLog << "," << grav[c * n + k];
+                for (int c = 0; c < 3; c++) trajLog << "," << goalCam[c * n + k];
+                for (int c = 0; c < 7; c++) trajLog << "," << fl.imagePose[c];
+                trajLog << "\n";
+              }
+            }
+          }
+        }
+      }
+      for (int64_t i = 0; i < N; i++) {                                        // :554-638 for every vehicle
+        Vec3d cmdAngVel;
+        double cmdThrust;
+        const agrifly_cli::Estimate &estState = estStates[(size_t)i];
+        Flight &fl = flight[(size_t)i];
+        const Vec3d offset(0, lineUp * (double)i, 0);
+        Vec3d wantPos = desiredPosition + offset, wantVel(0, 0, 0);
+        if (!flying) {                                                         // :623-627
+          ctrl.Run(estState.pos, estState.vel, estState.att, wantPos, Vec3d(0, 0, 0),
+                   Vec3d(0, 0, 0), desYawAngleDeg * M_PI / 180.0, cmdAngVel, cmdThrust);
+        } else {
+          Vec3d wantAcc(0, 0, 0), wantAngVel(0, 0, 0);
+          double wantThrust = 9.81;    // (the reference reads an uninitialised double here until the first plan)
+          if (!fl.planned) wantPos = noTrajectoryYet + offset;                 // :553-556
+          else {                                                               // :558-607
+            double traj_t = t.GetSeconds<double>() - fl.trajStart;
+            Vec3d trajPos, trajVel, trajAcc;
+            if (traj_t < fl.traj.duration) {
+              traj_t += 0.04;
+              trajPos = fl.traj.Position(traj_t);
+              trajVel = fl.traj.Velocity(traj_t);
+              trajAcc = fl.traj.Acceleration(traj_t);
+            } else {
+              trajPos = fl.traj.Position(fl.traj.duration);
+              trajVel = Vec3d(0, 0, 0);
+              trajAcc = Vec3d(0, 0, 0);
+            }
+            if (trajPos.z < 0) {       // never backwards, behind the camera
+              trajPos.z = 0;
+              if (trajVel.z < 0) trajVel.z = 0;
+              if (trajAcc.z < 0) trajAcc.z = 0;
+            }
+            wantPos = fl.trajAtt * trajPos + fl.trajOffset;
+            wantVel = fl.trajAtt * trajVel;
+            wantAcc = fl.trajAtt * trajAcc;
+            wantThrust = fl.traj.Thrust(traj_t);
+            wantAngVel = estState.att.Inverse() * (fl.trajAtt * fl.traj.Omega(traj_t, 0.02));
+          }
+          Rotationf cmdAtt;
+          ctrl.RunTracking(estState.pos, estState.vel, estState.att, wantPos, wantVel, wantAcc, desYawAngleDeg * M_PI / 180.0,
+                           wantThrust, wantAngVel, cmdAngVel, cmdThrust, cmdAtt);
+        }
+        fl.previousThrust = cmdThrust;                                         // :640
+        if (i == L) { desiredPositionLogged = wantPos; desiredVelocityLogged = wantVel; }
         if (useMocapEstimator)                                                 // :647-649
           est[(size_t)i].Announce(cmdAngVel, (estState.att * Vec3d(0, 0, 1) * cmdThrust - Vec3d(0, 0, 9.81)));
         if (i == L) estLogged = useMocapEstimator ? est[(size_t)i].Predict(0) : estState;   // :699-704
@@ -221,8 +411,8 @@ int main(int argc, char **argv) {
       logfile << toCSV(Vec3f(estLogged.vel), digits);
       logfile << toCSV(Rotationf(estLogged.att).ToEulerYPR(), digits);
       logfile << toCSV(Vec3f(estLogged.angVel), digits);
-      logfile << toCSV(desiredPosition, digits);
-      logfile << toCSV(desiredVelocity, digits);
+      logfile << toCSV(desiredPositionLogged, digits);
+      logfile << toCSV(desiredVelocityLogged, digits);
       logfile << int(dataPacket.panic_reason) << ",";
       for (int i = 0; i < 4; i++) logfile << double(lastRadioCommand[i]) << ",";
       logfile << "\n";
@@ -239,6 +429,11 @@ int main(int argc, char **argv) {
   afe_time_us(quad, &now);
   std::printf("Done. %lld vehicle(s), engine clock %.6f s, %llu logic ticks\n", (long long)N, now * 1e-6, (unsigned long long)ticks);
   logfile.close();
+  if (scene) {
+    std::printf("%d trajectories planned for vehicle %lld\n", plannedTrajCount, (long long)L);
+    afe_device_free(depthImages);
+    afe_scene_destroy(scene);
+  }
   afe_destroy(quad);
   return 0;
 }

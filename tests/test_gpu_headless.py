@@ -167,3 +167,90 @@ def test_reference_defaults_and_an_ensemble(tmp_path):
     assert a.shape == b.shape and np.isfinite(a).all() and np.isfinite(b).all()
     assert not np.array_equal(a[:, 10:13], b[:, 10:13])            # different noise streams, different body rates
     assert abs(a[-1, 3] - b[-1, 3]) < 0.05                         # same climb
+
+
+def test_flight_branch_renders_plans_and_tracks_on_the_gpu(tmp_path):
+    """--scene: the branch of the loop the reference runs after startFlightTime (main.cpp:478-608) -- a depth image
+    per camera period from the engine's own camera, DepthImagePlanner on every ready image, the planned trajectory
+    tracked with RunTracking.  One vehicle takes off in an aisle of the procedural orchard and flies down it.
+    Checked: (i) the glue -- every plan in PlannedTrajectory.csv is reproduced EXACTLY by rendering the logged
+    pose and planning on the logged inputs through the Python binding (same image, same winner, same eighteen
+    coefficients); (ii) the flight -- it makes way towards the goal and never comes near a trunk or a canopy;
+    (iii) the run is reproducible bit for bit."""
+    import torch  # noqa: F401
+    from tests.orchard_flight import clearance
+    tris, layout = afa.scenarios.orchard_mesh(rows=4, cols=8, seed=3, return_layout=True)
+    shift = np.array([5.0, -2.0, 0.0])                     # the origin (where the vehicle starts) in the first aisle, 5 m before the trees
+    tris = (tris.reshape(-1, 3, 3) + shift).reshape(-1, 9).astype(np.float32)
+    layout = layout.copy()
+    layout[:, 0:2] += shift[:2]
+    layout[:, 4:7] += shift
+    mesh = tmp_path / "orchard.f32"
+    tris.tofile(str(mesh))
+    goal = [5.0 + 7 * 3.0 + 8.0, 0.0, 1.2]
+    args = ["--scene", mesh, "--goal"] + goal + ["--hover", 1.2, "--start-flight", 2.0, "--seconds", 9.0, "--dt-us", 1000,
+                                                   "--candidates", 192, "--digits", 17, "--estimator", "truth"]
+    rows, txt = _run(tmp_path, *(args + ["--traj-log", tmp_path / "traj.csv"]))
+    n_planned = int([l for l in txt.split("\n") if "trajectories planned" in l][0].split()[0])
+    plans = np.loadtxt(str(tmp_path / "traj.csv"), delimiter=",", ndmin=2)
+    assert n_planned == len(plans) >= 20 and (plans[:, 0] == np.arange(1, n_planned + 1)).all()
+    # (i) the glue, plan by plan (every third: the checker side renders one view per call)
+    scene = afa.Scene(tris)
+    cam, mount = afa.camera_default(320, 240), afa.camera_default_mount()
+    p = afa.params_from_type(5)
+    cfg = afa.planner_default_config(320, 240, cam.depth_scale, cam.focal_length, 2 * p.arm_length, 3 * p.arm_length, 0.5)
+    cfg.cost_type = 1
+    samples = afa.planner_samples(0, 320, 240, 192)
+    for row in plans[::3]:
+        coeffs, t_plan, best = row[1:19].reshape(6, 3), row[27], int(row[28])
+        vel_c, acc_c, grav_c, goal_c, pose = row[29:32], row[32:35], row[35:38], row[38:41], row[41:48]
+        assert t_plan > 2.0 and row[25] == 0.0
+        img, _ = scene.render(cam, pose[:3, None], pose[3:, None], mount)
+        out, _, _ = afa.rappids_plan(cfg, np.asarray(img).reshape(1, 240, 320), vel_c[:, None], acc_c[:, None], grav_c[:, None], samples,
+                                     cost_vec=goal_c[:, None])
+        assert out[0].found and out[0].best_index == best
+        assert np.array_equal(np.array(out[0].coeffs), coeffs) and out[0].tf == row[26]
+    # (ii) the flight
+    pos = rows[:, 1:4].T
+    trunk, canopy = clearance(layout, pos)
+    after = rows[:, 0] > 2.5
+    # physicalVehicleRadius = 2 * armLength (main.cpp:167); outside every canopy ellipsoid
+    assert trunk[after].min() > 0.116 and canopy[after].min() > 1.0, (trunk[after].min(), canopy[after].min())
+    assert pos[0, -1] > 6.0 and pos[0].max() == pytest.approx(pos[0, -1], abs=0.5)      # it went in, and kept going
+    # (the planner's cost is progress towards the goal; nothing holds the altitude, the ground is an obstacle like any other)
+    assert pos[2, after].min() > 0.15 and pos[2, after].max() < 2.5 and np.abs(pos[1, after]).max() < 1.9, (pos[2, after].min(), pos[2, after].max(), np.abs(pos[1, after]).max())
+    print('flight branch: x %.2f m after 9 s, z %.2f..%.2f, |y| max %.2f, %d plans, trunk %.3f m, canopy %.2f' % (pos[0, -1], pos[2, after].min(), pos[2, after].max(), np.abs(pos[1, after]).max(), n_planned, trunk[after].min(), canopy[after].min()))
+    assert np.isfinite(rows).all()
+    # desired position / velocity columns follow the trajectory once there is one
+    assert np.abs(rows[after, 29:32] - rows[after, 1:4]).max() < 1.0 and np.abs(rows[after, 32]).max() > 0.2
+    MEASUREMENTS["headless_flight_branch"] = {"plans": n_planned, "x_after_9s": float(pos[0, -1]), "min_trunk_clearance_m": float(trunk[after].min()),
+                                              "min_canopy_level": float(canopy[after].min())}
+    # (iii) again: the same bytes
+    first = open(str(tmp_path / "simulation.csv")).read()
+    _run(tmp_path, *args)
+    assert open(str(tmp_path / "simulation.csv")).read() == first
+
+
+def test_flight_branch_with_the_estimator_and_several_vehicles(tmp_path):
+    """the same branch as the program runs it by default -- planning and tracking on the mocap estimator's 30 ms
+    prediction -- for three vehicles in three aisles at once (one render, one planner launch for all of them)"""
+    import torch  # noqa: F401
+    from tests.orchard_flight import clearance
+    tris, layout = afa.scenarios.orchard_mesh(rows=4, cols=8, seed=3, return_layout=True)
+    shift = np.array([5.0, -2.0, 0.0])
+    tris = (tris.reshape(-1, 3, 3) + shift).reshape(-1, 9).astype(np.float32)
+    layout = layout.copy()
+    layout[:, 0:2] += shift[:2]
+    layout[:, 4:7] += shift
+    mesh = tmp_path / "orchard.f32"
+    tris.tofile(str(mesh))
+    for logged in (0, 2):
+        rows, txt = _run(tmp_path, "--scene", mesh, "--goal", 34.0, 0.0, 1.2, "--hover", 1.2, "--start-flight", 2.0, "--seconds", 7.0,
+                         "--dt-us", 1000, "--candidates", 128, "--digits", 12, "--vehicles", 3, "--line-up", 4.0, "--log-vehicle", logged)
+        pos = rows[:, 1:4].T
+        after = rows[:, 0] > 2.5
+        trunk, canopy = clearance(layout, pos)
+        assert int([l for l in txt.split("\n") if "trajectories planned" in l][0].split()[0]) > 50
+        assert trunk[after].min() > 0.116 and canopy[after].min() > 1.0
+        assert pos[0, -1] > 4.0 and np.abs(pos[1, after] - 4.0 * logged).max() < 1.9
+        assert np.abs(rows[50:, 17:20] - rows[50:, 1:4]).max() < 0.05        # the estimate columns: an estimate, and a good one
