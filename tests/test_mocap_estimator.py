@@ -127,3 +127,80 @@ def test_cpp_controller_equals_the_numpy_restatement_bit_for_bit(tmp_path):
         got = np.array([th[0], w[0, 0], w[1, 0], w[2, 0]], np.float32)
         mism += not np.array_equal(got, cpp[i])
     assert mism == 0
+
+
+TRACKING_DRIVER = r'''
+#include <cstdio>
+#include "hover_controller.hpp"
+#include "planned_trajectory.hpp"
+int main() {
+  agrifly_cli::HoverController ctrl;
+  double in[45];
+  for (;;) {
+    int got = 0;
+    for (int k = 0; k < 45; k++) got += std::scanf("%lf", in + k) == 1;
+    if (got != 45) break;
+    agrifly_cli::PlannedTrajectory tr;
+    for (int q = 0; q < 6; q++) for (int a = 0; a < 3; a++) tr.c[q][a] = in[3 * q + a];
+    tr.gravity = Vec3d(in[18], in[19], in[20]);
+    const double t = in[21];
+    const Vec3d p = tr.Position(t), v = tr.Velocity(t), a = tr.Acceleration(t), w = tr.Omega(t, 0.02);
+    std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g", p.x, p.y, p.z, v.x, v.y, v.z, a.x, a.y, a.z,
+                tr.Thrust(t), w.x, w.y, w.z);
+    Vec3d cmdW; double cmdT; Rotationf cmdAtt;
+    ctrl.RunTracking(Vec3d(in[22], in[23], in[24]), Vec3d(in[25], in[26], in[27]), Rotationd(in[28], in[29], in[30], in[31]),
+                     Vec3d(in[32], in[33], in[34]), Vec3d(in[35], in[36], in[37]), Vec3d(in[38], in[39], in[40]), 0.0, in[41],
+                     Vec3d(in[42], in[43], in[44]), cmdW, cmdT, cmdAtt);
+    std::printf(" %.9g %.9g %.9g %.9g\n", cmdT, cmdW.x, cmdW.y, cmdW.z);
+  }
+  return 0;
+}
+'''
+
+
+def test_cpp_tracking_equals_the_numpy_restatement(tmp_path):
+    """agri-fly_amd/cli/planned_trajectory.hpp and HoverController::RunTracking against the numpy driver of the GPU
+    system tests (tests/orchard_flight.py: poly_eval, traj_omega, run_tracking -- the restatements of
+    RapidTrajectoryGenerator's evaluation and QuadcopterController::RunTracking the in-loop tests fly with), on
+    1 000 random trajectories and states.  The polynomials agree exactly; the angles go through numpy's own
+    arccos on one side and glibc's on the other, hence an ulp or two of slack there.  ASan + UBSan on the C++ side."""
+    import numpy as np
+    from tests.orchard_flight import poly_eval, run_tracking, traj_omega
+    src = tmp_path / "track.cpp"
+    src.write_text(TRACKING_DRIVER)
+    exe = tmp_path / "track"
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "agri-fly_amd", "cli"),
+                           str(src), "-o", str(exe)])
+    rng = np.random.default_rng(31)
+    n = 1000
+    coeffs = rng.normal(0, 1.0, (n, 6, 3)) * np.array([0.05, 0.1, 0.3, 0.5, 1.0, 1.0])[None, :, None]
+    grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n)) + rng.normal(0, 0.5, (3, n))
+    t = rng.uniform(0, 2.0, n)
+    pos, vel = rng.normal(0, 2.0, (3, n)), rng.normal(0, 1.0, (3, n))
+    q = rng.normal(size=(4, n)) * np.array([[1.0], [0.3], [0.3], [0.3]])
+    q /= np.linalg.norm(q, axis=0)
+    ref_pos, ref_vel, ref_acc = pos + rng.normal(0, 0.5, (3, n)), rng.normal(0, 1.0, (3, n)), rng.normal(0, 2.0, (3, n))
+    ref_thrust, ref_w = rng.uniform(5, 15, n), rng.normal(0, 1.0, (3, n))
+    ref_acc[:, 3] = -np.array([0.0, 0.0, 9.81]) - (ref_pos[:, 3] - pos[:, 3]) * 4 - (ref_vel[:, 3] - vel[:, 3]) * 2.8   # a vanishing proper acceleration
+    text = ""
+    for i in range(n):
+        vals = np.concatenate([coeffs[i].ravel(), grav[:, i], [t[i]], pos[:, i], vel[:, i], q[:, i], ref_pos[:, i], ref_vel[:, i], ref_acc[:, i],
+                               [ref_thrust[i]], ref_w[:, i]])
+        text += " ".join("%.17g" % x for x in vals) + "\n"
+    out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    cpp = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().split("\n")])
+    assert cpp.shape == (n, 17)
+    p, v, a = poly_eval(coeffs, t)
+    assert np.array_equal(cpp[:, 0:3], p.T) and np.array_equal(cpp[:, 3:6], v.T) and np.array_equal(cpp[:, 6:9], a.T)
+    thrust = np.sqrt(((a - grav) ** 2).sum(0))
+    np.testing.assert_allclose(cpp[:, 9], thrust, rtol=4e-16)
+    np.testing.assert_allclose(cpp[:, 10:13], traj_omega(coeffs, grav, t).T, rtol=1e-9, atol=1e-12)
+    th, w = run_tracking(pos, vel, q, ref_pos, ref_vel, ref_acc, ref_thrust, ref_w)
+    ok = np.ones(n, bool)
+    ok[3] = False                                   # 0 / 0 in the thrust direction: both sides say NaN, in their own way
+    # (the thrust: the C++ side adds the float correction to the double feed-forward like the reference, the numpy driver in float)
+    np.testing.assert_allclose(cpp[ok, 13], th[ok], rtol=3e-7, atol=2e-6)
+    np.testing.assert_allclose(cpp[ok, 14:17], w[:, ok].T, rtol=2e-5, atol=2e-5)
+    assert np.median(np.abs(cpp[ok, 14:17] - w[:, ok].T)) < 1e-6      # float ulps of rates of a few rad/s
