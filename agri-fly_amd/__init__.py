@@ -41,6 +41,7 @@ from .engine import (  # noqa: F401
     params_from_type,
     plan_ticks,
     planner_default_config,
+    planner_release_scratch,
     planner_samples,
     plans_as_array,
     rappids_plan,

@@ -3,6 +3,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <random>
 #include <vector>
 
@@ -51,13 +52,61 @@ extern "C" int afe_planner_samples(uint32_t seed, int width, int height, int n, 
 }
 
 namespace {
+// Device scratch of a plan call.  A call needs fifteen buffers (for config 3: 0.5 GB of pyramids, 1.5 GB of
+// candidate sections, ...); allocating and freeing them every call costs milliseconds at 30 plans a second, so the
+// library keeps them between calls -- one set per process, grown on demand, on the device of the last call -- and
+// plan calls take turns on it (they would take turns on the GPU anyway).  afe_planner_release_scratch() gives the
+// memory back.
+struct ScratchSlot {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+std::mutex g_scratch_mutex;
+ScratchSlot g_scratch[16];
+int g_scratch_device = -1;
+
+void release_scratch_locked() {
+  if (g_scratch_device >= 0) (void)hipSetDevice(g_scratch_device);
+  for (ScratchSlot &s : g_scratch) {
+    if (s.p) (void)hipFree(s.p);
+    s.p = nullptr;
+    s.cap = 0;
+  }
+  g_scratch_device = -1;
+}
+
 struct DevBuf {
   void *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess; }
+  int slot;
+  explicit DevBuf(int slot_) : slot(slot_) {}
+  bool alloc(size_t bytes) {
+    ScratchSlot &s = g_scratch[slot];
+    if (bytes == 0) bytes = 1;
+    if (s.cap < bytes) {
+      if (s.p) (void)hipFree(s.p);
+      s.p = nullptr;
+      s.cap = 0;
+      const size_t want = bytes + bytes / 8;
+      if (hipMalloc(&s.p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&s.p, bytes) != hipSuccess) { s.p = nullptr; return false; }
+        s.cap = bytes;
+      } else {
+        s.cap = want;
+      }
+    }
+    p = s.p;
+    return true;
+  }
   bool upload(const void *src, size_t bytes) { return alloc(bytes) && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) == hipSuccess; }
 };
 }  // namespace
+
+extern "C" int afe_planner_release_scratch(void) {
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  release_scratch_locked();
+  return AFE_OK;
+}
 
 static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const uint16_t *depth_images,
                      bool depth_on_device, int64_t n_images, const int32_t *image_index, const double *vel0,
@@ -87,8 +136,11 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
     return AFE_ERR_NO_DEVICE;
   if (hipSetDevice(device) != hipSuccess) return AFE_ERR_HIP;
 
+  std::lock_guard<std::mutex> scratch_lock(g_scratch_mutex);
+  if (g_scratch_device != device) { release_scratch_locked(); (void)hipSetDevice(device); g_scratch_device = device; }
   const size_t px = (size_t)cfg->width * cfg->height;
-  DevBuf d_img, d_imgT, d_cc, d_cb, d_cs, d_idx, d_v, d_a, d_g, d_c, d_s, d_t, d_pyr, d_out, d_flags;
+  DevBuf d_img(0), d_imgT(1), d_cc(2), d_cb(3), d_cs(4), d_idx(5), d_v(6), d_a(7), d_g(8), d_c(9), d_s(10), d_t(11), d_pyr(12), d_out(13),
+      d_flags(14);
   if ((!depth_on_device && !d_img.upload(depth_images, (size_t)n_images * px * 2)) || !d_v.upload(vel0, (size_t)n * 24) ||
       !d_a.upload(acc0, (size_t)n * 24) || !d_g.upload(grav, (size_t)n * 24) ||
       !d_s.upload(samples, (size_t)n_tables * n_candidates * 32))

@@ -36,7 +36,7 @@ ABI_FUNCTIONS = [
     "afe_radio_create_acceleration_command", "afe_radio_create_simple_command", "afe_radio_decode",
     "afe_telemetry_encode", "afe_telemetry_decode", "afe_set_commands_from_radio",
     "afe_set_max_fused_steps", "afe_set_addressing", "afe_step_kernel_info", "afe_planner_default_config", "afe_planner_samples", "afe_rappids_plan",
-    "afe_rappids_plan_device", "afe_camera_default", "afe_camera_default_mount", "afe_scene_create",
+    "afe_rappids_plan_device", "afe_planner_release_scratch", "afe_camera_default", "afe_camera_default_mount", "afe_scene_create",
     "afe_scene_destroy", "afe_scene_info", "afe_scene_set_walk", "afe_render_depth", "afe_render_depth_engine", "afe_render_depth_stats",
     "afe_device_alloc", "afe_device_free", "afe_device_download", "afe_scene_check_hierarchy",
     "afe_comm_unique_id", "afe_comm_create", "afe_comm_info", "afe_comm_destroy", "afe_comm_last_error",
@@ -249,6 +249,7 @@ def library():
         "afe_planner_samples": [C.c_uint32, ci, ci, ci, vp],
         "afe_rappids_plan": [ci, C.POINTER(PlannerConfig), i64, vp, i64, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp,
                              C.POINTER(C.c_float)],
+        "afe_planner_release_scratch": [],
         "afe_rappids_plan_device": [ci, C.POINTER(PlannerConfig), i64, vp, i64, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp,
                                     vp, C.POINTER(C.c_float)],
         "afe_camera_default": [C.POINTER(Camera), ci, ci],
@@ -356,6 +357,11 @@ def planner_samples(seed, width, height, n_candidates):
     if rc:
         raise AfeError(rc, "afe_planner_samples")
     return s
+
+
+def planner_release_scratch():
+    """afe_planner_release_scratch: give back the device scratch the planner keeps between calls"""
+    library().afe_planner_release_scratch()
 
 
 def rappids_plan(cfg, depth_images, vel0, acc0, grav, samples, image_index=None, cost_vec=None,

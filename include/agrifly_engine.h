@@ -390,6 +390,10 @@ int afe_device_alloc(int device, uint64_t bytes, void **out);
 int afe_device_free(void *p);
 int afe_device_download(void *host_dst, const void *dev_src, uint64_t bytes);
 
+/* The planner keeps its device scratch between calls (grown on demand, one set per process; plan calls take
+ * turns on it).  This gives the memory back; the next call allocates again. */
+int afe_planner_release_scratch(void);
+
 /* afe_rappids_plan with the depth images already in HBM (one per planner, or
  * indexed through image_index, which stays a host array).  The pointer must be
  * 16-byte aligned (anything from afe_device_alloc / hipMalloc is). */
