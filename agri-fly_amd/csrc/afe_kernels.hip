@@ -318,6 +318,10 @@ __device__ __forceinline__ void rotvec_to_quat(float rx, float ry, float rz,
   }
 }
 
+#ifndef AFE_LOGIC_LOADS_LATE
+#define AFE_LOGIC_LOADS_LATE 1
+#endif
+
 template <typename R> struct NormalOf { typedef double type; };
 template <> struct NormalOf<float> { typedef float type; };
 
@@ -471,19 +475,23 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   if (FEXT) { fex = AFE_LD(R, v.ext_force, 0, off); fey = AFE_LD(R, v.ext_force, 1, off); fez = AFE_LD(R, v.ext_force, 2, off); }
   if (TEXT) { tex = AFE_LD(R, v.ext_torque, 0, off); tey = AFE_LD(R, v.ext_torque, 1, off); tez = AFE_LD(R, v.ext_torque, 2, off); }
   LogicRegs lg;
-  if (LOGIC && v.tick_mask) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      lg.xm0[k] = AFE_LDL(float, v.lpf, k, off4);
-      lg.xm1[k] = AFE_LDL(float, v.lpf, 3 + k, off4);
-      lg.ym0[k] = AFE_LDL(float, v.lpf, 6 + k, off4);
-      lg.ym1[k] = AFE_LDL(float, v.lpf, 9 + k, off4);
-      lg.wdes[k] = AFE_LDL(float, v.rates_cmd, 1 + k, off4);
-    }
-    lg.thrust_norm = AFE_LDL(float, v.rates_cmd, 0, off4);
-    lg.imu_init = v.imu_init[(uint32_t)i];
-    lg.have_cmd = v.have_cmd[(uint32_t)i];
-  }
+#define AFE_LOAD_LOGIC_STATE()                                        \
+  do {                                                                \
+    _Pragma("unroll") for (int k = 0; k < 3; k++) {                   \
+      lg.xm0[k] = AFE_LDL(float, v.lpf, k, off4);                     \
+      lg.xm1[k] = AFE_LDL(float, v.lpf, 3 + k, off4);                 \
+      lg.ym0[k] = AFE_LDL(float, v.lpf, 6 + k, off4);                 \
+      lg.ym1[k] = AFE_LDL(float, v.lpf, 9 + k, off4);                 \
+      lg.wdes[k] = AFE_LDL(float, v.rates_cmd, 1 + k, off4);          \
+    }                                                                 \
+    lg.thrust_norm = AFE_LDL(float, v.rates_cmd, 0, off4);            \
+    lg.imu_init = v.imu_init[(uint32_t)i];                            \
+    lg.have_cmd = v.have_cmd[(uint32_t)i];                            \
+  } while (0)
+  // The logic's own state (filter memory, commands: 18 registers) is wanted only at the tick.  A launch of several
+  // sub-steps fetches it here with everything else; the one-step launch fetches it behind the rigid-body update
+  // (AFE_LOGIC_LOADS_LATE), where the draws and the dynamics no longer need the registers.
+  if (LOGIC && v.tick_mask && !(SINGLE && AFE_LOGIC_LOADS_LATE)) AFE_LOAD_LOGIC_STATE();
   float cmd_new[4] = {0, 0, 0, 0};
 
   const R dt = v.dt;
@@ -631,6 +639,10 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 
     // ---- onboard-logic gate fired on this sub-step: IMU synthesis ----
     if (tick) {
+      if (LOGIC && SINGLE && AFE_LOGIC_LOADS_LATE) {
+        __builtin_amdgcn_sched_barrier(0);   // or the scheduler hoists the loads back to the top, registers and all
+        AFE_LOAD_LOGIC_STATE();
+      }
       float tx_, ty_, tz_;
       mat_vec<float>(P.Rimu, (float)wx, (float)wy, (float)wz, tx_, ty_, tz_);  // :165-166
       gx = tx_ + ng[0]; gy = ty_ + ng[1]; gz = tz_ + ng[2];                    // :167-170
@@ -682,6 +694,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #undef AFE_LD
 #undef AFE_ST
 #undef AFE_LDL
+#undef AFE_LOAD_LOGIC_STATE
 #undef AFE_STL
 #undef AFE_SOFF
 }
