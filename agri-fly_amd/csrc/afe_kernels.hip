@@ -637,6 +637,14 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     q0 = n0; q1 = n1; q2 = n2; q3 = n3;
     wx = nwx; wy = nwy; wz = nwz;
 
+    // The one-step logic launch writes the rigid-body state back as soon as it is final instead of at the end:
+    // the registers are then free for the logic's own state (AFE_LOGIC_LOADS_LATE).
+    if (LOGIC && SINGLE && AFE_LOGIC_LOADS_LATE) {
+      AFE_ST(R, v.pos, 0, off, px); AFE_ST(R, v.pos, 1, off, py); AFE_ST(R, v.pos, 2, off, pz);
+      AFE_ST(R, v.vel, 0, off, vx); AFE_ST(R, v.vel, 1, off, vy); AFE_ST(R, v.vel, 2, off, vz);
+      AFE_ST(R, v.att, 0, off, q0); AFE_ST(R, v.att, 1, off, q1); AFE_ST(R, v.att, 2, off, q2); AFE_ST(R, v.att, 3, off, q3);
+      AFE_ST(R, v.ang_vel, 0, off, wx); AFE_ST(R, v.ang_vel, 1, off, wy); AFE_ST(R, v.ang_vel, 2, off, wz);
+    }
     // ---- onboard-logic gate fired on this sub-step: IMU synthesis ----
     if (tick) {
       if (LOGIC && SINGLE && AFE_LOGIC_LOADS_LATE) {
@@ -667,10 +675,12 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   }
 
   // ---- write back (in place: same lines this lane just read) ----
-  AFE_ST(R, v.pos, 0, off, px); AFE_ST(R, v.pos, 1, off, py); AFE_ST(R, v.pos, 2, off, pz);
-  AFE_ST(R, v.vel, 0, off, vx); AFE_ST(R, v.vel, 1, off, vy); AFE_ST(R, v.vel, 2, off, vz);
-  AFE_ST(R, v.att, 0, off, q0); AFE_ST(R, v.att, 1, off, q1); AFE_ST(R, v.att, 2, off, q2); AFE_ST(R, v.att, 3, off, q3);
-  AFE_ST(R, v.ang_vel, 0, off, wx); AFE_ST(R, v.ang_vel, 1, off, wy); AFE_ST(R, v.ang_vel, 2, off, wz);
+  if (!(LOGIC && SINGLE && AFE_LOGIC_LOADS_LATE)) {
+    AFE_ST(R, v.pos, 0, off, px); AFE_ST(R, v.pos, 1, off, py); AFE_ST(R, v.pos, 2, off, pz);
+    AFE_ST(R, v.vel, 0, off, vx); AFE_ST(R, v.vel, 1, off, vy); AFE_ST(R, v.vel, 2, off, vz);
+    AFE_ST(R, v.att, 0, off, q0); AFE_ST(R, v.att, 1, off, q1); AFE_ST(R, v.att, 2, off, q2); AFE_ST(R, v.att, 3, off, q3);
+    AFE_ST(R, v.ang_vel, 0, off, wx); AFE_ST(R, v.ang_vel, 1, off, wy); AFE_ST(R, v.ang_vel, 2, off, wz);
+  }
   if (v.motor_write) {  // wave-uniform; off for stateless motors driven by held commands (see afe_motor_from_cmd_kernel)
     AFE_ST(R, v.motor, 0, off, ms[0]); AFE_ST(R, v.motor, 1, off, ms[1]); AFE_ST(R, v.motor, 2, off, ms[2]); AFE_ST(R, v.motor, 3, off, ms[3]);
   }
