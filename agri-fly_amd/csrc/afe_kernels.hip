@@ -58,6 +58,10 @@ __device__ __forceinline__ void mat_vec(const M *A, R x, R y, R z, R &ox, R &oy,
 }
 
 // ---------------------------------------------------------------------------
+#ifndef AFE_ACCEPT_LOOP
+#define AFE_ACCEPT_LOOP 2   // 1: the first form of the acceptance loop (selects on a slot number), kept for A/B timing
+#endif
+
 // IMU noise: std::minstd_rand0 + libstdc++ std::normal_distribution<double>
 // (reference Quadcopter_T.hpp:122-123; bits/random.tcc), always in double.
 __device__ __forceinline__ uint32_t minstd_next(uint32_t &s) {
@@ -191,6 +195,44 @@ __device__ __forceinline__ void polar_candidate(uint32_t &s, double &x, double &
 //     integer and fp32 only.
 __device__ __forceinline__ void three_accepted(uint32_t &s, uint32_t &st0, uint32_t &st1, uint32_t &st2) {
 #pragma clang fp contract(off)
+#if AFE_ACCEPT_LOOP == 2
+  // Second form (same decisions, same words).  Issue cost, not instruction count, is what the tick launch is
+  // bound by, and on this chip a compare (it writes a scalar mask) costs 2.4x and a select 1.8x a plain integer
+  // instruction (tools/valu_rate_probe.hip).  So: the two-sided range test is ONE unsigned compare on the float's
+  // bit pattern (r2~ >= 0: bit patterns order like the values); "too close to call" is one more; and the three
+  // words are kept as a shift register that accepted lanes push into under the execution mask (three moves)
+  // instead of three compare + select pairs on a slot number.
+  st0 = s; st1 = s; st2 = s;   // after the loop: the engine word before the 1st / 2nd / 3rd accepted candidate
+  int got = 0;
+  const uint32_t kLo = __builtin_bit_cast(uint32_t, 1e-5f), kUp = __builtin_bit_cast(uint32_t, 1.0f - 1e-5f),
+                 kTop = __builtin_bit_cast(uint32_t, 1.0f + 1e-5f);
+  for (;;) {
+    const uint32_t before = s;
+    const uint32_t hx = minstd_mul(before, 282475249u);    // 16807^2
+    const uint32_t hy = minstd_mul(before, 984943658u);    // 16807^4 mod (2^31 - 1)
+    s = hy;
+    const float kInvR = 1.0f / 2147483646.0f;
+    const float xf = __builtin_fmaf((float)(hx - 1u), 2.0f * kInvR, -1.0f);
+    const float yf = __builtin_fmaf((float)(hy - 1u), 2.0f * kInvR, -1.0f);
+    const uint32_t rb = __builtin_bit_cast(uint32_t, __builtin_fmaf(xf, xf, yf * yf));
+    bool accept = (rb - (kLo + 1u)) < (kUp - kLo - 1u);     // 1e-5 < r2~ < 1 - 1e-5
+    const bool unsure = !accept && rb <= kTop;              // r2~ <= 1e-5, or within 1e-5 of 1: fp32 cannot tell
+    if (__ballot(unsure)) {   // wave-uniform on purpose: a real branch around the double-precision test, taken ~1e-3 of the time
+      if (unsure) {
+        uint32_t t = before;
+        asm volatile("" : "+v"(t));   // pins the double-precision test inside the branch
+        double x, y, r2;
+        polar_candidate(t, x, y, r2);
+        accept = !(r2 > 1.0 || r2 == 0.0);
+      }
+    }
+    if (accept) {   // moves under the execution mask (the asm keeps the compiler from turning them into selects)
+      asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %3" : "+v"(st0), "+v"(st1), "+v"(st2) : "v"(before));
+      got++;
+    }
+    if (got >= 3) break;
+  }
+#else
   st0 = s; st1 = s; st2 = s;   // engine word before the 1st / 2nd / 3rd accepted candidate
   int got = 0;
   while (got < 3) {
@@ -224,6 +266,7 @@ __device__ __forceinline__ void three_accepted(uint32_t &s, uint32_t &st0, uint3
     st2 = slot == 2 ? before : st2;
     got += accept ? 1 : 0;
   }
+#endif
 }
 
 // double precision throughout: the fp64 engine and the generator self-test (libstdc++'s values to 4e-15)

@@ -50,6 +50,31 @@ __global__ void __launch_bounds__(64) planar_buffer(float *base, long S, long n)
 #pragma unroll
   for (int k = 0; k < NW; k++) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k] * 1.0001f + acc), r, off, k * S4, 0);
 }
+// the same with WORK dependent-free FMAs per loaded value between the loads and the stores: what arithmetic of the
+// step kernel's size (~230 vector instructions off tick, ~800 on tick) costs a launch that streams these bytes
+template <int NRR, int NWW, int WORK>
+__global__ void __launch_bounds__(64) planar_buffer_work(float *base, long S, long n) {
+  const unsigned i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(NR * S * 4), 0x00020000);
+  const unsigned off = i * 4u;
+  const int S4 = (int)S * 4;
+  float v[NRR];
+#pragma unroll
+  for (int k = 0; k < NRR; k++) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, k * S4, 0));
+  float acc = 0;                                 // every load is used, whatever WORK is
+#pragma unroll
+  for (int k = NWW; k < NRR; k++) acc += v[k];
+#pragma unroll
+  for (int k = 0; k < NWW; k++) v[k] += acc;
+#pragma unroll
+  for (int w = 0; w < WORK; w++) {
+#pragma unroll
+    for (int k = 0; k < NWW; k++) v[k] = __builtin_fmaf(v[k], 1.0000001f, v[(k + 1 + w) % NRR] * 1e-9f);   // 2 instructions each
+  }
+#pragma unroll
+  for (int k = 0; k < NWW; k++) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), r, off, k * S4, 0);
+}
 __global__ void __launch_bounds__(64) planar64(const float *__restrict__ in, float *__restrict__ out, long S, long n) {
   const long i = (long)blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
@@ -136,6 +161,31 @@ int main(int argc, char **argv) {
       if (ms < best) best = ms;
     }
     printf("%-28s %.2f us/launch  %.0f GB/s\n", variant ? "64-lane groups, buffer rsrc" : "64-lane groups, global", best * 10, bytes / (best * 1e-5) / 1e9);
+  }
+  // 20 read + 13 write streams (132 B: the off-tick launch) and 24 + 17 (164 B: the tick launch) with 0 / ~230 / ~800
+  // vector instructions between loads and stores
+  for (int variant = 0; variant < 6; variant++) {
+    float best = 1e9;
+    for (int rep = 0; rep < 5; rep++) {
+      hipEventRecord(e0);
+      for (int it = 0; it < (n > (1 << 21) ? 20 : 100); it++) {
+        switch (variant) {
+          case 0: planar_buffer_work<20, 13, 0><<<(n + 63) / 64, 64>>>(a, S, n); break;
+          case 1: planar_buffer_work<20, 13, 9><<<(n + 63) / 64, 64>>>(a, S, n); break;     // 9 * 13 * 2 = 234
+          case 2: planar_buffer_work<20, 13, 31><<<(n + 63) / 64, 64>>>(a, S, n); break;    // 806
+          case 3: planar_buffer_work<24, 17, 0><<<(n + 63) / 64, 64>>>(a, S, n); break;
+          case 4: planar_buffer_work<24, 17, 7><<<(n + 63) / 64, 64>>>(a, S, n); break;     // 238
+          case 5: planar_buffer_work<24, 17, 24><<<(n + 63) / 64, 64>>>(a, S, n); break;    // 816
+        }
+      }
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      ms *= (n > (1 << 21) ? 5.0f : 1.0f);
+      if (ms < best) best = ms;
+    }
+    const char *names[] = {"132 B, no arithmetic", "132 B, ~230 instructions", "132 B, ~800 instructions", "164 B, no arithmetic", "164 B, ~230 instructions", "164 B, ~800 instructions"};
+    printf("%-28s %.2f us/launch\n", names[variant], best * 10);
   }
   return 0;
 }
