@@ -591,7 +591,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
         } else {
           // fp32 storage: (c old + (1 - c) cmd) - old cancels down to the rounding of a ~1e3 rad/s speed (6e-5)
           // and :78 divides that by dt -- at dt = 100 us, with J_m > 0, the rotor-acceleration torque then
-          // carries 0.6 rad/s^2 of noise per motor (found by tools/step_campaign.py: 1e-4 relative in ang_vel
+          // carries 0.6 rad/s^2 of noise per motor (found by tests/campaigns/step_campaign.py: 1e-4 relative in ang_vel
           // after 30 steps).  The increment is formed directly instead, (1 - c)(cmd - old) with 1 - c from the
           // host's double.
           w = fm(c, old, P.omc_lag * cmd[m]);

@@ -22,7 +22,7 @@ static const float RF_PI = 3.141592653589793238463;
 static const float RF_EPS = 1e-12;
 #define RF_2PI ((float)(2 * RF_PI))
 
-/* Test hook (sensitivity analysis, tools/planner_campaign.py): the k-th acos / cos / pow result of the
+/* Test hook (sensitivity analysis, tests/campaigns/planner_campaign.py): the k-th acos / cos / pow result of the
  * calling thread can be moved by a few ulps.  libm implementations differ by an ulp in these (glibc vs the
  * device's math library); a planner outcome that flips under such a nudge is one no two platforms agree on.
  * Off unless ora_planner_nudge() was called on this thread. */

@@ -1,12 +1,12 @@
 """One-off wide campaign of the batched RAPPIDS planner against the CPU checker (development tool; the test
 suite holds a 640-plan version of it): several orchards, image sizes (whole-word rows and ragged ones),
 camera heights / tilts, speeds, cost types -- every candidate's flags, the winner and the counters of EVERY
-plan must equal the checker's.   python tools/planner_campaign.py [plans_per_case]"""
+plan must equal the checker's.   python tests/campaigns/planner_campaign.py [plans_per_case]"""
 import importlib, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch  # noqa: F401
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 afa = importlib.import_module("agri-fly_amd")
 from oracle import oracle_py as ora
 

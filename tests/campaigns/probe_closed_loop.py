@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'/root/repo')
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch, numpy as np
 from tests.closed_loop import fly_engine, fly_oracle
 from tests.scenarios import afa

@@ -3,11 +3,11 @@ tests/test_gpu_parity.py::test_configuration_campaign runs a short version): ran
 motor lag, rotor inertia, CoM error, drag, IMU mount), 1..6 types laid out at random / type by type / all on
 record 0 (the three ways a parameter record reaches the kernel), random dt and logic period, wrench arrays
 on or off, IMU noise on or off under either seed policy, fused or single-step launches, ragged sizes, both
-precisions.   python tools/step_campaign.py [configurations] [seed]"""
+precisions.   python tests/campaigns/step_campaign.py [configurations] [seed]"""
 import importlib, os, sys
 import numpy as np
 import torch  # noqa: F401
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 afa = importlib.import_module("agri-fly_amd")
 from oracle import oracle_py as ora
 from tests.scenarios import FLOORS, rel_err_vec

@@ -1,11 +1,11 @@
 """Wide campaign of the uniform-grid neighbour query against the brute-force kernel (the O(N^2) definition on the
 GPU) -- random world shapes and sizes, cell sizes from absurdly small to absurdly large, shards of the ensemble,
 grids kept stale across changing worlds, non-finite positions: distances and indices must be identical for EVERY
-query.   python tools/world_campaign.py [worlds]"""
+query.   python tests/campaigns/world_campaign.py [worlds]"""
 import importlib, os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 afa = importlib.import_module("agri-fly_amd")
 
 

@@ -21,7 +21,7 @@ def _worst(log_e, log_o):
 # contains discontinuities (16-bit radio quantisation, float clamps): a 1e-7
 # difference ahead of a quantiser occasionally flips one code (1e-3 rad/s), so
 # the two runs are different realisations at the 1e-3 level in body rates while
-# staying together in position.  Measured on MI355X (tools/probe_closed_loop.py):
+# staying together in position.  Measured on MI355X (tests/campaigns/probe_closed_loop.py):
 # pos 6e-5, vel 2e-4, att 1.3e-4, ang_vel 3.7e-3 over 10 s; fp64 engine 1.4e-12.
 F32_FLIGHT_TOL = np.array([3e-4] * 3 + [1e-3] * 3 + [5e-4] * 4 + [2e-2] * 3).reshape(1, 13, 1)
 

@@ -713,7 +713,7 @@ def test_rotor_speeds_are_those_of_the_last_step_even_though_they_are_not_stored
 
 
 def test_configuration_campaign():
-    """150 random configurations x both precisions (tools/step_campaign.py): random type tables (mass, full inertia
+    """150 random configurations x both precisions (tests/campaigns/step_campaign.py): random type tables (mass, full inertia
     tensors, motor lag, rotor inertia, CoM error, drag, IMU mount), 1..6 types laid out at random / type by type /
     all on record 0 -- the three ways a parameter record reaches the kernel --, dt from 100 us to 4 ms, five logic
     periods, wrench arrays on or off, IMU noise on or off under either seed policy, fused or single-step
@@ -722,7 +722,7 @@ def test_configuration_campaign():
     shipped type) and <= 5e-5 with a lagged rotor, whose fp32 speed state limits it; RNG words and tick counts
     exact.  Vehicles the explicit integrator blows up in both (|w| dt > 0.5 rad per step) are not compared."""
     import importlib.util
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "step_campaign.py")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "campaigns", "step_campaign.py")
     spec = importlib.util.spec_from_file_location("step_campaign", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -219,7 +219,7 @@ def test_campaign_on_rendered_orchard_images(ora):
 
 def test_wide_campaign_every_mismatch_is_an_ulp_of_libm():
     """8 000 plans over four image sizes (rows of whole 64-pixel words and ragged ones), two orchards, both cost
-    types, tilts up to 35 degrees (tools/planner_campaign.py).  The planner's discrete outcome hangs on roots
+    types, tilts up to 35 degrees (tests/campaigns/planner_campaign.py).  The planner's discrete outcome hangs on roots
     that RootFinder.hpp computes with acos / cos / pow, and the device's math library and glibc differ by an
     ulp in those -- a few plans in ten thousand come out differently on ANY two platforms.  The rule here: a
     plan whose winner, candidate flags or counters differ from the checker's is accepted only if the checker
@@ -227,7 +227,7 @@ def test_wide_campaign_every_mismatch_is_an_ulp_of_libm():
     ulps (oracle hook ora_planner_nudge); anything else is a fault of the scans."""
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "planner_campaign.py")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "campaigns", "planner_campaign.py")
     spec = importlib.util.spec_from_file_location("planner_campaign", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -475,13 +475,13 @@ def test_device_view_matches_host_getters():
 
 
 def test_wide_campaign_grid_equals_brute_force_on_every_query():
-    """tools/world_campaign.py: 150 random worlds -- boxes at three scales, flats, clusters, lines, duplicates,
+    """tests/campaigns/world_campaign.py: 150 random worlds -- boxes at three scales, flats, clusters, lines, duplicates,
     lattices (all ties), two densities 1e5 apart, shells; 1 to 60 000 vehicles; non-finite positions and fly-aways;
     cell sizes from 1 mm to 10 km; shards of the ensemble; grids shaped on a DIFFERENT world and kept -- the grid
     query must return the brute-force kernel's distance bits and index for every single query."""
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "world_campaign.py")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "campaigns", "world_campaign.py")
     spec = importlib.util.spec_from_file_location("world_campaign", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
