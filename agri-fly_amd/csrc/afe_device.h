@@ -60,6 +60,7 @@ struct StepView {
   const DevParams<R> *table;
   int n_types;
   int64_t n;
+  int64_t first, end;   // this launch steps vehicles [first, end) of the n (afe_set_split_stepping: the two halves on two streams)
   int64_t stride;
   R dt;
   R inv_dt;  // 1/dt evaluated in double on the host

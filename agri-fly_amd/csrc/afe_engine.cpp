@@ -23,6 +23,12 @@ struct afe_engine {
   int64_t first_global = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  // afe_set_split_stepping(2): the second half of the ensemble steps on `side_stream`; `split_dirty`: it holds steps
+  // the main stream has not been ordered after yet (join_streams does that; everything but afe_step goes through it)
+  int split_parts = 1;
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  bool split_dirty = false;
 
   // device slabs
   void *arena = nullptr;
@@ -76,6 +82,11 @@ struct afe_engine {
 };
 
 namespace {
+void join_streams(afe_engine *e);
+hipStream_t main_stream(afe_engine *e);
+}  // namespace
+
+namespace {
 
 inline size_t elem(const afe_engine *e) { return e->precision == AFE_F64 ? 8 : 4; }
 
@@ -104,15 +115,15 @@ int check_range(afe_engine *e, int64_t first, int64_t count) {
 int copy_in(afe_engine *e, void *dev, size_t esz, int comps, int64_t first, int64_t count, const void *host) {
   if (!host || count == 0) return AFE_OK;
   AFE_HIP(e, hipMemcpy2DAsync((char *)dev + first * esz, e->stride * esz, host, count * esz,
-                              count * esz, comps, hipMemcpyHostToDevice, e->stream));
-  AFE_HIP(e, hipStreamSynchronize(e->stream));  // host buffer may be reused by the caller
+                              count * esz, comps, hipMemcpyHostToDevice, main_stream(e)));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));  // host buffer may be reused by the caller
   return AFE_OK;
 }
 int copy_out(afe_engine *e, const void *dev, size_t esz, int comps, int64_t first, int64_t count, void *host) {
   if (!host || count == 0) return AFE_OK;
   AFE_HIP(e, hipMemcpy2DAsync(host, count * esz, (const char *)dev + first * esz, e->stride * esz,
-                              count * esz, comps, hipMemcpyDeviceToHost, e->stream));
-  AFE_HIP(e, hipStreamSynchronize(e->stream));
+                              count * esz, comps, hipMemcpyDeviceToHost, main_stream(e)));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   return AFE_OK;
 }
 
@@ -189,7 +200,7 @@ int set_wrench(afe_engine *e, void *dev, bool &flag, int64_t first, int64_t coun
   AFE_HIP(e, hipSetDevice(e->device));
   if (!w3) {
     const size_t esz = elem(e);
-    AFE_HIP(e, hipMemset2DAsync((char *)dev + first * esz, e->stride * esz, 0, count * esz, 3, e->stream));
+    AFE_HIP(e, hipMemset2DAsync((char *)dev + first * esz, e->stride * esz, 0, count * esz, 3, main_stream(e)));
     return AFE_OK;
   }
   flag = true;
@@ -205,14 +216,14 @@ int refresh_table(afe_engine *e, double dt) {
     std::vector<DevParams<double>> &t = e->table_f64;
     t.resize(n);
     for (size_t k = 0; k < n; k++) to_device_params<double>(e->table[k], dt, t[k]);
-    AFE_HIP(e, hipMemcpyAsync(e->dev_table, t.data(), n * sizeof(t[0]), hipMemcpyHostToDevice, e->stream));
-    AFE_HIP(e, hipStreamSynchronize(e->stream));
+    AFE_HIP(e, hipMemcpyAsync(e->dev_table, t.data(), n * sizeof(t[0]), hipMemcpyHostToDevice, main_stream(e)));
+    AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   } else {
     std::vector<DevParams<float>> &t = e->table_f32;
     t.resize(n);
     for (size_t k = 0; k < n; k++) to_device_params<float>(e->table[k], dt, t[k]);
-    AFE_HIP(e, hipMemcpyAsync(e->dev_table, t.data(), n * sizeof(t[0]), hipMemcpyHostToDevice, e->stream));
-    AFE_HIP(e, hipStreamSynchronize(e->stream));
+    AFE_HIP(e, hipMemcpyAsync(e->dev_table, t.data(), n * sizeof(t[0]), hipMemcpyHostToDevice, main_stream(e)));
+    AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   }
   e->table_dt = dt;
   e->table_dirty = false;
@@ -230,8 +241,8 @@ int refresh_logic(afe_engine *e) {
     int rc = expand_logic(e->logic_params[k], period, e->logic_table[k], &why);
     if (rc) return fail(e, rc, "logic type " + std::to_string(k) + ": " + why);
   }
-  AFE_HIP(e, hipMemcpyAsync(e->dev_logic_table, e->logic_table.data(), n * sizeof(DevLogic), hipMemcpyHostToDevice, e->stream));
-  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  AFE_HIP(e, hipMemcpyAsync(e->dev_logic_table, e->logic_table.data(), n * sizeof(DevLogic), hipMemcpyHostToDevice, main_stream(e)));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   e->logic_table_period = period;
   return AFE_OK;
 }
@@ -252,9 +263,9 @@ int materialize_motor(afe_engine *e) {
   // the device table holds the parameters the last step ran with (refresh_table precedes every launch)
   const int lrc = e->precision == AFE_F64
       ? launch_motor_from_cmd_f64((double *)e->motor, e->cmd, e->types_uniform ? nullptr : e->type,
-                                  (const DevParams<double> *)e->dev_table, e->stride, e->n, e->stream)
+                                  (const DevParams<double> *)e->dev_table, e->stride, e->n, main_stream(e))
       : launch_motor_from_cmd_f32((float *)e->motor, e->cmd, e->types_uniform ? nullptr : e->type,
-                                  (const DevParams<float> *)e->dev_table, e->stride, e->n, e->stream);
+                                  (const DevParams<float> *)e->dev_table, e->stride, e->n, main_stream(e));
   if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("rotor-speed rebuild: ") + hipGetErrorString((hipError_t)lrc));
   e->motor_stale = false;
   return AFE_OK;
@@ -273,6 +284,7 @@ void fill_view(const afe_engine *e, StepView<R> &v) {
   v.table = (const DevParams<R> *)e->dev_table;
   v.n_types = (int)e->table.size();
   v.n = e->n; v.stride = e->stride;
+  v.first = 0; v.end = e->n;
   v.motor_stateless = motors_stateless(e);
   v.motor_write = !motor_lazy(e);
   v.sigma_gyro = (float)e->sigma_gyro;  // float(_stdDevRateGyroNoise), Quadcopter_T.cpp:170
@@ -282,6 +294,19 @@ void fill_view(const afe_engine *e, StepView<R> &v) {
   const bool fits = !e->force_global_addressing && e->arena_bytes < 0xffff0000ull && lbytes < 0xffff0000ull;
   v.buf_bytes = fits ? (uint32_t)e->arena_bytes : 0u;
   v.logic_buf_bytes = fits ? (uint32_t)lbytes : 0u;
+}
+
+// Orders the main stream after whatever the side stream still holds (split stepping).  Cheap when nothing is
+// pending.  Every entry point that touches device state or the stream reaches it through main_stream().
+void join_streams(afe_engine *e) {
+  if (!e->split_dirty) return;
+  e->split_dirty = false;
+  if (hipEventRecord(e->ev_side, e->side_stream) == hipSuccess) (void)hipStreamWaitEvent(e->stream, e->ev_side, 0);
+  else (void)hipStreamSynchronize(e->side_stream);
+}
+hipStream_t main_stream(afe_engine *e) {
+  join_streams(e);
+  return e->stream;
 }
 
 }  // namespace
@@ -335,7 +360,7 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
   const size_t bytes = S * (17 + 6) * es + S * (4 + 6) * 4 + S * 4 + S + 256 * sizeof(DevParams<double>);
   if ((err = hipMalloc(&e->arena, bytes)) != hipSuccess) return bail("hipMalloc", err);
   e->arena_bytes = bytes;
-  if ((err = hipMemsetAsync(e->arena, 0, bytes, e->stream)) != hipSuccess) return bail("hipMemset", err);
+  if ((err = hipMemsetAsync(e->arena, 0, bytes, main_stream(e))) != hipSuccess) return bail("hipMemset", err);
   char *p = (char *)e->arena;
   auto carve = [&](size_t nbytes) { void *r = p; p += nbytes; return r; };
   e->pos = carve(3 * S * es);
@@ -359,13 +384,13 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
       if (precision == AFE_F64) ((double *)ones.data())[k] = 1.0;
       else ((float *)ones.data())[k] = 1.0f;
     }
-    if ((err = hipMemcpyAsync(e->att, ones.data(), S * es, hipMemcpyHostToDevice, e->stream)) != hipSuccess)
+    if ((err = hipMemcpyAsync(e->att, ones.data(), S * es, hipMemcpyHostToDevice, main_stream(e))) != hipSuccess)
       return bail("hipMemcpy", err);
-    if ((err = hipStreamSynchronize(e->stream)) != hipSuccess) return bail("hipStreamSynchronize", err);
+    if ((err = hipStreamSynchronize(main_stream(e))) != hipSuccess) return bail("hipStreamSynchronize", err);
   }
-  if (launch_seed_rng(e->rng, e->n, e->first_global, e->seed_policy, e->stream) != 0)
+  if (launch_seed_rng(e->rng, e->n, e->first_global, e->seed_policy, main_stream(e)) != 0)
     return bail("seed kernel launch (is the gfx950 code object present?)", hipGetLastError());
-  if ((err = hipStreamSynchronize(e->stream)) != hipSuccess) return bail("seed kernel", err);
+  if ((err = hipStreamSynchronize(main_stream(e))) != hipSuccess) return bail("seed kernel", err);
   *out = e;
   return AFE_OK;
 }
@@ -373,7 +398,11 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
 extern "C" int afe_destroy(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   (void)hipSetDevice(e->device);
+  if (e->side_stream) (void)hipStreamSynchronize(e->side_stream);
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+  if (e->ev_main) (void)hipEventDestroy(e->ev_main);
+  if (e->ev_side) (void)hipEventDestroy(e->ev_side);
+  if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
   if (e->world) world_destroy(e->world);
   if (e->pack_scratch) (void)hipFree(e->pack_scratch);
   if (e->logic_arena) (void)hipFree(e->logic_arena);
@@ -388,7 +417,7 @@ extern "C" const char *afe_last_error(const afe_engine *e) { return e ? e->err.c
 extern "C" int afe_set_stream(afe_engine *e, void *hip_stream) {
   if (!e) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
-  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));   // (joins the side stream first)
   e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
   return AFE_OK;
 }
@@ -449,8 +478,8 @@ extern "C" int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count
       return fail(e, AFE_ERR_INVALID_ARG, "type index " + std::to_string(type_index[k]) + " of vehicle " +
                                               std::to_string(first + k) + " is outside the type table");
   AFE_HIP(e, hipSetDevice(e->device));
-  AFE_HIP(e, hipMemcpyAsync(e->type + first, type_index, (size_t)count, hipMemcpyHostToDevice, e->stream));
-  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  AFE_HIP(e, hipMemcpyAsync(e->type + first, type_index, (size_t)count, hipMemcpyHostToDevice, main_stream(e)));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   if (e->type_host.size() != (size_t)e->n) e->type_host.assign((size_t)e->n, 0);
   std::memcpy(e->type_host.data() + first, type_index, (size_t)count);
   refresh_type_flags(e, first, count);
@@ -473,7 +502,7 @@ extern "C" int afe_set_imu_noise(afe_engine *e, int enabled, double sigma_gyro, 
   if (seed_policy != e->seed_policy) {
     e->seed_policy = seed_policy;
     AFE_HIP(e, hipSetDevice(e->device));
-    if (launch_seed_rng(e->rng, e->n, e->first_global, seed_policy, e->stream) != 0)
+    if (launch_seed_rng(e->rng, e->n, e->first_global, seed_policy, main_stream(e)) != 0)
       return fail(e, AFE_ERR_HIP, "seed kernel launch failed");
   }
   return AFE_OK;
@@ -505,8 +534,8 @@ extern "C" int afe_set_rng_state(afe_engine *e, int64_t first, int64_t count, co
   for (int64_t k = 0; k < count; k++)
     if (state[k] == 0 || state[k] >= 2147483647u) return fail(e, AFE_ERR_INVALID_ARG, "minstd_rand0 state must be in [1, 2^31-2]");
   AFE_HIP(e, hipSetDevice(e->device));
-  AFE_HIP(e, hipMemcpyAsync(e->rng + first, state, (size_t)count * 4, hipMemcpyHostToDevice, e->stream));
-  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  AFE_HIP(e, hipMemcpyAsync(e->rng + first, state, (size_t)count * 4, hipMemcpyHostToDevice, main_stream(e)));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   return AFE_OK;
 }
 extern "C" int afe_get_rng_state(afe_engine *e, int64_t first, int64_t count, uint32_t *state) {
@@ -514,8 +543,8 @@ extern "C" int afe_get_rng_state(afe_engine *e, int64_t first, int64_t count, ui
   if (rc) return rc;
   if (!state) return fail(e, AFE_ERR_INVALID_ARG, "state is NULL");
   AFE_HIP(e, hipSetDevice(e->device));
-  AFE_HIP(e, hipMemcpyAsync(state, e->rng + first, (size_t)count * 4, hipMemcpyDeviceToHost, e->stream));
-  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  AFE_HIP(e, hipMemcpyAsync(state, e->rng + first, (size_t)count * 4, hipMemcpyDeviceToHost, main_stream(e)));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   return AFE_OK;
 }
 
@@ -540,7 +569,7 @@ extern "C" int afe_set_rates_logic(afe_engine *e, const afe_rates_logic_params *
   AFE_HIP(e, hipSetDevice(e->device));
   { const int mrc = materialize_motor(e); if (mrc) return mrc; }   // from here on the logic rewrites the commands
   if (!table) {
-    AFE_HIP(e, hipStreamSynchronize(e->stream));
+    AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
     e->logic_on = false;
     return AFE_OK;
   }
@@ -564,10 +593,10 @@ extern "C" int afe_set_rates_logic(afe_engine *e, const afe_rates_logic_params *
     e->imu_init = (uint8_t *)p;
   }
   // QuadcopterLogic::Initialise: filters at 0 (QuadcopterLogic.cpp:38,133), _kf.Reset(), FS_IDLE
-  AFE_HIP(e, hipMemsetAsync(e->lpf, 0, S * 12 * 4, e->stream));
-  AFE_HIP(e, hipMemsetAsync(e->rates_cmd, 0, S * 4 * 4, e->stream));
-  AFE_HIP(e, hipMemsetAsync(e->have_cmd, 0, S * 2, e->stream));
-  AFE_HIP(e, hipMemsetAsync(e->cmd, 0, S * 4 * 4, e->stream));
+  AFE_HIP(e, hipMemsetAsync(e->lpf, 0, S * 12 * 4, main_stream(e)));
+  AFE_HIP(e, hipMemsetAsync(e->rates_cmd, 0, S * 4 * 4, main_stream(e)));
+  AFE_HIP(e, hipMemsetAsync(e->have_cmd, 0, S * 2, main_stream(e)));
+  AFE_HIP(e, hipMemsetAsync(e->cmd, 0, S * 4 * 4, main_stream(e)));
   e->logic_params.assign(table, table + n_types);
   e->logic_table_period = -1.0f;
   e->logic_on = true;
@@ -583,7 +612,7 @@ extern "C" int afe_set_rates_commands(afe_engine *e, int64_t first, int64_t coun
   AFE_HIP(e, hipSetDevice(e->device));
   if ((rc = copy_in(e, e->rates_cmd, 4, 1, first, count, thrust_norm))) return rc;
   if ((rc = copy_in(e, e->rates_cmd + e->stride, 4, 3, first, count, ang_vel3))) return rc;
-  AFE_HIP(e, hipMemsetAsync(e->have_cmd + first, 1, (size_t)count, e->stream));
+  AFE_HIP(e, hipMemsetAsync(e->have_cmd + first, 1, (size_t)count, main_stream(e)));
   return AFE_OK;
 }
 
@@ -610,8 +639,8 @@ extern "C" int afe_set_commands_from_radio(afe_engine *e, int64_t first, int64_t
   }
   AFE_HIP(e, hipSetDevice(e->device));
   if ((rc = copy_in(e, e->rates_cmd, 4, 4, first, count, cmd.data()))) return rc;
-  AFE_HIP(e, hipMemcpyAsync(e->have_cmd + first, have.data(), (size_t)count, hipMemcpyHostToDevice, e->stream));
-  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  AFE_HIP(e, hipMemcpyAsync(e->have_cmd + first, have.data(), (size_t)count, hipMemcpyHostToDevice, main_stream(e)));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   return AFE_OK;
 }
 
@@ -655,17 +684,36 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     f.logic = e->logic_on && mask != 0;
     f.wave_uniform_types = !e->types_uniform && e->types_wave_uniform;
     const DevLogic *ulogic = (e->logic_on && e->types_uniform) ? &e->logic_table[0] : nullptr;
+    // split stepping: vehicles [0, half) on the main stream, [half, n) on the side stream -- the two chains of launches
+    // never wait for each other, so each one's drain-and-dispatch gap is covered by the other's streaming
+    const bool split = e->split_parts == 2 && e->n >= 1024;
+    const int64_t half = split ? ((e->n / 2) & ~int64_t(255)) : e->n;
+    if (split && !e->split_dirty) {   // the side stream first sees everything the main stream has been given so far
+      AFE_HIP(e, hipEventRecord(e->ev_main, e->stream));
+      AFE_HIP(e, hipStreamWaitEvent(e->side_stream, e->ev_main, 0));
+      e->split_dirty = true;
+    }
     int lrc;
     if (e->precision == AFE_F64) {
       StepView<double> v;
       fill_view(e, v);
       v.dt = dt; v.inv_dt = 1.0 / dt; v.n_steps = chunk; v.tick_mask = mask;
+      v.end = half;
       lrc = launch_step_f64(v, f, e->types_uniform ? &e->table_f64[0] : nullptr, ulogic, e->stream);
+      if (split && lrc == 0) {
+        v.first = half; v.end = e->n;
+        lrc = launch_step_f64(v, f, e->types_uniform ? &e->table_f64[0] : nullptr, ulogic, e->side_stream);
+      }
     } else {
       StepView<float> v;
       fill_view(e, v);
       v.dt = (float)dt; v.inv_dt = (float)(1.0 / dt); v.n_steps = chunk; v.tick_mask = mask;
+      v.end = half;
       lrc = launch_step_f32(v, f, e->types_uniform ? &e->table_f32[0] : nullptr, ulogic, e->stream);
+      if (split && lrc == 0) {
+        v.first = half; v.end = e->n;
+        lrc = launch_step_f32(v, f, e->types_uniform ? &e->table_f32[0] : nullptr, ulogic, e->side_stream);
+      }
     }
     if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
     if (motor_lazy(e)) e->motor_stale = true;
@@ -687,6 +735,19 @@ extern "C" int afe_step_kernel_info(const afe_engine *e, int *record_path, int *
 extern "C" int afe_set_addressing(afe_engine *e, int mode) {
   if (!e || (mode != 0 && mode != 1)) return fail(e, AFE_ERR_INVALID_ARG, "addressing mode must be 0 (automatic) or 1 (global)");
   e->force_global_addressing = mode == 1;
+  return AFE_OK;
+}
+
+extern "C" int afe_set_split_stepping(afe_engine *e, int parts) {
+  if (!e || (parts != 1 && parts != 2)) return fail(e, AFE_ERR_INVALID_ARG, "split stepping: 1 (off) or 2 parts");
+  AFE_HIP(e, hipSetDevice(e->device));
+  join_streams(e);
+  if (parts == 2 && !e->side_stream) {
+    AFE_HIP(e, hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+    AFE_HIP(e, hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
+    AFE_HIP(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
+  }
+  e->split_parts = parts;
   return AFE_OK;
 }
 
@@ -713,7 +774,7 @@ extern "C" int afe_steps_until_tick(const afe_engine *e, uint64_t dt_us, int *n_
 extern "C" int afe_sync(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
-  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   return AFE_OK;
 }
 
@@ -739,7 +800,7 @@ extern "C" int afe_get_imu(afe_engine *e, int64_t first, int64_t count, float *g
 namespace afe {
 // for the other translation units of the library (afe_render.hip)
 void engine_stream_device(afe_engine *e, void **stream, int *device) {
-  *stream = (void *)e->stream;
+  *stream = (void *)main_stream(e);
   *device = e->device;
 }
 void engine_shard(const afe_engine *e, int64_t *first_global, int64_t *n) {
@@ -806,7 +867,7 @@ extern "C" int afe_event_destroy(void *event) {
 extern "C" int afe_event_record(afe_engine *e, void *event) {
   if (!e || !event) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
-  AFE_HIP(e, hipEventRecord((hipEvent_t)event, e->stream));
+  AFE_HIP(e, hipEventRecord((hipEvent_t)event, main_stream(e)));
   return AFE_OK;
 }
 extern "C" int afe_event_elapsed_ms(void *start, void *stop, float *ms) {
@@ -875,7 +936,7 @@ extern "C" int afe_save_checkpoint(afe_engine *e, void *host_buffer, uint64_t by
   if (bytes < need) return fail(e, AFE_ERR_INVALID_ARG, "checkpoint buffer too small");
   AFE_HIP(e, hipSetDevice(e->device));
   { const int mrc = materialize_motor(e); if (mrc) return mrc; }
-  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   CheckpointHeader h = {};
   h.magic = kCheckpointMagic; h.n = (uint64_t)e->n; h.stride = (uint64_t)e->stride; h.precision = (uint64_t)e->precision;
   h.arena_bytes = (uint64_t)e->arena_bytes; h.logic_bytes = e->logic_on ? (uint64_t)logic_arena_bytes(e) : 0;
@@ -913,7 +974,7 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
       !(h.sigma_gyro >= 0) || !(h.sigma_acc >= 0))
     return fail(e, AFE_ERR_INVALID_ARG, "checkpoint header holds an invalid configuration");
   AFE_HIP(e, hipSetDevice(e->device));
-  AFE_HIP(e, hipStreamSynchronize(e->stream));
+  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   const char *p = (const char *)host_buffer + sizeof(h);
   AFE_HIP(e, hipMemcpy(e->arena, p, e->arena_bytes, hipMemcpyHostToDevice));
   p += e->arena_bytes;
@@ -960,9 +1021,9 @@ int selftest_normals_any(afe_engine *e, const uint32_t *seeds, int64_t n, void *
   AFE_HIP(e, hipMalloc((void **)&d_out, (size_t)n * 6 * elem_bytes));
   int rc = AFE_OK;
   if (hipMemcpy(d_seed, seeds, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
-      (elem_bytes == 8 ? launch_normals_selftest(d_seed, n, (double *)d_out, d_state, e->stream)
-                       : launch_normals_selftest_f32(d_seed, n, (float *)d_out, d_state, e->stream)) != 0 ||
-      hipStreamSynchronize(e->stream) != hipSuccess ||
+      (elem_bytes == 8 ? launch_normals_selftest(d_seed, n, (double *)d_out, d_state, main_stream(e))
+                       : launch_normals_selftest_f32(d_seed, n, (float *)d_out, d_state, main_stream(e))) != 0 ||
+      hipStreamSynchronize(main_stream(e)) != hipSuccess ||
       hipMemcpy(normals6, d_out, (size_t)n * 6 * elem_bytes, hipMemcpyDeviceToHost) != hipSuccess ||
       hipMemcpy(state_after, d_state, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
     rc = fail(e, AFE_ERR_HIP, "normals selftest failed");
@@ -982,8 +1043,8 @@ extern "C" int afe_pack_positions(afe_engine *e, float *device_xyz) {
   if (!e || !device_xyz) return fail(e, AFE_ERR_INVALID_ARG, "device_xyz is NULL");
   AFE_HIP(e, hipSetDevice(e->device));
   int rc = (e->precision == AFE_F64)
-               ? launch_pack_positions_f64((const double *)e->pos, e->stride, e->n, device_xyz, e->stream)
-               : launch_pack_positions_f32((const float *)e->pos, e->stride, e->n, device_xyz, e->stream);
+               ? launch_pack_positions_f64((const double *)e->pos, e->stride, e->n, device_xyz, main_stream(e))
+               : launch_pack_positions_f32((const float *)e->pos, e->stride, e->n, device_xyz, main_stream(e));
   if (rc) return fail(e, AFE_ERR_HIP, "pack kernel launch failed");
   return AFE_OK;
 }
@@ -1001,7 +1062,7 @@ extern "C" int afe_nearest_neighbour_grid(afe_engine *e, const float *all_xyz, i
     return fail(e, AFE_ERR_OUT_OF_RANGE, "the gathered ensemble is smaller than this shard's global range");
   AFE_HIP(e, hipSetDevice(e->device));
   if (!e->world) { const int rc = world_create(e->device, &e->world); if (rc) return fail(e, rc, "shared-world scratch"); }
-  const int rc = world_nearest(e->world, (void *)e->stream, all_xyz, n_all, e->first_global, e->n, cell_size, dist2_out, index_out);
+  const int rc = world_nearest(e->world, (void *)main_stream(e), all_xyz, n_all, e->first_global, e->n, cell_size, dist2_out, index_out);
   if (rc) return fail(e, rc, world_last_error(e->world));
   return AFE_OK;
 }
@@ -1024,7 +1085,7 @@ extern "C" int afe_nearest_neighbour_bruteforce(afe_engine *e, const float *all_
     return fail(e, AFE_ERR_INVALID_ARG, "bad nearest-neighbour arguments");
   AFE_HIP(e, hipSetDevice(e->device));
   if (!e->world) { const int rc = world_create(e->device, &e->world); if (rc) return fail(e, rc, "shared-world scratch"); }
-  const int rc = world_nearest_bruteforce(e->world, (void *)e->stream, all_xyz, n_all, e->first_global, dev_queries, n_queries,
+  const int rc = world_nearest_bruteforce(e->world, (void *)main_stream(e), all_xyz, n_all, e->first_global, dev_queries, n_queries,
                                           dist2_out, index_out);
   if (rc) return fail(e, rc, world_last_error(e->world));
   return AFE_OK;

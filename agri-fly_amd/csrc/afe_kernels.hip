@@ -763,8 +763,8 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE, bool BUF>
 __global__ void __launch_bounds__(AFE_BLOCK, AFE_LB_WAVES)
 afe_step_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G) {
-  const int64_t i = (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;
-  if (i >= v.n) return;
+  const int64_t i = v.first + (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;
+  if (i >= v.end) return;
   run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE, BUF>(v, P, G, i);
 }
 
@@ -785,8 +785,8 @@ afe_step_kernel_table(const StepView<R> v) {
     }
   }
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= v.n) return;
+  const int64_t i = v.first + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= v.end) return;
   const unsigned t = v.type[(uint32_t)i];
   const DevParams<R> &P = reinterpret_cast<const DevParams<R> *>(lds_raw)[t];
   const DevLogic &G = reinterpret_cast<const DevLogic *>(lds_raw + (size_t)words_p * 4)[LOGIC ? t : 0];
@@ -800,8 +800,8 @@ afe_step_kernel_table(const StepView<R> v) {
 template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool BUF>
 __global__ void __launch_bounds__(AFE_BLOCK, AFE_LB_WAVES)
 afe_step_kernel_wave_types(const StepView<R> v) {
-  const int64_t i = (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;
-  if (i >= v.n) return;
+  const int64_t i = v.first + (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;   // first is a multiple of 64: waves stay on aligned runs
+  if (i >= v.end) return;
   const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)v.type[i]);
   const DevParams<R> P = v.table[t];
   DevLogic G = {};
@@ -812,9 +812,10 @@ afe_step_kernel_wave_types(const StepView<R> v) {
 template <typename R>
 static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevParams<R> *uniform,
                        const DevLogic *uniform_logic, hipStream_t st) {
-  if (v.n <= 0) return 0;
-  const unsigned grid = (unsigned)((v.n + 255) / 256);
-  const unsigned grid_u = (unsigned)((v.n + AFE_BLOCK - 1) / AFE_BLOCK);
+  const int64_t count = v.end - v.first;
+  if (count <= 0) return 0;
+  const unsigned grid = (unsigned)((count + 255) / 256);
+  const unsigned grid_u = (unsigned)((count + AFE_BLOCK - 1) / AFE_BLOCK);
   const size_t lds = (size_t)v.n_types * (sizeof(DevParams<R>) + (f.logic ? sizeof(DevLogic) : 0));
   DevLogic no_logic = {};
   const DevLogic &G = uniform_logic ? *uniform_logic : no_logic;

@@ -36,7 +36,7 @@ ABI_FUNCTIONS = [
     "afe_radio_create_acceleration_command", "afe_radio_create_simple_command", "afe_radio_decode",
     "afe_telemetry_encode", "afe_telemetry_decode", "afe_set_commands_from_radio",
     "afe_set_max_fused_steps", "afe_set_addressing", "afe_step_kernel_info", "afe_planner_default_config", "afe_planner_samples", "afe_rappids_plan",
-    "afe_rappids_plan_device", "afe_planner_release_scratch", "afe_camera_default", "afe_camera_default_mount", "afe_scene_create",
+    "afe_set_split_stepping", "afe_rappids_plan_device", "afe_planner_release_scratch", "afe_camera_default", "afe_camera_default_mount", "afe_scene_create",
     "afe_scene_destroy", "afe_scene_info", "afe_scene_set_walk", "afe_render_depth", "afe_render_depth_engine", "afe_render_depth_stats",
     "afe_device_alloc", "afe_device_free", "afe_device_download", "afe_scene_check_hierarchy",
     "afe_comm_unique_id", "afe_comm_create", "afe_comm_info", "afe_comm_destroy", "afe_comm_last_error",
@@ -243,6 +243,7 @@ def library():
         "afe_telemetry_decode": [vp, C.POINTER(TelemetryPacket)],
         "afe_set_commands_from_radio": [eng, i64, i64, vp],
         "afe_set_max_fused_steps": [eng, ci],
+        "afe_set_split_stepping": [eng, ci],
         "afe_set_addressing": [eng, ci],
         "afe_step_kernel_info": [eng, C.POINTER(ci), C.POINTER(ci)],
         "afe_planner_default_config": [C.POINTER(PlannerConfig), ci, ci] + [C.c_double] * 5,
@@ -744,6 +745,10 @@ class Ensemble:
 
     def set_max_fused_steps(self, k):
         self._ck(self._L.afe_set_max_fused_steps(self._h, int(k)))
+
+    def set_split_stepping(self, parts):
+        """afe_set_split_stepping: 2 = the two halves of the ensemble step on two streams (see the header)"""
+        self._ck(self._L.afe_set_split_stepping(self._h, int(parts)))
 
     def steps_until_tick(self, dt_us):
         n = C.c_int(0)

@@ -428,6 +428,18 @@ int afe_set_addressing(afe_engine *e, int mode);
  * 2 = type table in LDS; addressing 0 = buffer resources, 1 = global addresses.  Either pointer may be NULL. */
 int afe_step_kernel_info(const afe_engine *e, int *record_path, int *addressing);
 
+/* Split stepping.  parts = 2: afe_step launches the first half of the ensemble on the engine's stream and the
+ * second half on a stream of its own, and the two chains of launches never wait for each other -- each one's
+ * drain-and-dispatch gap (a fixed ~2.7 us per launch) is covered by the other's streaming.  At 2^20 vehicles a
+ * 1 ms step takes 21.4 instead of 24.2 us; per-vehicle results are the same bits (vehicles do not interact).
+ * What changes is WHEN the engine's stream is ordered after the steps: not at the return of afe_step but at the
+ * next engine call that touches device state or the stream (afe_sync, getters and setters, afe_event_record,
+ * afe_pack_positions, the queries, the depth camera, checkpoints, ... every entry point but afe_step joins the
+ * two streams first).  A host that queues its OWN work on the engine's stream (afe_set_stream) and expects it
+ * to see the stepped state must call afe_sync or afe_event_record in between.  parts = 1 (default): one launch,
+ * one stream, ordered at return as before. */
+int afe_set_split_stepping(afe_engine *e, int parts);
+
 /* How many sub-steps afe_step may fuse into one kernel launch (1..64, default
  * 64).  1 = one launch per step (state goes through HBM every step: the
  * per-step-observable mode bench.py reports); results are bitwise identical

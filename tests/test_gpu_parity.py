@@ -782,3 +782,89 @@ def test_buffer_and_global_addressing_are_bitwise_equal(precision, layout):
     assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
     assert np.isfinite(a[0]["pos"]).all()
+
+
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+@pytest.mark.parametrize("layout", ["one type", "by type", "shuffled"])
+def test_split_stepping_is_bitwise_the_single_stream_engine(precision, layout):
+    """afe_set_split_stepping(2): the two halves of the ensemble step on two streams that never wait for each other.
+    Same bits as one launch on one stream -- state, IMU, commands, engine words, clock and tick counts -- through
+    a sequence that mixes everything the deferred join has to survive: single steps, fused launches, a native loop
+    of many launches, getters and setters between steps (each must see every step before it and be seen by every
+    step after it), the on-device logic, a wrench, odd ensemble sizes (halves not a multiple of anything), switching
+    the mode off and on mid-flight, and a checkpoint taken while the side stream is still ahead."""
+    rng = np.random.default_rng(77)
+    n = 70001
+    ens = random_ensemble(n, seed=61, with_wrench=True)
+    d = ens.data
+    params = [afa.params_from_type(t) for t in d.type_ids]
+    if layout == "one type":
+        types = np.zeros(n, np.uint8)
+    elif layout == "by type":
+        types = np.repeat(np.sort(d.types)[::64], 64)[:n].astype(np.uint8)          # constant over aligned runs of 64
+    else:
+        types = np.asarray(d.types, np.uint8)
+
+    def make(split):
+        e = afa.Ensemble(n, precision=precision)
+        e.set_type_table(params)
+        e.set_vehicle_types(types)
+        e.set_logic_period(1 / 500)
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+        e.set_state(d.pos, d.vel, d.att, d.ang_vel, d.motor_speed)
+        e.set_motor_cmds(d.motor_cmd)
+        e.set_external_force(d.ext_force)
+        e.set_rates_logic([afa.rates_logic_params_from_type(t) for t in d.type_ids])
+        e.set_rates_commands(np.full(n, 9.0, np.float32), (0.1 * rng.standard_normal((3, n))).astype(np.float32))
+        if split:
+            e.set_split_stepping(2)
+        return e
+
+    rng = np.random.default_rng(78)
+    a = make(False)
+    rng = np.random.default_rng(78)
+    b = make(True)
+    blob = None
+    script = [("step", 1000, 1)] * 5 + [("get",), ("step", 1000, 7), ("cmd",), ("step", 500, 3), ("step", 1000, 1), ("force",),
+              ("native", 1000, 40), ("off",), ("step", 1000, 2), ("on",), ("step", 2000, 9), ("save",), ("step", 1000, 5), ("get",)]
+    cmd2 = np.clip(d.motor_cmd * 1.05, 0, None)
+    thrust2 = np.full(n, 10.5, np.float32)
+    for op in script:
+        for e in (a, b):
+            if op[0] == "step":
+                e.step(op[1], op[2])
+            elif op[0] == "native":
+                e.set_max_fused_steps(1); e.step(op[1], op[2]); e.set_max_fused_steps(64)
+            elif op[0] == "cmd":
+                e.set_rates_commands(thrust2, np.zeros((3, n), np.float32))
+            elif op[0] == "force":
+                e.set_external_force(d.ext_force * 0.5)
+            elif op[0] == "off" and e is b:
+                e.set_split_stepping(1)
+            elif op[0] == "on" and e is b:
+                e.set_split_stepping(2)
+            elif op[0] == "save" and e is b:
+                blob = e.save_checkpoint()
+        if op[0] in ("get", "save"):
+            sa, sb = a.get_state(), b.get_state()
+            for k in sa:
+                assert np.array_equal(sa[k], sb[k], equal_nan=True), (op, k)
+            for x, y in zip(a.get_imu() + (a.get_rng_state(), a.get_motor_cmds()), b.get_imu() + (b.get_rng_state(), b.get_motor_cmds())):
+                assert np.array_equal(x, y, equal_nan=True), op
+            assert a.time_us == b.time_us and a.logic_ticks == b.logic_ticks
+    # the checkpoint taken mid-flight resumes to the same end state in a third engine, itself stepping split
+    rng = np.random.default_rng(78)
+    c = make(True)
+    c.load_checkpoint(blob)
+    c.step(1000, 5)
+    sa, sc = a.get_state(), c.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sc[k], equal_nan=True), k
+    # what the mode is for: its events time the steps of BOTH halves
+    ev0, ev1 = b.event(), b.event()
+    b.record(ev0)
+    b.step(1000, 50)
+    b.record(ev1)
+    assert b.elapsed_ms(ev0, ev1) > 0.0
+    for e in (a, b, c):
+        e.close()
