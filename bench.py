@@ -155,14 +155,14 @@ def companion_rows(afa, n_local, device, sync, barrier, split=False):
 
 
 def committed_traffic(n_local):
-    """PMC-derived HBM bytes per launch of this exact workload, from the rocprofv3
+    """PMC-derived HBM bytes per step (= per launch on one stream, two launches when the shard steps as two halves) of this exact workload, from the rocprofv3
     summary committed under profiles/ (counters cannot be read inside the run)"""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(path))
         w = t["workload"]
         if w["vehicles_per_gpu"] == n_local and w["dt_us"] == DT_US and w["fext"] and w["noise"]:
-            return t["traffic_bytes_per_launch"], t["source"]
+            return t.get("traffic_bytes_per_step", t["traffic_bytes_per_launch"]), t["source"]
     except (OSError, KeyError, ValueError):
         pass
     return None, None
@@ -448,6 +448,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-shared-world", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the launches of the timed cadence (for rocprofv3 passes: no single-stream comparison, no per-kernel breakdown)")
     ap.add_argument("--watchdog", type=int, default=240, help="seconds the shared-world part may take before the line is printed without it")
     args = ap.parse_args()
 
@@ -506,10 +508,12 @@ def main():
         t_kernel = kernel_time_events(e, min(args.steps, 1000))       # per step: with split stepping, of both halves' launches
         achieved = n_local * bytes_step / t_kernel / 1e9
         # the same engine on one stream (one launch per step for the whole shard), for comparison
-        e.set_split_stepping(1)
-        time_steps(e, 100, 1, sync, lambda: None)
-        t_single = kernel_time_events(e, min(args.steps, 1000))
-        e.set_split_stepping(2 if split else 1)
+        t_single = t_kernel
+        if split and not args.headline_only:
+            e.set_split_stepping(1)
+            time_steps(e, 100, 1, sync, lambda: None)
+            t_single = kernel_time_events(e, min(args.steps, 1000))
+            e.set_split_stepping(2)
         traffic, traffic_src = committed_traffic(n_local)
         out = {
             "metric": "vehicle-steps/sec @dt=1ms",
@@ -554,7 +558,7 @@ def main():
                 "kernel_us": t_kernel * 1e6,
                 "algorithmic_bytes_per_vehicle_step": bytes_step,
                 "imu_tick_fraction": tick_frac,
-                "per_kernel": per_kernel_breakdown(afa, n_local, local_rank),
+                "per_kernel": None if args.headline_only else per_kernel_breakdown(afa, n_local, local_rank),
                 "single_stream": {"kernel_us": t_single * 1e6, "achieved_GBs": n_local * bytes_step / t_single / 1e9,
                                   "frac": n_local * bytes_step / t_single / 1e9 / HBM_PEAK_GBS,
                                   "note": "the same engine with afe_set_split_stepping(1): one launch per step for the whole shard"},

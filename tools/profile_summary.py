@@ -18,6 +18,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 note = sys.argv[2] if len(sys.argv) > 2 else ""
+# vehicles per LAUNCH: 2^20 on one stream, 2^19 when the bench steps its shard as two halves (afe_set_split_stepping)
+N_LAUNCH = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
+N_SHARD = 1 << 20
 out = os.path.join(ROOT, "gpurun_out")
 prof = os.path.join(ROOT, "profiles")
 
@@ -55,7 +58,7 @@ for src, dst in (("prof_%s" % tag, "%s_kernel_stats.csv" % tag), ("prof_full_%s"
 f = one("prof_%s/**/*_kernel_stats.csv" % tag)
 stats = {short(r["Name"]): r for r in csv.DictReader(open(f))} if f else {}
 fetch, write, sq = counters("pmc_fetch_%s" % tag), counters("pmc_write_%s" % tag), counters("pmc_sq_%s" % tag)
-N = 1 << 20
+N = N_LAUNCH
 BYTES = {"0": 132.0, "1": 164.0}     # algorithmic B per vehicle-step of the bench workload, off / on tick
 tot_alg = tot_pmc = tot_n = 0
 for k, r in stats.items():
@@ -85,8 +88,10 @@ for k, r in stats.items():
 if tot_n:
     summary["traffic"] = {"pmc_bytes_per_launch_mean": tot_pmc / tot_n, "algorithmic_bytes_per_launch_mean": tot_alg / tot_n,
                           "ratio": tot_pmc / tot_alg}
-    json.dump({"workload": {"vehicles_per_gpu": N, "fext": True, "noise": True, "dt_us": 1000, "logic_period_s": 0.002},
+    json.dump({"workload": {"vehicles_per_gpu": N_SHARD, "fext": True, "noise": True, "dt_us": 1000, "logic_period_s": 0.002},
+               "vehicles_per_launch": N, "launches_per_step": N_SHARD // N,
                "traffic_bytes_per_launch": tot_pmc / tot_n,
+               "traffic_bytes_per_step": tot_pmc / tot_n * (N_SHARD // N),
                "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                          "FETCH_SIZE x2 gfx950 correction)" % tag}, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(prof, "%s_summary.json" % tag), "w"), indent=1)
