@@ -96,6 +96,8 @@ def run_campaign(n_cfg=40, seed=1, verbose=True, only=None):
         lagged = any(p.motor_time_const > 0 or p.motor_inertia > 0 for p in plist)
         for precision, tag, tol in ((afa.AFE_F64, "f64", 2e-11), (afa.AFE_F32, "f32", 5e-5 if lagged else 1e-5)):
             with afa.Ensemble(n, precision=precision, first_global_index=first_global) as e:
+                if os.environ.get("STEP_CAMPAIGN_SPLIT"):            # the same campaign with the two halves on two streams
+                    e.set_split_stepping(2)
                 e.set_type_table(plist)
                 e.set_vehicle_types(types)
                 e.set_logic_period(period)
@@ -195,6 +197,8 @@ def run_logic_campaign(n_cfg=30, seed=1, verbose=True):
         ticks = afa.plan_ticks(period, 0, dt_us, steps)[0]
         for precision, tag, tol in ((afa.AFE_F64, "f64", 1e-9), (afa.AFE_F32, "f32", 1e-5)):
             with afa.Ensemble(n, precision=precision) as e:
+                if os.environ.get("STEP_CAMPAIGN_SPLIT"):
+                    e.set_split_stepping(2)
                 e.set_type_table([afa.params_from_type(t) for t in ids])
                 e.set_vehicle_types(types)
                 e.set_logic_period(period)
