@@ -94,5 +94,19 @@ if tot_n:
                "traffic_bytes_per_step": tot_pmc / tot_n * (N_SHARD // N),
                "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                          "FETCH_SIZE x2 gfx950 correction)" % tag}, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+# how many step kernels are in flight over the timed cadence (1 on one stream; ~2 with split stepping): sum of the
+# kernels' durations / time from the first start to the last end, from the kernel trace of the --stats pass
+tr = one("prof_%s/**/*_kernel_trace.csv" % tag)
+if tr:
+    ks = [r for r in csv.DictReader(open(tr)) if "afe_step_kernel" in r["Kernel_Name"]]
+    ks.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ks = ks[len(ks) // 5:]                       # past the warm-up
+    if len(ks) > 10:
+        busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ks)
+        span = max(int(r["End_Timestamp"]) for r in ks) - int(ks[0]["Start_Timestamp"])
+        per_step = N_SHARD // N
+        summary["cadence"] = {"step_kernels_in_flight_mean": busy / span, "launches": len(ks), "launches_per_step": per_step,
+                              "time_per_step_us": span / (len(ks) / per_step) / 1e3,
+                              "algorithmic_GBs_over_the_cadence": (tot_alg / tot_n if tot_n else 0) * len(ks) / span}
 json.dump(summary, open(os.path.join(prof, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
