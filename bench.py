@@ -565,7 +565,8 @@ def main():
                 "note": "achieved = algorithmic bytes per step / HIP-event time per step over the timed cadence (kernel_us). "
                         + ("A step is two launches of the same kernel, one per half of the shard, on two streams that never wait "
                            "for each other; rocprofv3 shows each at about the duration of a step (two in flight at any time), so "
-                           "per-launch bytes / per-launch duration is half of `achieved`. " if split else "")
+                           "per-launch bytes / per-launch duration is half of `achieved` (profiles/r02i_summary.json `cadence`: 1.98 step kernels in flight "
+                           "from the kernel trace). " if split else "")
                         + "In-place state (%.0f MB per step) fits the 256 MiB Infinity Cache; traffic = HBM bytes per step from the "
                         "committed rocprofv3 PMC summary (per_kernel: the full-shard launches of the single-stream mode)"
                         % (n_local * bytes_step / 1e6),
