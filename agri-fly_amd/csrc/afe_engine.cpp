@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,7 +26,7 @@ struct afe_engine {
   hipStream_t stream = nullptr;
   // afe_set_split_stepping(2): the second half of the ensemble steps on `side_stream`; `split_dirty`: it holds steps
   // the main stream has not been ordered after yet (join_streams does that; everything but afe_step goes through it)
-  int split_parts = 1;
+  int split_parts = 0;      // 0: automatic (two parts for 2^19 vehicles and more while the engine owns its stream), 1: off, 2: on
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_main = nullptr, ev_side = nullptr;
   bool split_dirty = false;
@@ -391,6 +392,10 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
   if (launch_seed_rng(e->rng, e->n, e->first_global, e->seed_policy, main_stream(e)) != 0)
     return bail("seed kernel launch (is the gfx950 code object present?)", hipGetLastError());
   if ((err = hipStreamSynchronize(main_stream(e))) != hipSuccess) return bail("seed kernel", err);
+  if (std::getenv("AFE_FORCE_SPLIT")) {   // test hook: every engine of this process steps split (tests/: the whole GPU suite runs this way once)
+    const int src = afe_set_split_stepping(e, 2);
+    if (src) { afe_destroy(e); return src; }
+  }
   *out = e;
   return AFE_OK;
 }
@@ -686,7 +691,12 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     const DevLogic *ulogic = (e->logic_on && e->types_uniform) ? &e->logic_table[0] : nullptr;
     // split stepping: vehicles [0, half) on the main stream, [half, n) on the side stream -- the two chains of launches
     // never wait for each other, so each one's drain-and-dispatch gap is covered by the other's streaming
-    const bool split = e->split_parts == 2 && e->n >= 1024;
+    const bool split = e->n >= 1024 && (e->split_parts == 2 || (e->split_parts == 0 && e->stream == e->own_stream && e->n >= (int64_t(1) << 19)));
+    if (split && !e->side_stream) {
+      AFE_HIP(e, hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+      AFE_HIP(e, hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
+      AFE_HIP(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
+    }
     const int64_t half = split ? ((e->n / 2) & ~int64_t(255)) : e->n;
     if (split && !e->split_dirty) {   // the side stream first sees everything the main stream has been given so far
       AFE_HIP(e, hipEventRecord(e->ev_main, e->stream));
@@ -739,14 +749,9 @@ extern "C" int afe_set_addressing(afe_engine *e, int mode) {
 }
 
 extern "C" int afe_set_split_stepping(afe_engine *e, int parts) {
-  if (!e || (parts != 1 && parts != 2)) return fail(e, AFE_ERR_INVALID_ARG, "split stepping: 1 (off) or 2 parts");
+  if (!e || parts < 0 || parts > 2) return fail(e, AFE_ERR_INVALID_ARG, "split stepping: 0 (automatic), 1 (off) or 2 parts");
   AFE_HIP(e, hipSetDevice(e->device));
   join_streams(e);
-  if (parts == 2 && !e->side_stream) {
-    AFE_HIP(e, hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
-    AFE_HIP(e, hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
-    AFE_HIP(e, hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
-  }
   e->split_parts = parts;
   return AFE_OK;
 }

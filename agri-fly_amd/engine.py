@@ -747,7 +747,7 @@ class Ensemble:
         self._ck(self._L.afe_set_max_fused_steps(self._h, int(k)))
 
     def set_split_stepping(self, parts):
-        """afe_set_split_stepping: 2 = the two halves of the ensemble step on two streams (see the header)"""
+        """afe_set_split_stepping: 0 automatic (default), 1 off, 2 = the two halves of the ensemble step on two streams (see the header)"""
         self._ck(self._L.afe_set_split_stepping(self._h, int(parts)))
 
     def steps_until_tick(self, dt_us):

@@ -101,6 +101,7 @@ def per_kernel_breakdown(afa, n_local, device):
     res = {}
     for name, period in (("off_tick", 1000.0), ("on_tick", 0.0005)):
         e = build_shard(afa, n_local, 0, n_local, device)
+        e.set_split_stepping(1)      # the kernels themselves: one launch per step for the whole shard
         e.set_logic_period(period)
         for _ in range(50):
             e.step(DT_US, 1)
@@ -576,6 +577,7 @@ def main():
             sweep = []
             for n in (1024, 4096, 65536, 262144, 4 << 20):
                 es = build_shard(afa, n, 0, n, local_rank)
+                es.set_split_stepping(1)     # the sweep compares launch forms on one stream
                 k = 400 if n >= 262144 else 2000
                 time_steps(es, 50, 1, sync, barrier)
                 t1 = time_steps(es, k, 1, sync, barrier)

@@ -428,16 +428,21 @@ int afe_set_addressing(afe_engine *e, int mode);
  * 2 = type table in LDS; addressing 0 = buffer resources, 1 = global addresses.  Either pointer may be NULL. */
 int afe_step_kernel_info(const afe_engine *e, int *record_path, int *addressing);
 
-/* Split stepping.  parts = 2: afe_step launches the first half of the ensemble on the engine's stream and the
+/* Split stepping.  With two parts afe_step launches the first half of the ensemble on the engine's stream and the
  * second half on a stream of its own, and the two chains of launches never wait for each other -- each one's
  * drain-and-dispatch gap (a fixed ~2.7 us per launch) is covered by the other's streaming.  At 2^20 vehicles a
- * 1 ms step takes 21.4 instead of 24.2 us; per-vehicle results are the same bits (vehicles do not interact).
+ * 1 ms step takes 22.1 instead of 24.4 us; per-vehicle results are the same bits (vehicles do not interact).
  * What changes is WHEN the engine's stream is ordered after the steps: not at the return of afe_step but at the
  * next engine call that touches device state or the stream (afe_sync, getters and setters, afe_event_record,
  * afe_pack_positions, the queries, the depth camera, checkpoints, ... every entry point but afe_step joins the
- * two streams first).  A host that queues its OWN work on the engine's stream (afe_set_stream) and expects it
- * to see the stepped state must call afe_sync or afe_event_record in between.  parts = 1 (default): one launch,
- * one stream, ordered at return as before. */
+ * two streams first).  While the engine uses its OWN stream nobody else can queue work on it, so the difference
+ * cannot be observed.
+ *   parts = 0 (default): automatic -- two parts for ensembles of 2^19 vehicles and more as long as the engine owns
+ *     its stream; one launch on one stream otherwise (smaller ensembles lose: the second launch costs more host
+ *     time than it hides; a caller-owned stream keeps the order-at-return behaviour).
+ *   parts = 1: never.   parts = 2: always (ensembles of 1 024 vehicles and more), also on a caller-owned stream
+ *     (afe_set_stream) -- a host that queues its own work there and expects it to see the stepped state must
+ *     then call afe_sync or afe_event_record in between. */
 int afe_set_split_stepping(afe_engine *e, int parts);
 
 /* How many sub-steps afe_step may fuse into one kernel launch (1..64, default

@@ -7,6 +7,7 @@ p = afa.params_from_type(5)
 data = afa.scenarios.gust_ensemble(n, p, seed=4)
 def run(types, nt, logic=False, period=0.002):
     e = afa.Ensemble(n)
+    e.set_split_stepping(1)      # kernel timing: one launch per step
     tab = [afa.params_from_type([5,1,2,4][k % 4]) for k in range(nt)]
     e.set_type_table(tab)
     if types is not None: e.set_vehicle_types(types)

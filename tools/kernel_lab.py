@@ -28,7 +28,7 @@ res = {}
 for name, period, fext in (("off", 1000.0, True), ("on", 0.0005, True), ("mix", 0.002, True), ("off_nofext", 1000.0, False),
                            ("on_nonoise", 0.0005, True)):
     e = afa.Ensemble(n)
-    e.set_type_table([p]); e.set_logic_period(period)
+    e.set_type_table([p]); e.set_logic_period(period); e.set_split_stepping(1)   # kernel timing: one launch per step
     e.set_imu_noise(name != "on_nonoise", 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
     e.set_state(data.pos, data.vel, data.att, data.ang_vel, data.motor_speed)
     e.set_motor_cmds(data.motor_cmd)

@@ -20,6 +20,7 @@ data = afa.scenarios.gust_ensemble(n, p, seed=4)
 e = afa.Ensemble(n)
 e.set_type_table([p])
 e.set_logic_period(period)
+e.set_split_stepping(1)     # one launch per step unless the mode asks otherwise
 e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
 e.set_state(data.pos, data.vel, data.att, data.ang_vel, data.motor_speed)
 e.set_motor_cmds(data.motor_cmd)
