@@ -506,7 +506,8 @@ def main():
     out = None
     if rank == 0:
         bytes_step, tick_frac = mean_bytes_per_step(e, afa, args.steps)
-        t_kernel = kernel_time_events(e, min(args.steps, 1000))       # per step: with split stepping, of both halves' launches
+        # per step (with split stepping: of both halves' launches); the median of three event-bracketed runs
+        t_kernel = sorted(kernel_time_events(e, min(args.steps, 1000)) for _ in range(3))[1]
         achieved = n_local * bytes_step / t_kernel / 1e9
         # the same engine on one stream (one launch per step for the whole shard), for comparison
         t_single = t_kernel
