@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -203,6 +204,10 @@ extern "C" int afe_group_create(afe_group **out, int64_t n_vehicles, int precisi
     afe_engine *e = nullptr;
     const int rc = afe_create(&e, cnt, precision, devices[k], first);
     if (rc != AFE_OK) { afe_group_destroy(g); return rc; }
+    // One host thread launches for every device of the group: a second launch per shard and step (the automatic
+    // split stepping of large engines) would make that thread, not the devices, the limit.  The host can still ask
+    // for it per shard (afe_group_shard + afe_set_split_stepping).
+    if (n_devices > 1 && std::getenv("AFE_FORCE_SPLIT") == nullptr) (void)afe_set_split_stepping(e, 1);
     g->engines.push_back(e);
     g->devices.push_back(devices[k]);
     g->first.push_back(first);

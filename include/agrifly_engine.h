@@ -440,6 +440,8 @@ int afe_step_kernel_info(const afe_engine *e, int *record_path, int *addressing)
  *   parts = 0 (default): automatic -- two parts for ensembles of 2^19 vehicles and more as long as the engine owns
  *     its stream; one launch on one stream otherwise (smaller ensembles lose: the second launch costs more host
  *     time than it hides; a caller-owned stream keeps the order-at-return behaviour).
+ *     (Engines an afe_group creates for several devices start with parts = 1: one host thread launches for all of
+ *     them, and a second launch per shard and step would make that thread the limit.)
  *   parts = 1: never.   parts = 2: always (ensembles of 1 024 vehicles and more), also on a caller-owned stream
  *     (afe_set_stream) -- a host that queues its own work there and expects it to see the stepped state must
  *     then call afe_sync or afe_event_record in between. */
