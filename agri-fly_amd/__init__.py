@@ -16,6 +16,9 @@ from .engine import (  # noqa: F401
     AFE_F64,
     AFE_SEED_DECORRELATED,
     AFE_SEED_REFERENCE,
+    AFE_STEP_AUTO,
+    AFE_STEP_LAUNCH,
+    AFE_STEP_PERSISTENT,
     AfeError,
     Camera,
     Comm,

@@ -93,6 +93,35 @@ struct LaunchFlags {
   bool wave_uniform_types = false;
 };
 
+// ---------------------------------------------------------------------------
+// Persistent stepping (afe_set_step_mode(AFE_STEP_PERSISTENT)): ONE resident grid steps the ensemble for as long
+// as the host keeps authorising steps.  A step is one 64-bit ring entry the host writes into pinned memory:
+//   entry = (absolute step index + 1) << 2 | park << 1 | tick        (index in bits 2-47)
+// (a slot whose index part does not match is not written yet).  Workgroup 0 -- the pump -- copies new entries
+// from the host ring into a device ring; every other workgroup (one wave each) polls the device ring and steps
+// ITS vehicles through every entry it finds: loads, the step, stores -- the body of the one-step launch, state
+// back in HBM after every step.  Vehicles do not interact, so no wave ever waits for another one; what a kernel
+// boundary costs between two dependent launches (drain, dispatch, ramp-up) is simply not there.  A park entry
+// ends the launch; the pump writes one itself when the host has not authorised anything for `idle_ticks`
+// (nothing ever waits on a host that went away), and every spin gives up after `give_up_ticks`.
+struct PersistArgs {
+  const unsigned long long *host_ring;   // pinned host memory, as the device sees it
+  unsigned long long *host_status;       // pinned: [0] park position + 1 (0 while running), [1] steps every worker has consumed, [2] error code
+  unsigned long long *dev_ring;          // device copy of the ring (workers poll this one)
+  unsigned long long *done;              // per worker wave: steps consumed
+  unsigned long long start;              // first step of this launch (absolute index)
+  unsigned int host_mask, dev_mask;      // ring sizes - 1 (powers of two)
+  int n_workers;                         // worker waves (= workgroups - 1)
+  int n_chunks;                          // aligned runs of 64 vehicles; worker w steps chunks w, w + n_workers, ...
+  unsigned int idle_ticks;               // 100 MHz ticks (s_memrealtime)
+  unsigned int give_up_ticks;
+  unsigned int epoch;                    // launch counter (stamps the device ring's entries)
+};
+#define AFE_PERSIST_TICK 1ull
+#define AFE_PERSIST_PARK 2ull
+#define AFE_PERSIST_HOST_RING 4096
+#define AFE_PERSIST_DEV_RING 1024
+
 // kernel launchers (afe_kernels.hip); stream is a hipStream_t
 // `uniform` != nullptr: every vehicle uses this one record, passed by value in
 // the kernel-argument segment (scalar registers); otherwise v.table is staged
@@ -101,6 +130,14 @@ int launch_step_f32(const StepView<float> &v, const LaunchFlags &f, const DevPar
                     const DevLogic *uniform_logic, void *stream);
 int launch_step_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> *uniform,
                     const DevLogic *uniform_logic, void *stream);
+// the persistent grid: 1 + a.n_workers one-wave workgroups (homogeneous ensembles, no external torque, buffer addressing)
+int launch_persistent_f32(const StepView<float> &v, const LaunchFlags &f, const DevParams<float> &uniform,
+                          const DevLogic *uniform_logic, const PersistArgs &a, void *stream);
+int launch_persistent_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> &uniform,
+                          const DevLogic *uniform_logic, const PersistArgs &a, void *stream);
+// one-wave workgroups of that instantiation a CU keeps resident (0: the query failed)
+int persistent_capacity_f32(const LaunchFlags &f);
+int persistent_capacity_f64(const LaunchFlags &f);
 // rotor speeds of stateless motors from the commands: w = clamp(max(0, cmd), w_min, w_max)
 int launch_motor_from_cmd_f32(float *motor, const float *cmd, const uint8_t *type, const DevParams<float> *table,
                               int64_t stride, int64_t n, void *stream);

@@ -3,6 +3,7 @@
 // kernels of afe_kernels.hip.  Compiled with hipcc; there is no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -78,6 +79,23 @@ struct afe_engine {
   uint64_t logic_elapsed_us = 0;
   uint64_t n_ticks = 0;
   int max_fused = 64;
+  uint64_t steps_issued = 0;   // afe_steps_completed
+
+  // persistent stepping (afe_set_step_mode; afe_device.h PersistArgs)
+  int step_mode = AFE_STEP_LAUNCH;
+  bool p_running = false;   // a resident grid is on the device
+  bool p_failed = false;    // a resident grid gave up: the ensemble may be torn between two steps, stepping is refused
+  unsigned long long *p_host = nullptr;      // pinned host memory: ring[AFE_PERSIST_HOST_RING] + status[8]
+  unsigned long long *p_host_dev = nullptr;  // the same memory as the device addresses it
+  unsigned long long *p_dev = nullptr;       // device memory: ring[AFE_PERSIST_DEV_RING] + done[p_workers]
+  int p_workers = 0;
+  int p_cus = 0;
+  int p_shrink_num = 16;    // sixteenths of the computed capacity still trusted (a stalled grid takes one off)
+  uint64_t p_next = 0;      // ring entries written so far == index of the next step to authorise
+  uint64_t p_resume = 0;    // where the next grid starts (every worker's done[] stands there while none runs)
+  uint64_t p_dt_us = 0;     // what the resident grid was launched with
+  unsigned p_epoch = 0;     // launches so far
+  LaunchFlags p_flags = {};
 
   std::string err;
 };
@@ -85,6 +103,7 @@ struct afe_engine {
 namespace {
 void join_streams(afe_engine *e);
 hipStream_t main_stream(afe_engine *e);
+int persist_park(afe_engine *e);
 }  // namespace
 
 namespace {
@@ -307,7 +326,168 @@ void join_streams(afe_engine *e) {
 }
 hipStream_t main_stream(afe_engine *e) {
   join_streams(e);
+  if (e->p_running) (void)persist_park(e);   // a failure is sticky (p_failed) and reported by the next afe_step / afe_sync
   return e->stream;
+}
+
+// ---- persistent stepping, host side -------------------------------------------------------------------------
+inline volatile unsigned long long *p_status(afe_engine *e) { return e->p_host + AFE_PERSIST_HOST_RING; }
+
+int persist_alloc(afe_engine *e) {
+  if (e->p_host) return AFE_OK;
+  hipDeviceProp_t prop;
+  AFE_HIP(e, hipGetDeviceProperties(&prop, e->device));
+  e->p_cus = prop.multiProcessorCount;
+  const int64_t chunks = (e->n + 63) / 64;
+  const int64_t most = (int64_t)e->p_cus * 32;      // a CU has 32 wave slots: done[] never needs more
+  const size_t hbytes = (AFE_PERSIST_HOST_RING + 8) * sizeof(unsigned long long);
+  AFE_HIP(e, hipHostMalloc((void **)&e->p_host, hbytes, hipHostMallocCoherent | hipHostMallocMapped));
+  std::memset(e->p_host, 0, hbytes);
+  AFE_HIP(e, hipHostGetDevicePointer((void **)&e->p_host_dev, e->p_host, 0));
+  const size_t dbytes = ((size_t)AFE_PERSIST_DEV_RING + (size_t)(chunks < most ? chunks : most)) * sizeof(unsigned long long);
+  AFE_HIP(e, hipMalloc((void **)&e->p_dev, dbytes));
+  AFE_HIP(e, hipMemsetAsync(e->p_dev, 0, dbytes, e->stream));
+  return AFE_OK;
+}
+
+// worker waves of the grid about to be launched: one per chunk if the device keeps that many resident, else
+// every resident slot but the pump's (the instantiation's occupancy x CUs), less whatever earlier stalls took off
+void persist_size_grid(afe_engine *e) {
+  int per_cu = e->precision == AFE_F64 ? persistent_capacity_f64(e->p_flags) : persistent_capacity_f32(e->p_flags);
+  if (per_cu < 1) per_cu = 1;
+  if (const char *s = std::getenv("AFE_PERSIST_WAVES_PER_CU")) { const int k = std::atoi(s); if (k >= 1 && k <= 32) per_cu = k; }
+  const int64_t chunks = (e->n + 63) / 64;
+  int64_t cap = (int64_t)e->p_cus * per_cu - 1;     // the pump takes one slot
+  cap = cap * e->p_shrink_num / 16;
+  if (cap < 1) cap = 1;
+  e->p_workers = (int)(chunks < cap ? chunks : cap);
+}
+
+// the configuration a resident grid carries in its kernel arguments
+LaunchFlags persist_flags(const afe_engine *e) {
+  LaunchFlags f;
+  f.ext_force = e->has_ext_force; f.ext_torque = false; f.noise = e->noise; f.logic = e->logic_on;
+  return f;
+}
+bool persist_eligible(const afe_engine *e) {
+  if (e->step_mode == AFE_STEP_LAUNCH || e->p_failed) return false;
+  if (e->step_mode == AFE_STEP_AUTO && e->n > (int64_t(1) << 20)) return false;   // measured: DESIGN.md section 6 (beyond the Infinity Cache the split launches are ahead)
+  if (!e->types_uniform || e->has_ext_torque || e->stream != e->own_stream || e->force_global_addressing) return false;
+  return e->arena_bytes < 0xffff0000ull && logic_arena_bytes(e) < 0xffff0000ull;
+}
+
+int persist_launch(afe_engine *e) {
+  volatile unsigned long long *st = p_status(e);
+  st[0] = 0; st[1] = e->p_resume; st[2] = 0;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  persist_size_grid(e);
+  PersistArgs a;
+  a.host_ring = e->p_host_dev;
+  a.host_status = e->p_host_dev + AFE_PERSIST_HOST_RING;
+  a.dev_ring = e->p_dev;
+  a.done = e->p_dev + AFE_PERSIST_DEV_RING;
+  a.start = e->p_resume;
+  a.host_mask = AFE_PERSIST_HOST_RING - 1; a.dev_mask = AFE_PERSIST_DEV_RING - 1;
+  a.n_workers = e->p_workers;
+  a.n_chunks = (int)((e->n + 63) / 64);
+  a.idle_ticks = 20000;         // 200 us
+  a.give_up_ticks = 5000000;    // 50 ms without any progress while steps are waiting
+  a.epoch = ++e->p_epoch;
+  const double dt = us_to_seconds(e->p_dt_us);
+  const LaunchFlags &f = e->p_flags;
+  const DevLogic *ulogic = e->logic_on ? &e->logic_table[0] : nullptr;
+  int lrc;
+  if (e->precision == AFE_F64) {
+    StepView<double> v;
+    fill_view(e, v);
+    v.dt = dt; v.inv_dt = 1.0 / dt; v.n_steps = 1; v.tick_mask = 0;
+    lrc = launch_persistent_f64(v, f, e->table_f64[0], ulogic, a, e->stream);
+  } else {
+    StepView<float> v;
+    fill_view(e, v);
+    v.dt = (float)dt; v.inv_dt = (float)(1.0 / dt); v.n_steps = 1; v.tick_mask = 0;
+    lrc = launch_persistent_f32(v, f, e->table_f32[0], ulogic, a, e->stream);
+  }
+  if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("persistent step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+  e->p_running = true;
+  return AFE_OK;
+}
+
+// The resident grid has left the device (or is leaving: the stream says when): where did it stop?
+int persist_collect(afe_engine *e) {
+  const hipError_t herr = hipStreamSynchronize(e->stream);
+  e->p_running = false;
+  volatile unsigned long long *st = p_status(e);
+  if (herr == hipSuccess && st[0] != 0 && st[2] == 1 && e->p_shrink_num > 1) {
+    // The pump saw steps waiting and no worker moving for 50 ms: the grid was not co-resident (workgroups that never
+    // started held the ring's window shut).  It parked at st[0] - 1 and every workgroup, late ones included, stopped
+    // there: nothing is torn.  The next grid is cut smaller.
+    e->p_shrink_num--;
+    std::fprintf(stderr, "agrifly_engine: a resident grid of %d worker waves stalled; continuing with %d/16 of the computed capacity\n",
+                 e->p_workers, e->p_shrink_num);
+  } else if (herr != hipSuccess || st[0] == 0 || st[2] != 0) {
+    e->p_failed = true;
+    return fail(e, AFE_ERR_HIP, herr != hipSuccess ? std::string("persistent step kernel: ") + hipGetErrorString(herr)
+                                   : st[2] ? "persistent step kernel gave up waiting (code " + std::to_string(st[2]) + "); the ensemble may be torn between two steps"
+                                           : std::string("persistent step kernel ended without parking"));
+  }
+  e->p_resume = st[0] - 1;
+  return AFE_OK;
+}
+
+// End the resident grid after the last authorised step; returns with the stream idle and every step done.
+int persist_park(afe_engine *e) {
+  if (!e->p_running) return AFE_OK;
+  (void)hipSetDevice(e->device);
+  __atomic_store_n(&e->p_host[e->p_next & (AFE_PERSIST_HOST_RING - 1)], ((e->p_next + 1) << 2) | AFE_PERSIST_PARK, __ATOMIC_RELEASE);
+  for (;;) {
+    int rc = persist_collect(e);
+    if (rc) return rc;
+    if (e->p_resume == e->p_next) return AFE_OK;
+    // the grid had parked itself earlier (the host was quiet for a while): a new one finishes the rest
+    if (e->p_resume > e->p_next) { e->p_failed = true; return fail(e, AFE_ERR_HIP, "persistent step kernel ran past the authorised steps"); }
+    if ((rc = persist_launch(e))) return rc;
+  }
+}
+
+// afe_step in persistent mode: n_steps more ring entries; a grid is started if none is resident
+int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
+  int rc = persist_alloc(e);
+  if (rc) return rc;
+  const LaunchFlags f = persist_flags(e);
+  if (e->p_running && (e->p_dt_us != dt_us || f.ext_force != e->p_flags.ext_force || f.noise != e->p_flags.noise || f.logic != e->p_flags.logic))
+    if ((rc = persist_park(e))) return rc;
+  volatile unsigned long long *st = p_status(e);
+  if (e->p_running && st[0] != 0) {       // it parked itself (idle): collect it, a new grid starts below
+    if ((rc = persist_collect(e))) return rc;
+  }
+  for (int s = 0; s < n_steps; s++) {
+    // room in the host ring: never more than a ring (less a margin) ahead of the slowest worker
+    for (unsigned spins = 0;; spins++) {
+      const uint64_t floor_ = e->p_running ? std::max<uint64_t>(st[1], e->p_resume) : e->p_resume;
+      if (e->p_next - floor_ < AFE_PERSIST_HOST_RING - 128) break;
+      if (!e->p_running) {                // entries are waiting and nobody reads them
+        e->p_dt_us = dt_us; e->p_flags = f;
+        if ((rc = persist_launch(e))) return rc;
+      } else if (st[0] != 0) {
+        if ((rc = persist_collect(e))) return rc;
+      } else if (spins > 2000000000u) {
+        return fail(e, AFE_ERR_HIP, "persistent step kernel makes no progress");
+      }
+    }
+    e->now_us += dt_us;  // ManualTimer::AdvanceMicroSeconds, main.cpp:392
+    unsigned long long entry = (e->p_next + 1) << 2;
+    if (gate_step(e->logic_period, e->logic_elapsed_us, dt_us)) { entry |= AFE_PERSIST_TICK; e->n_ticks++; }
+    __atomic_store_n(&e->p_host[e->p_next & (AFE_PERSIST_HOST_RING - 1)], entry, __ATOMIC_RELEASE);
+    e->p_next++;
+    e->steps_issued++;
+  }
+  if (!e->p_running) {
+    e->p_dt_us = dt_us; e->p_flags = f;
+    if ((rc = persist_launch(e))) return rc;
+  }
+  if (motor_lazy(e)) e->motor_stale = true;
+  return AFE_OK;
 }
 
 }  // namespace
@@ -403,6 +583,9 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
 extern "C" int afe_destroy(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   (void)hipSetDevice(e->device);
+  if (e->p_running) (void)persist_park(e);
+  if (e->p_dev) (void)hipFree(e->p_dev);
+  if (e->p_host) (void)hipHostFree(e->p_host);
   if (e->side_stream) (void)hipStreamSynchronize(e->side_stream);
   if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
   if (e->ev_main) (void)hipEventDestroy(e->ev_main);
@@ -501,6 +684,7 @@ extern "C" int afe_set_imu_noise(afe_engine *e, int enabled, double sigma_gyro, 
   if (!e || !(sigma_gyro >= 0) || !(sigma_acc >= 0) ||
       (seed_policy != AFE_SEED_REFERENCE && seed_policy != AFE_SEED_DECORRELATED))
     return fail(e, AFE_ERR_INVALID_ARG, "bad noise configuration");
+  { const int prc = persist_park(e); if (prc) return prc; }   // a resident grid carries the old configuration
   e->noise = enabled != 0;
   e->sigma_gyro = sigma_gyro;
   e->sigma_acc = sigma_acc;
@@ -668,6 +852,9 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   int rc = refresh_table(e, dt);
   if (rc) return rc;
   if (e->logic_on && (rc = refresh_logic(e))) return rc;
+  if (e->p_failed) return fail(e, AFE_ERR_HIP, "a persistent step kernel failed earlier (" + e->err + "); create a new engine");
+  if (persist_eligible(e)) return persist_step(e, dt_us, n_steps);
+  if (e->p_running && (rc = persist_park(e))) return rc;
   LaunchFlags f;
   f.ext_force = e->has_ext_force;
   f.ext_torque = e->has_ext_torque;
@@ -728,7 +915,42 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
     if (motor_lazy(e)) e->motor_stale = true;
     done += chunk;
+    e->steps_issued += (uint64_t)chunk;
   }
+  return AFE_OK;
+}
+
+extern "C" int afe_set_step_mode(afe_engine *e, int mode) {
+  if (!e || mode < AFE_STEP_LAUNCH || mode > AFE_STEP_AUTO) return fail(e, AFE_ERR_INVALID_ARG, "step mode: 0 (launches), 1 (persistent) or 2 (automatic)");
+  AFE_HIP(e, hipSetDevice(e->device));
+  const int rc = persist_park(e);
+  if (rc) return rc;
+  e->step_mode = mode;
+  return AFE_OK;
+}
+
+extern "C" int afe_steps_completed(afe_engine *e, uint64_t *steps) {
+  if (!e || !steps) return AFE_ERR_INVALID_ARG;
+  uint64_t pending = 0;
+  if (e->p_running && p_status(e)[0] != 0) {
+    // the grid has parked itself (a quiet host): steps authorised around that moment wait for a new grid -- start it here,
+    // or a host that only watches this word would watch for ever
+    AFE_HIP(e, hipSetDevice(e->device));
+    int rc = persist_collect(e);
+    if (rc) return rc;
+    if (e->p_resume < e->p_next && (rc = persist_launch(e))) return rc;
+  }
+  if (e->p_running) {
+    const uint64_t seen = std::max<uint64_t>(p_status(e)[1], e->p_resume);
+    pending = e->p_next - std::min<uint64_t>(seen, e->p_next);
+  }
+  *steps = e->steps_issued - pending;
+  return AFE_OK;
+}
+
+extern "C" int afe_persistent_running(const afe_engine *e, int *running) {
+  if (!e || !running) return AFE_ERR_INVALID_ARG;
+  *running = e->p_running ? 1 : 0;
   return AFE_OK;
 }
 
@@ -780,6 +1002,7 @@ extern "C" int afe_sync(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
   AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
+  if (e->p_failed) return fail(e, AFE_ERR_HIP, e->err);
   return AFE_OK;
 }
 

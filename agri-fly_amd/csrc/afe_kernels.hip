@@ -467,7 +467,7 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
 
 template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE, bool BUF>
 __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParams<R> &P, const DevLogic &G,
-                                            const int64_t i) {
+                                            const int64_t i, const unsigned long long tick_mask, const int n_steps_arg) {
   // No implicit FMA contraction: every rounding is the one the source spells
   // out, so all instantiations (noise on/off, wrench on/off, table/uniform,
   // fused or single-step) produce bit-identical physics, and the operation
@@ -503,7 +503,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   // this launch's first logic tick (which need nothing else) run while the ~24
   // state loads behind it are still in flight.
   uint32_t rng = 0;
-  if (NOISE && v.tick_mask) rng = AFE_LD(uint32_t, v.rng, 0, off4);
+  if (NOISE && tick_mask) rng = AFE_LD(uint32_t, v.rng, 0, off4);
   R px = AFE_LD(R, v.pos, 0, off), py = AFE_LD(R, v.pos, 1, off), pz = AFE_LD(R, v.pos, 2, off);
   R vx = AFE_LD(R, v.vel, 0, off), vy = AFE_LD(R, v.vel, 1, off), vz = AFE_LD(R, v.vel, 2, off);
   R q0 = AFE_LD(R, v.att, 0, off), q1 = AFE_LD(R, v.att, 1, off), q2 = AFE_LD(R, v.att, 2, off), q3 = AFE_LD(R, v.att, 3, off);
@@ -534,7 +534,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   // The logic's own state (filter memory, commands: 18 registers) is wanted only at the tick.  A launch of several
   // sub-steps fetches it here with everything else; the one-step launch fetches it behind the rigid-body update
   // (AFE_LOGIC_LOADS_LATE), where the draws and the dynamics no longer need the registers.
-  if (LOGIC && v.tick_mask && !(SINGLE && AFE_LOGIC_LOADS_LATE)) AFE_LOAD_LOGIC_STATE();
+  if (LOGIC && tick_mask && !(SINGLE && AFE_LOGIC_LOADS_LATE)) AFE_LOAD_LOGIC_STATE();
   float cmd_new[4] = {0, 0, 0, 0};
 
   const R dt = v.dt;
@@ -550,9 +550,9 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   for (int m = 0; m < 4; m++) { cmd[m] = (R)cmd_f[m]; if (cmd[m] < 0) cmd[m] = 0; }
 
   // SINGLE: one sub-step per launch (the per-step-observable mode): no loop
-  const int n_steps = SINGLE ? 1 : v.n_steps;
+  const int n_steps = SINGLE ? 1 : n_steps_arg;
   for (int step = 0; step < n_steps; step++) {
-    const bool tick = (v.tick_mask >> step) & 1ull;        // Quadcopter_T.cpp:159 (wave-uniform)
+    const bool tick = (tick_mask >> step) & 1ull;          // Quadcopter_T.cpp:159 (wave-uniform)
     if (NOISE && tick) {
       // The six Gaussian draws of this sub-step's logic tick need only the engine
       // word, so they are made FIRST: on the first sub-step they run while the
@@ -765,7 +765,7 @@ __global__ void __launch_bounds__(AFE_BLOCK, AFE_LB_WAVES)
 afe_step_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G) {
   const int64_t i = v.first + (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;
   if (i >= v.end) return;
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE, BUF>(v, P, G, i);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE, BUF>(v, P, G, i, v.tick_mask, v.n_steps);
 }
 
 // heterogeneous ensemble: type tables staged into LDS, one record per lane
@@ -790,7 +790,7 @@ afe_step_kernel_table(const StepView<R> v) {
   const unsigned t = v.type[(uint32_t)i];
   const DevParams<R> &P = reinterpret_cast<const DevParams<R> *>(lds_raw)[t];
   const DevLogic &G = reinterpret_cast<const DevLogic *>(lds_raw + (size_t)words_p * 4)[LOGIC ? t : 0];
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false, BUF>(v, P, G, i);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false, BUF>(v, P, G, i, v.tick_mask, v.n_steps);
 }
 
 // heterogeneous ensemble, but every wave (aligned run of 64 vehicles) is of one type -- the host checked
@@ -806,7 +806,165 @@ afe_step_kernel_wave_types(const StepView<R> v) {
   const DevParams<R> P = v.table[t];
   DevLogic G = {};
   if (LOGIC) G = v.logic_table[t];
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false, BUF>(v, P, G, i);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false, BUF>(v, P, G, i, v.tick_mask, v.n_steps);
+}
+
+// ---------------------------------------------------------------------------
+// Persistent stepping (afe_device.h PersistArgs; host side: afe_engine.cpp persist_*).
+typedef unsigned long long u64_t;
+__device__ __forceinline__ u64_t ld_agent(const u64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(u64_t *p, u64_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64_t ld_system(const u64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_system(u64_t *p, u64_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u64_t ticks100() { return __builtin_amdgcn_s_memrealtime(); }   // 100 MHz, constant
+__device__ __forceinline__ int ones_from_bit0(u64_t m) { return m == ~0ull ? 64 : (int)__builtin_ctzll(~m); }
+// ring entry: bits 0-1 flags, 2-47 step index + 1, 48-63 the launch that published it (device ring only: a park entry
+// left behind by an earlier launch at the very index this one starts from must not end it)
+__device__ __forceinline__ u64_t entry_index(u64_t e) { return (e >> 2) & ((1ull << 46) - 1); }
+__device__ __forceinline__ u64_t entry_stamp(u64_t e, unsigned epoch) { return (e & ((1ull << 48) - 1)) | ((u64_t)(epoch & 0xffffu) << 48); }
+
+// Workgroup 0.  Keeps three things moving, one sweep after the other: the workers' progress (the minimum over
+// done[] -> flow control of the device ring and the host's `completed` word), new host entries -> device ring, and
+// the two ways out: a park entry from the host, or one of its own when the host has gone quiet.
+__device__ __forceinline__ void persist_pump(const PersistArgs &a) {
+  const int lane = (int)threadIdx.x;
+  u64_t p = a.start;                    // next entry to republish
+  const u64_t t_start = ticks100();
+  u64_t t_fed = t_start;                // when the host last had something for us
+  u64_t t_moving = t_start;             // when entries last moved (or there were none to move)
+  u64_t m_seen = a.start;
+  u64_t park_pos;
+  u64_t err = 0;
+  for (;;) {
+    // (1) progress of the slowest worker
+    u64_t m = ~0ull;
+    for (int w = lane; w < a.n_workers; w += 64) { const u64_t d = ld_agent(a.done + w); m = d < m ? d : m; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u64_t other = __shfl_xor(m, o, 64); m = other < m ? other : m; }
+    if (lane == 0) st_system(a.host_status + 1, m);
+    // (2) up to 64 new entries, in order, never more than a device ring (less one sweep) ahead of that worker
+    const u64_t idx = p + (u64_t)lane;
+    const u64_t h = ld_system(a.host_ring + (idx & a.host_mask));
+    const bool ready = entry_index(h) == idx + 1;
+    const bool room = idx + 64 < m + (u64_t)a.dev_mask + 1;
+    int cnt = ones_from_bit0(__ballot(ready && room));
+    const u64_t parks = __ballot(ready && (h & AFE_PERSIST_PARK)) & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1));
+    if (parks) cnt = (int)__builtin_ctzll(parks) + 1;      // the park entry is the last one anybody reads
+    if (lane < cnt) st_agent(a.dev_ring + (idx & a.dev_mask), entry_stamp(h, a.epoch));
+    p += (u64_t)cnt;
+    if (parks) { park_pos = p - 1; break; }
+    const u64_t now = ticks100();
+    const bool fed = (__ballot(ready) & 1ull) != 0;       // the host is ahead of us (there may just be no room yet)
+    if (fed || m < p) t_fed = now;                         // patience runs only while the workers have nothing left to do:
+                                                           // the completion word stays true to the end, and a grid with work never leaves
+    if (cnt > 0 || !fed || m != m_seen) t_moving = now;    // not stuck: entries moved, or there were none to move, or the slowest worker advanced
+    m_seen = m;
+    // (3) nobody feeds us: park at p.  Slot p is free: p < min_done + ring by (2).
+    const bool idle = now - t_fed > (u64_t)a.idle_ticks;
+    const bool gave_up = now - t_moving > (u64_t)a.give_up_ticks;   // entries waiting and the workers never made room
+    if (idle || gave_up) {
+      if (lane == 0) st_agent(a.dev_ring + (p & a.dev_mask), entry_stamp(((p + 1) << 2) | AFE_PERSIST_PARK, a.epoch));
+      park_pos = p;
+      if (gave_up) err = 1;
+      break;
+    }
+  }
+  if (lane == 0) {
+    if (err) st_system(a.host_status + 2, err);
+    st_system(a.host_status + 0, park_pos + 1);
+  }
+}
+
+template <typename R, bool FEXT, bool NOISE, bool LOGIC>
+__global__ void __launch_bounds__(64)
+afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G, const PersistArgs a) {
+  if (blockIdx.x == 0) { persist_pump(a); return; }
+  const int lane = (int)threadIdx.x;
+  const int w = (int)blockIdx.x - 1;
+  u64_t s = a.start;
+  u64_t t_wait = ticks100();
+  for (;;) {
+    const u64_t idx = s + (u64_t)lane;
+    const u64_t e = ld_agent(a.dev_ring + (idx & a.dev_mask));
+    const bool ready = entry_index(e) == idx + 1 && (!(e & AFE_PERSIST_PARK) || (unsigned)(e >> 48) == (a.epoch & 0xffffu));
+    const int cnt = ones_from_bit0(__ballot(ready));
+    if (cnt == 0) {
+      if (ticks100() - t_wait > (u64_t)a.give_up_ticks + 50000000ull) {   // the pump gives up first and parks us; this is the last resort
+        if (lane == 0) st_system(a.host_status + 2, 2);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    const u64_t low = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
+    const u64_t ticks = __ballot(ready && (e & AFE_PERSIST_TICK)) & low;
+    const u64_t parks = __ballot(ready && (e & AFE_PERSIST_PARK)) & low;
+    const int run = parks ? (int)__builtin_ctzll(parks) : cnt;             // steps in front of the park entry
+    for (int k = 0; k < run; k++) {
+      const u64_t tick = (ticks >> k) & 1ull;                              // wave-uniform (scalar)
+      for (int c = w; c < a.n_chunks; c += a.n_workers) {
+        const int64_t i = (int64_t)c * 64 + lane;
+        if (i < v.n) run_vehicle<R, FEXT, false, NOISE, LOGIC, true, true>(v, P, G, i, tick, 1);
+      }
+    }
+    s += (u64_t)run;
+    if (lane == 0) st_agent(a.done + w, s);
+    if (parks) return;
+    t_wait = ticks100();
+  }
+}
+
+// occupancy != 0: do not launch, report how many of the instantiation's one-wave workgroups a CU holds
+template <typename R>
+static int launch_persistent(const StepView<R> &v, const LaunchFlags &f, const DevParams<R> &uniform,
+                             const DevLogic *uniform_logic, const PersistArgs &a, hipStream_t st, int *occupancy) {
+  DevLogic no_logic = {};
+  const DevLogic &G = uniform_logic ? *uniform_logic : no_logic;
+  const dim3 grid((unsigned)(1 + a.n_workers)), block(64);
+#define AFE_PL(FE, NO, LO)                                                                                              \
+  do {                                                                                                                  \
+    if (occupancy) {                                                                                                    \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, afe_step_persistent_kernel<R, FE, NO, LO>, 64, 0) != hipSuccess) \
+        *occupancy = 0;                                                                                                 \
+    } else {                                                                                                            \
+      hipLaunchKernelGGL((afe_step_persistent_kernel<R, FE, NO, LO>), grid, block, 0, st, v, uniform, G, a);            \
+    }                                                                                                                   \
+  } while (0)
+#define AFE_PL_LO(FE, NO) do { if (f.logic) AFE_PL(FE, NO, true); else AFE_PL(FE, NO, false); } while (0)
+#define AFE_PL_NO(FE) do { if (f.noise) AFE_PL_LO(FE, true); else AFE_PL_LO(FE, false); } while (0)
+  if (f.ext_force) AFE_PL_NO(true); else AFE_PL_NO(false);
+#undef AFE_PL_NO
+#undef AFE_PL_LO
+#undef AFE_PL
+  return (int)hipGetLastError();
+}
+
+// Resident one-wave workgroups per CU the grid may count on.  The occupancy query answers for registers and LDS;
+// what it does not see is the scalar-register file: these kernels keep their ~100 argument dwords in SGPRs
+// (106 allocated), which admits 6 waves per SIMD where 71 VGPRs alone would admit 7 (MI355X_MICROARCH.md, residency
+// rule: floor(800 / (ceil(sgpr / 16) * 16 + 16)); measured here: a 6 145-workgroup grid is the first that is not
+// co-resident, tools/persist_waves_probe.py).  Should a grid nevertheless be cut too large, the pump notices
+// that nothing moves, parks it, and the host tries again with fewer workers (afe_engine.cpp persist_collect).
+template <typename R>
+static int persistent_capacity(const LaunchFlags &f) {
+  StepView<R> v = {};
+  DevParams<R> P = {};
+  PersistArgs a = {};
+  int per_cu = 0;
+  (void)launch_persistent<R>(v, f, P, nullptr, a, nullptr, &per_cu);
+  const int sgpr_bound = 6 * 4;
+  return per_cu < sgpr_bound ? per_cu : sgpr_bound;
+}
+int persistent_capacity_f32(const LaunchFlags &f) { return persistent_capacity<float>(f); }
+int persistent_capacity_f64(const LaunchFlags &f) { return persistent_capacity<double>(f); }
+
+int launch_persistent_f32(const StepView<float> &v, const LaunchFlags &f, const DevParams<float> &uniform,
+                          const DevLogic *uniform_logic, const PersistArgs &a, void *stream) {
+  return launch_persistent<float>(v, f, uniform, uniform_logic, a, (hipStream_t)stream, nullptr);
+}
+int launch_persistent_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> &uniform,
+                          const DevLogic *uniform_logic, const PersistArgs &a, void *stream) {
+  return launch_persistent<double>(v, f, uniform, uniform_logic, a, (hipStream_t)stream, nullptr);
 }
 
 template <typename R>

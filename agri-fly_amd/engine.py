@@ -16,6 +16,7 @@ _LIB = os.environ.get("AGRIFLY_ENGINE_LIB") or os.path.join(_HERE, "lib", "libag
 
 AFE_F32, AFE_F64 = 0, 1
 AFE_SEED_REFERENCE, AFE_SEED_DECORRELATED = 0, 1
+AFE_STEP_LAUNCH, AFE_STEP_PERSISTENT, AFE_STEP_AUTO = 0, 1, 2
 
 # every symbol include/agrifly_engine.h declares (checked by tests/test_abi.py)
 ABI_FUNCTIONS = [
@@ -44,6 +45,7 @@ ABI_FUNCTIONS = [
     "afe_group_step", "afe_group_sync", "afe_group_gather_positions", "afe_group_last_error",
     "afe_nearest_neighbour_grid", "afe_neighbour_grid_info", "afe_set_neighbour_grid_refresh", "afe_nearest_neighbour_bruteforce",
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
+    "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running",
 ]
 
 
@@ -244,6 +246,9 @@ def library():
         "afe_set_commands_from_radio": [eng, i64, i64, vp],
         "afe_set_max_fused_steps": [eng, ci],
         "afe_set_split_stepping": [eng, ci],
+        "afe_set_step_mode": [eng, ci],
+        "afe_steps_completed": [eng, C.POINTER(u64)],
+        "afe_persistent_running": [eng, C.POINTER(ci)],
         "afe_set_addressing": [eng, ci],
         "afe_step_kernel_info": [eng, C.POINTER(ci), C.POINTER(ci)],
         "afe_planner_default_config": [C.POINTER(PlannerConfig), ci, ci] + [C.c_double] * 5,
@@ -749,6 +754,23 @@ class Ensemble:
     def set_split_stepping(self, parts):
         """afe_set_split_stepping: 0 automatic (default), 1 off, 2 = the two halves of the ensemble step on two streams (see the header)"""
         self._ck(self._L.afe_set_split_stepping(self._h, int(parts)))
+
+    def set_step_mode(self, mode):
+        """afe_set_step_mode: AFE_STEP_LAUNCH (0), AFE_STEP_PERSISTENT (1: one resident grid, afe_step only authorises steps), AFE_STEP_AUTO (2)"""
+        self._ck(self._L.afe_set_step_mode(self._h, int(mode)))
+
+    @property
+    def steps_completed(self):
+        """steps every vehicle has been advanced through (the resident grid's completion word; steps issued in launch mode)"""
+        n = C.c_uint64(0)
+        self._ck(self._L.afe_steps_completed(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def persistent_running(self):
+        r = C.c_int(0)
+        self._ck(self._L.afe_persistent_running(self._h, C.byref(r)))
+        return bool(r.value)
 
     def steps_until_tick(self, dt_us):
         n = C.c_int(0)

@@ -447,6 +447,36 @@ int afe_step_kernel_info(const afe_engine *e, int *record_path, int *addressing)
  *     then call afe_sync or afe_event_record in between. */
 int afe_set_split_stepping(afe_engine *e, int parts);
 
+/* Persistent stepping: afe_step without a kernel launch per step.  The step loop of the reference
+ * (`for each vehicle: Run(); clock += dt`, Simulator/Rappids_Simulator/main.cpp:330,391-392;
+ * AIFS_ROS/hiperlab_rostools/src/Simulator/main.cpp:323-325) has no barrier between vehicles, so nothing in it
+ * asks for one between two steps of different vehicles either.  In this mode ONE resident grid of one-wave
+ * workgroups stays on the device; afe_step(e, dt, k) authorises k more steps by writing k 8-byte descriptors
+ * (step number, logic-tick flag) into a ring in pinned host memory and returns; every wave advances ITS vehicles
+ * through each descriptor as it appears -- loads, the step, stores: the body of the one-step launch, the state
+ * back in HBM after every step, bit for bit the launched kernels' results.  What a dependent launch costs on top
+ * of its streaming time (2.7 us here: drain, dispatch, ramp-up) is not paid; an ensemble of 131 072 vehicles --
+ * one GPU's shard of the 1 M-vehicle configuration on eight -- steps in [see DESIGN.md section 6] instead of 5.6 us.
+ * The grid leaves the device ("parks") when any other entry point needs the stream or the state (afe_sync, getters,
+ * setters, events, queries, checkpoints ...: they all do it implicitly and the next afe_step starts a new grid), and
+ * by itself when the host has not authorised a step for ~200 us, so nothing -- not even a device-wide
+ * synchronisation issued elsewhere -- can wait on it for ever.
+ *   mode = AFE_STEP_LAUNCH (0, default): one kernel launch per step (or per afe_set_max_fused_steps chunk).
+ *   mode = AFE_STEP_PERSISTENT (1): as above, whenever the ensemble qualifies -- every vehicle on type record 0,
+ *     no external torque, the engine's own stream, an arena below 4 GiB; otherwise the launches, silently.
+ *   mode = AFE_STEP_AUTO (2): persistent for ensembles of up to 2^20 vehicles, launches (split, see above) beyond
+ *     (measured table: DESIGN.md section 6).
+ * afe_steps_completed: the number of steps (since afe_create) that EVERY vehicle has been advanced through -- the
+ * per-step completion word of the resident grid, readable at any time without disturbing it; in launch mode the
+ * number of steps issued.  (Reading the state itself goes through the getters, which park the grid first.) */
+#define AFE_STEP_LAUNCH 0
+#define AFE_STEP_PERSISTENT 1
+#define AFE_STEP_AUTO 2
+int afe_set_step_mode(afe_engine *e, int mode);
+int afe_steps_completed(afe_engine *e, uint64_t *steps);
+/* 1 while a resident grid is on the device, 0 otherwise (diagnostic; tests use it) */
+int afe_persistent_running(const afe_engine *e, int *running);
+
 /* How many sub-steps afe_step may fuse into one kernel launch (1..64, default
  * 64).  1 = one launch per step (state goes through HBM every step: the
  * per-step-observable mode bench.py reports); results are bitwise identical

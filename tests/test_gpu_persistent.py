@@ -1,0 +1,178 @@
+"""Persistent stepping (afe_set_step_mode): one resident grid, afe_step only authorises steps.
+Everything is compared BITWISE with the launched kernels -- the two modes run the same per-vehicle code,
+so state, IMU samples, commands, engine words, clock and tick counts must be identical -- through the
+situations the hand-shake has to survive: getters and setters between steps (each parks the grid), a host that
+goes quiet (the grid parks itself), more steps than the rings hold, several chunks per worker wave, mode
+switches, configuration changes, the on-device logic, checkpoints.
+
+Reference loop being replaced: Simulator/Rappids_Simulator/main.cpp:330,391-392 and
+AIFS_ROS/hiperlab_rostools/src/Simulator/main.cpp:323-325 (`for each vehicle: Run()`, no barrier)."""
+import importlib
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from tests.scenarios import random_ensemble
+
+afa = importlib.import_module("agri-fly_amd")
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make(n, precision, persistent, logic=False, seed=5, wrench=True):
+    ens = random_ensemble(n, seed=seed, with_wrench=wrench, type_ids=(5,))
+    d = ens.data
+    e = afa.Ensemble(n, precision=precision)
+    e.set_type_table([afa.params_from_type(d.type_ids[0])])
+    e.set_logic_period(1 / 500)
+    e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+    e.set_state(d.pos, d.vel, d.att, d.ang_vel, d.motor_speed)
+    e.set_motor_cmds(d.motor_cmd)
+    if wrench:
+        e.set_external_force(d.ext_force)
+    if logic:
+        e.set_rates_logic([afa.rates_logic_params_from_type(d.type_ids[0])])
+        rng = np.random.default_rng(3)
+        e.set_rates_commands(np.full(n, 9.5, np.float32), (0.2 * rng.standard_normal((3, n))).astype(np.float32))
+    e.set_split_stepping(1)
+    e.set_step_mode(afa.AFE_STEP_PERSISTENT if persistent else afa.AFE_STEP_LAUNCH)
+    return e, d
+
+
+def everything(e):
+    st = e.get_state()
+    gyro, acc = e.get_imu()
+    return dict(st, gyro=gyro, acc=acc, rng=e.get_rng_state(), cmd=e.get_motor_cmds(), time=np.array([e.time_us, e.logic_ticks]))
+
+
+def assert_same(a, b, what=""):
+    xa, xb = everything(a), everything(b)
+    for k in xa:
+        assert np.array_equal(xa[k], xb[k], equal_nan=True), (what, k)
+
+
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+@pytest.mark.parametrize("logic", [False, True])
+def test_persistent_steps_are_bitwise_the_launched_steps(precision, logic):
+    n = 70001                      # 1 094 chunks, the last one ragged
+    a, d = make(n, precision, False, logic)
+    b, _ = make(n, precision, True, logic)
+    script = ([("step", 1000, 1)] * 6 + [("get",), ("step", 1000, 9), ("cmd",), ("step", 500, 3), ("step", 1000, 1), ("force",),
+              ("step", 1000, 40), ("launch",), ("step", 1000, 3), ("persistent",), ("step", 2000, 7), ("noise_off",), ("step", 1000, 4),
+              ("noise_on",), ("step", 1000, 5), ("get",)])
+    for op in script:
+        for e in (a, b):
+            if op[0] == "step":
+                e.step(op[1], op[2])
+            elif op[0] == "cmd":
+                if logic:
+                    e.set_rates_commands(np.full(n, 10.5, np.float32), np.zeros((3, n), np.float32))
+                else:
+                    e.set_motor_cmds(np.clip(d.motor_cmd * 1.05, 0, None))
+            elif op[0] == "force":
+                e.set_external_force(d.ext_force * 0.5)
+            elif op[0] == "launch" and e is b:
+                e.set_step_mode(afa.AFE_STEP_LAUNCH)
+            elif op[0] == "persistent" and e is b:
+                e.set_step_mode(afa.AFE_STEP_PERSISTENT)
+            elif op[0] == "noise_off":
+                e.set_imu_noise(False, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+            elif op[0] == "noise_on":
+                e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+        if op[0] == "get":
+            assert_same(a, b, op)
+    assert b.steps_completed == a.steps_completed == 6 + 9 + 3 + 1 + 40 + 3 + 7 + 4 + 5
+    a.close(); b.close()
+
+
+def test_one_step_per_call_is_observable_and_a_quiet_host_parks_the_grid():
+    """afe_step(dt, 1) again and again: the completion word follows, never runs ahead; after the host has been quiet
+    for longer than the grid's patience (200 us) the grid has left by itself and the next step starts a new one."""
+    n = 131072
+    a, _ = make(n, afa.AFE_F32, False)
+    b, _ = make(n, afa.AFE_F32, True)
+    issued = 0
+    for burst in (1, 3, 50, 400, 1, 2000):
+        for _ in range(burst):
+            b.step(1000, 1)
+            issued += 1
+            assert b.steps_completed <= issued
+        a.step(1000, burst)
+        t0 = time.perf_counter()
+        while b.steps_completed < issued:            # the completion word arrives without any call that parks
+            assert time.perf_counter() - t0 < 5.0, "the resident grid never reported step %d" % issued
+        time.sleep(0.01)                              # 50 x the patience: the grid has parked itself; nothing was lost
+        assert b.steps_completed == issued
+        assert not b.persistent_running               # (the call above noticed)
+    assert_same(a, b)
+    a.close(); b.close()
+
+
+def test_more_steps_than_the_rings_hold_in_one_call_and_in_many():
+    n = 4096
+    a, _ = make(n, afa.AFE_F32, False, wrench=False)
+    b, _ = make(n, afa.AFE_F32, True, wrench=False)
+    a.step(1000, 9000)
+    b.step(1000, 9000)                   # one call: the host throttles itself on the completion word
+    assert_same(a, b, "one call")
+    for _ in range(5000):                # many calls, nothing in between
+        b.step(1000, 1)
+    a.step(1000, 5000)
+    assert_same(a, b, "many calls")
+    a.close(); b.close()
+
+
+def test_several_chunks_per_worker_wave():
+    """AFE_PERSIST_WAVES_PER_CU=1 leaves 255 worker waves: a 65 536-vehicle ensemble is 1 024 chunks, four or five per
+    wave.  Runs in a child process (the variable is read when the grid is first sized)."""
+    code = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_persistent import make, assert_same
+afa = importlib.import_module("agri-fly_amd")
+a, _ = make(65536 + 77, afa.AFE_F32, False)
+b, _ = make(65536 + 77, afa.AFE_F32, True)
+for k in (1, 2, 30, 1):
+    a.step(1000, k); b.step(1000, k)
+assert_same(a, b)
+print("ok")
+''' % ROOT
+    env = dict(os.environ, AFE_PERSIST_WAVES_PER_CU="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_checkpoint_while_the_grid_is_resident_resumes_bitwise():
+    n = 20000
+    a, _ = make(n, afa.AFE_F32, True, logic=True)
+    a.step(1000, 25)
+    blob = a.save_checkpoint()
+    a.step(1000, 30)
+    b, _ = make(n, afa.AFE_F32, True, logic=True)
+    b.load_checkpoint(blob)
+    b.step(1000, 30)
+    assert_same(a, b)
+    a.close(); b.close()
+
+
+def test_ineligible_ensembles_fall_back_to_launches():
+    """external torque and heterogeneous type slabs are not in the resident grid's repertoire: the mode is accepted
+    and the launches serve (same bits either way)."""
+    n = 5000
+    ens = random_ensemble(n, seed=9, with_wrench=True)
+    d = ens.data
+    engines = []
+    for mode in (afa.AFE_STEP_LAUNCH, afa.AFE_STEP_PERSISTENT):
+        e = ens.to_engine(afa.AFE_F32)
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_REFERENCE)
+        e.set_step_mode(mode)
+        e.step(1000, 12)
+        assert not e.persistent_running
+        engines.append(e)
+    assert_same(*engines)
+    for e in engines:
+        e.close()

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 afa = importlib.import_module("agri-fly_amd")
 import bench
 
-for n in (65536, 262144, 524288, 1 << 20, 2 << 20, 4 << 20):
+for n in (65536, 131072, 262144, 524288, 1 << 20, 2 << 20, 4 << 20):
     steps = 2000 if n <= (1 << 20) else 500
     row = []
     for parts in (1, 2):
