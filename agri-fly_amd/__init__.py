@@ -52,6 +52,7 @@ from .engine import (  # noqa: F401
     radio_decode,
     rates_logic_params_from_type,
     scene_check_hierarchy,
+    stream_probe,
     type_from_id,
 )
 from . import scenarios  # noqa: F401

@@ -147,6 +147,7 @@ int launch_pack_positions_f32(const float *pos, int64_t stride, int64_t n, float
 int launch_pack_positions_f64(const double *pos, int64_t stride, int64_t n, float *out, void *stream);
 int launch_normals_selftest(const uint32_t *seeds, int64_t n, double *out, uint32_t *state_out, void *stream);
 int launch_normals_selftest_f32(const uint32_t *seeds, int64_t n, float *out, uint32_t *state_out, void *stream);
+int launch_stream_probe(float *base, int64_t stride, int64_t n, int n_read, int n_write, void *stream);
 int launch_seed_rng(uint32_t *rng, int64_t n, int64_t first_global, int policy, void *stream);
 
 }  // namespace afe

@@ -1081,6 +1081,40 @@ extern "C" int afe_algorithmic_bytes_per_step(const afe_engine *e, int imu_tick,
   return AFE_OK;
 }
 
+extern "C" int afe_stream_probe(int device, int64_t n, int n_read, int n_write, int launches, float *us_per_launch) {
+  if (n <= 0 || launches < 1 || !us_per_launch || !((n_read == 20 && n_write == 13) || (n_read == 24 && n_write == 17))) return AFE_ERR_INVALID_ARG;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return AFE_ERR_NO_DEVICE;
+  int64_t stride = (n + 255) / 256 * 256;      // the engine's slab stride: 256 x an odd count
+  if ((stride / 256) % 2 == 0) stride += 256;
+  if ((uint64_t)stride * 4 * (uint64_t)n_read >= 0xffff0000ull) return AFE_ERR_INVALID_ARG;
+  float *buf = nullptr;
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = AFE_ERR_HIP;
+  float best = 1e30f;
+  if (hipMalloc((void **)&buf, (size_t)stride * 4 * n_read) != hipSuccess) return AFE_ERR_HIP;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) goto out;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) goto out;
+  if (hipMemsetAsync(buf, 0, (size_t)stride * 4 * n_read, st) != hipSuccess) goto out;
+  for (int rep = 0; rep < 4; rep++) {          // the first repetition warms up
+    if (hipEventRecord(e0, st) != hipSuccess) goto out;
+    for (int k = 0; k < launches; k++)
+      if (launch_stream_probe(buf, stride, n, n_read, n_write, st) != 0) goto out;
+    if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) goto out;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) goto out;
+    if (rep > 0 && ms < best) best = ms;
+  }
+  *us_per_launch = best * 1e3f / (float)launches;
+  rc = AFE_OK;
+out:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
+  (void)hipFree(buf);
+  return rc;
+}
+
 extern "C" int afe_event_create(void **event) {
   if (!event) return AFE_ERR_INVALID_ARG;
   hipEvent_t ev;

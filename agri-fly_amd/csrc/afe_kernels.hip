@@ -835,16 +835,30 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
   u64_t m_seen = a.start;
   u64_t park_pos;
   u64_t err = 0;
+  u64_t m = a.start;                    // every worker has consumed at least this much (a lower bound: done[] only grows)
+  u64_t acc = ~0ull;                    // this lane's minimum over the part of done[] swept so far in the current cycle
+  int sw = 0;                           // where the next partial sweep starts
   for (;;) {
-    // (1) progress of the slowest worker
-    u64_t m = ~0ull;
-    for (int w = lane; w < a.n_workers; w += 64) { const u64_t d = ld_agent(a.done + w); m = d < m ? d : m; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const u64_t other = __shfl_xor(m, o, 64); m = other < m ? other : m; }
-    if (lane == 0) st_system(a.host_status + 1, m);
-    // (2) up to 64 new entries, in order, never more than a device ring (less one sweep) ahead of that worker
+    // (1) the host's next entries and a slice of the workers' progress, both in flight together: the host read takes
+    // ~1.5 us, and an iteration must not take much longer than that (a park entry waits for one iteration).  512 workers
+    // per iteration; a cycle over a full grid of 6 143 takes 12 iterations, so `m` and the host's completion word are at
+    // most ~30 us old -- `m` errs low, which only makes the ring's window and the patience below conservative.
     const u64_t idx = p + (u64_t)lane;
     const u64_t h = ld_system(a.host_ring + (idx & a.host_mask));
+    u64_t d[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const int w = sw + lane + 64 * j; d[j] = w < a.n_workers ? ld_agent(a.done + w) : ~0ull; }
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc = d[j] < acc ? d[j] : acc;
+    sw += 512;
+    if (sw >= a.n_workers) {
+      u64_t r = acc;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const u64_t other = __shfl_xor(r, o, 64); r = other < r ? other : r; }
+      m = r; acc = ~0ull; sw = 0;
+      if (lane == 0) st_system(a.host_status + 1, m);
+    }
+    // (2) up to 64 new entries, in order, never more than a device ring (less one sweep) ahead of the slowest worker
     const bool ready = entry_index(h) == idx + 1;
     const bool room = idx + 64 < m + (u64_t)a.dev_mask + 1;
     int cnt = ones_from_bit0(__ballot(ready && room));
@@ -1108,6 +1122,37 @@ int launch_normals_selftest(const uint32_t *seeds, int64_t n, double *out, uint3
   if (n <= 0) return 0;
   hipLaunchKernelGGL(afe_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, seeds, n, out, state_out);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// afe_stream_probe: what this box streams in the step kernel's own launch shape -- one-wave workgroups, one lane per
+// element, NRD planar dword read streams and NWR write streams (in place) through one buffer resource, no arithmetic
+// to speak of.  bench.py prints it next to the nominal 8 TB/s ("use the box's measured copy figure
+// alongside the nominal peak and report both").
+template <int NRD, int NWR>
+__global__ void __launch_bounds__(64) afe_stream_probe_kernel(float *base, int64_t stride, int64_t n) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if ((int64_t)i >= n) return;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(NRD * stride * 4), 0x00020000);
+  const uint32_t off = i * 4u;
+  const uint32_t S4 = (uint32_t)stride * 4u;
+  float v[NRD];
+#pragma unroll
+  for (int k = 0; k < NRD; k++) v[k] = buf_ld<float>(r, off, k * S4);
+  float acc = 0;
+#pragma unroll
+  for (int k = NWR; k < NRD; k++) acc += v[k];
+#pragma unroll
+  for (int k = 0; k < NWR; k++) buf_st<float>(r, off, k * S4, v[k] * 1.0001f + acc);
+}
+
+int launch_stream_probe(float *base, int64_t stride, int64_t n, int n_read, int n_write, void *stream) {
+  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_read == 20 && n_write == 13) hipLaunchKernelGGL((afe_stream_probe_kernel<20, 13>), grid, block, 0, st, base, stride, n);        // 132 B: the off-tick launch
+  else if (n_read == 24 && n_write == 17) hipLaunchKernelGGL((afe_stream_probe_kernel<24, 17>), grid, block, 0, st, base, stride, n);   // 164 B: the tick launch
+  else return (int)hipErrorInvalidValue;
   return (int)hipGetLastError();
 }
 

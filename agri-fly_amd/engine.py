@@ -45,7 +45,7 @@ ABI_FUNCTIONS = [
     "afe_group_step", "afe_group_sync", "afe_group_gather_positions", "afe_group_last_error",
     "afe_nearest_neighbour_grid", "afe_neighbour_grid_info", "afe_set_neighbour_grid_refresh", "afe_nearest_neighbour_bruteforce",
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
-    "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running",
+    "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running", "afe_stream_probe",
 ]
 
 
@@ -155,6 +155,15 @@ class DeviceView(C.Structure):
     ]
 
 
+def stream_probe(n, n_read=24, n_write=17, launches=100, device=-1):
+    """afe_stream_probe: microseconds per launch of a pure streaming kernel in the step kernel's launch shape"""
+    us = C.c_float(0)
+    rc = library().afe_stream_probe(int(device), int(n), int(n_read), int(n_write), int(launches), C.byref(us))
+    if rc:
+        raise AfeError(rc, "afe_stream_probe")
+    return us.value
+
+
 def library_path():
     return _LIB
 
@@ -247,6 +256,7 @@ def library():
         "afe_set_max_fused_steps": [eng, ci],
         "afe_set_split_stepping": [eng, ci],
         "afe_set_step_mode": [eng, ci],
+        "afe_stream_probe": [ci, i64, ci, ci, ci, C.POINTER(C.c_float)],
         "afe_steps_completed": [eng, C.POINTER(u64)],
         "afe_persistent_running": [eng, C.POINTER(ci)],
         "afe_set_addressing": [eng, ci],

@@ -3,9 +3,14 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over the whole ensemble: one launch of the
-step kernel advancing every vehicle by dt = 1 ms, state read from and written
-back to HBM (no temporal fusion in the headline number).  Workload: the
+A "step" is one pass of the hot path over the whole ensemble: every vehicle
+advanced by dt = 1 ms, state read from and written back to HBM (no temporal
+fusion in the headline number), one afe_step(e, dt, 1) call per step.  The
+engine runs in AFE_STEP_AUTO: up to 2^20 vehicles per GPU one resident grid
+serves the steps (afe_set_step_mode: no kernel boundary between two steps),
+beyond that one launch per step and half of the shard.  The timed region is
+repeated -- blocks of exactly K steps, each bracketed by barrier + synchronise --
+until 50 ms have been timed; the line carries the median block.  Workload: the
 config-4 shape of BASELINE.json -- a hovering MINIQUAD ensemble with a
 per-vehicle wind-gust force through the SetExternalForce port, IMU synthesis
 with on-device libstdc++-compatible noise at the 500 Hz onboard-logic cadence --
@@ -56,12 +61,20 @@ def build_shard(afa, n_local, first_global, n_global, device, fext=True, precisi
     e.set_motor_cmds(data.motor_cmd)
     if fext:
         e.set_external_force(data.ext_force)
+    e.set_step_mode(afa.AFE_STEP_AUTO)      # one resident grid up to 2^20 vehicles, (split) launches beyond
     return e
 
 
+def uses_persistent(afa, mode, n):
+    mode = afa.AFE_STEP_AUTO if mode is None else mode
+    return mode == afa.AFE_STEP_PERSISTENT or (mode == afa.AFE_STEP_AUTO and n <= (1 << 20))
+
+
 def time_steps(e, steps, per_launch, sync, barrier):
-    """wall time of `steps` physics steps issued as launches of `per_launch`"""
+    """wall time of `steps` physics steps issued as afe_step calls of `per_launch` steps each, bracketed by
+    barrier + synchronise on both sides (e.sync() first: it ends a resident grid after the last authorised step)"""
     barrier()
+    e.sync()
     sync()
     t0 = time.perf_counter()
     done = 0
@@ -69,14 +82,32 @@ def time_steps(e, steps, per_launch, sync, barrier):
         k = min(per_launch, steps - done)
         e.step(DT_US, k)
         done += k
+    e.sync()
     sync()
     barrier()
     return time.perf_counter() - t0
 
 
+def timed_blocks(e, steps, per_launch, sync, barrier, reduce_max, min_total_s=0.05, min_blocks=5, max_blocks=2000):
+    """blocks of exactly `steps` steps, each bracketed like time_steps, until `min_total_s` seconds have been timed;
+    reduce_max makes every rank see the slowest rank's time of a block, so all ranks run the same number of blocks"""
+    blocks, total = [], 0.0
+    while len(blocks) < min_blocks or (total < min_total_s and len(blocks) < max_blocks):
+        t = reduce_max(time_steps(e, steps, per_launch, sync, barrier))
+        blocks.append(t)
+        total += t
+    return blocks
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
 def kernel_time_events(e, launches):
-    """average duration of one step-kernel launch, HIP events on the engine's
-    stream bracketing a back-to-back run of single-step launches"""
+    """device time per step: HIP events on the engine's stream bracketing a back-to-back run of `launches` single-step
+    afe_step calls (launch mode: that many kernel launches; persistent mode: one resident grid serving them all, from
+    its launch to its exit)"""
     ev0, ev1 = e.event(), e.event()
     e.sync()
     e.record(ev0)
@@ -87,6 +118,16 @@ def kernel_time_events(e, launches):
     e.destroy_event(ev0)
     e.destroy_event(ev1)
     return ms * 1e-3 / launches
+
+
+def event_blocks(e, launches, min_total_s=0.05, min_blocks=5, max_blocks=400):
+    """kernel_time_events repeated until min_total_s of device time has been measured: (median, min, max, repeats)"""
+    ts, total = [], 0.0
+    while len(ts) < min_blocks or (total < min_total_s and len(ts) < max_blocks):
+        t = kernel_time_events(e, launches)
+        ts.append(t)
+        total += t * launches
+    return median(ts), min(ts), max(ts), len(ts)
 
 
 def mean_bytes_per_step(e, afa, steps):
@@ -101,6 +142,7 @@ def per_kernel_breakdown(afa, n_local, device):
     res = {}
     for name, period in (("off_tick", 1000.0), ("on_tick", 0.0005)):
         e = build_shard(afa, n_local, 0, n_local, device)
+        e.set_step_mode(afa.AFE_STEP_LAUNCH)
         e.set_split_stepping(1)      # the kernels themselves: one launch per step for the whole shard
         e.set_logic_period(period)
         for _ in range(50):
@@ -120,7 +162,9 @@ def companion_rows(afa, n_local, device, sync, barrier, split=False):
     f64 -- the same kernel in the reference's own precision (AFE_F64), one launch per step."""
     rows = {}
     e = build_shard(afa, n_local, 0, n_local, device)
-    e.set_split_stepping(2 if split else 1)      # like the headline
+    e.set_step_mode(afa.AFE_STEP_LAUNCH)         # a fused launch is a launch
+    e.set_split_stepping(2 if n_local >= (1 << 19) else 1)
+    split = n_local >= (1 << 19)
     k = 1000
     time_steps(e, 100, 2, sync, barrier)
     t = time_steps(e, k, 2, sync, barrier)
@@ -141,14 +185,13 @@ def companion_rows(afa, n_local, device, sync, barrier, split=False):
     e.destroy_event(ev0)
     e.destroy_event(ev1)
     e.close()
-    e = build_shard(afa, n_local, 0, n_local, device, precision=afa.AFE_F64)
-    e.set_split_stepping(2 if split else 1)
+    e = build_shard(afa, n_local, 0, n_local, device, precision=afa.AFE_F64)      # stepping: automatic, like the headline
     time_steps(e, 50, 1, sync, barrier)
     k = 400
     t = time_steps(e, k, 1, sync, barrier)
     t_kernel = kernel_time_events(e, 200)
     bytes_step, _ = mean_bytes_per_step(e, afa, k)
-    rows["f64"] = {"value": n_local * k / t, "unit": "vehicle-steps/s", "dtype": "f64", "kernel_us": t_kernel * 1e6,
+    rows["f64"] = {"value": n_local * k / t, "unit": "vehicle-steps/s", "dtype": "f64", "stepping": "persistent" if uses_persistent(afa, None, n_local) else "launches", "kernel_us": t_kernel * 1e6,
                    "algorithmic_bytes_per_vehicle_step": bytes_step, "achieved_GBs": n_local * bytes_step / t_kernel / 1e9,
                    "frac": n_local * bytes_step / t_kernel / 1e9 / HBM_PEAK_GBS}
     e.close()
@@ -379,38 +422,40 @@ def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, ba
     # physics with a query every 10 steps (100 Hz at dt = 1 ms) vs physics alone
     def run(k_steps, every):
         barrier()
+        e.sync()
         sync()
         t0 = time.perf_counter()
         for s in range(k_steps):
             e.step(DT_US, 1)
             if every and (s + 1) % every == 0:
                 query(with_uwb=False)     # the UWB read-back would serialise the host; timed above on its own
+        e.sync()
         sync()
         barrier()
         return time.perf_counter() - t0
     run(50, 10)
     k = 400
     t_without = run(k, 0)
-    # With a query every 10 steps the two-stream stepping has little to hide behind (every query joins the streams):
-    # time both ways of stepping and report the faster one, named.  Every rank takes the same decision (rank 0's).
+    # every query ends a resident grid / joins the two streams: time the ways of stepping between queries and report the
+    # fastest one, named.  Every rank takes the same decision (the slowest rank's times).
     t_by_mode = {}
-    for parts_n in ((2, 1) if split else (1,)):
+    modes = {"automatic (one resident grid between queries)" if n_local <= (1 << 20) else "automatic (two streams)": (afa.AFE_STEP_AUTO, 0),
+             "launches, one stream": (afa.AFE_STEP_LAUNCH, 1)}
+    for name, (m, parts_n) in modes.items():
+        e.set_step_mode(m)
         e.set_split_stepping(parts_n)
         run(50, 10)
-        t_by_mode[parts_n] = run(k, 10)
+        t_by_mode[name] = run(k, 10)
     if dist is not None:
-        tm = torch.tensor([t_by_mode.get(2, 1e30), t_by_mode[1]], dtype=torch.float64, device="cuda")
+        names = sorted(t_by_mode)
+        tm = torch.tensor([t_by_mode[x] for x in names] + [t_without], dtype=torch.float64, device="cuda")
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        if split:
-            t_by_mode[2] = float(tm[0])
-        t_by_mode[1] = float(tm[1])
+        t_by_mode = {x: float(tm[i]) for i, x in enumerate(names)}
+        t_without = float(tm[-1])
     best_mode = min(t_by_mode, key=t_by_mode.get)
     t_with = t_by_mode[best_mode]
-    e.set_split_stepping(2 if split else 1)
-    if dist is not None:
-        t = torch.tensor([t_with, t_without], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_with, t_without = float(t[0]), float(t[1])
+    e.set_step_mode(afa.AFE_STEP_AUTO)
+    e.set_split_stepping(0)
     info = e.neighbour_grid_info()
     out = dict(parts)
     out.update({
@@ -418,7 +463,8 @@ def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, ba
         "vehicles_gathered": n_all,
         "allgather_bytes_per_rank": 12 * n_local,
         "query_cadence": "every 10 steps of 1 ms (100 Hz simulated time)",
-        "stepping_between_queries": "two streams (afe_set_split_stepping 2)" if best_mode == 2 else "one stream",
+        "stepping_between_queries": best_mode,
+        "ms_per_400_steps_by_stepping": {x: t * 1e3 for x, t in t_by_mode.items()},
         "neighbour_grid_reshaped_every_n_queries": 16,
         "query_ms": parts["allgather_ms"] + parts["nearest_neighbour_ms"],
         "vsteps_per_s_with_queries": n_all * k / t_with,
@@ -440,17 +486,49 @@ def launch_ranks(args):
     print(launch.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
 
+def shard_row(afa, n, device, sync, barrier, reduce_max, block_steps, mode=None, parts=None, min_total_s=0.05):
+    """one ensemble size, measured like the headline (repeated bracketed blocks, median): microseconds per step,
+    vehicle-steps/s and the roofline fraction on algorithmic bytes; mode/parts override the engine's automatic choice"""
+    e = build_shard(afa, n, 0, n, device)
+    if mode is not None:
+        e.set_step_mode(mode)
+    if parts is not None:
+        e.set_split_stepping(parts)
+    time_steps(e, 100, 1, sync, barrier)
+    blocks = timed_blocks(e, block_steps, 1, sync, barrier, reduce_max, min_total_s=min_total_s)
+    t = median(blocks) / block_steps
+    bytes_step, _ = mean_bytes_per_step(e, afa, block_steps)
+    row = {"vehicles": n, "us_per_step": t * 1e6, "vsteps_per_s": n / t, "frac": n * bytes_step / t / 1e9 / HBM_PEAK_GBS,
+           "stepping": "persistent" if uses_persistent(afa, mode, n) else ("split launches" if n >= (1 << 19) and parts != 1 else "launches"),
+           "block_steps": block_steps, "repeats": len(blocks)}
+    return e, row
+
+
+_REAL_STDOUT = os.dup(1)       # the line goes here whatever fd 1 points at when it is printed
+_PRINTED = __import__("threading").Lock()
+
+
+def print_line_once(out):
+    """exactly one JSON line on the real stdout, whoever gets here first (main thread or the watchdog)"""
+    if not _PRINTED.acquire(blocking=False):
+        return False
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT, (json.dumps(out) + "\n").encode())
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--vehicles", type=int, default=1 << 20, help="vehicles per GPU")
+    ap.add_argument("--vehicles", type=int, default=1 << 20, help="vehicles per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-shared-world", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
-                    help="only the launches of the timed cadence (for rocprofv3 passes: no single-stream comparison, no per-kernel breakdown)")
+                    help="only the timed cadence (for rocprofv3 passes: no comparisons, no per-kernel breakdown, no sweep)")
+    ap.add_argument("--step-mode", choices=("auto", "launch", "persistent"), default="auto")
     ap.add_argument("--watchdog", type=int, default=240, help="seconds the shared-world part may take before the line is printed without it")
     args = ap.parse_args()
 
@@ -484,39 +562,76 @@ def main():
     def sync():
         torch.cuda.synchronize()
 
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     afa = importlib.import_module("agri-fly_amd")
+    mode = {"auto": afa.AFE_STEP_AUTO, "launch": afa.AFE_STEP_LAUNCH, "persistent": afa.AFE_STEP_PERSISTENT}[args.step_mode]
     n_local = args.vehicles
     n_global = n_local * world
     e = build_shard(afa, n_local, rank * n_local, n_global, local_rank)
+    e.set_step_mode(mode)
 
-    # Large ensembles step as two halves on two streams (afe_set_split_stepping): the same kernels, the same bytes and
-    # the same per-vehicle bits, one launch per step and per half; each half's drain-and-dispatch gap is covered by
-    # the other half's streaming.  Below 2^19 vehicles per GPU the second launch costs more host time than it hides.
-    split = n_local >= (1 << 19)
-    e.set_split_stepping(2 if split else 1)
-    # ---- the headline measurement: W warmup steps, then exactly K timed ----
+    # ---- the headline measurement: W warmup steps, then blocks of exactly K timed steps (median block) ----
     time_steps(e, args.warmup, 1, sync, barrier)
-    elapsed = time_steps(e, args.steps, 1, sync, barrier)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    blocks = timed_blocks(e, args.steps, 1, sync, barrier, reduce_max)
+    persistent = uses_persistent(afa, mode, n_local)
+    split = (not persistent) and n_local >= (1 << 19)
+    elapsed = median(blocks)
     value = n_global * args.steps / elapsed
+
+    # ---- config 4 as BASELINE.json states it: 2^20 vehicles in total, sharded over the ranks (strong scaling) ----
+    strong = None
+    n_strong = (1 << 20) // world
+    if not args.headline_only:
+        es = build_shard(afa, n_strong, rank * n_strong, n_strong * world, local_rank)
+        es.set_step_mode(mode)
+        time_steps(es, args.warmup, 1, sync, barrier)
+        sblocks = timed_blocks(es, args.steps, 1, sync, barrier, reduce_max)
+        long_steps = max(args.steps, 2000)
+        slong = timed_blocks(es, long_steps, 1, sync, barrier, reduce_max, min_blocks=3)
+        sbytes, _ = mean_bytes_per_step(es, afa, args.steps)
+        ts, tl = median(sblocks) / args.steps, median(slong) / long_steps
+        strong = {"what": "BASELINE config 4 as stated: 1,048,576 vehicles in total, %d per GPU on %d GPU(s); same workload, same timing protocol" % (n_strong, world),
+                  "scaling": "strong", "vehicles_total": n_strong * world, "vehicles_per_gpu": n_strong, "n_gpus": world,
+                  "stepping": "persistent" if uses_persistent(afa, mode, n_strong) else "launches",
+                  "value": n_strong * world / ts, "unit": "vehicle-steps/s", "ms_per_step": ts * 1e3, "steps": args.steps, "repeats": len(sblocks),
+                  "frac_per_gpu": n_strong * sbytes / ts / 1e9 / HBM_PEAK_GBS,
+                  "steady_state": {"steps": long_steps, "ms_per_step": tl * 1e3, "value": n_strong * world / tl,
+                                   "frac_per_gpu": n_strong * sbytes / tl / 1e9 / HBM_PEAK_GBS}}
+        es.close()
 
     out = None
     if rank == 0:
         bytes_step, tick_frac = mean_bytes_per_step(e, afa, args.steps)
-        # per step (with split stepping: of both halves' launches); the median of three event-bracketed runs
-        t_kernel = sorted(kernel_time_events(e, min(args.steps, 1000)) for _ in range(3))[1]
+        # device time per step over the timed cadence: HIP events on the engine's stream around K steps, repeated
+        t_kernel, t_kmin, t_kmax, k_rep = event_blocks(e, args.steps)
         achieved = n_local * bytes_step / t_kernel / 1e9
-        # the same engine on one stream (one launch per step for the whole shard), for comparison
-        t_single = t_kernel
-        if split and not args.headline_only:
-            e.set_split_stepping(1)
+        # the same over a long run: a resident grid's launch and exit (and a stream's first launches) amortised away
+        long_steps = max(args.steps, 2000)
+        t_long = median([kernel_time_events(e, long_steps) for _ in range(3)])
+        # the same engine stepping by launches (one per step; per half of the shard from 2^19 vehicles up), for comparison
+        t_launch = None
+        if persistent and not args.headline_only:
+            e.set_step_mode(afa.AFE_STEP_LAUNCH)
             time_steps(e, 100, 1, sync, lambda: None)
-            t_single = kernel_time_events(e, min(args.steps, 1000))
-            e.set_split_stepping(2)
+            t_launch = median([kernel_time_events(e, long_steps) for _ in range(3)])
+            e.set_step_mode(mode)
         traffic, traffic_src = committed_traffic(n_local)
+        # what the box streams in this launch shape, in this run (measured figure next to the nominal peak)
+        probe = None
+        if not args.headline_only:
+            e.sync()
+            us164 = afa.stream_probe(n_local, 24, 17, 200, local_rank)
+            us132 = afa.stream_probe(n_local, 20, 13, 200, local_rank)
+            probe = {"GBs_164B": n_local * 164 / us164 / 1e3, "GBs_132B": n_local * 132 / us132 / 1e3,
+                     "us_164B": us164, "us_132B": us132,
+                     "what": "afe_stream_probe: back-to-back launches of a pure streaming kernel in the step kernel's shape (one-wave workgroups, "
+                             "24+17 / 20+13 planar dword streams in place), same ensemble size, this run"}
         out = {
             "metric": "vehicle-steps/sec @dt=1ms",
             "value": value,
@@ -525,6 +640,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "repeats": len(blocks),
+            "ms_per_step_min": min(blocks) / args.steps * 1e3,
+            "ms_per_step_max": max(blocks) / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -533,14 +651,17 @@ def main():
             "config": {
                 "workload": "config 4 shape: hovering CF_MINIQUAD ensemble, per-vehicle wind-gust external force, "
                             "IMU synthesis + on-device minstd_rand0/normal noise at the 500 Hz logic gate, "
-                            "one kernel launch per 1 ms step (no temporal fusion)" +
-                            (" and per half of the shard: the two halves step on two streams (afe_set_split_stepping)" if split else ""),
+                            "one afe_step call per 1 ms step, state through HBM every step (no temporal fusion); " +
+                            ("stepping by one resident grid (afe_set_step_mode: every wave advances its vehicles through each authorised step, "
+                             "no kernel boundary between steps)" if persistent else
+                             "one kernel launch per step" + (" and per half of the shard: the two halves step on two streams (afe_set_split_stepping)" if split else "")),
                 "vehicles_per_gpu": n_local,
                 "vehicles_total": n_global,
                 "dt_us": DT_US,
                 "logic_period_s": LOGIC_PERIOD,
-                "steps_per_launch": 1,
-                "launches_per_step": 2 if split else 1,
+                "steps_per_call": 1,
+                "stepping": "persistent" if persistent else ("split launches" if split else "launches"),
+                "timing": "median of %d blocks of exactly %d steps, each bracketed by barrier + synchronise (min / max in ms_per_step_min / _max)" % (len(blocks), args.steps),
                 "parallelism": "ensemble sharded contiguously, %d rank(s), no data-path collective" % world,
             },
             "roofline": {
@@ -549,89 +670,120 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "peak_measured": probe,
+                "frac_of_measured": None if probe is None else achieved / probe["GBs_164B"],
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": n_local * bytes_step / (2 if split else 1),
-                "launches_per_step": 2 if split else 1,
-                "concurrent_launches": 2 if split else 1,
-                "kernel": "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, LOGIC=0, SINGLE=1>, 64-lane workgroups -- the timed region "
-                          "alternates NOISE=0 (no logic tick) and NOISE=1 (tick: IMU + six Gaussian draws) launches; "
-                          "the NOISE=1 launch is the dominant kernel (per_kernel.on_tick, profiles/r02*_summary.json)",
+                "kernel": ("afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=1, LOGIC=0>: one launch serves every step between two "
+                           "synchronisations; its rocprofv3 duration / the steps it served = kernel_us" if persistent else
+                           "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, LOGIC=0, SINGLE=1>, 64-lane workgroups -- the timed region "
+                           "alternates NOISE=0 (no logic tick) and NOISE=1 (tick: IMU + six Gaussian draws) launches"),
                 "kernel_us": t_kernel * 1e6,
+                "kernel_us_min": t_kmin * 1e6, "kernel_us_max": t_kmax * 1e6, "kernel_repeats": k_rep,
+                "steps_per_event_block": args.steps,
                 "algorithmic_bytes_per_vehicle_step": bytes_step,
+                "algorithmic_bytes_per_step": n_local * bytes_step,
                 "imu_tick_fraction": tick_frac,
+                "steady_state": {"steps": long_steps, "kernel_us": t_long * 1e6, "achieved_GBs": n_local * bytes_step / t_long / 1e9,
+                                 "frac": n_local * bytes_step / t_long / 1e9 / HBM_PEAK_GBS},
+                "launch_mode": None if t_launch is None else {
+                    "kernel_us": t_launch * 1e6, "achieved_GBs": n_local * bytes_step / t_launch / 1e9,
+                    "frac": n_local * bytes_step / t_launch / 1e9 / HBM_PEAK_GBS,
+                    "note": "the same engine with afe_set_step_mode(AFE_STEP_LAUNCH): one kernel launch per step" +
+                            (" and half of the shard (two streams)" if n_local >= (1 << 19) else "")},
                 "per_kernel": None if args.headline_only else per_kernel_breakdown(afa, n_local, local_rank),
-                "single_stream": {"kernel_us": t_single * 1e6, "achieved_GBs": n_local * bytes_step / t_single / 1e9,
-                                  "frac": n_local * bytes_step / t_single / 1e9 / HBM_PEAK_GBS,
-                                  "note": "the same engine with afe_set_split_stepping(1): one launch per step for the whole shard"},
-                "note": "achieved = algorithmic bytes per step / HIP-event time per step over the timed cadence (kernel_us). "
-                        + ("A step is two launches of the same kernel, one per half of the shard, on two streams that never wait "
-                           "for each other; rocprofv3 shows each at about the duration of a step (two in flight at any time), so "
-                           "per-launch bytes / per-launch duration is half of `achieved` (profiles/r02i_summary.json `cadence`: 1.98 step kernels in flight "
-                           "from the kernel trace). " if split else "")
-                        + "In-place state (%.0f MB per step) fits the 256 MiB Infinity Cache; traffic = HBM bytes per step from the "
-                        "committed rocprofv3 PMC summary (per_kernel: the full-shard launches of the single-stream mode)"
-                        % (n_local * bytes_step / 1e6),
+                "note": "achieved = algorithmic bytes per step / HIP-event time per step over the timed cadence (kernel_us: events on the "
+                        "engine's stream around %d steps, median of kernel_repeats).  In-place state (%.0f MB per step) fits the 256 MiB "
+                        "Infinity Cache; beyond_cache holds the same measurement at 2^22 vehicles.  traffic = HBM bytes per step from the "
+                        "committed rocprofv3 PMC summary" % (args.steps, n_local * bytes_step / 1e6),
             },
+            "config4_as_stated": strong,
         }
-        if world == 1 and not args.no_sweep:
+        if world == 1 and not args.no_sweep and not args.headline_only:
+            # beyond the Infinity Cache: 2^22 vehicles (620 MB per step)
+            nb = 4 << 20
+            eb, rowb = shard_row(afa, nb, local_rank, sync, barrier, reduce_max, 200)
+            eb.sync()
+            usb = afa.stream_probe(nb, 24, 17, 40, local_rank)
+            eb.close()
+            rowb["achieved_GBs"] = rowb["frac"] * HBM_PEAK_GBS
+            rowb["peak_measured_GBs_164B"] = nb * 164 / usb / 1e3
+            rowb["frac_of_measured"] = rowb["achieved_GBs"] / rowb["peak_measured_GBs_164B"]
+            out["roofline"]["beyond_cache"] = rowb
+            # the north-star shard: one GPU's share of config 4 on eight (131,072 vehicles), and its neighbours
             sweep = []
-            for n in (1024, 4096, 65536, 262144, 4 << 20):
-                es = build_shard(afa, n, 0, n, local_rank)
-                es.set_split_stepping(1)     # the sweep compares launch forms on one stream
-                k = 400 if n >= 262144 else 2000
+            for n in (1024, 4096, 65536, 131072, 262144, 524288, 1 << 20, 2 << 20):
+                es, row = shard_row(afa, n, local_rank, sync, barrier, reduce_max, 400)
+                bytes_n, _ = mean_bytes_per_step(es, afa, 400)
+                es.set_step_mode(afa.AFE_STEP_LAUNCH)
+                es.set_split_stepping(1)
+                k = 400
                 time_steps(es, 50, 1, sync, barrier)
-                t1 = time_steps(es, k, 1, sync, barrier)
-                tf = time_steps(es, k, 2, sync, barrier)
-                t50 = time_steps(es, k, 50, sync, barrier)
-                es.set_max_fused_steps(1)       # still one launch per step, issued by the engine's C++ loop
-                tc = time_steps(es, k, k, sync, barrier)
-                es.set_max_fused_steps(64)
-                sweep.append({"vehicles": n, "vsteps_per_s": n * k / t1, "vsteps_per_s_native_loop": n * k / tc,
-                              "vsteps_per_s_fused2": n * k / tf, "vsteps_per_s_fused50": n * k / t50})
+                t1 = median([time_steps(es, k, 1, sync, barrier) for _ in range(3)])
+                es.set_split_stepping(2)
+                time_steps(es, 50, 1, sync, barrier)
+                t2 = median([time_steps(es, k, 1, sync, barrier) for _ in range(3)])
+                es.set_split_stepping(1)
+                tf = median([time_steps(es, k, 2, sync, barrier) for _ in range(3)])
+                t50 = median([time_steps(es, k, 50, sync, barrier) for _ in range(3)])
+                fr = lambda t: n * bytes_n / (t / k) / 1e9 / HBM_PEAK_GBS
+                row.update({"launches": {"us_per_step": t1 / k * 1e6, "vsteps_per_s": n * k / t1, "frac": fr(t1)},
+                            "split_launches": {"us_per_step": t2 / k * 1e6, "vsteps_per_s": n * k / t2, "frac": fr(t2)},
+                            "fused2": {"us_per_step": tf / k * 1e6, "vsteps_per_s": n * k / tf},
+                            "fused50": {"us_per_step": t50 / k * 1e6, "vsteps_per_s": n * k / t50}})
+                sweep.append(row)
                 es.close()
+            out["sweep"] = sweep
+            out["sweep_note"] = ("per size: the engine's automatic mode (top level: us_per_step, vsteps_per_s, frac = algorithmic bytes / time / 8 TB/s, "
+                                 "median of bracketed 400-step blocks), then the same shard stepped by launches on one stream, by launches on two streams "
+                                 "(afe_set_split_stepping 2), with two steps per launch (fused2: nothing is observable between 500 Hz logic ticks) and with "
+                                 "50 steps per launch (fused50: state in registers, open-loop commands).  131,072 vehicles is one GPU's shard of BASELINE "
+                                 "config 4 on 8 GPUs")
+            ns = [r for r in sweep if r["vehicles"] == 131072][0]
+            out["north_star_shard"] = {"vehicles_per_gpu": 131072, "us_per_step": ns["us_per_step"], "vsteps_per_s_per_gpu": ns["vsteps_per_s"],
+                                       "frac": ns["frac"], "launch_mode_frac": ns["launches"]["frac"],
+                                       "note": "one GPU's shard of the 1M-vehicle ensemble on 8 GPUs, measured on this one GPU; shards do not communicate while stepping "
+                                               "(no data-path collective), so 8 ranks deliver 8x this rate up to barrier skew -- a projection until the driver's --gpus 8 run"}
             # config 2 closed on the GPU: on-device onboard rates logic, hover command
             closed = []
-            for n in (4096, 1 << 20):
+            for n in (4096, 131072, 1 << 20):
                 es = build_shard(afa, n, 0, n, local_rank)
                 es.set_rates_logic([afa.rates_logic_params_from_type(5)])
                 es.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
-                es.set_split_stepping(2 if n >= (1 << 19) else 1)
                 k = 400
                 time_steps(es, 50, 1, sync, barrier)
-                t1 = time_steps(es, k, 1, sync, barrier)
-                t10 = time_steps(es, k, 10, sync, barrier)
+                t1 = median([time_steps(es, k, 1, sync, barrier) for _ in range(3)])
+                es.set_step_mode(afa.AFE_STEP_LAUNCH)
+                t10 = median([time_steps(es, k, 10, sync, barrier) for _ in range(3)])
                 closed.append({"vehicles": n, "vsteps_per_s": n * k / t1, "vsteps_per_s_fused10": n * k / t10})
                 es.close()
             out["closed_loop_on_device"] = closed
             out["companions"] = companion_rows(afa, n_local, local_rank, sync, barrier, split)
             out["perception_rows"] = perception_rows(afa)
-            out["sweep"] = sweep
-            out["sweep_note"] = ("vsteps_per_s = one launch per step issued from Python; native_loop = the same "
-                                 "launches issued by afe_step's C++ loop (afe_set_max_fused_steps(1)); fused2 = two 1 ms steps per launch (nothing is observable between 500 Hz logic "
-                                 "ticks); fused50 = 50 steps per launch, state in registers (open-loop commands)")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             out["cpu_baseline"] = cpu_baseline(afa)
     # The headline is measured.  What follows (the shared-world exchange: a second communicator, collectives at
     # query cadence) must never cost the line already in hand: if it has not finished within the watchdog's
     # time -- a rank stuck in a collective, whatever the cause -- rank 0 prints the line with the failure
-    # recorded and every rank leaves.
+    # recorded and every rank leaves with a non-zero status.
     import threading
 
     def bail():
         if rank == 0:
             out["shared_world"] = {"error": "did not finish within %d s; headline and roofline above are unaffected" % args.watchdog}
-            print(json.dumps(out), flush=True)
-        os._exit(0)
+            print_line_once(out)
+        os._exit(3)
 
     dog = threading.Timer(args.watchdog, bail)
     dog.daemon = True
     dog.start()
-    if not args.no_shared_world:
+    sw_failed = False
+    if not args.no_shared_world and not args.headline_only:
         try:
             sw = shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, barrier, split)   # collective: every rank
         except Exception as ex:                      # the other ranks may be waiting for this one: the watchdog frees them
             sw = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            sw_failed = True
             sys.stderr.write("bench.py rank %d: shared_world failed: %s\n" % (rank, sw["error"]))
         if rank == 0:
             out["shared_world"] = sw
@@ -641,7 +793,9 @@ def main():
         dist.destroy_process_group()
     dog.cancel()
     if rank == 0:
-        print(json.dumps(out))
+        print_line_once(out)
+    if sw_failed:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -647,6 +647,14 @@ int afe_neighbour_grid_info(const afe_engine *e, int dims[3], float *cell_size, 
 int afe_nearest_neighbour_bruteforce(afe_engine *e, const float *all_xyz, int64_t n_all, const int32_t *dev_queries,
                                      int64_t n_queries, float *dist2_out, int32_t *index_out);
 
+/* Measurement aid (bench.py's `roofline.peak_measured`; SURVEY 8d asks for the box's measured streaming figure next
+ * to the nominal peak): `launches` back-to-back launches of a kernel in the step kernel's own launch shape -- one-wave
+ * workgroups, one lane per element, n_read planar dword read streams and n_write write streams in place through one
+ * buffer resource, slab stride 256 x odd, no arithmetic to speak of -- on a scratch buffer of its own; returns the
+ * best of three event-timed runs.  (n_read, n_write) = (20, 13): the 132 bytes of the off-tick step launch,
+ * (24, 17): the 164 bytes of the tick launch.  No reference counterpart. */
+int afe_stream_probe(int device, int64_t n, int n_read, int n_write, int launches, float *us_per_launch);
+
 /* UWB ranging network: Simulation::UWBNetwork (Components/Components/Simulation/
  * UWBNetwork.hpp:16-50, UWBNetwork.cpp:8-89).  afe_uwb_create = the constructor's
  * rng.seed(0) (:19); afe_uwb_set_noise = SetNoiseProperties (UWBNetwork.hpp:28-33).

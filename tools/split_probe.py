@@ -12,6 +12,7 @@ for n in (65536, 131072, 262144, 524288, 1 << 20, 2 << 20, 4 << 20):
     row = []
     for parts in (1, 2):
         e = bench.build_shard(afa, n, 0, n, 0)
+        e.set_step_mode(afa.AFE_STEP_LAUNCH)
         e.set_split_stepping(parts)
         for _ in range(200): e.step(1000, 1)
         e.sync()
