@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 output of tools/profile_r03.sh <tag> [vehicles] (under gpurun_out/) into the committed summaries:
+    python tools/profile_summary_r03.py <tag> "<build note>" [vehicles]
+  profiles/<tag>_kernel_stats.csv / _domain_stats.csv   rocprofv3 --stats of the headline cadence, blocks of 2000 steps
+  profiles/<tag>_k20_kernel_stats.csv                   the same with the driver's arguments (blocks of 20 steps)
+  profiles/<tag>_full_kernel_stats.csv                  the whole default bench
+  profiles/<tag>_summary.json   the resident grid per step: duration / steps, algorithmic bytes, FETCH_SIZE / WRITE_SIZE
+                                (separate passes; FETCH_SIZE x 2 per the gfx950 note of MI355X_MICROARCH.md, KiB units),
+                                SQ counters per wave and step
+  profiles/traffic.json         PMC HBM bytes per step of the bench workload (read by bench.py) -- only for 2^20 vehicles"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+note = sys.argv[2] if len(sys.argv) > 2 else ""
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
+out = os.path.join(ROOT, "gpurun_out")
+prof = os.path.join(ROOT, "profiles")
+BYTES_MEAN = 148.0      # algorithmic B per vehicle-step of the bench workload: 132 off tick, 164 on tick, every 2nd step ticks
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(out, pattern), recursive=True)
+    return g[0] if g else None
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def persistent_rows(dirname, suffix):
+    f = one(dirname + "/**/*_" + suffix + ".csv")
+    return [r for r in csv.DictReader(open(f))] if f else []
+
+
+def launches(dirname):
+    """durations (ns) of the resident grid's launches in a pass's kernel trace, in start order"""
+    rows = [r for r in persistent_rows(dirname, "kernel_trace") if "afe_step_persistent_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    return [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+
+
+def counter_per_launch(dirname):
+    agg = collections.defaultdict(list)
+    for r in persistent_rows(dirname, "counter_collection"):
+        if "afe_step_persistent_kernel" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+summary = {"build": note, "tag": tag, "script": "tools/profile_r03.sh %s %d" % (tag, N), "vehicles": N,
+           "kernel": "afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=1, LOGIC=0> (one launch per synchronised block of steps)"}
+for src, dst in (("prof_%s" % tag, "%s_kernel_stats.csv" % tag), ("prof_k20_%s" % tag, "%s_k20_kernel_stats.csv" % tag),
+                 ("prof_full_%s" % tag, "%s_full_kernel_stats.csv" % tag)):
+    f = one(src + "/**/*_kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(prof, dst))
+    d = one(src + "/**/*_domain_stats.csv")
+    if d and src == "prof_" + tag:
+        shutil.copy(d, os.path.join(prof, dst.replace("kernel_stats", "domain_stats")))
+
+for name, src, steps in (("blocks_of_2000_steps", "prof_%s" % tag, 2000), ("blocks_of_20_steps", "prof_k20_%s" % tag, 20)):
+    d = launches(src)
+    if not d:
+        continue
+    full = [x for x in d if x > 0.5 * median(d)]          # the warm-up launch serves fewer steps than the blocks
+    t = median(full) / steps
+    summary[name] = {"launches": len(d), "median_launch_us": median(full) / 1e3, "us_per_step": t / 1e3,
+                     "algorithmic_GBs": N * BYTES_MEAN / t, "frac_of_8TBs": N * BYTES_MEAN / t / 8000.0}
+steps = 200
+fetch, write, sq = counter_per_launch("pmc_fetch_%s" % tag), counter_per_launch("pmc_write_%s" % tag), counter_per_launch("pmc_sq_%s" % tag)
+if fetch.get("FETCH_SIZE") and write.get("WRITE_SIZE"):
+    fs, ws = median(fetch["FETCH_SIZE"]), median(write["WRITE_SIZE"])      # the 200-step blocks outnumber the warm-up launch
+    per_step = (2 * 1024 * fs + 1024 * ws) / steps
+    summary["traffic"] = {"FETCH_SIZE_KiB_per_launch": fs, "WRITE_SIZE_KiB_per_launch": ws, "steps_per_launch": steps,
+                          "hbm_bytes_per_step": per_step, "hbm_bytes_per_vehicle_step": per_step / N,
+                          "algorithmic_bytes_per_step": N * BYTES_MEAN, "ratio": per_step / (N * BYTES_MEAN)}
+    if N == 1 << 20:
+        json.dump({"workload": {"vehicles_per_gpu": N, "fext": True, "noise": True, "dt_us": 1000, "logic_period_s": 0.002},
+                   "traffic_bytes_per_step": per_step,
+                   "traffic_bytes_per_launch": per_step,
+                   "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over resident-grid launches of %d steps, separate passes, "
+                             "FETCH_SIZE x2 gfx950 correction)" % (tag, steps)}, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+if sq.get("SQ_WAVES"):
+    rec = {c: median(v) for c, v in sorted(sq.items())}
+    waves = rec["SQ_WAVES"]
+    summary["sq_per_launch_of_200_steps"] = rec
+    summary["valu_instructions_per_wave_and_step"] = rec.get("SQ_INSTS_VALU", 0) / waves / steps
+    summary["salu_instructions_per_wave_and_step"] = rec.get("SQ_INSTS_SALU", 0) / waves / steps
+    summary["note_sq"] = "a wave of the resident grid steps ceil(chunks / waves) chunks of 64 vehicles per step; the pump wave is one of SQ_WAVES"
+json.dump(summary, open(os.path.join(prof, "%s_summary.json" % tag), "w"), indent=1)
+print(json.dumps(summary, indent=1)[:4000])
