@@ -221,16 +221,27 @@ extern "C" int afe_group_create(afe_group **out, int64_t n_vehicles, int precisi
     g->pulled.push_back(ev2);
     first += cnt;
   }
-  // let every device read every other one's memory directly (xGMI); already-enabled is fine
+  // every device reads every other one's memory directly (xGMI): afe_group_gather_positions issues device-to-device
+  // copies between the shards' scratch buffers.  A pair without peer access cannot serve them -- say so here, with
+  // the pair, instead of failing in the middle of a gather later.
   for (int a = 0; a < n_devices; a++)
     for (int b = 0; b < n_devices; b++) {
       if (devices[a] == devices[b]) continue;
       int can = 0;
-      if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+      hipError_t perr = hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
+      if (perr == hipSuccess && can) {
         (void)hipSetDevice(devices[a]);
-        const hipError_t perr = hipDeviceEnablePeerAccess(devices[b], 0);
-        if (perr != hipSuccess && perr != hipErrorPeerAccessAlreadyEnabled) { /* copies fall back to staging through the runtime */ }
+        perr = hipDeviceEnablePeerAccess(devices[b], 0);
+        if (perr == hipErrorPeerAccessAlreadyEnabled) perr = hipSuccess;
         (void)hipGetLastError();
+      } else if (perr == hipSuccess) {
+        perr = hipErrorPeerAccessUnsupported;
+      }
+      if (perr != hipSuccess) {
+        std::fprintf(stderr, "agrifly_engine: afe_group_create: device %d cannot access device %d's memory (%s); a group needs peer access between all its devices\n",
+                     devices[a], devices[b], hipGetErrorString(perr));
+        afe_group_destroy(g);
+        return AFE_ERR_HIP;
       }
     }
   *out = g;
@@ -299,22 +310,22 @@ extern "C" int afe_group_gather_positions(afe_group *g, float **dev_xyz_all_out)
     int dev = 0;
     engine_stream_device(g->engines[k], &sv, &dev);
     streams[k] = (hipStream_t)sv;
-    if (hipSetDevice(dev) != hipSuccess) return AFE_ERR_HIP;
+    if (hipSetDevice(dev) != hipSuccess) { g->err = "hipSetDevice failed"; return AFE_ERR_HIP; }
     if (!g->all_xyz[k] && hipMalloc((void **)&g->all_xyz[k], (size_t)g->n_total * 3 * sizeof(float)) != hipSuccess) {
       g->err = "hipMalloc of the gathered-position buffer failed";
       return AFE_ERR_HIP;
     }
     const int rc = engine_pack_to_scratch(g->engines[k], &scratch[k]);
     if (rc) { g->err = afe_last_error(g->engines[k]); return rc; }
-    if (hipEventRecord(g->packed[k], streams[k]) != hipSuccess) return AFE_ERR_HIP;
+    if (hipEventRecord(g->packed[k], streams[k]) != hipSuccess) { g->err = "hipEventRecord (packed) failed"; return AFE_ERR_HIP; }
   }
   // destination d pulls source s's block: one strided copy per pair (3 rows of count_s floats),
   // ordered on d's stream behind s's pack
   for (size_t d = 0; d < G; d++) {
-    if (hipSetDevice(g->devices[d]) != hipSuccess) return AFE_ERR_HIP;
+    if (hipSetDevice(g->devices[d]) != hipSuccess) { g->err = "hipSetDevice failed"; return AFE_ERR_HIP; }
     for (size_t off = 0; off < G; off++) {
       const size_t s = (d + off) % G;   // start with the own block, then walk the ring so the links load evenly
-      if (s != d && hipStreamWaitEvent(streams[d], g->packed[s], 0) != hipSuccess) return AFE_ERR_HIP;
+      if (s != d && hipStreamWaitEvent(streams[d], g->packed[s], 0) != hipSuccess) { g->err = "hipStreamWaitEvent (packed) failed"; return AFE_ERR_HIP; }
       const hipError_t err = hipMemcpy2DAsync(g->all_xyz[d] + g->first[s], (size_t)g->n_total * 4, scratch[s], (size_t)g->count[s] * 4,
                                               (size_t)g->count[s] * 4, 3, hipMemcpyDeviceToDevice, streams[d]);
       if (err != hipSuccess) { g->err = std::string("peer copy: ") + hipGetErrorString(err); return AFE_ERR_HIP; }
@@ -324,11 +335,11 @@ extern "C" int afe_group_gather_positions(afe_group *g, float **dev_xyz_all_out)
   // a shard's scratch must not be repacked before every reader has pulled it: readers' streams are
   // joined back into the owner's stream
   for (size_t d = 0; d < G; d++) {
-    if (hipSetDevice(g->devices[d]) != hipSuccess) return AFE_ERR_HIP;
-    if (hipEventRecord(g->pulled[d], streams[d]) != hipSuccess) return AFE_ERR_HIP;
+    if (hipSetDevice(g->devices[d]) != hipSuccess) { g->err = "hipSetDevice failed"; return AFE_ERR_HIP; }
+    if (hipEventRecord(g->pulled[d], streams[d]) != hipSuccess) { g->err = "hipEventRecord (pulled) failed"; return AFE_ERR_HIP; }
   }
   for (size_t s = 0; s < G; s++)
     for (size_t d = 0; d < G; d++)
-      if (d != s && hipStreamWaitEvent(streams[s], g->pulled[d], 0) != hipSuccess) return AFE_ERR_HIP;
+      if (d != s && hipStreamWaitEvent(streams[s], g->pulled[d], 0) != hipSuccess) { g->err = "hipStreamWaitEvent (pulled) failed"; return AFE_ERR_HIP; }
   return AFE_OK;
 }

@@ -1235,8 +1235,29 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
   if ((h.seed_policy != AFE_SEED_REFERENCE && h.seed_policy != AFE_SEED_DECORRELATED) || !(h.logic_period > 0) ||
       !(h.sigma_gyro >= 0) || !(h.sigma_acc >= 0))
     return fail(e, AFE_ERR_INVALID_ARG, "checkpoint header holds an invalid configuration");
+  // Everything the kernels will index or loop on is checked in the HOST buffer, before a byte reaches the device or
+  // the engine's own state changes: a refused checkpoint leaves the engine exactly as it was.
+  std::vector<uint8_t> types((size_t)e->n);
+  {
+    const char *arena_in_ckp = (const char *)host_buffer + sizeof(h);
+    std::memcpy(types.data(), arena_in_ckp + ((const char *)e->type - (const char *)e->arena), (size_t)e->n);
+    for (size_t k = 0; k < types.size(); k++)
+      if (types[k] >= e->table.size()) return fail(e, AFE_ERR_INVALID_ARG, "checkpoint holds a type index outside the type table");
+    // minstd_rand0 words live in [1, 2^31 - 2]: 0 is a fixed point of the generator and anything else is not a state of
+    // it -- the acceptance loop of the Gaussian draws would never end on such a word
+    const uint32_t *words = (const uint32_t *)(arena_in_ckp + ((const char *)e->rng - (const char *)e->arena));
+    for (int64_t k = 0; k < e->n; k++) {
+      uint32_t w;
+      std::memcpy(&w, words + k, 4);
+      if (w == 0 || w >= 2147483647u)
+        return fail(e, AFE_ERR_INVALID_ARG, "checkpoint holds an engine word outside [1, 2^31-2] (vehicle " + std::to_string(k) + ")");
+    }
+  }
   AFE_HIP(e, hipSetDevice(e->device));
   AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
+  // from here on the arena is being overwritten: whatever happens, nothing derived from the old one may survive
+  e->table_dirty = true;
+  e->logic_table_period = -1.0f;
   const char *p = (const char *)host_buffer + sizeof(h);
   AFE_HIP(e, hipMemcpy(e->arena, p, e->arena_bytes, hipMemcpyHostToDevice));
   p += e->arena_bytes;
@@ -1253,16 +1274,9 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
   e->logic_period = h.logic_period;
   // the kernel-argument fast path is only valid when every vehicle uses record 0: decide from the
   // restored per-vehicle type slab, not from what this engine was told before the load
-  {
-    std::vector<uint8_t> types((size_t)e->n);
-    const char *type_in_ckp = (const char *)host_buffer + sizeof(h) + ((const char *)e->type - (const char *)e->arena);
-    std::memcpy(types.data(), type_in_ckp, (size_t)e->n);
-    for (size_t k = 0; k < types.size(); k++)
-      if (types[k] >= e->table.size()) return fail(e, AFE_ERR_INVALID_ARG, "checkpoint holds a type index outside the type table");
-    e->type_host = types;
-    e->run_nonzero.clear();          // re-derive everything from the restored slab
-    refresh_type_flags(e);
-  }
+  e->type_host.swap(types);
+  e->run_nonzero.clear();          // re-derive everything from the restored slab
+  refresh_type_flags(e);
   // the arena also holds the device copy of the type table for the checkpoint's dt: rebuild on next step
   e->table_dirty = true;
   e->logic_table_period = -1.0f;

@@ -227,7 +227,7 @@ __device__ __forceinline__ void three_accepted(uint32_t &s, uint32_t &st0, uint3
       }
     }
     if (accept) {   // moves under the execution mask (the asm keeps the compiler from turning them into selects)
-      asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %3" : "+v"(st0), "+v"(st1), "+v"(st2) : "v"(before));
+      asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %3" : "+&v"(st0), "+&v"(st1), "+&v"(st2) : "v"(before));   // early-clobber: `before` is read last and must not share a register with an output
       got++;
     }
     if (got >= 3) break;

@@ -701,9 +701,13 @@ int afe::world_nearest_bruteforce(afe_world *w, void *hip_stream, const float *a
 // UWB ranging network (reference Components/Components/Simulation/UWBNetwork.{hpp,cpp})
 
 struct afe_uwb_network {
-  // the reference's file-scope generator and distributions, UWBNetwork.cpp:4-6 -- the same libstdc++
-  // classes, so the stream (engine words, generate_canonical, the polar method's cached second value)
-  // is the reference's by construction
+  // the reference's generator and distributions, UWBNetwork.cpp:4-6 -- the same libstdc++ classes, so the
+  // stream (engine words, generate_canonical, the polar method's cached second value) of ONE network, created
+  // first in its process, is the reference's by construction.  The reference keeps them at FILE scope: a second
+  // UWBNetwork there re-seeds the shared engine (rng.seed(0), :19) without clearing the normal distribution's
+  // cached value, and networks running interleaved draw from one stream.  Here every network owns its stream
+  // (what `rng.seed(0)` "to be repeatible" asks for); a host that has to reproduce a reference process with
+  // several networks draws for all of them from one afe_uwb_network.
   std::mt19937 rng;
   std::uniform_real_distribution<double> dist_uniform{0, 1};
   std::normal_distribution<double> dist_normal{0, 1};

@@ -820,6 +820,8 @@ class Ensemble:
         return b.value
 
     # -- checkpoint / resume --------------------------------------------------
+    CHECKPOINT_HEADER_BYTES = 20 * 8    # CheckpointHeader (afe_engine.cpp): 17 x uint64 + 3 x double; the arena follows
+
     def save_checkpoint(self):
         n = C.c_uint64(0)
         self._ck(self._L.afe_checkpoint_size(self._h, C.byref(n)))

@@ -12,7 +12,8 @@
 //          Quadcopter_T.cpp:163-189 is reproduced exactly.
 // The physics between those seams runs on the GPU.  No exceptions escape in
 // the reference (void functions, assert only); here a failing engine call
-// aborts with the engine's message, the closest equivalent.
+// aborts with the engine's message by default, or goes to the host's handler
+// (agrifly::SetErrorHandler) and comes back as agrifly::last_status().
 //
 // Two shapes:
 //   agrifly::Quadcopter_T<logicType>  one vehicle = one 1-vehicle ensemble; IS-A
@@ -39,12 +40,26 @@
 
 namespace agrifly {
 
-inline void check(afe_engine *e, int rc, const char *what) {
-  if (rc != AFE_OK) {
-    std::fprintf(stderr, "agrifly: %s failed: %s (%s)\n", what, afe_status_string(rc),
-                 e ? afe_last_error(e) : "");
-    std::abort();
+// Failure policy.  The reference's interface has nowhere to return an error to (void functions, assert only), so
+// by default a failing engine call ends the process with the engine's message -- what its assert would do.  A host
+// that wants the error instead installs a handler: it is called with the status, the failing call and the engine's
+// message, and the facade call then returns to its caller having done nothing further (state unchanged; last_status()
+// keeps the code).  The handler may also throw, which unwinds out of the facade call.
+typedef void (*ErrorHandler)(int status, const char *what, const char *message);
+inline ErrorHandler &error_handler() { static ErrorHandler h = 0; return h; }
+inline int &last_status() { static int s = AFE_OK; return s; }
+inline void SetErrorHandler(ErrorHandler h) { error_handler() = h; }
+
+inline bool check(afe_engine *e, int rc, const char *what) {
+  if (rc == AFE_OK) return true;
+  last_status() = rc;
+  const char *msg = e ? afe_last_error(e) : "";
+  if (error_handler()) {
+    error_handler()(rc, what, msg);
+    return false;
   }
+  std::fprintf(stderr, "agrifly: %s failed: %s (%s)\n", what, afe_status_string(rc), msg);
+  std::abort();
 }
 
 // The ctor arguments of Quadcopter_T (Quadcopter_T.hpp:24-32) as a record.

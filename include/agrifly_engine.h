@@ -663,7 +663,9 @@ int afe_stream_probe(int device, int64_t n, int n_read, int n_write, int launche
  * gives the noise, range = float(|p_requester - p_responder| + noise) or
  * float(normal * outlierStdDev) -- same generator and distribution classes
  * (std::mt19937, uniform_real_distribution, normal_distribution incl. its cached
- * second value), one stream for the network's lifetime.  The true positions come
+ * second value), one stream for the network's lifetime (the reference's are file-scope objects shared by every
+ * UWBNetwork of the process, UWBNetwork.cpp:4-6: the first network of a process matches it draw for draw; a process
+ * with several networks is reproduced by drawing for all of them from ONE afe_uwb_network).  The true positions come
  * from the gathered buffer (requester / responder are GLOBAL vehicle indices, host
  * arrays); the norm is evaluated in double like Vec3d::GetNorm2.  range_out
  * (host, n_pairs floats) is what every radio "hears" (:77-80); outlier_out is

@@ -2,8 +2,8 @@
 //   std::shared_ptr<Simulation::SimulationObject6DOF> vehicle     (AIFS_ROS/.../Simulator/main.cpp:83)
 // Everything goes through the base class: the non-virtual state setters / getters that work on the
 // base's members, the virtual Run / SetCommandRadioMsg / GetTelemetryDataPackets / GetAccelerometer /
-// GetRateGyro / AddUWBRadioTarget / GetRadio, and a Simulation::UWBNetwork ranging between two
-// vehicles' radios.  Prints a JSON trace; tests/test_gpu_facade.py checks it against the direct
+// GetRateGyro / AddUWBRadioTarget / GetRadio, and a ranging exchange between two vehicles' radios
+// (the radios are what a ranging network -- the tree's Simulation::UWBNetwork -- works on).  Prints a JSON trace; tests/test_gpu_facade.py checks it against the direct
 // (derived-class) trace and the oracle.
 #include <cmath>
 #include <cstdio>
@@ -13,7 +13,6 @@
 #include <vector>
 
 #include "agrifly/Quadcopter_T.hpp"
-#include "agrifly/UWBNetwork.hpp"
 
 struct TapLogic {
   float cmd[4];
@@ -49,6 +48,49 @@ struct TapLogic {
 
 typedef agrifly::Quadcopter_T<TapLogic> Quad;
 
+// Test driver for the radios the facade hands out: a ranging service with the timing of a two-phase exchange.
+// Every `period` seconds it does ONE thing -- either it latches the first radio that asks for a range, or it
+// answers the latched request: true distance between the two radios plus one draw of the engine's UWB noise
+// stream (afe_uwb_draw), broadcast to every radio.  Inside the agri-fly tree the tree's own network class drives
+// the same radios; this is only what the test needs to see the hand-off work.
+struct RangingService {
+  typedef std::shared_ptr<Simulation::UWBRadio> Radio;
+  std::vector<Radio> radios;
+  Timer since;
+  double period;
+  afe_uwb_network *noise;
+  int from, to;      // latched request (radio ids), 0 = none
+  RangingService(BaseTimer *t, double period_s, double sigma, double p_outlier, double sigma_outlier)
+      : since(t), period(period_s), noise(0), from(0), to(0) {
+    afe_uwb_create(&noise);
+    afe_uwb_set_noise(noise, sigma, p_outlier, sigma_outlier);
+  }
+  ~RangingService() { afe_uwb_destroy(noise); }
+  Radio find(int id) const {
+    for (size_t k = 0; k < radios.size(); k++) if (radios[k]->GetId() == id) return radios[k];
+    return Radio();
+  }
+  void Poll() {
+    for (size_t k = 0; k < radios.size(); k++) radios[k]->Run();
+    if (since.GetSeconds<double>() < period) return;
+    if (from && to) {
+      const Radio a = find(from), b = find(to);
+      double n = 0;
+      uint8_t outlier = 0;
+      afe_uwb_draw(noise, 1, &n, &outlier);
+      Simulation::UWBRadio::RangingMeasurement m;
+      m.range = outlier ? (float)n : (float)((a->GetPosition() - b->GetPosition()).GetNorm2() + n);
+      m.haveNew = true; m.failure = false; m.responderId = (uint8_t)to;
+      for (size_t k = 0; k < radios.size(); k++) radios[k]->SetMeasurement(m);
+      from = to = 0;
+      return;
+    }
+    for (size_t k = 0; k < radios.size() && !from; k++)
+      if (radios[k]->GetNextRangingTargetId()) { from = radios[k]->GetId(); to = radios[k]->GetNextRangingTargetId(); }
+    since.Reset();
+  }
+};
+
 // a radio's position is a default-constructed (NaN) Vec3d until the first logic tick hands it the vehicle's
 static std::string num(double v) {
   char buf[40];
@@ -67,7 +109,26 @@ static std::shared_ptr<Quad> make(BaseTimer *t, uint8_t id, int precision, doubl
                                 c.motor_inertia, Vec3d(0.1, 0.1, 0.1), id, 5, period, precision);
 }
 
+static int g_handled = 0, g_last = 0;
+static void on_error(int status, const char *, const char *) { g_handled++; g_last = status; }
+
 int main(int argc, char **argv) {
+  // a failing engine call reaches the host's handler instead of ending the process: a vehicle that cannot exist
+  // (negative mass -> AFE_ERR_INVALID_ARG from afe_set_type_table, and every later call on it is refused)
+  agrifly::SetErrorHandler(on_error);
+  {
+    ManualTimer t0;
+    afe_vehicle_params c;
+    afe_params_from_type(5, &c);
+    agrifly::Matrix33 I;
+    for (int k = 0; k < 9; k++) I.m[k] = c.inertia[k];
+    Quad bad(&t0, -1.0, I, c.arm_length, Vec3d(0, 0, 0), c.motor_min_speed, c.motor_max_speed, c.prop_thrust_from_speed_sqr,
+             c.prop_torque_from_speed_sqr, c.motor_time_const, c.motor_inertia, Vec3d(0, 0, 0), 1, 5, 0.002, AFE_F32);
+    t0.AdvanceMicroSeconds(1000);
+    bad.Run();
+  }
+  const int handled = g_handled, handled_status = g_last;
+  agrifly::SetErrorHandler(0);
   const int precision = (argc > 1 && !std::strcmp(argv[1], "f64")) ? AFE_F64 : AFE_F32;
   const uint64_t dt_us = argc > 2 ? (uint64_t)atoll(argv[2]) : 1000;
   const double period = argc > 3 ? atof(argv[3]) : 0.0005;
@@ -93,17 +154,16 @@ int main(int argc, char **argv) {
     q.Logic().cmd[2] = float(wh * 1.01); q.Logic().cmd[3] = float(wh * 0.98);
   }
   vehicles[0]->AddUWBRadioTarget(2, Vec3f(0, 0, 0));   // vehicle 1 wants to range to radio 2
-  Simulation::UWBNetwork net(&simTimer, 0.0015);
-  net.SetNoiseProperties(0.05, 0.0, 3.0);
-  for (size_t k = 0; k < vehicles.size(); k++) net.AddRadio(vehicles[k]->GetRadio());
+  RangingService net(&simTimer, 0.0015, 0.05, 0.0, 3.0);
+  for (size_t k = 0; k < vehicles.size(); k++) net.radios.push_back(vehicles[k]->GetRadio());
   RadioTypes::RadioMessageDecoded::RawMessage raw;
   const float w0[3] = {0.1f, -0.2f, 0.3f};
   afe_radio_create_rates_command(0, 9.81f, w0, raw.raw);
 
-  std::printf("{\"precision\": %d, \"trace\": [\n", precision);
+  std::printf("{\"precision\": %d, \"handled_errors\": %d, \"handled_status\": %d, \"trace\": [\n", precision, handled, handled_status);
   for (int s = 0; s < runs; s++) {
     for (size_t k = 0; k < vehicles.size(); k++) vehicles[k]->Run();   // main.cpp:323-325
-    net.Run();
+    net.Poll();
     simTimer.AdvanceMicroSeconds(dt_us);
     if (s == 1) vehicles[0]->SetCommandRadioMsg(raw);
     if (s == 2) vehicles[1]->SetVelocity(Vec3d(0, 0, 0));              // a setter between two Run()s must take effect

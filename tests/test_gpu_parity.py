@@ -479,6 +479,46 @@ def test_checkpoint_resumes_in_a_fresh_engine(precision, logic):
     g.close()
 
 
+def test_a_refused_checkpoint_leaves_the_engine_as_it_was():
+    """afe_load_checkpoint checks what the kernels would index or loop on -- type indices, minstd_rand0 words -- in
+    the host buffer BEFORE a byte reaches the device or the engine's bookkeeping changes: a word of 0 would keep the
+    Gaussian draws' acceptance loop spinning for ever, a type index past the table reads past it.  A refused
+    checkpoint must leave the engine stepping exactly as one that never saw it."""
+    n = 3000
+    ens = random_ensemble(n, seed=12)
+    d = ens.data
+
+    def make():
+        e = ens.to_engine(afa.AFE_F32)
+        e.set_logic_period(1 / 500)
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+        return e
+
+    a, b = make(), make()
+    a.step(1000, 7); b.step(1000, 7)
+    ck = b.save_checkpoint()
+    view = b.device_view()
+    header = afa.Ensemble.CHECKPOINT_HEADER_BYTES
+    rng_at = header + (view.rng - view.pos)
+    type_at = header + (view.type_index - view.pos)
+    for what, at, value in (("engine word 0", rng_at + 4 * 17, np.uint32(0)), ("engine word 2^31 - 1", rng_at + 4 * 2999, np.uint32(2147483647)),
+                            ("type index past the table", type_at + 1234, np.uint8(len(d.type_ids)))):
+        bad = ck.copy()
+        raw = np.frombuffer(value.tobytes(), np.uint8)
+        bad[at:at + raw.size] = raw
+        b.step(1000, 3); a.step(1000, 3)
+        with pytest.raises(afa.AfeError):
+            b.load_checkpoint(bad)
+        b.step(1000, 2); a.step(1000, 2)        # the clock, the type flags, the device table: nothing moved
+        sa, sb = a.get_state(), b.get_state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), (what, k)
+        assert np.array_equal(a.get_rng_state(), b.get_rng_state()) and a.time_us == b.time_us and a.logic_ticks == b.logic_ticks
+    b.load_checkpoint(ck)                         # the intact one loads, and rewinds
+    assert b.time_us == 7000
+    a.close(); b.close()
+
+
 def test_diverged_vehicles_do_not_hang_the_step():
     """A lane whose |w| dt overflows (inf / 1e25 / NaN body rates, e.g. a tumbling vehicle that diverged)
     must poison itself like the reference (sin/cos of a non-finite angle -> NaN state) and the launch must
