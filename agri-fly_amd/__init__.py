@@ -14,6 +14,7 @@ from .engine import (  # noqa: F401
     ABI_FUNCTIONS,
     AFE_F32,
     AFE_F64,
+    AFE_SEED_COUNTER,
     AFE_SEED_DECORRELATED,
     AFE_SEED_REFERENCE,
     AFE_STEP_AUTO,

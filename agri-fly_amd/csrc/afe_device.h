@@ -84,10 +84,15 @@ struct StepView {
   // fit 32-bit offsets (> 4 GiB: ensembles beyond ~31 M fp32 vehicles), which selects the global-address kernels.
   uint32_t buf_bytes;
   uint32_t logic_buf_bytes;
+  // AFE_SEED_COUNTER (counter-based IMU noise): sample = f(noise_seed, first_global + i, logic-tick number)
+  uint64_t noise_seed;
+  uint64_t tick_base;       // logic ticks before this launch (persistent grid: before its first step)
+  int64_t first_global;     // this shard's offset in the whole ensemble
 };
 
 struct LaunchFlags {
   bool ext_force, ext_torque, noise, logic;
+  bool counter_noise = false;   // noise from the counter-based generator (AFE_SEED_COUNTER) instead of the per-vehicle libstdc++ stream
   // heterogeneous ensemble whose type index is constant over every aligned run of 64 vehicles (fleets
   // laid out type by type): each wave then reads its one record by scalar loads -- no LDS table
   bool wave_uniform_types = false;
@@ -116,6 +121,10 @@ struct PersistArgs {
   unsigned int idle_ticks;               // 100 MHz ticks (s_memrealtime)
   unsigned int give_up_ticks;
   unsigned int epoch;                    // launch counter (stamps the device ring's entries)
+  // gust process (afe_set_gust_process; gust_period_us == 0: off).  A step's start time is t0_us + (its index - start) * dt_us;
+  // its epoch floor(time / period) is tracked incrementally from gust_epoch0 = epoch of t0_us.
+  unsigned long long gust_period_us, gust_seed, gust_n_global, gust_epoch0, gust_epoch_applied, t0_us, dt_us;
+  double gust_sigma_max;
 };
 #define AFE_PERSIST_TICK 1ull
 #define AFE_PERSIST_PARK 2ull
@@ -147,6 +156,10 @@ int launch_pack_positions_f32(const float *pos, int64_t stride, int64_t n, float
 int launch_pack_positions_f64(const double *pos, int64_t stride, int64_t n, float *out, void *stream);
 int launch_normals_selftest(const uint32_t *seeds, int64_t n, double *out, uint32_t *state_out, void *stream);
 int launch_normals_selftest_f32(const uint32_t *seeds, int64_t n, float *out, uint32_t *state_out, void *stream);
+int launch_gust_f32(float *ext_force, int64_t stride, int64_t n, int64_t first_global, uint64_t n_global, uint64_t seed, uint64_t epoch,
+                    double sigma_max, void *stream);
+int launch_gust_f64(double *ext_force, int64_t stride, int64_t n, int64_t first_global, uint64_t n_global, uint64_t seed, uint64_t epoch,
+                    double sigma_max, void *stream);
 int launch_stream_probe(float *base, int64_t stride, int64_t n, int n_read, int n_write, void *stream);
 int launch_seed_rng(uint32_t *rng, int64_t n, int64_t first_global, int policy, void *stream);
 

@@ -69,6 +69,12 @@ struct afe_engine {
   bool noise = true;
   double sigma_gyro = 0.1, sigma_acc = 0.2;  // Quadcopter_T.cpp:5-6
   int seed_policy = AFE_SEED_REFERENCE;
+  uint64_t noise_seed = 0;  // AFE_SEED_COUNTER: the key of the counter-based generator
+  // gust process (afe_set_gust_process): the ext_force slab holds the force of epoch `gust_applied`
+  bool gust_on = false;
+  uint64_t gust_seed = 0, gust_period_us = 0, gust_n_global = 0;
+  double gust_sigma_max = 0;
+  uint64_t gust_applied = ~0ull;   // epoch whose force is in the slab (~0: none yet)
   bool has_ext_force = false, has_ext_torque = false;
   // stateless motors (tau_m == 0, J_m == 0) driven by held commands: the rotor-speed slab is not
   // written by the step kernel; motor_stale says it has to be rebuilt from the commands first
@@ -95,6 +101,7 @@ struct afe_engine {
   uint64_t p_resume = 0;    // where the next grid starts (every worker's done[] stands there while none runs)
   uint64_t p_dt_us = 0;     // what the resident grid was launched with
   unsigned p_epoch = 0;     // launches so far
+  uint64_t p_seg_start = 0, p_seg_t0_us = 0, p_seg_gust_applied = ~0ull;   // the current run of equally long steps: its first index, the engine time and the slab's gust epoch there
   LaunchFlags p_flags = {};
 
   std::string err;
@@ -104,6 +111,7 @@ namespace {
 void join_streams(afe_engine *e);
 hipStream_t main_stream(afe_engine *e);
 int persist_park(afe_engine *e);
+int gust_resample(afe_engine *e, uint64_t epoch);
 }  // namespace
 
 namespace {
@@ -309,6 +317,9 @@ void fill_view(const afe_engine *e, StepView<R> &v) {
   v.motor_write = !motor_lazy(e);
   v.sigma_gyro = (float)e->sigma_gyro;  // float(_stdDevRateGyroNoise), Quadcopter_T.cpp:170
   v.sigma_acc = (float)e->sigma_acc;
+  v.noise_seed = e->noise_seed;
+  v.tick_base = e->n_ticks;
+  v.first_global = e->first_global;
   // one buffer resource spans the arena (pos is its first slab), another the logic arena (lpf first)
   const size_t lbytes = logic_arena_bytes(e);
   const bool fits = !e->force_global_addressing && e->arena_bytes < 0xffff0000ull && lbytes < 0xffff0000ull;
@@ -367,7 +378,18 @@ void persist_size_grid(afe_engine *e) {
 LaunchFlags persist_flags(const afe_engine *e) {
   LaunchFlags f;
   f.ext_force = e->has_ext_force; f.ext_torque = false; f.noise = e->noise; f.logic = e->logic_on;
+  f.counter_noise = e->seed_policy == AFE_SEED_COUNTER;
   return f;
+}
+
+// launch mode: the gust force of `epoch` into the ext_force slab, stream-ordered before the step that needs it
+int gust_resample(afe_engine *e, uint64_t epoch) {
+  const int lrc = e->precision == AFE_F64
+      ? launch_gust_f64((double *)e->ext_force, e->stride, e->n, e->first_global, e->gust_n_global, e->gust_seed, epoch, e->gust_sigma_max, main_stream(e))
+      : launch_gust_f32((float *)e->ext_force, e->stride, e->n, e->first_global, e->gust_n_global, e->gust_seed, epoch, e->gust_sigma_max, main_stream(e));
+  if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("gust kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+  e->gust_applied = epoch;
+  return AFE_OK;
 }
 bool persist_eligible(const afe_engine *e) {
   if (e->step_mode == AFE_STEP_LAUNCH || e->p_failed) return false;
@@ -393,6 +415,19 @@ int persist_launch(afe_engine *e) {
   a.idle_ticks = 20000;         // 200 us
   a.give_up_ticks = 5000000;    // 50 ms without any progress while steps are waiting
   a.epoch = ++e->p_epoch;
+  // The books at step p_resume, where this grid starts (the host's own clock, tick count and gust epoch are already
+  // those of step p_next, the end of everything authorised): its start time is linear in the step index since
+  // p_seg_start; the ticks before it are the engine's count less the tick flags of the entries still ahead of it;
+  // the slab holds the gust of the step before it (or what it held when the run began).
+  const uint64_t t0 = e->p_seg_t0_us + (e->p_resume - e->p_seg_start) * e->p_dt_us;
+  uint64_t ticks_ahead = 0;
+  for (uint64_t k = e->p_resume; k < e->p_next; k++) ticks_ahead += e->p_host[k & (AFE_PERSIST_HOST_RING - 1)] & AFE_PERSIST_TICK;
+  const uint64_t ticks0 = e->n_ticks - ticks_ahead;
+  a.t0_us = t0; a.dt_us = e->p_dt_us;
+  a.gust_period_us = e->gust_on ? e->gust_period_us : 0;
+  a.gust_seed = e->gust_seed; a.gust_n_global = e->gust_n_global; a.gust_sigma_max = e->gust_sigma_max;
+  a.gust_epoch0 = e->gust_on ? t0 / e->gust_period_us : 0;
+  a.gust_epoch_applied = !e->gust_on ? 0 : (e->p_resume > e->p_seg_start ? (t0 - e->p_dt_us) / e->gust_period_us : e->p_seg_gust_applied);
   const double dt = us_to_seconds(e->p_dt_us);
   const LaunchFlags &f = e->p_flags;
   const DevLogic *ulogic = e->logic_on ? &e->logic_table[0] : nullptr;
@@ -400,12 +435,12 @@ int persist_launch(afe_engine *e) {
   if (e->precision == AFE_F64) {
     StepView<double> v;
     fill_view(e, v);
-    v.dt = dt; v.inv_dt = 1.0 / dt; v.n_steps = 1; v.tick_mask = 0;
+    v.dt = dt; v.inv_dt = 1.0 / dt; v.n_steps = 1; v.tick_mask = 0; v.tick_base = ticks0;
     lrc = launch_persistent_f64(v, f, e->table_f64[0], ulogic, a, e->stream);
   } else {
     StepView<float> v;
     fill_view(e, v);
-    v.dt = (float)dt; v.inv_dt = (float)(1.0 / dt); v.n_steps = 1; v.tick_mask = 0;
+    v.dt = (float)dt; v.inv_dt = (float)(1.0 / dt); v.n_steps = 1; v.tick_mask = 0; v.tick_base = ticks0;
     lrc = launch_persistent_f32(v, f, e->table_f32[0], ulogic, a, e->stream);
   }
   if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("persistent step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
@@ -455,11 +490,20 @@ int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   int rc = persist_alloc(e);
   if (rc) return rc;
   const LaunchFlags f = persist_flags(e);
-  if (e->p_running && (e->p_dt_us != dt_us || f.ext_force != e->p_flags.ext_force || f.noise != e->p_flags.noise || f.logic != e->p_flags.logic))
+  if (e->p_running && (e->p_dt_us != dt_us || f.ext_force != e->p_flags.ext_force || f.noise != e->p_flags.noise || f.logic != e->p_flags.logic || f.counter_noise != e->p_flags.counter_noise))
     if ((rc = persist_park(e))) return rc;
   volatile unsigned long long *st = p_status(e);
   if (e->p_running && st[0] != 0) {       // it parked itself (idle): collect it, a new grid starts below
     if ((rc = persist_collect(e))) return rc;
+  }
+  if (!e->p_running && e->p_resume == e->p_next) {
+    // nothing pending: a new run of equally long steps begins here.  Step index -> start time is linear from now on
+    // (a resident grid derives the gust epoch of each of its steps from it, and so does persist_launch for a grid that
+    // has to pick up in the middle of the run).
+    e->p_seg_start = e->p_next;
+    e->p_seg_t0_us = e->now_us;
+    e->p_seg_gust_applied = e->gust_applied;
+    e->p_dt_us = dt_us; e->p_flags = f;
   }
   for (int s = 0; s < n_steps; s++) {
     // room in the host ring: never more than a ring (less a margin) ahead of the slowest worker
@@ -467,7 +511,6 @@ int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
       const uint64_t floor_ = e->p_running ? std::max<uint64_t>(st[1], e->p_resume) : e->p_resume;
       if (e->p_next - floor_ < AFE_PERSIST_HOST_RING - 128) break;
       if (!e->p_running) {                // entries are waiting and nobody reads them
-        e->p_dt_us = dt_us; e->p_flags = f;
         if ((rc = persist_launch(e))) return rc;
       } else if (st[0] != 0) {
         if ((rc = persist_collect(e))) return rc;
@@ -475,6 +518,7 @@ int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
         return fail(e, AFE_ERR_HIP, "persistent step kernel makes no progress");
       }
     }
+    if (e->gust_on) e->gust_applied = e->now_us / e->gust_period_us;   // what the slab holds once this step has run
     e->now_us += dt_us;  // ManualTimer::AdvanceMicroSeconds, main.cpp:392
     unsigned long long entry = (e->p_next + 1) << 2;
     if (gate_step(e->logic_period, e->logic_elapsed_us, dt_us)) { entry |= AFE_PERSIST_TICK; e->n_ticks++; }
@@ -482,10 +526,7 @@ int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     e->p_next++;
     e->steps_issued++;
   }
-  if (!e->p_running) {
-    e->p_dt_us = dt_us; e->p_flags = f;
-    if ((rc = persist_launch(e))) return rc;
-  }
+  if (!e->p_running && (rc = persist_launch(e))) return rc;
   if (motor_lazy(e)) e->motor_stale = true;
   return AFE_OK;
 }
@@ -682,7 +723,7 @@ extern "C" int afe_set_logic_period(afe_engine *e, double seconds) {
 
 extern "C" int afe_set_imu_noise(afe_engine *e, int enabled, double sigma_gyro, double sigma_acc, int seed_policy) {
   if (!e || !(sigma_gyro >= 0) || !(sigma_acc >= 0) ||
-      (seed_policy != AFE_SEED_REFERENCE && seed_policy != AFE_SEED_DECORRELATED))
+      (seed_policy != AFE_SEED_REFERENCE && seed_policy != AFE_SEED_DECORRELATED && seed_policy != AFE_SEED_COUNTER))
     return fail(e, AFE_ERR_INVALID_ARG, "bad noise configuration");
   { const int prc = persist_park(e); if (prc) return prc; }   // a resident grid carries the old configuration
   e->noise = enabled != 0;
@@ -691,7 +732,8 @@ extern "C" int afe_set_imu_noise(afe_engine *e, int enabled, double sigma_gyro, 
   if (seed_policy != e->seed_policy) {
     e->seed_policy = seed_policy;
     AFE_HIP(e, hipSetDevice(e->device));
-    if (launch_seed_rng(e->rng, e->n, e->first_global, seed_policy, main_stream(e)) != 0)
+    // (the counter policy keeps no per-vehicle word; the slab stays what it was -- valid minstd_rand0 words)
+    if (seed_policy != AFE_SEED_COUNTER && launch_seed_rng(e->rng, e->n, e->first_global, seed_policy, main_stream(e)) != 0)
       return fail(e, AFE_ERR_HIP, "seed kernel launch failed");
   }
   return AFE_OK;
@@ -862,7 +904,16 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   f.logic = e->logic_on;
   int done = 0;
   while (done < n_steps) {
-    const int chunk = (n_steps - done) < e->max_fused ? (n_steps - done) : e->max_fused;
+    int chunk = (n_steps - done) < e->max_fused ? (n_steps - done) : e->max_fused;
+    if (e->gust_on) {
+      // the force is constant within an epoch of the gust process: resample (one small launch) when this launch's first
+      // step starts in another epoch than the slab holds, and end the launch before the next epoch begins
+      const uint64_t ep = e->now_us / e->gust_period_us;
+      if (ep != e->gust_applied && (rc = gust_resample(e, ep))) return rc;
+      const uint64_t left = ((ep + 1) * e->gust_period_us - e->now_us + dt_us - 1) / dt_us;   // steps that start inside this epoch
+      if ((uint64_t)chunk > left) chunk = (int)left;
+    }
+    const uint64_t tick_base = e->n_ticks;
     unsigned long long mask = 0;
     for (int s = 0; s < chunk; s++) {
       e->now_us += dt_us;  // ManualTimer::AdvanceMicroSeconds, main.cpp:392
@@ -873,6 +924,7 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     }
     // launches without a logic tick draw no noise: use the lean instantiation
     f.noise = e->noise && mask != 0;
+    f.counter_noise = e->seed_policy == AFE_SEED_COUNTER;
     f.logic = e->logic_on && mask != 0;
     f.wave_uniform_types = !e->types_uniform && e->types_wave_uniform;
     const DevLogic *ulogic = (e->logic_on && e->types_uniform) ? &e->logic_table[0] : nullptr;
@@ -894,7 +946,7 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     if (e->precision == AFE_F64) {
       StepView<double> v;
       fill_view(e, v);
-      v.dt = dt; v.inv_dt = 1.0 / dt; v.n_steps = chunk; v.tick_mask = mask;
+      v.dt = dt; v.inv_dt = 1.0 / dt; v.n_steps = chunk; v.tick_mask = mask; v.tick_base = tick_base;
       v.end = half;
       lrc = launch_step_f64(v, f, e->types_uniform ? &e->table_f64[0] : nullptr, ulogic, e->stream);
       if (split && lrc == 0) {
@@ -904,7 +956,7 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     } else {
       StepView<float> v;
       fill_view(e, v);
-      v.dt = (float)dt; v.inv_dt = (float)(1.0 / dt); v.n_steps = chunk; v.tick_mask = mask;
+      v.dt = (float)dt; v.inv_dt = (float)(1.0 / dt); v.n_steps = chunk; v.tick_mask = mask; v.tick_base = tick_base;
       v.end = half;
       lrc = launch_step_f32(v, f, e->types_uniform ? &e->table_f32[0] : nullptr, ulogic, e->stream);
       if (split && lrc == 0) {
@@ -918,6 +970,40 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     e->steps_issued += (uint64_t)chunk;
   }
   return AFE_OK;
+}
+
+extern "C" int afe_set_noise_seed(afe_engine *e, uint64_t seed) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  const int rc = persist_park(e);
+  if (rc) return rc;
+  e->noise_seed = seed;
+  return AFE_OK;
+}
+
+extern "C" int afe_set_gust_process(afe_engine *e, int enabled, uint64_t seed, double sigma_max, uint64_t period_us, int64_t n_global) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  if (enabled && (!(sigma_max >= 0) || !std::isfinite(sigma_max) || period_us == 0 || (n_global > 0 && n_global < e->first_global + e->n)))
+    return fail(e, AFE_ERR_INVALID_ARG, "gust process: sigma_max >= 0, period > 0, n_global >= first_global_index + n_vehicles (or 0: this ensemble alone)");
+  AFE_HIP(e, hipSetDevice(e->device));
+  const int rc = persist_park(e);
+  if (rc) return rc;
+  e->gust_on = enabled != 0;
+  e->gust_seed = seed;
+  e->gust_sigma_max = sigma_max;
+  e->gust_period_us = period_us;
+  e->gust_n_global = (uint64_t)(n_global > 0 ? n_global : e->first_global + e->n);
+  e->gust_applied = ~0ull;              // the next step resamples whatever the slab holds
+  if (e->gust_on) e->has_ext_force = true;
+  return AFE_OK;
+}
+
+extern "C" int afe_get_external_force(afe_engine *e, int64_t first, int64_t count, double *force3) {
+  int rc = check_range(e, first, count);
+  if (rc) return rc;
+  if (!force3) return fail(e, AFE_ERR_INVALID_ARG, "force3 is NULL");
+  AFE_HIP(e, hipSetDevice(e->device));
+  if (e->precision == AFE_F64) return get_field<double>(e, e->ext_force, 3, first, count, force3);
+  return get_field<float>(e, e->ext_force, 3, first, count, force3);
 }
 
 extern "C" int afe_set_step_mode(afe_engine *e, int mode) {
@@ -1074,7 +1160,7 @@ extern "C" int afe_algorithmic_bytes_per_step(const afe_engine *e, int imu_tick,
   if (e->has_ext_torque) b += 3 * es;
   if (imu_tick) {
     b += 6 * 4;                // gyro + accelerometer sample
-    if (e->noise) b += 8;      // RNG word read + write
+    if (e->noise && e->seed_policy != AFE_SEED_COUNTER) b += 8;   // RNG word read + write (the counter policy keeps no word)
     if (e->logic_on) b += 12 * 4 * 2 + 4 * 4 + 4 * 4 + 3;  // LPF state r/w, rates cmd, motor cmd write, flags
   }
   *bytes = b;
@@ -1151,8 +1237,10 @@ struct CheckpointHeader {
   uint64_t n_types, table_hash, logic_hash;
   uint64_t noise, seed_policy;
   double sigma_gyro, sigma_acc, logic_period;
+  uint64_t noise_seed, gust_on, gust_seed, gust_period_us, gust_n_global, gust_applied;
+  double gust_sigma_max;
 };
-const uint64_t kCheckpointMagic = 0x4146452d434b5032ull;  // "AFE-CKP2"
+const uint64_t kCheckpointMagic = 0x4146452d434b5033ull;  // "AFE-CKP3"
 size_t logic_arena_bytes(const afe_engine *e) {
   const size_t S = (size_t)e->stride;
   return e->logic_arena ? S * 12 * 4 + S * 4 * 4 + S * 2 + 256 * sizeof(DevLogic) : 0;
@@ -1207,6 +1295,8 @@ extern "C" int afe_save_checkpoint(afe_engine *e, void *host_buffer, uint64_t by
   h.n_types = (uint64_t)e->table.size(); h.table_hash = table_fingerprint(e); h.logic_hash = logic_fingerprint(e);
   h.noise = e->noise; h.seed_policy = (uint64_t)e->seed_policy;
   h.sigma_gyro = e->sigma_gyro; h.sigma_acc = e->sigma_acc; h.logic_period = e->logic_period;
+  h.noise_seed = e->noise_seed; h.gust_on = e->gust_on; h.gust_seed = e->gust_seed; h.gust_period_us = e->gust_period_us;
+  h.gust_n_global = e->gust_n_global; h.gust_applied = e->gust_applied; h.gust_sigma_max = e->gust_sigma_max;
   char *p = (char *)host_buffer;
   std::memcpy(p, &h, sizeof(h));
   p += sizeof(h);
@@ -1232,8 +1322,8 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
     return fail(e, AFE_ERR_INVALID_ARG, "checkpoint was taken with a different vehicle type table (afe_set_type_table first)");
   if (h.logic_hash != logic_fingerprint(e))
     return fail(e, AFE_ERR_INVALID_ARG, "checkpoint was taken with different on-device logic parameters");
-  if ((h.seed_policy != AFE_SEED_REFERENCE && h.seed_policy != AFE_SEED_DECORRELATED) || !(h.logic_period > 0) ||
-      !(h.sigma_gyro >= 0) || !(h.sigma_acc >= 0))
+  if ((h.seed_policy != AFE_SEED_REFERENCE && h.seed_policy != AFE_SEED_DECORRELATED && h.seed_policy != AFE_SEED_COUNTER) || !(h.logic_period > 0) ||
+      !(h.sigma_gyro >= 0) || !(h.sigma_acc >= 0) || (h.gust_on && (h.gust_period_us == 0 || !(h.gust_sigma_max >= 0) || h.gust_n_global < (uint64_t)(e->first_global + e->n))))
     return fail(e, AFE_ERR_INVALID_ARG, "checkpoint header holds an invalid configuration");
   // Everything the kernels will index or loop on is checked in the HOST buffer, before a byte reaches the device or
   // the engine's own state changes: a refused checkpoint leaves the engine exactly as it was.
@@ -1272,6 +1362,9 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
   e->sigma_gyro = h.sigma_gyro;
   e->sigma_acc = h.sigma_acc;
   e->logic_period = h.logic_period;
+  e->noise_seed = h.noise_seed;
+  e->gust_on = h.gust_on != 0; e->gust_seed = h.gust_seed; e->gust_period_us = h.gust_period_us; e->gust_n_global = h.gust_n_global;
+  e->gust_applied = h.gust_applied; e->gust_sigma_max = h.gust_sigma_max;
   // the kernel-argument fast path is only valid when every vehicle uses record 0: decide from the
   // restored per-vehicle type slab, not from what this engine was told before the load
   e->type_host.swap(types);

@@ -306,6 +306,89 @@ __device__ __forceinline__ void six_normals(uint32_t &s, float d[6]) {
 }
 
 // ---------------------------------------------------------------------------
+// Counter-based noise: AFE_SEED_COUNTER and the gust process (afe_set_gust_process).  Philox4x32-10 (Salmon et al.,
+// SC'11; Random123) addressed by (seed; vehicle index, stream, block, ordinal) -- no state to load or store, no
+// rejection loop (nothing diverges), any vehicle's sample at any tick computable by anybody: the definition is in
+// oracle/agrifly_oracle_counter.h (the checker implements it in double with libm), in short
+//   u_r = ((x_even >> 9) + 0.5) 2^-23,  u_a = (x_odd >> 8) 2^-24      -- both exact in fp32
+//   r = sqrt(-2 ln u_r);  z_a = r cos(2 pi u_a);  z_b = r sin(2 pi u_a)
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint32_t h0 = __umulhi(M0, c[0]), l0 = M0 * c[0], h1 = __umulhi(M1, c[2]), l1 = M1 * c[2];
+    c[0] = h1 ^ c[1] ^ k0; c[1] = l1; c[2] = h0 ^ c[3] ^ k1; c[3] = l0;
+    k0 += W0; k1 += W1;
+  }
+}
+#define AFE_STREAM_IMU 1u
+#define AFE_STREAM_GUST 2u
+__device__ __forceinline__ void counter_block(uint64_t seed, uint64_t index, uint32_t stream, uint32_t block, uint64_t ordinal, uint32_t w[4]) {
+  w[0] = (uint32_t)index;
+  w[1] = (uint32_t)((index >> 32) & 0xffffu) | (stream << 16) | (block << 24);
+  w[2] = (uint32_t)ordinal;
+  w[3] = (uint32_t)(ordinal >> 32);
+  philox4x32_10(w, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+// fp32: ln by the range reduction of polar_multiplier_f32 (m - 1 is exact, so nothing cancels as u_r -> 1 where the
+// sample goes to zero), hardware reciprocal / square root, v_sin_f32 / v_cos_f32 on the angle in revolutions
+__device__ __forceinline__ void box_muller(uint32_t xe, uint32_t xo, float &za, float &zb) {
+#pragma clang fp contract(off)
+  const float u_r = ((float)(xe >> 9) + 0.5f) * (1.0f / 8388608.0f);
+  const float u_a = (float)(xo >> 8) * (1.0f / 16777216.0f);
+  float m = __builtin_amdgcn_frexp_mantf(u_r);   // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_expf(u_r);
+  if (m < 0.70710678f) { m = m + m; e -= 1; }
+  const float f = m - 1.0f;
+  const float sq = f * __builtin_amdgcn_rcpf(2.0f + f);
+  const float z = sq * sq;
+  float p = 1.0f / 9.0f;
+  p = __builtin_fmaf(p, z, 1.0f / 7.0f);
+  p = __builtin_fmaf(p, z, 1.0f / 5.0f);
+  p = __builtin_fmaf(p, z, 1.0f / 3.0f);
+  const float two_s = sq + sq;
+  const float lnm = __builtin_fmaf(two_s * z, p, two_s);
+  const float ln_u = __builtin_fmaf((float)e, 0.693147182f, lnm);      // <= ln(1 - 2^-24) < 0
+  const float r = __builtin_amdgcn_sqrtf(-2.0f * ln_u);
+  za = r * __builtin_amdgcn_cosf(u_a);
+  zb = r * __builtin_amdgcn_sinf(u_a);
+}
+__device__ __forceinline__ void box_muller(uint32_t xe, uint32_t xo, double &za, double &zb) {
+#pragma clang fp contract(off)
+  const double u_r = ((double)(xe >> 9) + 0.5) * (1.0 / 8388608.0);
+  const double u_a = (double)(xo >> 8) * (1.0 / 16777216.0);
+  const double r = sqrt(-2.0 * log(u_r));
+  double sn, cs;
+  sincos(6.283185307179586476925286766559 * u_a, &sn, &cs);
+  za = r * cs;
+  zb = r * sn;
+}
+// six N(0,1) of vehicle `index` at logic tick `tick`: gyro x y z, accelerometer x y z
+template <typename N>
+__device__ __forceinline__ void counter_six_normals(uint64_t seed, uint64_t index, uint64_t tick, N d[6]) {
+  uint32_t a[4], b[4];
+  counter_block(seed, index, AFE_STREAM_IMU, 0, tick, a);
+  counter_block(seed, index, AFE_STREAM_IMU, 1, tick, b);
+  N unused0, unused1;
+  box_muller(a[0], a[1], d[0], d[1]);
+  box_muller(a[2], a[3], d[2], d[3]);
+  box_muller(b[0], b[1], d[4], d[5]);
+  (void)unused0; (void)unused1;
+}
+// the gust force of vehicle `index` during `epoch`: sigma_i (z0, z1, z2), sigma_i = sigma_max index / (n_global - 1)
+template <typename R>
+__device__ __forceinline__ void gust_force(uint64_t seed, uint64_t index, uint64_t n_global, uint64_t epoch, double sigma_max, R f[3]) {
+#pragma clang fp contract(off)
+  uint32_t w[4];
+  counter_block(seed, index, AFE_STREAM_GUST, 0, epoch, w);
+  R z0, z1, z2, z3;
+  box_muller(w[0], w[1], z0, z1);
+  box_muller(w[2], w[3], z2, z3);
+  const R sigma = (R)(sigma_max * (double)index / (double)(n_global > 1 ? n_global - 1 : 1));
+  f[0] = sigma * z0; f[1] = sigma * z1; f[2] = sigma * z2;
+}
+
+// ---------------------------------------------------------------------------
 // Quaternion increment FromRotationVector(angVel*dt), Rotation.hpp:84-97.
 // fp64: the reference's formula (sqrt, sin, cos, three divisions).
 __device__ __forceinline__ void rotvec_to_quat(double rx, double ry, double rz,
@@ -465,9 +548,9 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
   else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), r, (int)voff, (int)soff, 0);
 }
 
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE, bool BUF>
+template <typename R, bool FEXT, bool TEXT, int NOISE, bool LOGIC, bool SINGLE, bool BUF>
 __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParams<R> &P, const DevLogic &G,
-                                            const int64_t i, const unsigned long long tick_mask, const int n_steps_arg) {
+                                            const int64_t i, const unsigned long long tick_mask, const int n_steps_arg, const uint64_t tick_ordinal0) {
   // No implicit FMA contraction: every rounding is the one the source spells
   // out, so all instantiations (noise on/off, wrench on/off, table/uniform,
   // fused or single-step) produce bit-identical physics, and the operation
@@ -503,7 +586,8 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   // this launch's first logic tick (which need nothing else) run while the ~24
   // state loads behind it are still in flight.
   uint32_t rng = 0;
-  if (NOISE && tick_mask) rng = AFE_LD(uint32_t, v.rng, 0, off4);
+  if (NOISE == 1 && tick_mask) rng = AFE_LD(uint32_t, v.rng, 0, off4);
+  uint64_t tick_ordinal = tick_ordinal0;   // NOISE == 2: the logic-tick number addresses the sample (wave-uniform)
   R px = AFE_LD(R, v.pos, 0, off), py = AFE_LD(R, v.pos, 1, off), pz = AFE_LD(R, v.pos, 2, off);
   R vx = AFE_LD(R, v.vel, 0, off), vy = AFE_LD(R, v.vel, 1, off), vz = AFE_LD(R, v.vel, 2, off);
   R q0 = AFE_LD(R, v.att, 0, off), q1 = AFE_LD(R, v.att, 1, off), q2 = AFE_LD(R, v.att, 2, off), q3 = AFE_LD(R, v.att, 3, off);
@@ -553,7 +637,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   const int n_steps = SINGLE ? 1 : n_steps_arg;
   for (int step = 0; step < n_steps; step++) {
     const bool tick = (tick_mask >> step) & 1ull;          // Quadcopter_T.cpp:159 (wave-uniform)
-    if (NOISE && tick) {
+    if (NOISE == 1 && tick) {
       // The six Gaussian draws of this sub-step's logic tick need only the engine
       // word, so they are made FIRST: on the first sub-step they run while the
       // state loads issued above are still in flight.  g++ evaluates the ctor
@@ -563,6 +647,15 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
       six_normals(rng, d);
       ng[0] = v.sigma_gyro * (float)d[2]; ng[1] = v.sigma_gyro * (float)d[1]; ng[2] = v.sigma_gyro * (float)d[0];
       na[0] = v.sigma_acc * (float)d[5]; na[1] = v.sigma_acc * (float)d[4]; na[2] = v.sigma_acc * (float)d[3];
+    }
+    if (NOISE == 2 && tick) {
+      // AFE_SEED_COUNTER: the sample of (vehicle, tick) is a function of the two -- nothing to load, nothing to
+      // store, no loop; like the draws above it runs under the state loads' latency
+      typename NormalOf<R>::type d[6];
+      counter_six_normals(v.noise_seed, (uint64_t)(v.first_global + i), tick_ordinal, d);
+      ng[0] = v.sigma_gyro * (float)d[0]; ng[1] = v.sigma_gyro * (float)d[1]; ng[2] = v.sigma_gyro * (float)d[2];
+      na[0] = v.sigma_acc * (float)d[3]; na[1] = v.sigma_acc * (float)d[4]; na[2] = v.sigma_acc * (float)d[5];
+      tick_ordinal++;
     }
     // ---- 4 motors: Motor::Run, Motor.cpp:39-84 ----
     R Fz = 0;                       // totalForce_b (thrust axes are all +z)
@@ -730,7 +823,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   if (have_imu) {
     AFE_ST(float, v.gyro, 0, off4, gx); AFE_ST(float, v.gyro, 1, off4, gy); AFE_ST(float, v.gyro, 2, off4, gz);
     AFE_ST(float, v.acc, 0, off4, ax_m); AFE_ST(float, v.acc, 1, off4, ay_m); AFE_ST(float, v.acc, 2, off4, az_m);
-    if (NOISE) AFE_ST(uint32_t, v.rng, 0, off4, rng);
+    if (NOISE == 1) AFE_ST(uint32_t, v.rng, 0, off4, rng);
     if (LOGIC) {
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -760,16 +853,16 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #endif
 
 // homogeneous ensemble: the one parameter record rides in the kernel arguments
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool SINGLE, bool BUF>
+template <typename R, bool FEXT, bool TEXT, int NOISE, bool LOGIC, bool SINGLE, bool BUF>
 __global__ void __launch_bounds__(AFE_BLOCK, AFE_LB_WAVES)
 afe_step_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G) {
   const int64_t i = v.first + (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;
   if (i >= v.end) return;
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE, BUF>(v, P, G, i, v.tick_mask, v.n_steps);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE, BUF>(v, P, G, i, v.tick_mask, v.n_steps, v.tick_base);
 }
 
 // heterogeneous ensemble: type tables staged into LDS, one record per lane
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool BUF>
+template <typename R, bool FEXT, bool TEXT, int NOISE, bool LOGIC, bool BUF>
 __global__ void __launch_bounds__(256)
 afe_step_kernel_table(const StepView<R> v) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -790,14 +883,14 @@ afe_step_kernel_table(const StepView<R> v) {
   const unsigned t = v.type[(uint32_t)i];
   const DevParams<R> &P = reinterpret_cast<const DevParams<R> *>(lds_raw)[t];
   const DevLogic &G = reinterpret_cast<const DevLogic *>(lds_raw + (size_t)words_p * 4)[LOGIC ? t : 0];
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false, BUF>(v, P, G, i, v.tick_mask, v.n_steps);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false, BUF>(v, P, G, i, v.tick_mask, v.n_steps, v.tick_base);
 }
 
 // heterogeneous ensemble, but every wave (aligned run of 64 vehicles) is of one type -- the host checked
 // the type slab (afe_engine.cpp refresh_type_flags): the wave's record is copied out of the global table by
 // scalar loads before anything is stored, and from there on the kernel is the homogeneous one (parameters
 // in scalar registers, one-wave workgroups, no LDS)
-template <typename R, bool FEXT, bool TEXT, bool NOISE, bool LOGIC, bool BUF>
+template <typename R, bool FEXT, bool TEXT, int NOISE, bool LOGIC, bool BUF>
 __global__ void __launch_bounds__(AFE_BLOCK, AFE_LB_WAVES)
 afe_step_kernel_wave_types(const StepView<R> v) {
   const int64_t i = v.first + (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;   // first is a multiple of 64: waves stay on aligned runs
@@ -806,7 +899,7 @@ afe_step_kernel_wave_types(const StepView<R> v) {
   const DevParams<R> P = v.table[t];
   DevLogic G = {};
   if (LOGIC) G = v.logic_table[t];
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false, BUF>(v, P, G, i, v.tick_mask, v.n_steps);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, false, BUF>(v, P, G, i, v.tick_mask, v.n_steps, v.tick_base);
 }
 
 // ---------------------------------------------------------------------------
@@ -889,7 +982,7 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
   }
 }
 
-template <typename R, bool FEXT, bool NOISE, bool LOGIC>
+template <typename R, bool FEXT, int NOISE, bool LOGIC>
 __global__ void __launch_bounds__(64)
 afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G, const PersistArgs a) {
   if (blockIdx.x == 0) { persist_pump(a); return; }
@@ -897,6 +990,11 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
   const int w = (int)blockIdx.x - 1;
   u64_t s = a.start;
   u64_t t_wait = ticks100();
+  u64_t tick_no = v.tick_base;                       // logic ticks so far (the counter policy's sample address)
+  // gust process (afe_set_gust_process): the force of epoch floor(t / period) lives in the ext_force slab; this wave
+  // rewrites ITS vehicles' entries when a step starts in an epoch other than the one the slab holds
+  u64_t gust_in_slab = a.gust_epoch_applied, gust_epoch = a.gust_epoch0;
+  u64_t gust_next_us = (a.gust_epoch0 + 1) * a.gust_period_us, t_us = a.t0_us;
   for (;;) {
     const u64_t idx = s + (u64_t)lane;
     const u64_t e = ld_agent(a.dev_ring + (idx & a.dev_mask));
@@ -916,16 +1014,56 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
     const int run = parks ? (int)__builtin_ctzll(parks) : cnt;             // steps in front of the park entry
     for (int k = 0; k < run; k++) {
       const u64_t tick = (ticks >> k) & 1ull;                              // wave-uniform (scalar)
+      if (a.gust_period_us) {
+        while (t_us >= gust_next_us) { gust_epoch++; gust_next_us += a.gust_period_us; }
+        if (gust_epoch != gust_in_slab) {
+          for (int c = w; c < a.n_chunks; c += a.n_workers) {
+            const int64_t i = (int64_t)c * 64 + lane;
+            if (i < v.n) {
+              R f[3];
+              gust_force<R>(a.gust_seed, (uint64_t)(v.first_global + i), a.gust_n_global, gust_epoch, a.gust_sigma_max, f);
+              R *slab = const_cast<R *>(v.ext_force);
+              slab[i] = f[0]; slab[v.stride + i] = f[1]; slab[2 * v.stride + i] = f[2];
+            }
+          }
+          gust_in_slab = gust_epoch;
+        }
+        t_us += a.dt_us;
+      }
       for (int c = w; c < a.n_chunks; c += a.n_workers) {
         const int64_t i = (int64_t)c * 64 + lane;
-        if (i < v.n) run_vehicle<R, FEXT, false, NOISE, LOGIC, true, true>(v, P, G, i, tick, 1);
+        if (i < v.n) run_vehicle<R, FEXT, false, NOISE, LOGIC, true, true>(v, P, G, i, tick, 1, tick_no);
       }
+      tick_no += tick;
     }
     s += (u64_t)run;
     if (lane == 0) st_agent(a.done + w, s);
     if (parks) return;
     t_wait = ticks100();
   }
+}
+
+// the same resampling for the launched kernels: one small launch when a step starts in a new epoch
+template <typename R>
+__global__ void __launch_bounds__(256) afe_gust_kernel(R *ext_force, int64_t stride, int64_t n, int64_t first_global, uint64_t n_global,
+                                                        uint64_t seed, uint64_t epoch, double sigma_max) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  R f[3];
+  gust_force<R>(seed, (uint64_t)(first_global + i), n_global, epoch, sigma_max, f);
+  ext_force[i] = f[0]; ext_force[stride + i] = f[1]; ext_force[2 * stride + i] = f[2];
+}
+int launch_gust_f32(float *ext_force, int64_t stride, int64_t n, int64_t first_global, uint64_t n_global, uint64_t seed, uint64_t epoch,
+                    double sigma_max, void *stream) {
+  hipLaunchKernelGGL(afe_gust_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ext_force, stride, n, first_global,
+                     n_global, seed, epoch, sigma_max);
+  return (int)hipGetLastError();
+}
+int launch_gust_f64(double *ext_force, int64_t stride, int64_t n, int64_t first_global, uint64_t n_global, uint64_t seed, uint64_t epoch,
+                    double sigma_max, void *stream) {
+  hipLaunchKernelGGL(afe_gust_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ext_force, stride, n, first_global,
+                     n_global, seed, epoch, sigma_max);
+  return (int)hipGetLastError();
 }
 
 // occupancy != 0: do not launch, report how many of the instantiation's one-wave workgroups a CU holds
@@ -945,7 +1083,7 @@ static int launch_persistent(const StepView<R> &v, const LaunchFlags &f, const D
     }                                                                                                                   \
   } while (0)
 #define AFE_PL_LO(FE, NO) do { if (f.logic) AFE_PL(FE, NO, true); else AFE_PL(FE, NO, false); } while (0)
-#define AFE_PL_NO(FE) do { if (f.noise) AFE_PL_LO(FE, true); else AFE_PL_LO(FE, false); } while (0)
+#define AFE_PL_NO(FE) do { if (!f.noise) AFE_PL_LO(FE, 0); else if (f.counter_noise) AFE_PL_LO(FE, 2); else AFE_PL_LO(FE, 1); } while (0)
   if (f.ext_force) AFE_PL_NO(true); else AFE_PL_NO(false);
 #undef AFE_PL_NO
 #undef AFE_PL_LO
@@ -1012,7 +1150,7 @@ static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevPara
   /* buffer addressing whenever the arenas fit 32-bit offsets (StepView::buf_bytes) */
 #define AFE_LAUNCH(FE, TE, NO, LO) do { if (v.buf_bytes) AFE_LAUNCH_B(FE, TE, NO, LO, true); else AFE_LAUNCH_B(FE, TE, NO, LO, false); } while (0)
 #define AFE_SEL_LO(FE, TE, NO) do { if (f.logic) AFE_LAUNCH(FE, TE, NO, true); else AFE_LAUNCH(FE, TE, NO, false); } while (0)
-#define AFE_SEL_NO(FE, TE) do { if (f.noise) AFE_SEL_LO(FE, TE, true); else AFE_SEL_LO(FE, TE, false); } while (0)
+#define AFE_SEL_NO(FE, TE) do { if (!f.noise) AFE_SEL_LO(FE, TE, 0); else if (f.counter_noise) AFE_SEL_LO(FE, TE, 2); else AFE_SEL_LO(FE, TE, 1); } while (0)
 #define AFE_SEL_TE(FE) do { if (f.ext_torque) AFE_SEL_NO(FE, true); else AFE_SEL_NO(FE, false); } while (0)
   if (f.ext_force) AFE_SEL_TE(true); else AFE_SEL_TE(false);
 #undef AFE_SEL_TE

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.environ.get("AGRIFLY_ENGINE_LIB") or os.path.join(_HERE, "lib", "libagrifly_engine.so")
 
 AFE_F32, AFE_F64 = 0, 1
-AFE_SEED_REFERENCE, AFE_SEED_DECORRELATED = 0, 1
+AFE_SEED_REFERENCE, AFE_SEED_DECORRELATED, AFE_SEED_COUNTER = 0, 1, 2
 AFE_STEP_LAUNCH, AFE_STEP_PERSISTENT, AFE_STEP_AUTO = 0, 1, 2
 
 # every symbol include/agrifly_engine.h declares (checked by tests/test_abi.py)
@@ -46,6 +46,7 @@ ABI_FUNCTIONS = [
     "afe_nearest_neighbour_grid", "afe_neighbour_grid_info", "afe_set_neighbour_grid_refresh", "afe_nearest_neighbour_bruteforce",
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
     "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running", "afe_stream_probe",
+    "afe_set_noise_seed", "afe_set_gust_process", "afe_get_external_force",
 ]
 
 
@@ -256,6 +257,9 @@ def library():
         "afe_set_max_fused_steps": [eng, ci],
         "afe_set_split_stepping": [eng, ci],
         "afe_set_step_mode": [eng, ci],
+        "afe_set_noise_seed": [eng, u64],
+        "afe_set_gust_process": [eng, ci, u64, C.c_double, u64, i64],
+        "afe_get_external_force": [eng, i64, i64, vp],
         "afe_stream_probe": [ci, i64, ci, ci, ci, C.POINTER(C.c_float)],
         "afe_steps_completed": [eng, C.POINTER(u64)],
         "afe_persistent_running": [eng, C.POINTER(ci)],
@@ -765,6 +769,19 @@ class Ensemble:
         """afe_set_split_stepping: 0 automatic (default), 1 off, 2 = the two halves of the ensemble step on two streams (see the header)"""
         self._ck(self._L.afe_set_split_stepping(self._h, int(parts)))
 
+    def set_noise_seed(self, seed):
+        self._ck(self._L.afe_set_noise_seed(self._h, int(seed)))
+
+    def set_gust_process(self, enabled, seed=0, sigma_max=0.5, period_us=100000, n_global=0):
+        """afe_set_gust_process: per-vehicle piecewise-constant wind gusts resampled on the device (BASELINE config 4)"""
+        self._ck(self._L.afe_set_gust_process(self._h, int(bool(enabled)), int(seed), float(sigma_max), int(period_us), int(n_global)))
+
+    def get_external_force(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.empty((3, count), np.float64)
+        self._ck(self._L.afe_get_external_force(self._h, int(first), int(count), out.ctypes.data))
+        return out
+
     def set_step_mode(self, mode):
         """afe_set_step_mode: AFE_STEP_LAUNCH (0), AFE_STEP_PERSISTENT (1: one resident grid, afe_step only authorises steps), AFE_STEP_AUTO (2)"""
         self._ck(self._L.afe_set_step_mode(self._h, int(mode)))
@@ -820,7 +837,7 @@ class Ensemble:
         return b.value
 
     # -- checkpoint / resume --------------------------------------------------
-    CHECKPOINT_HEADER_BYTES = 20 * 8    # CheckpointHeader (afe_engine.cpp): 17 x uint64 + 3 x double; the arena follows
+    CHECKPOINT_HEADER_BYTES = 27 * 8    # CheckpointHeader (afe_engine.cpp): 17 x uint64, 3 x double, 6 x uint64, 1 x double; the arena follows
 
     def save_checkpoint(self):
         n = C.c_uint64(0)

@@ -48,19 +48,29 @@ DT_US = 1000
 LOGIC_PERIOD = 1.0 / 500.0
 
 
-def build_shard(afa, n_local, first_global, n_global, device, fext=True, precision=None):
+GUST_SEED, NOISE_SEED, GUST_SIGMA_MAX, GUST_PERIOD_US = 4, 5, 0.5, 100000
+
+
+def build_shard(afa, n_local, first_global, n_global, device, fext=True, precision=None, exact_stream=False):
+    """config 4: hovering CF_MINIQUAD ensemble in one shared world (4 m lattice by GLOBAL index), per-vehicle wind gusts
+    from the on-device gust process (sigma swept 0 .. 0.5 N over the global index, resampled every 100 ms), IMU synthesis
+    with Gaussian noise at the 500 Hz logic gate -- from the counter-based generator (AFE_SEED_COUNTER), or with
+    exact_stream=True from per-vehicle libstdc++ minstd_rand0 / normal_distribution streams (AFE_SEED_DECORRELATED)"""
     p = afa.params_from_type(5)  # QC_TYPE_CF_MINIQUAD: vehicle id 1 of every shipped main
-    # one shared world: 4 m lattice by global index (the dynamics are translation invariant)
-    data = afa.scenarios.gust_ensemble(n_local, p, seed=4, first_global=first_global, n_global=n_global, spacing=4.0)
+    data = afa.scenarios.hover_ensemble(n_local, p)
+    idx = np.arange(first_global, first_global + n_local)
+    data.pos[0] = (idx % 1024) * 4.0        # the dynamics are translation invariant
+    data.pos[1] = (idx // 1024) * 4.0
     e = afa.Ensemble(n_local, precision=afa.AFE_F32 if precision is None else precision, device=device,
                      first_global_index=first_global)
     e.set_type_table([p])
     e.set_logic_period(LOGIC_PERIOD)
-    e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+    e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED if exact_stream else afa.AFE_SEED_COUNTER)
+    e.set_noise_seed(NOISE_SEED)
     e.set_state(data.pos, data.vel, data.att, data.ang_vel, data.motor_speed)
     e.set_motor_cmds(data.motor_cmd)
     if fext:
-        e.set_external_force(data.ext_force)
+        e.set_gust_process(True, seed=GUST_SEED, sigma_max=GUST_SIGMA_MAX, period_us=GUST_PERIOD_US, n_global=n_global)
     e.set_step_mode(afa.AFE_STEP_AUTO)      # one resident grid up to 2^20 vehicles, (split) launches beyond
     return e
 
@@ -184,6 +194,18 @@ def companion_rows(afa, n_local, device, sync, barrier, split=False):
                                           "Gaussian draws, not on HBM"}
     e.destroy_event(ev0)
     e.destroy_event(ev1)
+    e.close()
+    # the headline's workload with the reference's own noise machinery: per-vehicle std::minstd_rand0 + std::normal_distribution
+    # streams (AFE_SEED_DECORRELATED), bit-exact engine words and polar-method decisions
+    e = build_shard(afa, n_local, 0, n_local, device, exact_stream=True)
+    time_steps(e, 100, 1, sync, barrier)
+    k = 2000
+    t = median([time_steps(e, k, 1, sync, barrier) for _ in range(3)])
+    bytes_step, _ = mean_bytes_per_step(e, afa, k)
+    rows["libstdcxx_noise_streams"] = {"value": n_local * k / t, "unit": "vehicle-steps/s", "us_per_step": t / k * 1e6,
+                                       "algorithmic_bytes_per_vehicle_step": bytes_step, "frac": n_local * bytes_step / (t / k) / 1e9 / HBM_PEAK_GBS,
+                                       "stepping": "persistent" if uses_persistent(afa, None, n_local) else "launches",
+                                       "note": "IMU noise from per-vehicle libstdc++-exact streams (seed 1 + global index) instead of the counter-based generator"}
     e.close()
     e = build_shard(afa, n_local, 0, n_local, device, precision=afa.AFE_F64)      # stepping: automatic, like the headline
     time_steps(e, 50, 1, sync, barrier)
@@ -320,35 +342,70 @@ def cpu_baseline(afa, budget_vehicle_steps=100_000_000):
     from oracle import oracle_py
     n, steps = 16384, max(10, budget_vehicle_steps // 16384)
     p = afa.params_from_type(5)
-    data = afa.scenarios.gust_ensemble(n, p, seed=4, n_global=1 << 20)
+    data = afa.scenarios.hover_ensemble(n, p)
     b = oracle_py.Batch(n, [oracle_py.params_from_type(5)])
     b.pos[:], b.vel[:], b.att[:], b.ang_vel[:] = data.pos, data.vel, data.att, data.ang_vel
     b.motor_speed[:], b.motor_cmd[:] = data.motor_speed, data.motor_cmd
-    b.ext_force[:] = data.ext_force
-    b.rng[:] = 1 + np.arange(n)
-    ticks, _ = afa.plan_ticks(LOGIC_PERIOD, 0, DT_US, steps)
-    b.step(DT_US * 1e-6, 10, ticks=ticks[:10])  # warm
-    t0 = time.perf_counter()
-    b.step(DT_US * 1e-6, steps, ticks=ticks)
-    dt = time.perf_counter() - t0
+
+    def run(k, t0_us, tick_base):
+        ticks, _ = afa.plan_ticks(LOGIC_PERIOD, 0, DT_US, k)
+        t0 = time.perf_counter()
+        oracle_py.step_counter(b, DT_US, k, ticks, counter_noise=True, seed=NOISE_SEED, first_global=0, tick_base=tick_base,
+                               gust_period_us=GUST_PERIOD_US, t0_us=t0_us, n_global=1 << 20, sigma_max=GUST_SIGMA_MAX)
+        return time.perf_counter() - t0, int(ticks.sum())
+
+    run(10, 0, 0)  # warm
+    dt, nt = run(steps, 10 * DT_US, 5)
     out = {"value": n * steps / dt, "unit": "vehicle-steps/s", "cores": 1, "kind": "port",
-           "sample": "%d vehicles x %d steps of the same workload (gust force, IMU+noise every 2nd step), "
-                     "oracle/agrifly_oracle.c double precision, gcc -O2, 1 thread, %.1f s" % (n, steps, dt),
+           "sample": "%d vehicles x %d steps of the same workload (gust process, IMU + counter-based noise every 2nd step), "
+                     "oracle/agrifly_oracle.c + agrifly_oracle_counter.c double precision, gcc -O2, 1 thread, %.1f s" % (n, steps, dt),
            "host_cpus": os.cpu_count()}
     # the same port spread over every host core (OpenMP over vehicles), SURVEY 8d CPU-baseline (ii)
     threads = os.cpu_count() or 1
     if threads > 1:
         oracle_py.lib().ora_set_batch_threads(threads)
-        b.step(DT_US * 1e-6, 10, ticks=ticks[:10])
+        run(10, 0, 0)
         steps_mt = steps * min(threads, 32) // 4
-        ticks_mt, _ = afa.plan_ticks(LOGIC_PERIOD, 0, DT_US, steps_mt)
-        t0 = time.perf_counter()
-        b.step(DT_US * 1e-6, steps_mt, ticks=ticks_mt)
-        dt_mt = time.perf_counter() - t0
+        dt_mt, _ = run(steps_mt, 0, 0)
         oracle_py.lib().ora_set_batch_threads(1)
         out["all_cores"] = {"value": n * steps_mt / dt_mt, "unit": "vehicle-steps/s", "cores": threads,
                             "sample": "%d vehicles x %d steps, %d OpenMP threads, %.1f s" % (n, steps_mt, threads, dt_mt)}
     return out
+
+
+def disturbance_sweep(afa, device, n=1 << 20, seconds=10.0):
+    """BASELINE config 4 as the Monte-Carlo sweep it names: n vehicles hover in closed loop (on-device rates logic, thrust
+    command g, rate command 0) for `seconds` under the gust process, sigma swept 0 .. 0.5 N over the vehicle index; the
+    result is the RMS horizontal deviation from the start position per sigma bin, next to the closed form for a level
+    vehicle under piecewise-constant white acceleration (Var x(T) = (sigma/m)^2 tau^4 sum_j (j + 1/2)^2)."""
+    p = afa.params_from_type(5)
+    e = build_shard(afa, n, 0, n, device)
+    e.set_rates_logic([afa.rates_logic_params_from_type(5)])
+    e.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
+    p0 = e.get_state()["pos"]
+    steps = int(round(seconds * 1e6 / DT_US))
+    t0 = time.perf_counter()
+    e.step(DT_US, steps)
+    e.sync()
+    wall = time.perf_counter() - t0
+    st = e.get_state()
+    e.close()
+    dev2 = (st["pos"][0] - p0[0]) ** 2 + (st["pos"][1] - p0[1]) ** 2
+    sigma = GUST_SIGMA_MAX * np.arange(n) / (n - 1)
+    K, tau = steps * DT_US // GUST_PERIOD_US, GUST_PERIOD_US * 1e-6
+    unit = tau ** 4 * sum((j + 0.5) ** 2 for j in range(K))          # per axis, per (m/s^2)^2
+    bins = []
+    edges = np.linspace(0, n, 9).astype(int)
+    for a, b in zip(edges[:-1], edges[1:]):
+        closed = np.sqrt(2 * unit * np.mean((sigma[a:b] / p.mass) ** 2))
+        bins.append({"sigma_N": [float(sigma[a]), float(sigma[b - 1])], "rms_xy_m": float(np.sqrt(dev2[a:b].mean())),
+                     "gust_only_closed_form_m": float(closed), "on_the_ground_fraction": float((st["pos"][2, a:b] <= 0).mean())})
+    return {"vehicles": n, "simulated_seconds": seconds, "steps": steps, "wall_s": wall, "vsteps_per_s": n * steps / wall,
+            "gust": {"sigma_max_N": GUST_SIGMA_MAX, "epoch_ms": GUST_PERIOD_US / 1e3, "seed": GUST_SEED},
+            "bins": bins,
+            "note": "closed-loop hover: IMU synthesis + onboard rates logic on the device every 2 ms; no position or attitude loop (those are "
+                    "offboard / host-side in the reference), so a vehicle drifts with the integrated gust acceleration -- the closed form -- plus what "
+                    "the gyro noise does to its attitude through the rates loop (the sigma = 0 end of the sweep)"}
 
 
 class stdout_to_stderr:
@@ -649,8 +706,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "config 4 shape: hovering CF_MINIQUAD ensemble, per-vehicle wind-gust external force, "
-                            "IMU synthesis + on-device minstd_rand0/normal noise at the 500 Hz logic gate, "
+                "workload": "config 4: hovering CF_MINIQUAD ensemble, per-vehicle wind gusts from the on-device gust process (sigma swept 0..0.5 N over "
+                            "the global index, piecewise constant, resampled every 100 ms; afe_set_gust_process), IMU synthesis with Gaussian noise from the "
+                            "counter-based generator (AFE_SEED_COUNTER: Philox4x32-10 + Box-Muller per vehicle and tick) at the 500 Hz logic gate, "
                             "one afe_step call per 1 ms step, state through HBM every step (no temporal fusion); " +
                             ("stepping by one resident grid (afe_set_step_mode: every wave advances its vehicles through each authorised step, "
                              "no kernel boundary between steps)" if persistent else
@@ -674,7 +732,7 @@ def main():
                 "frac_of_measured": None if probe is None else achieved / probe["GBs_164B"],
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": ("afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=1, LOGIC=0>: one launch serves every step between two "
+                "kernel": ("afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=2 (counter), LOGIC=0>: one launch serves every step between two "
                            "synchronisations; its rocprofv3 duration / the steps it served = kernel_us" if persistent else
                            "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, LOGIC=0, SINGLE=1>, 64-lane workgroups -- the timed region "
                            "alternates NOISE=0 (no logic tick) and NOISE=1 (tick: IMU + six Gaussian draws) launches"),
@@ -758,6 +816,7 @@ def main():
                 closed.append({"vehicles": n, "vsteps_per_s": n * k / t1, "vsteps_per_s_fused10": n * k / t10})
                 es.close()
             out["closed_loop_on_device"] = closed
+            out["disturbance_sweep"] = disturbance_sweep(afa, local_rank)
             out["companions"] = companion_rows(afa, n_local, local_rank, sync, barrier, split)
             out["perception_rows"] = perception_rows(afa)
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:

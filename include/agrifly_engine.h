@@ -56,7 +56,13 @@ typedef enum afe_seed_policy {
    * reference ensemble does (Quadcopter_T.cpp:27) */
   AFE_SEED_REFERENCE = 0,
   /* seed = 1 + global vehicle index: independent Monte-Carlo streams */
-  AFE_SEED_DECORRELATED = 1
+  AFE_SEED_DECORRELATED = 1,
+  /* Monte-Carlo ensembles that need no libstdc++ stream: the six normals of (vehicle, logic tick) come from a
+   * counter-based generator -- Philox4x32-10 keyed by afe_set_noise_seed, addressed by the GLOBAL vehicle index and
+   * the tick number, Box-Muller on top (definition: oracle/agrifly_oracle_counter.h).  No per-vehicle engine word
+   * is loaded or stored, nothing diverges (no rejection loop); the samples do not depend on how the ensemble is
+   * sharded, stepped or fused.  The reference produces no such stream (it seeds every vehicle with 1). */
+  AFE_SEED_COUNTER = 2
 } afe_seed_policy;
 
 /* The per-vehicle constant record: the arguments of
@@ -446,6 +452,21 @@ int afe_step_kernel_info(const afe_engine *e, int *record_path, int *addressing)
  *     (afe_set_stream) -- a host that queues its own work there and expects it to see the stepped state must
  *     then call afe_sync or afe_event_record in between. */
 int afe_set_split_stepping(afe_engine *e, int parts);
+
+/* Key of the counter-based noise generator (AFE_SEED_COUNTER); default 0. */
+int afe_set_noise_seed(afe_engine *e, uint64_t seed);
+
+/* BASELINE config 4's disturbance process on the device: a per-vehicle wind-gust force through the SetExternalForce
+ * port (Components/Components/Simulation/Quadcopter_T.hpp:45, applied at Quadcopter_T.cpp:132; the reference has the
+ * port and no model behind it).  While enabled the engine owns the external-force slab: during epoch
+ * k = floor(step start time / period_us) vehicle i feels F = sigma_i (z0, z1, z2) with sigma_i = sigma_max * g / (n_global - 1),
+ * g = first_global_index + i, and z = N(0,1) from the counter-based generator at (seed, g, epoch k) -- piecewise
+ * constant, resampled on the device when a step starts in a new epoch ("N(0, sigma^2), sigma swept
+ * 0...0.5 N, piecewise-constant 100 ms").  No host upload, no per-step cost; the force of (vehicle, epoch) does not
+ * depend on sharding or on how the steps are issued.  n_global <= 0: this ensemble alone.  enabled = 0 leaves the
+ * slab as it is (afe_set_external_force takes over).  afe_get_external_force reads the slab back. */
+int afe_set_gust_process(afe_engine *e, int enabled, uint64_t seed, double sigma_max, uint64_t period_us, int64_t n_global);
+int afe_get_external_force(afe_engine *e, int64_t first, int64_t count, double *force3);
 
 /* Persistent stepping: afe_step without a kernel launch per step.  The step loop of the reference
  * (`for each vehicle: Run(); clock += dt`, Simulator/Rappids_Simulator/main.cpp:330,391-392;

@@ -518,6 +518,7 @@ void ora_clock_advance(ora_clock *c, uint64_t dt_us) { c->now_us += dt_us; }
 static int g_batch_threads = 1;
 /* threads ora_step_batch spreads the vehicles over (OpenMP); 1 = the scalar port */
 void ora_set_batch_threads(int n) { g_batch_threads = n > 0 ? n : 1; }
+int ora_get_batch_threads(void) { return g_batch_threads; }
 
 void ora_step_batch(int64_t n, int n_steps, const ora_params *table,
                     const uint8_t *types, double *pos, double *vel,

@@ -137,6 +137,7 @@ void ora_clock_advance(ora_clock *c, uint64_t dt_us);
  * planar: pos[3*n] = x[0..n) y[0..n) z[0..n) etc.  types[i] indexes table. */
 /* threads ora_step_batch spreads the vehicles over (OpenMP); default 1 */
 void ora_set_batch_threads(int n);
+int ora_get_batch_threads(void);
 void ora_step_batch(int64_t n, int n_steps, const ora_params *table,
                     const uint8_t *types, double *pos, double *vel,
                     double *att, double *ang_vel, double *motor_speed,

@@ -119,6 +119,20 @@ def lib():
         L.ora_step_batch.restype = None
         L.ora_set_batch_threads.argtypes = [C.c_int]
         L.ora_set_batch_threads.restype = None
+        u32p, u64 = C.POINTER(C.c_uint32), C.c_uint64
+        L.ora_philox4x32_10.argtypes = [u32p, u32p, u32p]
+        L.ora_philox4x32_10.restype = None
+        L.ora_counter_block.argtypes = [u64, u64, C.c_uint, C.c_uint, u64, u32p]
+        L.ora_counter_block.restype = None
+        L.ora_counter_normals4.argtypes = [u32p, dp]
+        L.ora_counter_normals4.restype = None
+        L.ora_imu_normals.argtypes = [u64, u64, u64, dp]
+        L.ora_imu_normals.restype = None
+        L.ora_gust_force.argtypes = [u64, u64, u64, u64, C.c_double, dp]
+        L.ora_gust_force.restype = None
+        L.ora_step_batch_counter.argtypes = [C.c_int64, C.c_int, C.POINTER(OraParams)] + [C.c_void_p] * 10 + [u64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, u64, u64, u64, u64, u64, u64, C.c_double]
+        L.ora_step_batch_counter.restype = None
         _lib = L
     return _lib
 
@@ -206,6 +220,42 @@ class Batch:
                              self.ext_force.ctypes.data, self.ext_torque.ctypes.data,
                              float(dt), ticks.ctypes.data, self.gyro.ctypes.data,
                              self.acc.ctypes.data)
+
+
+def philox4x32_10(ctr, key):
+    c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+    lib().ora_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+def imu_normals(seed, index, tick):
+    """the six N(0,1) of the counter policy: gyro x y z, accelerometer x y z (agrifly_oracle_counter.h)"""
+    z = np.zeros(6)
+    lib().ora_imu_normals(int(seed), int(index), int(tick), _dp(z))
+    return z
+
+
+def gust_force(seed, index, n_global, epoch, sigma_max):
+    f = np.zeros(3)
+    lib().ora_gust_force(int(seed), int(index), int(n_global), int(epoch), float(sigma_max), _dp(f))
+    return f
+
+
+def gust_forces(seed, first, count, n_global, epoch, sigma_max):
+    """planar [3, count] forces of vehicles first .. first + count - 1 during `epoch`"""
+    return np.stack([gust_force(seed, first + i, n_global, epoch, sigma_max) for i in range(count)], axis=1)
+
+
+def step_counter(b, dt_us, n_steps, ticks, counter_noise=True, seed=0, first_global=0, tick_base=0, gust_period_us=0, t0_us=0,
+                 n_global=None, sigma_max=0.0):
+    """Batch.step with the counter policy / the gust process (ora_step_batch_counter); b.ext_force receives the last gust"""
+    ticks = np.ascontiguousarray(ticks, dtype=np.uint8)
+    assert ticks.shape == (n_steps,)
+    lib().ora_step_batch_counter(b.n, n_steps, b.table, b.types.ctypes.data, b.pos.ctypes.data, b.vel.ctypes.data, b.att.ctypes.data,
+                                 b.ang_vel.ctypes.data, b.motor_speed.ctypes.data, b.rng.ctypes.data, b.motor_cmd.ctypes.data,
+                                 b.ext_force.ctypes.data, b.ext_torque.ctypes.data, int(dt_us), ticks.ctypes.data, b.gyro.ctypes.data,
+                                 b.acc.ctypes.data, int(bool(counter_noise)), int(seed), int(first_global), int(tick_base),
+                                 int(gust_period_us), int(t0_us), int(b.n if n_global is None else n_global), float(sigma_max))
 
 
 def clock_ticks(loop_dt, period, n_runs):

@@ -1,0 +1,216 @@
+"""Counter-based noise on the device: the AFE_SEED_COUNTER policy and the gust process of BASELINE config 4
+(afe_set_gust_process), against the checker's definition (oracle/agrifly_oracle_counter.h: Philox4x32-10 pinned to the
+Random123 known answers in tests/test_counter_oracle.py; Box-Muller in double with libm) and against themselves:
+a sample is a function of (seed, global vehicle index, tick or epoch) and of nothing else, so every way of stepping
+and every sharding must give the same BITS.
+
+Port the gusts enter through: Components/Components/Simulation/Quadcopter_T.hpp:45 (SetExternalForce), applied at
+Quadcopter_T.cpp:132.  The reference has no gust model and seeds every vehicle's noise with 1 (Quadcopter_T.cpp:27)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as ora
+from tests.scenarios import FLOORS, random_ensemble, rel_err_vec
+
+afa = importlib.import_module("agri-fly_amd")
+pytestmark = pytest.mark.gpu
+
+TOL_F32_NORMAL = 1e-6        # |z_device - z_checker| for the fp32 engine's Box-Muller (hardware reciprocal / square root / sin / cos): measured worst 6.0e-7 over 5.9e5 samples, mean 5e-8
+TOL_F64_NORMAL = 1e-13
+
+
+def hover(n, precision, first_global=0, mode=None):
+    p = afa.params_from_type(5)
+    e = afa.Ensemble(n, precision=precision, first_global_index=first_global)
+    e.set_type_table([p])
+    e.set_logic_period(1 / 500)
+    data = afa.scenarios.hover_ensemble(n, p)
+    e.set_state(data.pos, data.vel, data.att, data.ang_vel, data.motor_speed)
+    e.set_motor_cmds(data.motor_cmd)
+    e.set_split_stepping(1)
+    e.set_step_mode(afa.AFE_STEP_LAUNCH if mode is None else mode)
+    return e
+
+
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+def test_counter_normals_are_the_checkers(precision):
+    """a hovering vehicle at rest has a zero rate-gyro signal: with sigma_gyro = 1 the gyro sample IS the normal.
+    Compared per tick and vehicle with ora_imu_normals(seed, global index, tick number)."""
+    n, first, seed = 4096, 1_000_000_007, 0xfeedface12345678
+    e = hover(n, precision, first_global=first)
+    e.set_imu_noise(True, 1.0, 0.0, afa.AFE_SEED_COUNTER)
+    e.set_noise_seed(seed)
+    worst = 0.0
+    for tick in range(4):
+        e.step(1000, e.steps_until_tick(1000))
+        gyro, _ = e.get_imu()
+        want = np.array([ora.imu_normals(seed, first + i, tick)[:3] for i in range(n)]).T
+        worst = max(worst, np.abs(gyro - want.astype(np.float32)).max())
+    tol = TOL_F32_NORMAL if precision == afa.AFE_F32 else 2e-7     # the sample is a float either way
+    assert worst <= tol, worst
+    # the accelerometer draws are the other three: proper acceleration of a hovering vehicle is (0, 0, 9.81)
+    e.set_imu_noise(True, 0.0, 1.0, afa.AFE_SEED_COUNTER)
+    e.step(1000, e.steps_until_tick(1000))
+    _, acc = e.get_imu()
+    want = np.array([ora.imu_normals(seed, first + i, 4)[3:] for i in range(n)]).T
+    assert np.abs(acc - np.array([[0.0], [0.0], [9.81]]) - want).max() <= 2e-5    # 9.81 + z rounded to float, thrust = weight to 1e-6
+    e.close()
+
+
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+def test_counter_policy_rollout_against_the_checker(precision):
+    """random ensemble, 12 steps with 6 ticks: the engine with AFE_SEED_COUNTER against ora_step_batch_counter"""
+    n, first, seed = 3000, 77, 5
+    ens = random_ensemble(n, seed=3, type_ids=(5,))
+    d = ens.data
+    e = afa.Ensemble(n, precision=precision, first_global_index=first)
+    e.set_type_table([afa.params_from_type(5)])
+    e.set_logic_period(1 / 500)
+    e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_COUNTER)
+    e.set_noise_seed(seed)
+    e.set_state(d.pos, d.vel, d.att, d.ang_vel, d.motor_speed)
+    e.set_motor_cmds(d.motor_cmd)
+    e.set_external_force(d.ext_force)
+    b = ens.to_oracle_batch()
+    b.ext_torque[:] = 0
+    ticks, _ = afa.plan_ticks(1 / 500, 0, 1000, 12)
+    e.step(1000, 12)
+    ora.step_counter(b, 1000, 12, ticks, counter_noise=True, seed=seed, first_global=first)
+    st = e.get_state()
+    gyro, acc = e.get_imu()
+    got = dict(st, gyro=gyro, acc=acc)
+    tol = 1e-5 if precision == afa.AFE_F32 else 1e-6
+    for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, gyro=b.gyro, acc=b.acc).items():
+        assert rel_err_vec(got[k], ref, FLOORS[k]) <= (tol if k in ("gyro", "acc") or precision == afa.AFE_F32 else 1e-11), k
+    assert e.logic_ticks == int(ticks.sum())
+    e.close()
+
+
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+def test_gust_force_is_the_checkers_and_changes_at_epoch_boundaries(precision):
+    n, first, n_global, seed = 5000, 12345, 40000, 99
+    e = hover(n, precision, first_global=first)
+    e.set_gust_process(True, seed=seed, sigma_max=0.5, period_us=100000, n_global=n_global)
+    seen = {}
+    for steps_so_far, epoch in ((1, 0), (100, 0), (101, 1), (350, 3)):
+        e.step(1000, steps_so_far - e.time_us // 1000)
+        f = e.get_external_force()
+        want = ora.gust_forces(seed, first, n, n_global, epoch, 0.5)
+        sigma = 0.5 * (first + np.arange(n)) / (n_global - 1)
+        tol = (TOL_F32_NORMAL + 2e-7 * 6) if precision == afa.AFE_F32 else TOL_F64_NORMAL
+        assert (np.abs(f - want) <= tol * sigma + 1e-300).all(), (steps_so_far, np.abs(f - want).max())
+        seen[epoch] = f
+    assert np.array_equal(seen[0], e.get_external_force()) is False
+    # sigma sweeps the GLOBAL index: the sample standard deviation of F / sigma is 1 everywhere
+    z = seen[3] / (0.5 * (first + np.arange(n)) / (n_global - 1))
+    assert abs(z.std() - 1) < 0.02 and abs(z.mean()) < 0.03
+    e.close()
+
+
+def roll(e, plan):
+    for dt, k in plan:
+        e.step(dt, k)
+    st = e.get_state()
+    gyro, acc = e.get_imu()
+    return dict(st, gyro=gyro, acc=acc, force=e.get_external_force(), t=np.array([e.time_us, e.logic_ticks]))
+
+
+@pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
+@pytest.mark.parametrize("logic", [False, True])
+def test_samples_do_not_depend_on_how_the_ensemble_is_stepped_or_sharded(precision, logic):
+    """one ensemble of 9 001 vehicles, gusts (30 ms epochs) and counter noise on, flown 260 steps -- by single launches,
+    by fused launches, by the resident grid (with a getter in the middle, and with a quiet host), and as three shards:
+    bitwise the same state, IMU samples and forces."""
+    n, seed = 9001, 4
+    ens = random_ensemble(n, seed=8, type_ids=(5,), with_wrench=False)
+    d = ens.data
+
+    def make(first, count, mode):
+        e = afa.Ensemble(count, precision=precision, first_global_index=first)
+        e.set_type_table([afa.params_from_type(5)])
+        e.set_logic_period(1 / 500)
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_COUNTER)
+        e.set_noise_seed(seed)
+        sl = slice(first, first + count)
+        e.set_state(d.pos[:, sl], d.vel[:, sl], d.att[:, sl], d.ang_vel[:, sl], d.motor_speed[:, sl])
+        e.set_motor_cmds(d.motor_cmd[:, sl])
+        e.set_gust_process(True, seed=seed + 1, sigma_max=0.3, period_us=30000, n_global=n)
+        if logic:
+            e.set_rates_logic([afa.rates_logic_params_from_type(5)])
+            e.set_rates_commands(np.full(count, 9.81, np.float32), np.zeros((3, count), np.float32))
+        e.set_split_stepping(1)
+        e.set_step_mode(mode)
+        return e
+
+    plan_single = [(1000, 1)] * 260
+    plan_fused = [(1000, 7), (1000, 64), (1000, 29), (1000, 160)]
+    ref = roll(make(0, n, afa.AFE_STEP_LAUNCH), plan_single)
+    for name, mode, plan in (("fused launches", afa.AFE_STEP_LAUNCH, plan_fused), ("resident grid, one call", afa.AFE_STEP_PERSISTENT, [(1000, 260)]),
+                             ("resident grid, step by step", afa.AFE_STEP_PERSISTENT, plan_single)):
+        got = roll(make(0, n, mode), plan)
+        for k in ref:
+            assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
+    # a getter in the middle (parks the grid between two epochs and between two ticks) and a host that goes quiet
+    e = make(0, n, afa.AFE_STEP_PERSISTENT)
+    e.step(1000, 45)
+    e.get_imu()
+    e.step(1000, 16)
+    import time
+    time.sleep(0.005)
+    got = roll(e, [(1000, 199)])
+    for k in ref:
+        assert np.array_equal(ref[k], got[k], equal_nan=True), ("parked mid-way", k)
+    # three shards
+    cuts = [0, 3000, 3001, n]
+    parts = [roll(make(cuts[i], cuts[i + 1] - cuts[i], afa.AFE_STEP_PERSISTENT if i != 1 else afa.AFE_STEP_LAUNCH), plan_fused) for i in range(3)]
+    for k in ref:
+        if k == "t":
+            continue
+        assert np.array_equal(ref[k], np.concatenate([p[k] for p in parts], axis=-1), equal_nan=True), ("sharded", k)
+
+
+def test_checkpoint_carries_the_gust_process_and_the_counter_policy():
+    n = 6000
+    def make():
+        e = hover(n, afa.AFE_F32, first_global=10, mode=afa.AFE_STEP_PERSISTENT)
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_COUNTER)
+        e.set_noise_seed(31)
+        e.set_gust_process(True, seed=32, sigma_max=0.4, period_us=20000, n_global=n + 10)
+        return e
+    a = make()
+    a.step(1000, 33)
+    blob = a.save_checkpoint()
+    a.step(1000, 50)
+    b = hover(n, afa.AFE_F32, first_global=10, mode=afa.AFE_STEP_LAUNCH)      # configured by the checkpoint alone
+    b.load_checkpoint(blob)
+    b.step(1000, 50)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(a.get_external_force(), b.get_external_force())
+    assert all(np.array_equal(x, y) for x, y in zip(a.get_imu(), b.get_imu()))
+    a.close(); b.close()
+
+
+def test_gust_random_walk_matches_its_closed_form():
+    """physics, not the checker: a vehicle held level by hover thrust and pushed by piecewise-constant white
+    acceleration a ~ N(0, (sigma / m)^2) per epoch tau drifts horizontally with Var x(T) = (sigma / m)^2 tau^2 K^3 / 3
+    (+ lower orders), K = T / tau epochs.  16 384 vehicles at one sigma, 2 s, closed form within 5 %."""
+    n, sigma, tau_us, steps = 16384, 0.2, 100000, 2000
+    p = afa.params_from_type(5)
+    e = hover(n, afa.AFE_F32, first_global=n, mode=afa.AFE_STEP_PERSISTENT)     # global indices n .. 2n - 1 of 2n - 1 + ...: sigma ~ constant
+    e.set_gust_process(True, seed=3, sigma_max=sigma, period_us=tau_us, n_global=2 * n)
+    e.set_imu_noise(False, 0.1, 0.2, afa.AFE_SEED_COUNTER)
+    e.step(1000, steps)
+    st = e.get_state()
+    s_i = sigma * (n + np.arange(n)) / (2 * n - 1)
+    a_i = s_i / p.mass
+    K, tau = steps * 1000 // tau_us, tau_us * 1e-6
+    # x(T) = sum_k a_k tau^2 ((K - k - 1) + 1/2): variance = a^2 tau^4 sum_j (j + 1/2)^2
+    var_unit = tau ** 4 * sum((j + 0.5) ** 2 for j in range(K))
+    for axis in (0, 1):
+        ratio = np.mean((st["pos"][axis] / a_i) ** 2) / var_unit
+        assert abs(ratio - 1) < 0.05, (axis, ratio)
+    e.close()

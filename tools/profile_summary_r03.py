@@ -22,7 +22,7 @@ note = sys.argv[2] if len(sys.argv) > 2 else ""
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
 out = os.path.join(ROOT, "gpurun_out")
 prof = os.path.join(ROOT, "profiles")
-BYTES_MEAN = 148.0      # algorithmic B per vehicle-step of the bench workload: 132 off tick, 164 on tick, every 2nd step ticks
+BYTES_MEAN = float(sys.argv[4]) if len(sys.argv) > 4 else 144.0      # algorithmic B per vehicle-step of the bench workload: 132 off tick, 156 on tick (counter noise: no engine word), every 2nd step ticks
 
 
 def one(pattern):
