@@ -991,6 +991,7 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
   u64_t s = a.start;
   u64_t t_wait = ticks100();
   u64_t tick_no = v.tick_base;                       // logic ticks so far (the counter policy's sample address)
+  int idle_polls = 0;
   // gust process (afe_set_gust_process): the force of epoch floor(t / period) lives in the ext_force slab; this wave
   // rewrites ITS vehicles' entries when a step starts in an epoch other than the one the slab holds
   u64_t gust_in_slab = a.gust_epoch_applied, gust_epoch = a.gust_epoch0;
@@ -1005,9 +1006,16 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
         if (lane == 0) st_system(a.host_status + 2, 2);
         return;
       }
+      // back off: a wave that has run into the ring's window (or waits for the host) must not hammer the memory system
+      // the working waves live on -- thousands of waves polling every 60 ns cost the others 10 % of their bandwidth.
+      // 0.06, 0.12, ... up to ~2 us between polls (a step of a large ensemble takes tens of microseconds; a small one is
+      // never more than a few polls behind)
+      if (idle_polls < 5) idle_polls++;
       __builtin_amdgcn_s_sleep(2);
+      for (int b = 1; b < (1 << idle_polls); b++) __builtin_amdgcn_s_sleep(2);
       continue;
     }
+    idle_polls = 0;
     const u64_t low = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
     const u64_t ticks = __ballot(ready && (e & AFE_PERSIST_TICK)) & low;
     const u64_t parks = __ballot(ready && (e & AFE_PERSIST_PARK)) & low;
