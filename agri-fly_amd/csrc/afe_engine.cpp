@@ -51,6 +51,10 @@ struct afe_engine {
   bool types_wave_uniform = true;   // the type index is constant over every aligned run of 64 vehicles
   float *pack_scratch = nullptr;  // 3*n floats, lazily allocated
   afe_world *world = nullptr;     // shared-world query scratch (uniform grid), lazily created
+  // afe_nearest_neighbour_async: the query runs on its own stream behind a snapshot of the gathered positions
+  hipStream_t query_stream = nullptr;
+  hipEvent_t ev_q_start = nullptr, ev_q_done = nullptr;
+  bool query_pending = false;
   // on-device rates logic (allocated by afe_set_rates_logic)
   bool logic_on = false;
   void *logic_arena = nullptr;
@@ -640,6 +644,10 @@ extern "C" int afe_destroy(afe_engine *e) {
   if (e->ev_main) (void)hipEventDestroy(e->ev_main);
   if (e->ev_side) (void)hipEventDestroy(e->ev_side);
   if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
+  if (e->query_stream) (void)hipStreamSynchronize(e->query_stream);
+  if (e->ev_q_start) (void)hipEventDestroy(e->ev_q_start);
+  if (e->ev_q_done) (void)hipEventDestroy(e->ev_q_done);
+  if (e->query_stream) (void)hipStreamDestroy(e->query_stream);
   if (e->world) world_destroy(e->world);
   if (e->pack_scratch) (void)hipFree(e->pack_scratch);
   if (e->logic_arena) (void)hipFree(e->logic_arena);
@@ -1129,8 +1137,17 @@ void engine_shard(const afe_engine *e, int64_t *first_global, int64_t *n) {
   *first_global = e->first_global;
   *n = e->n;
 }
+// An asynchronous neighbour query may still be reading the gathered buffer and the world scratch: whatever is about to
+// rewrite them on the main stream is ordered behind it (a device-side wait; in steady state the query issued a cycle
+// ago is long done and this costs nothing).
+void engine_query_join(afe_engine *e) {
+  if (!e->query_pending) return;
+  (void)hipStreamWaitEvent(main_stream(e), e->ev_q_done, 0);
+  e->query_pending = false;
+}
 // this shard's positions as planar fp32 [3][n] in the engine's own scratch, on its stream
 int engine_pack_to_scratch(afe_engine *e, float **scratch) {
+  engine_query_join(e);
   AFE_HIP(e, hipSetDevice(e->device));
   if (!e->pack_scratch) AFE_HIP(e, hipMalloc((void **)&e->pack_scratch, (size_t)e->n * 3 * sizeof(float)));
   const int rc = afe_pack_positions(e, e->pack_scratch);
@@ -1419,6 +1436,7 @@ extern "C" int afe_selftest_normals_f32(afe_engine *e, const uint32_t *seeds, in
 extern "C" int afe_pack_positions(afe_engine *e, float *device_xyz) {
   if (!e || !device_xyz) return fail(e, AFE_ERR_INVALID_ARG, "device_xyz is NULL");
   AFE_HIP(e, hipSetDevice(e->device));
+  engine_query_join(e);
   int rc = (e->precision == AFE_F64)
                ? launch_pack_positions_f64((const double *)e->pos, e->stride, e->n, device_xyz, main_stream(e))
                : launch_pack_positions_f32((const float *)e->pos, e->stride, e->n, device_xyz, main_stream(e));
@@ -1439,8 +1457,40 @@ extern "C" int afe_nearest_neighbour_grid(afe_engine *e, const float *all_xyz, i
     return fail(e, AFE_ERR_OUT_OF_RANGE, "the gathered ensemble is smaller than this shard's global range");
   AFE_HIP(e, hipSetDevice(e->device));
   if (!e->world) { const int rc = world_create(e->device, &e->world); if (rc) return fail(e, rc, "shared-world scratch"); }
+  engine_query_join(e);
   const int rc = world_nearest(e->world, (void *)main_stream(e), all_xyz, n_all, e->first_global, e->n, cell_size, dist2_out, index_out);
   if (rc) return fail(e, rc, world_last_error(e->world));
+  return AFE_OK;
+}
+
+// The same query on a stream of its own: ordered behind everything the engine's stream holds now (the gather that filled
+// all_xyz), it runs while the engine goes on stepping -- afe_step is not ordered behind it; what rewrites the buffer or
+// the query's scratch is (engine_query_join).  Results are complete after afe_query_sync.
+extern "C" int afe_nearest_neighbour_async(afe_engine *e, const float *all_xyz, int64_t n_all, float *dist2_out, int32_t *index_out) {
+  if (!e || !all_xyz || n_all <= 0 || !dist2_out || !index_out) return fail(e, AFE_ERR_INVALID_ARG, "bad nearest-neighbour arguments");
+  if (e->first_global + e->n > n_all) return fail(e, AFE_ERR_OUT_OF_RANGE, "the gathered ensemble is smaller than this shard's global range");
+  AFE_HIP(e, hipSetDevice(e->device));
+  if (!e->world) { const int rc = world_create(e->device, &e->world); if (rc) return fail(e, rc, "shared-world scratch"); }
+  if (!e->query_stream) {
+    AFE_HIP(e, hipStreamCreateWithFlags(&e->query_stream, hipStreamNonBlocking));
+    AFE_HIP(e, hipEventCreateWithFlags(&e->ev_q_start, hipEventDisableTiming));
+    AFE_HIP(e, hipEventCreateWithFlags(&e->ev_q_done, hipEventDisableTiming));
+  }
+  e->query_pending = false;      // a query already on the query stream is ordered before this one by the stream itself
+  AFE_HIP(e, hipEventRecord(e->ev_q_start, main_stream(e)));
+  AFE_HIP(e, hipStreamWaitEvent(e->query_stream, e->ev_q_start, 0));
+  const int rc = world_nearest(e->world, (void *)e->query_stream, all_xyz, n_all, e->first_global, e->n, 0.0f, dist2_out, index_out);
+  if (rc) return fail(e, rc, world_last_error(e->world));
+  AFE_HIP(e, hipEventRecord(e->ev_q_done, e->query_stream));
+  e->query_pending = true;
+  return AFE_OK;
+}
+
+extern "C" int afe_query_sync(afe_engine *e) {
+  if (!e) return AFE_ERR_INVALID_ARG;
+  if (!e->query_stream) return AFE_OK;
+  AFE_HIP(e, hipSetDevice(e->device));
+  AFE_HIP(e, hipStreamSynchronize(e->query_stream));
   return AFE_OK;
 }
 
@@ -1462,6 +1512,7 @@ extern "C" int afe_nearest_neighbour_bruteforce(afe_engine *e, const float *all_
     return fail(e, AFE_ERR_INVALID_ARG, "bad nearest-neighbour arguments");
   AFE_HIP(e, hipSetDevice(e->device));
   if (!e->world) { const int rc = world_create(e->device, &e->world); if (rc) return fail(e, rc, "shared-world scratch"); }
+  engine_query_join(e);
   const int rc = world_nearest_bruteforce(e->world, (void *)main_stream(e), all_xyz, n_all, e->first_global, dev_queries, n_queries,
                                           dist2_out, index_out);
   if (rc) return fail(e, rc, world_last_error(e->world));

@@ -308,8 +308,8 @@ __device__ __forceinline__ void six_normals(uint32_t &s, float d[6]) {
 // ---------------------------------------------------------------------------
 // Counter-based noise: AFE_SEED_COUNTER and the gust process (afe_set_gust_process).  Philox4x32-10 (Salmon et al.,
 // SC'11; Random123) addressed by (seed; vehicle index, stream, block, ordinal) -- no state to load or store, no
-// rejection loop (nothing diverges), any vehicle's sample at any tick computable by anybody: the definition is in
-// oracle/agrifly_oracle_counter.h (the checker implements it in double with libm), in short
+// rejection loop (nothing diverges), any vehicle's sample at any tick computable by anybody.  The definition
+// (include/agrifly_engine.h, afe_seed_policy; the test suite's checker implements it in double with libm):
 //   u_r = ((x_even >> 9) + 0.5) 2^-23,  u_a = (x_odd >> 8) 2^-24      -- both exact in fp32
 //   r = sqrt(-2 ln u_r);  z_a = r cos(2 pi u_a);  z_b = r sin(2 pi u_a)
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {

@@ -46,7 +46,7 @@ ABI_FUNCTIONS = [
     "afe_nearest_neighbour_grid", "afe_neighbour_grid_info", "afe_set_neighbour_grid_refresh", "afe_nearest_neighbour_bruteforce",
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
     "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running", "afe_stream_probe",
-    "afe_set_noise_seed", "afe_set_gust_process", "afe_get_external_force",
+    "afe_set_noise_seed", "afe_set_gust_process", "afe_get_external_force", "afe_nearest_neighbour_async", "afe_query_sync",
 ]
 
 
@@ -257,6 +257,8 @@ def library():
         "afe_set_max_fused_steps": [eng, ci],
         "afe_set_split_stepping": [eng, ci],
         "afe_set_step_mode": [eng, ci],
+        "afe_nearest_neighbour_async": [eng, vp, i64, vp, vp],
+        "afe_query_sync": [eng],
         "afe_set_noise_seed": [eng, u64],
         "afe_set_gust_process": [eng, ci, u64, C.c_double, u64, i64],
         "afe_get_external_force": [eng, i64, i64, vp],
@@ -897,6 +899,14 @@ class Ensemble:
     def nearest_neighbour(self, all_xyz_ptr, n_all, dist2_ptr, index_ptr, cell_size=0.0):
         self._ck(self._L.afe_nearest_neighbour_grid(self._h, C.c_void_p(int(all_xyz_ptr)), int(n_all), float(cell_size),
                                                     C.c_void_p(int(dist2_ptr)), C.c_void_p(int(index_ptr))))
+
+    def nearest_neighbour_async(self, all_xyz_ptr, n_all, dist2_ptr, index_ptr):
+        """afe_nearest_neighbour_async: the query on its own stream behind the gather; later steps are not ordered behind it"""
+        self._ck(self._L.afe_nearest_neighbour_async(self._h, C.c_void_p(int(all_xyz_ptr)), int(n_all),
+                                                     C.c_void_p(int(dist2_ptr)), C.c_void_p(int(index_ptr))))
+
+    def query_sync(self):
+        self._ck(self._L.afe_query_sync(self._h))
 
     def nearest_neighbour_bruteforce(self, all_xyz_ptr, n_all, queries_ptr, n_queries, dist2_ptr, index_ptr):
         self._ck(self._L.afe_nearest_neighbour_bruteforce(self._h, C.c_void_p(int(all_xyz_ptr)), int(n_all),

@@ -426,12 +426,13 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
-def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, barrier, split=False):
-    """The path's only exchange, at its cadence: every 10 ms of simulated time (100 Hz) the shards
-    all-gather their positions (afe_gather_positions: pack + ncclAllGather on the engine's stream)
-    and run the consumers on the gathered buffer (uniform-grid nearest neighbour for every local
-    vehicle; 1024 UWB ranging transactions).  Reports the HIP-event time of one query and the
-    whole-job rate with a query every 10 steps."""
+def shared_world(afa, n_local, rank, world, local_rank, dist, torch, sync, barrier):
+    """The path's only exchange, at its cadence: every 10 ms of simulated time (100 Hz) the shards all-gather their
+    positions (afe_gather_positions: pack + ncclAllGather on the engine's stream) and run the consumers on the gathered
+    buffer (uniform-grid nearest neighbour for every local vehicle; 1024 UWB ranging transactions).  Two worlds of
+    defined age -- the 4 m lattice as it starts, and the same ensemble after 3000 steps of gusts -- each with the
+    query in the engine's stream (the steps wait for it) and on a stream of its own (afe_nearest_neighbour_async: the
+    next ten steps run beside it)."""
     n_all = n_local * world
     uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
     if rank == 0:
@@ -440,8 +441,6 @@ def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, ba
         dist.broadcast(uid, 0)
     with stdout_to_stderr():
         comm = afa.Comm(uid.cpu().numpy(), rank, world, device=local_rank)
-        e.gather_positions(comm, torch.empty((3, n_all), dtype=torch.float32, device="cuda").data_ptr())
-        e.sync()
     xyz = torch.empty((3, n_all), dtype=torch.float32, device="cuda")
     d2 = torch.empty(n_local, dtype=torch.float32, device="cuda")
     idx = torch.empty(n_local, dtype=torch.int32, device="cuda")
@@ -449,87 +448,84 @@ def shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, ba
     rng = np.random.default_rng(7)
     req = rng.integers(0, n_all, 1024).astype(np.int32)
     res = rng.integers(0, n_all, 1024).astype(np.int32)
-    torch.cuda.synchronize()
 
-    e.set_neighbour_grid_refresh(16)     # re-shape the grid (one read-back) every 16th query; exact either way
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    def query(with_uwb=True):
-        e.gather_positions(comm, xyz.data_ptr())
-        e.nearest_neighbour(xyz.data_ptr(), n_all, d2.data_ptr(), idx.data_ptr())
-        if with_uwb:
-            net.range(e, xyz.data_ptr(), n_all, req, res)
+    out = {"rccl_ranks": None, "vehicles_gathered": n_all, "allgather_bytes_per_rank": 12 * n_local,
+           "query_cadence": "every 10 steps of 1 ms (100 Hz simulated time)", "neighbour_grid_reshaped_every_n_queries": 16, "worlds": {}}
+    for world_name, age in (("lattice_as_started", 0), ("after_3000_steps_of_gusts", 3000)):
+        e = build_shard(afa, n_local, rank * n_local, n_all, local_rank)
+        with stdout_to_stderr():
+            e.gather_positions(comm, xyz.data_ptr())     # RCCL's first call on this communicator
+            e.sync()
+        if age:
+            e.step(DT_US, age)
+        e.set_neighbour_grid_refresh(16)     # re-shape the grid (one read-back) every 16th query; exact either way
 
-    for _ in range(3):
-        query()
-    sync()
-    barrier()
-    parts = {}
-    for name, fn in (("allgather_ms", lambda: e.gather_positions(comm, xyz.data_ptr())),
-                     ("nearest_neighbour_ms", lambda: e.nearest_neighbour(xyz.data_ptr(), n_all, d2.data_ptr(), idx.data_ptr())),
-                     ("uwb_1024_ranges_ms", lambda: net.range(e, xyz.data_ptr(), n_all, req, res))):
-        ev0, ev1 = e.event(), e.event()
-        barrier()
-        e.record(ev0)
-        for _ in range(10):
-            fn()
-        e.record(ev1)
-        parts[name] = e.elapsed_ms(ev0, ev1) / 10
-        e.destroy_event(ev0)
-        e.destroy_event(ev1)
-    # physics with a query every 10 steps (100 Hz at dt = 1 ms) vs physics alone
-    def run(k_steps, every):
-        barrier()
-        e.sync()
-        sync()
-        t0 = time.perf_counter()
-        for s in range(k_steps):
-            e.step(DT_US, 1)
-            if every and (s + 1) % every == 0:
-                query(with_uwb=False)     # the UWB read-back would serialise the host; timed above on its own
-        e.sync()
-        sync()
-        barrier()
-        return time.perf_counter() - t0
-    run(50, 10)
-    k = 400
-    t_without = run(k, 0)
-    # every query ends a resident grid / joins the two streams: time the ways of stepping between queries and report the
-    # fastest one, named.  Every rank takes the same decision (the slowest rank's times).
-    t_by_mode = {}
-    modes = {"automatic (one resident grid between queries)" if n_local <= (1 << 20) else "automatic (two streams)": (afa.AFE_STEP_AUTO, 0),
-             "launches, one stream": (afa.AFE_STEP_LAUNCH, 1)}
-    for name, (m, parts_n) in modes.items():
-        e.set_step_mode(m)
-        e.set_split_stepping(parts_n)
+        def query(asynchronous=False, with_uwb=False):
+            e.gather_positions(comm, xyz.data_ptr())
+            if asynchronous:
+                e.nearest_neighbour_async(xyz.data_ptr(), n_all, d2.data_ptr(), idx.data_ptr())
+            else:
+                e.nearest_neighbour(xyz.data_ptr(), n_all, d2.data_ptr(), idx.data_ptr())
+            if with_uwb:
+                net.range(e, xyz.data_ptr(), n_all, req, res)
+
+        for _ in range(3):
+            query(with_uwb=True)
+        e.sync(); sync(); barrier()
+        parts = {}
+        for name, fn in (("allgather_ms", lambda: e.gather_positions(comm, xyz.data_ptr())),
+                         ("nearest_neighbour_ms", lambda: e.nearest_neighbour(xyz.data_ptr(), n_all, d2.data_ptr(), idx.data_ptr())),
+                         ("uwb_1024_ranges_ms", lambda: net.range(e, xyz.data_ptr(), n_all, req, res))):
+            ev0, ev1 = e.event(), e.event()
+            barrier()
+            e.record(ev0)
+            for _ in range(10):
+                fn()
+            e.record(ev1)
+            parts[name] = e.elapsed_ms(ev0, ev1) / 10
+            e.destroy_event(ev0)
+            e.destroy_event(ev1)
+
+        # physics with a query every 10 steps (100 Hz at dt = 1 ms) vs physics alone
+        def run(k_steps, every, asynchronous=False):
+            barrier()
+            e.query_sync(); e.sync(); sync()
+            t0 = time.perf_counter()
+            for s in range(0, k_steps, 10):
+                e.step(DT_US, 10)
+                if every:
+                    query(asynchronous)     # (the UWB read-back would serialise the host; timed above on its own)
+            e.query_sync(); e.sync(); sync()
+            barrier()
+            return time.perf_counter() - t0
+        k = 400
         run(50, 10)
-        t_by_mode[name] = run(k, 10)
-    if dist is not None:
-        names = sorted(t_by_mode)
-        tm = torch.tensor([t_by_mode[x] for x in names] + [t_without], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        t_by_mode = {x: float(tm[i]) for i, x in enumerate(names)}
-        t_without = float(tm[-1])
-    best_mode = min(t_by_mode, key=t_by_mode.get)
-    t_with = t_by_mode[best_mode]
-    e.set_step_mode(afa.AFE_STEP_AUTO)
-    e.set_split_stepping(0)
-    info = e.neighbour_grid_info()
-    out = dict(parts)
-    out.update({
-        "rccl_ranks": comm.info()[1],
-        "vehicles_gathered": n_all,
-        "allgather_bytes_per_rank": 12 * n_local,
-        "query_cadence": "every 10 steps of 1 ms (100 Hz simulated time)",
-        "stepping_between_queries": best_mode,
-        "ms_per_400_steps_by_stepping": {x: t * 1e3 for x, t in t_by_mode.items()},
-        "neighbour_grid_reshaped_every_n_queries": 16,
-        "query_ms": parts["allgather_ms"] + parts["nearest_neighbour_ms"],
-        "vsteps_per_s_with_queries": n_all * k / t_with,
-        "vsteps_per_s_physics_only": n_all * k / t_without,
-        "neighbour_grid": {"dims": list(info["dims"]), "cell_size_m": info["cell_size"],
-                           "queries_finished_by_brute_force": info["n_bruteforce"]},
-        "min_separation_m": float(torch.sqrt(d2.min()).item()),
-    })
+        t_without = reduce_max(median([run(k, 0) for _ in range(3)]))
+        t_sync = reduce_max(median([run(k, 10) for _ in range(3)]))
+        run(50, 10, True)
+        t_async = reduce_max(median([run(k, 10, True) for _ in range(3)]))
+        info = e.neighbour_grid_info()
+        e.query_sync(); e.sync()
+        w = dict(parts)
+        w.update({"query_ms": parts["allgather_ms"] + parts["nearest_neighbour_ms"],
+                  "vsteps_per_s_physics_only": n_all * k / t_without,
+                  "vsteps_per_s_query_in_stream": n_all * k / t_sync, "fraction_query_in_stream": t_without / t_sync,
+                  "vsteps_per_s_query_on_own_stream": n_all * k / t_async, "fraction_query_on_own_stream": t_without / t_async,
+                  "neighbour_grid": {"dims": list(info["dims"]), "cell_size_m": info["cell_size"], "queries_finished_by_brute_force": info["n_bruteforce"]},
+                  "min_separation_m": float(torch.sqrt(d2.min()).item())})
+        out["worlds"][world_name] = w
+        out["rccl_ranks"] = comm.info()[1]
+        e.close()
+    out["note"] = ("a query = all-gather + exact nearest neighbour of every local vehicle among all gathered ones.  Both the steps and the query live on the "
+                   "memory system: running the query beside the next ten steps (own stream) hides its launch gaps and little else -- fraction_* = rate with "
+                   "queries / rate without")
     net.close()
     with stdout_to_stderr():
         comm.close()
@@ -839,7 +835,7 @@ def main():
     sw_failed = False
     if not args.no_shared_world and not args.headline_only:
         try:
-            sw = shared_world(afa, e, n_local, rank, world, local_rank, dist, torch, sync, barrier, split)   # collective: every rank
+            sw = shared_world(afa, n_local, rank, world, local_rank, dist, torch, sync, barrier)   # collective: every rank
         except Exception as ex:                      # the other ranks may be waiting for this one: the watchdog frees them
             sw = {"error": "%s: %s" % (type(ex).__name__, ex)}
             sw_failed = True

@@ -59,7 +59,14 @@ typedef enum afe_seed_policy {
   AFE_SEED_DECORRELATED = 1,
   /* Monte-Carlo ensembles that need no libstdc++ stream: the six normals of (vehicle, logic tick) come from a
    * counter-based generator -- Philox4x32-10 keyed by afe_set_noise_seed, addressed by the GLOBAL vehicle index and
-   * the tick number, Box-Muller on top (definition: oracle/agrifly_oracle_counter.h).  No per-vehicle engine word
+   * the tick number, Box-Muller on top:
+   *   key = (seed low, seed high); counter = (index low, index high (16 bits) | stream << 16 | block << 24, ordinal low,
+   *   ordinal high); stream 1 = IMU noise (ordinal = logic-tick number; blocks 0 and 1 give z0..z7: gyro x y z = z0 z1 z2,
+   *   accelerometer x y z = z3 z4 z5), stream 2 = gusts (ordinal = epoch; block 0: force = sigma_i (z0, z1, z2));
+   *   per pair of words: u_r = ((x_even >> 9) + 0.5) 2^-23, u_a = (x_odd >> 8) 2^-24 (both exact in fp32),
+   *   r = sqrt(-2 ln u_r), z_a = r cos(2 pi u_a), z_b = r sin(2 pi u_a)   (|z| <= 5.65).
+   * The AFE_F64 engine evaluates this in double (1e-13 of a libm evaluation), the AFE_F32 engine in float with the
+   * hardware reciprocal / square root / sine / cosine (measured worst 6e-7 absolute).  No per-vehicle engine word
    * is loaded or stored, nothing diverges (no rejection loop); the samples do not depend on how the ensemble is
    * sharded, stepped or fused.  The reference produces no such stream (it seeds every vehicle with 1). */
   AFE_SEED_COUNTER = 2
@@ -654,6 +661,14 @@ int afe_nearest_neighbour(afe_engine *e, const float *all_xyz, int64_t n_all,
                           float *dist2_out, int32_t *index_out);
 int afe_nearest_neighbour_grid(afe_engine *e, const float *all_xyz, int64_t n_all, float cell_size,
                                float *dist2_out, int32_t *index_out);
+/* The same query (automatic cell size) without stalling the steps: it runs on a stream of its own, ordered behind what
+ * the engine's stream holds at the call (the gather that filled all_xyz), while later afe_step calls proceed.  Whatever
+ * would rewrite the gathered buffer or the query's scratch (afe_gather_positions, afe_pack_positions, another query) is
+ * ordered behind it on the device; the host joins with afe_query_sync before it reads dist2_out / index_out.
+ * (Measured, DESIGN.md section 5: the query and the steps both live on the memory system, so running them together
+ * hides the query's launch gaps, not its traffic.) */
+int afe_nearest_neighbour_async(afe_engine *e, const float *all_xyz, int64_t n_all, float *dist2_out, int32_t *index_out);
+int afe_query_sync(afe_engine *e);
 /* How often the grid is re-shaped from the ensemble's current bounds and spread: every
  * `every_n_queries` queries (default 1).  Re-shaping needs one 6 KB read-back, i.e. it synchronises
  * the stream; in between, queries are fully asynchronous.  Results do not depend on it (the query is

@@ -47,6 +47,35 @@ def test_pack_positions_and_nearest_neighbour(precision, ora):
         np.testing.assert_array_equal(d2, ref_d)          # the same fp32 roundings: bit-identical
 
 
+def test_query_on_its_own_stream_gives_the_same_answers_while_the_steps_go_on(ora):
+    """afe_nearest_neighbour_async: snapshot (pack) -> query on a stream of its own -> the engine steps on at once.
+    The answers belong to the snapshot, whatever the vehicles do meanwhile; a new pack into the same buffer and a new
+    query are ordered behind the running one on the device; both stepping modes."""
+    import torch
+    n = 50000
+    ens = random_ensemble(n, seed=23, type_ids=(5,))
+    for mode in (afa.AFE_STEP_LAUNCH, afa.AFE_STEP_PERSISTENT):
+        with ens.to_engine(afa.AFE_F32) as e:
+            e.set_step_mode(mode)
+            xyz = torch.empty((3, n), dtype=torch.float32, device="cuda")
+            d2 = torch.empty(n, dtype=torch.float32, device="cuda")
+            idx = torch.empty(n, dtype=torch.int32, device="cuda")
+            want = []
+            for cycle in range(4):
+                e.pack_positions(xyz.data_ptr())                  # ordered behind the query of the cycle before
+                e.nearest_neighbour_async(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr())
+                e.step(1000, 10)                                  # not ordered behind the query
+                e.query_sync()
+                got_d, got_i = d2.cpu().numpy().copy(), idx.cpu().numpy().copy()
+                snap = xyz.cpu().numpy()
+                ref_d, ref_i = ora.nearest_neighbour(snap)
+                np.testing.assert_array_equal(got_i, ref_i)
+                np.testing.assert_array_equal(got_d, ref_d)
+                want.append(snap)
+            assert not np.array_equal(want[0], want[-1])          # the vehicles did move between the snapshots
+            e.sync()
+
+
 def test_nearest_neighbour_in_a_sharded_world(ora):
     """shard = the middle third of a gathered ensemble: self-exclusion must use
     the GLOBAL index (first_global_index + i)"""
