@@ -39,6 +39,7 @@ from .engine import (  # noqa: F401
     VehicleParams,
     build_library,
     camera_default,
+    gather_exchange,
     camera_default_mount,
     library,
     library_path,

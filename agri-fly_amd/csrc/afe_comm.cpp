@@ -139,6 +139,63 @@ extern "C" const char *afe_comm_last_error(const afe_comm *c) {
   return c->err.c_str();
 }
 
+// The exchange itself, whatever moves the bytes: which rank's block goes where in the gathered buffer (counts, offsets,
+// one all-gather per component when the shards are equal, one broadcast per rank and component when they are not).
+// Pure host logic over opaque buffers -- afe_gather_positions runs it with RCCL on device memory, a host with its own
+// transport (MPI, torch.distributed) runs it with that, and the CPU test suite runs it over gloo on host memory:
+// the same code with only the transport swapped.
+extern "C" int afe_gather_exchange(const afe_gather_transport *t, int rank, int n_ranks, const int64_t *counts, int64_t n_local,
+                                   const float *packed_xyz, float *xyz_all) {
+  if (!t || !t->all_gather || !t->broadcast || n_ranks < 1 || rank < 0 || rank >= n_ranks || n_local <= 0 || !packed_xyz || !xyz_all)
+    return AFE_ERR_INVALID_ARG;
+  bool equal = true;
+  int64_t n_all = n_local * n_ranks;
+  std::vector<int64_t> firsts((size_t)n_ranks, 0);
+  if (counts) {
+    if (counts[rank] != n_local) return AFE_ERR_INVALID_ARG;
+    n_all = 0;
+    for (int k = 0; k < n_ranks; k++) {
+      if (counts[k] <= 0) return AFE_ERR_INVALID_ARG;
+      firsts[(size_t)k] = n_all;
+      n_all += counts[k];
+      equal = equal && counts[k] == n_local;
+    }
+  }
+  int rc = t->group_start ? t->group_start(t->ctx) : 0;
+  for (int comp = 0; comp < 3 && rc == 0; comp++) {
+    if (equal) {
+      rc = t->all_gather(t->ctx, packed_xyz + comp * n_local, xyz_all + comp * n_all, n_local);
+    } else {
+      for (int k = 0; k < n_ranks && rc == 0; k++)
+        rc = t->broadcast(t->ctx, packed_xyz + comp * n_local, xyz_all + comp * n_all + firsts[(size_t)k], counts[k], k);
+    }
+  }
+  const int erc = t->group_end ? t->group_end(t->ctx) : 0;
+  if (rc == 0) rc = erc;
+  return rc == 0 ? AFE_OK : AFE_ERR_COMM;
+}
+
+namespace {
+struct RcclCtx { Rccl *r; afe_comm *c; hipStream_t st; ncclResult_t last; };
+int rccl_all_gather(void *ctx, const float *send, float *recv, int64_t count) {
+  RcclCtx *x = (RcclCtx *)ctx;
+  x->last = x->r->AllGather(send, recv, (size_t)count, ncclFloat, x->c->comm, x->st);
+  return x->last == ncclSuccess ? 0 : 1;
+}
+int rccl_broadcast(void *ctx, const float *send, float *recv, int64_t count, int root) {
+  RcclCtx *x = (RcclCtx *)ctx;
+  x->last = x->r->Broadcast(send, recv, (size_t)count, ncclFloat, root, x->c->comm, x->st);
+  return x->last == ncclSuccess ? 0 : 1;
+}
+int rccl_group_start(void *ctx) { RcclCtx *x = (RcclCtx *)ctx; x->last = x->r->GroupStart(); return x->last == ncclSuccess ? 0 : 1; }
+int rccl_group_end(void *ctx) {
+  RcclCtx *x = (RcclCtx *)ctx;
+  const ncclResult_t e = x->r->GroupEnd();
+  if (e != ncclSuccess) x->last = e;
+  return e == ncclSuccess ? 0 : 1;
+}
+}  // namespace
+
 // counts[r] = vehicles of rank r (NULL: every rank holds as many as this one).  Output: planar
 // fp32 [3][n_all] on the device, vehicles in global order.
 extern "C" int afe_gather_positions(afe_engine *e, afe_comm *c, const int64_t *counts, float *dev_xyz_all) {
@@ -149,33 +206,18 @@ extern "C" int afe_gather_positions(afe_engine *e, afe_comm *c, const int64_t *c
   int device = 0;
   engine_stream_device(e, &stream_v, &device);
   if (device != c->device) { c->err = "engine and communicator live on different devices"; return AFE_ERR_INVALID_ARG; }
-  hipStream_t st = (hipStream_t)stream_v;
   int64_t first = 0, n = 0;
   engine_shard(e, &first, &n);
+  if (counts && counts[c->rank] != n) { c->err = "counts[rank] differs from the engine's vehicle count"; return AFE_ERR_INVALID_ARG; }
   float *scratch = nullptr;
   int rc = engine_pack_to_scratch(e, &scratch);
   if (rc) return rc;
-  bool equal = true;
-  int64_t n_all = n * c->n_ranks;
-  std::vector<int64_t> firsts((size_t)c->n_ranks, 0);
-  if (counts) {
-    if (counts[c->rank] != n) { c->err = "counts[rank] differs from the engine's vehicle count"; return AFE_ERR_INVALID_ARG; }
-    n_all = 0;
-    for (int k = 0; k < c->n_ranks; k++) { firsts[(size_t)k] = n_all; n_all += counts[k]; equal = equal && counts[k] == n; }
-  }
-  ncclResult_t nrc = r->GroupStart();
-  for (int comp = 0; comp < 3 && nrc == ncclSuccess; comp++) {
-    if (equal) {
-      nrc = r->AllGather(scratch + comp * n, dev_xyz_all + comp * n_all, (size_t)n, ncclFloat, c->comm, st);
-    } else {
-      for (int k = 0; k < c->n_ranks && nrc == ncclSuccess; k++)
-        nrc = r->Broadcast(scratch + comp * n, dev_xyz_all + comp * n_all + firsts[(size_t)k], (size_t)counts[k], ncclFloat, k, c->comm, st);
-    }
-  }
-  const ncclResult_t erc = r->GroupEnd();
-  if (nrc == ncclSuccess) nrc = erc;
-  if (nrc != ncclSuccess) { c->err = std::string("RCCL all-gather: ") + r->GetErrorString(nrc); return AFE_ERR_COMM; }
-  return AFE_OK;
+  RcclCtx x = {r, c, (hipStream_t)stream_v, ncclSuccess};
+  const afe_gather_transport t = {&x, rccl_all_gather, rccl_broadcast, rccl_group_start, rccl_group_end};
+  rc = afe_gather_exchange(&t, c->rank, c->n_ranks, counts, n, scratch, dev_xyz_all);
+  if (rc == AFE_ERR_COMM) c->err = std::string("RCCL all-gather: ") + r->GetErrorString(x.last);
+  else if (rc) c->err = "bad counts";
+  return rc;
 }
 
 // ---------------------------------------------------------------------------

@@ -47,6 +47,7 @@ ABI_FUNCTIONS = [
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
     "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running", "afe_stream_probe",
     "afe_set_noise_seed", "afe_set_gust_process", "afe_get_external_force", "afe_nearest_neighbour_async", "afe_query_sync",
+    "afe_gather_exchange",
 ]
 
 
@@ -180,6 +181,46 @@ def build_library(force=False):
     return _LIB
 
 
+_AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+_BC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+_GR = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class GatherTransport(C.Structure):
+    """afe_gather_transport: the collectives afe_gather_exchange runs on"""
+    _fields_ = [("ctx", C.c_void_p), ("all_gather", _AG), ("broadcast", _BC), ("group_start", _GR), ("group_end", _GR)]
+
+
+def gather_exchange(all_gather, broadcast, rank, n_ranks, counts, packed_xyz, xyz_all):
+    """afe_gather_exchange over host arrays with Python collectives:
+    all_gather(send: float32[count], recv: float32[n_ranks * count]); broadcast(send, recv: float32[count], root).
+    packed_xyz float32 [3, n_local], xyz_all float32 [3, n_all] (both C-contiguous, written in place)."""
+    def view(ptr, count):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(int(count),))
+
+    def ag(_, send, recv, count):
+        try:
+            all_gather(view(send, count), view(recv, count * n_ranks))
+            return 0
+        except Exception:      # noqa: BLE001  (an exception must not cross the C frame)
+            return 1
+
+    def bc(_, send, recv, count, root):
+        try:
+            broadcast(view(send, count), view(recv, count), int(root))
+            return 0
+        except Exception:      # noqa: BLE001
+            return 1
+
+    t = GatherTransport(None, _AG(ag), _BC(bc), _GR(), _GR())
+    cnt = None if counts is None else np.ascontiguousarray(counts, dtype=np.int64)
+    assert packed_xyz.dtype == np.float32 and xyz_all.dtype == np.float32 and packed_xyz.flags.c_contiguous and xyz_all.flags.c_contiguous
+    rc = library().afe_gather_exchange(C.byref(t), int(rank), int(n_ranks), None if cnt is None else cnt.ctypes.data,
+                                       int(packed_xyz.shape[1]), packed_xyz.ctypes.data, xyz_all.ctypes.data)
+    if rc:
+        raise AfeError(rc, "afe_gather_exchange")
+
+
 class Camera(C.Structure):
     """afe_camera: the pinhole depth camera of Rappids_Simulator/main.cpp:120-122,360."""
     _fields_ = [
@@ -259,6 +300,7 @@ def library():
         "afe_set_step_mode": [eng, ci],
         "afe_nearest_neighbour_async": [eng, vp, i64, vp, vp],
         "afe_query_sync": [eng],
+        "afe_gather_exchange": [C.POINTER(GatherTransport), ci, ci, vp, i64, vp, vp],
         "afe_set_noise_seed": [eng, u64],
         "afe_set_gust_process": [eng, ci, u64, C.c_double, u64, i64],
         "afe_get_external_force": [eng, i64, i64, vp],

@@ -622,6 +622,21 @@ const char *afe_comm_last_error(const afe_comm *c);
  * as this one.  dev_xyz_all: DEVICE buffer of 3*n_all floats, planar [3][n_all],
  * vehicles in global order (rank 0's block first).  Asynchronous like afe_step. */
 int afe_gather_positions(afe_engine *e, afe_comm *c, const int64_t *counts, float *dev_xyz_all);
+/* The exchange behind it with the transport as an argument: which block goes where (counts, offsets; one all-gather per
+ * component for equal shards, one broadcast per rank and component for unequal ones), over opaque buffers.  A host that
+ * brings its own collective (MPI, torch.distributed) passes it here -- packed_xyz is this rank's [3][n_local] block as
+ * afe_pack_positions wrote it, xyz_all the [3][n_all] result, both in whatever memory the transport moves; the
+ * callbacks return 0 on success.  afe_gather_positions is this routine with RCCL on device memory; the CPU test suite
+ * runs it over gloo on host memory (tests/test_sharding_gloo.py).  Pure host code: usable without a GPU. */
+typedef struct afe_gather_transport {
+  void *ctx;
+  int (*all_gather)(void *ctx, const float *send, float *recv, int64_t count);            /* recv holds n_ranks x count */
+  int (*broadcast)(void *ctx, const float *send, float *recv, int64_t count, int root);  /* root's send into everybody's recv */
+  int (*group_start)(void *ctx);                                                          /* optional (NULL) */
+  int (*group_end)(void *ctx);
+} afe_gather_transport;
+int afe_gather_exchange(const afe_gather_transport *t, int rank, int n_ranks, const int64_t *counts, int64_t n_local,
+                        const float *packed_xyz, float *xyz_all);
 
 /* One process, several GPUs -- the reference's own process model, one loop over a
  * std::vector of vehicles (AIFS_ROS/hiperlab_rostools/src/Simulator/main.cpp:

@@ -85,6 +85,81 @@ def test_gather_positions_equals_host_concatenate(world, n_global):
         assert ok and shape == (3, n_global)
 
 
+def _exchange_worker(rank, world, port, counts, q):
+    """one rank of the PRODUCT's exchange routine (afe_gather_exchange, the code behind afe_gather_positions and so behind
+    bench.py's shared-world part) with gloo collectives on host memory in place of RCCL on device memory"""
+    import importlib
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    afa = importlib.import_module("agri-fly_amd")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        n_all = int(sum(counts))
+        rng = np.random.Generator(np.random.PCG64(11))
+        allpos = rng.normal(size=(3, n_all)).astype(np.float32)
+        first = int(sum(counts[:rank]))
+        local = np.ascontiguousarray(allpos[:, first:first + counts[rank]])
+        out = np.full((3, n_all), np.nan, np.float32)
+        calls = {"all_gather": 0, "broadcast": 0}
+
+        def all_gather(send, recv):
+            calls["all_gather"] += 1
+            dist.all_gather_into_tensor(torch.from_numpy(recv), torch.from_numpy(send.copy()))
+
+        def broadcast(send, recv, root):
+            calls["broadcast"] += 1
+            t = torch.from_numpy(recv)
+            if rank == root:
+                t.copy_(torch.from_numpy(send.copy()))
+            dist.broadcast(t, root)
+
+        equal = len(set(counts)) == 1
+        afa.gather_exchange(all_gather, broadcast, rank, world, None if equal else counts, local, out)
+        # the consumer's bookkeeping on top: this shard's vehicles are global indices first .. first + count - 1
+        d, i = afa.sharding.nearest_neighbour_reference(out, first, min(counts[rank], 8))
+        dr, ir = afa.sharding.nearest_neighbour_reference(allpos, first, min(counts[rank], 8))
+        q.put((rank, bool(np.array_equal(out, allpos)), calls, bool(np.array_equal(i, ir) and np.array_equal(d, dr))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [(2048, 2048), (334, 333, 333), (5, 1000, 64), (1, 1)])
+def test_the_products_exchange_routine_over_gloo(counts):
+    """afe_gather_exchange -- counts, offsets, all-gather for equal shards, one broadcast per rank and component for
+    unequal ones -- is what afe_gather_positions runs over RCCL; here every rank runs the same C routine over gloo.
+    World sizes 2 and 3, equal, nearly equal and wildly unequal shards."""
+    import torch.multiprocessing as mp
+    world = len(counts)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, list(counts), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == list(range(world))
+    equal = len(set(counts)) == 1
+    for _, ok, calls, nn_ok in results:
+        assert ok and nn_ok
+        assert calls == ({"all_gather": 3, "broadcast": 0} if equal else {"all_gather": 0, "broadcast": 3 * world})
+
+
+def test_exchange_routine_refuses_inconsistent_counts(afa):
+    out = np.zeros((3, 10), np.float32)
+    local = np.zeros((3, 4), np.float32)
+    noop = lambda *a: None
+    with pytest.raises(afa.AfeError):
+        afa.gather_exchange(noop, noop, 0, 2, [5, 5], local, out)          # counts[rank] != n_local
+    with pytest.raises(afa.AfeError):
+        afa.gather_exchange(noop, noop, 0, 2, [4, 0], local, out)          # an empty shard
+    with pytest.raises(afa.AfeError):
+        afa.gather_exchange(noop, noop, 2, 2, None, local, out)            # rank outside the communicator
+
+
 def test_nearest_neighbour_reference_helper(afa):
     xyz = np.array([[0, 1, 5, 5.5], [0, 0, 0, 0], [0, 0, 0, 0]], np.float32)
     d, i = afa.sharding.nearest_neighbour_reference(xyz, 0, 4)
