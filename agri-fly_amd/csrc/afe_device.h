@@ -152,8 +152,8 @@ int launch_motor_from_cmd_f32(float *motor, const float *cmd, const uint8_t *typ
                               int64_t stride, int64_t n, void *stream);
 int launch_motor_from_cmd_f64(double *motor, const float *cmd, const uint8_t *type, const DevParams<double> *table,
                               int64_t stride, int64_t n, void *stream);
-int launch_pack_positions_f32(const float *pos, int64_t stride, int64_t n, float *out, void *stream);
-int launch_pack_positions_f64(const double *pos, int64_t stride, int64_t n, float *out, void *stream);
+int launch_pack_positions_f32(const float *pos, const double *anchor_xy, int64_t stride, int64_t n, float *out, void *stream);
+int launch_pack_positions_f64(const double *pos, const double *anchor_xy, int64_t stride, int64_t n, float *out, void *stream);
 int launch_normals_selftest(const uint32_t *seeds, int64_t n, double *out, uint32_t *state_out, void *stream);
 int launch_normals_selftest_f32(const uint32_t *seeds, int64_t n, float *out, uint32_t *state_out, void *stream);
 int launch_gust_f32(float *ext_force, int64_t stride, int64_t n, int64_t first_global, uint64_t n_global, uint64_t seed, uint64_t epoch,

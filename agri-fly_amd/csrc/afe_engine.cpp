@@ -35,11 +35,13 @@ struct afe_engine {
   // device slabs
   void *arena = nullptr;
   size_t arena_bytes = 0;
+  size_t kernel_bytes = 0;   // the part of the arena the step kernels address (pos .. type): what a buffer resource has to span
   void *pos = nullptr, *vel = nullptr, *att = nullptr, *ang_vel = nullptr, *motor = nullptr;
   void *ext_force = nullptr, *ext_torque = nullptr;
   float *cmd = nullptr, *gyro = nullptr, *acc = nullptr;
   uint32_t *rng = nullptr;
   uint8_t *type = nullptr;
+  double *anchor = nullptr;   // [2][stride]: where each vehicle's x, y were last set; the pos slab holds x, y RELATIVE to it (fp32 engine)
   void *dev_table = nullptr;  // n_types DevParams<R>
   std::vector<DevParams<float>> table_f32;   // host copies of the device table
   std::vector<DevParams<double>> table_f64;
@@ -180,6 +182,58 @@ int get_field(afe_engine *e, const void *dev, int comps, int64_t first, int64_t 
 
 int materialize_motor(afe_engine *e);   // defined below
 
+// Positions.  The dynamics are translation invariant, and an fp32 position far from the origin cannot resolve a slow
+// vehicle's motion (at 4 km an ulp is 0.24 mm; a hovering vehicle in a light gust moves microns per step and an absolute
+// fp32 x simply stops changing: measured 1.1 cm of lost displacement in 150 steps on bench.py's 4 km lattice).  So the
+// fp32 engine integrates x and y RELATIVE to where they were last set: the slab holds the offset, `anchor` (double, never
+// touched by the step kernel: no extra bytes per step) holds the set point, and everything that means an absolute
+// position -- getters, afe_pack_positions, the depth camera's poses -- adds the two in double.  z stays absolute (the
+// ground-contact test of Quadcopter_T.cpp:146 is on it, and altitudes are small).  The fp64 engine keeps absolute
+// positions like the reference; its anchors are zero.
+template <typename H>
+int set_positions(afe_engine *e, int64_t first, int64_t count, const H *pos3) {
+  if (!pos3 || count == 0) return AFE_OK;
+  int rc;
+  std::vector<double> anchors((size_t)2 * count, 0.0);
+  if (e->precision == AFE_F64) {
+    if ((rc = set_field<double>(e, e->pos, 3, first, count, pos3))) return rc;
+  } else {
+    std::vector<float> off((size_t)3 * count, 0.0f);
+    for (int64_t k = 0; k < count; k++) {
+      anchors[(size_t)k] = (double)pos3[k];
+      anchors[(size_t)(count + k)] = (double)pos3[count + k];
+      off[(size_t)(2 * count + k)] = (float)pos3[2 * count + k];
+    }
+    if ((rc = copy_in(e, e->pos, 4, 3, first, count, off.data()))) return rc;
+  }
+  return copy_in(e, e->anchor, 8, 2, first, count, anchors.data());
+}
+template <typename H>
+int get_positions(afe_engine *e, int64_t first, int64_t count, H *pos3) {
+  if (!pos3 || count == 0) return AFE_OK;
+  int rc;
+  std::vector<double> anchors((size_t)2 * count);
+  if ((rc = copy_out(e, e->anchor, 8, 2, first, count, anchors.data()))) return rc;
+  if (e->precision == AFE_F64) {
+    std::vector<double> p((size_t)3 * count);
+    if ((rc = copy_out(e, e->pos, 8, 3, first, count, p.data()))) return rc;
+    for (int64_t k = 0; k < count; k++) {
+      pos3[k] = (H)(anchors[(size_t)k] + p[(size_t)k]);
+      pos3[count + k] = (H)(anchors[(size_t)(count + k)] + p[(size_t)(count + k)]);
+      pos3[2 * count + k] = (H)p[(size_t)(2 * count + k)];
+    }
+  } else {
+    std::vector<float> p((size_t)3 * count);
+    if ((rc = copy_out(e, e->pos, 4, 3, first, count, p.data()))) return rc;
+    for (int64_t k = 0; k < count; k++) {
+      pos3[k] = (H)(anchors[(size_t)k] + (double)p[(size_t)k]);
+      pos3[count + k] = (H)(anchors[(size_t)(count + k)] + (double)p[(size_t)(count + k)]);
+      pos3[2 * count + k] = (H)p[(size_t)(2 * count + k)];
+    }
+  }
+  return AFE_OK;
+}
+
 template <typename H>
 int set_state_any(afe_engine *e, int64_t first, int64_t count, const H *pos3, const H *vel3,
                   const H *att4, const H *ang_vel3, const H *motor4) {
@@ -188,13 +242,13 @@ int set_state_any(afe_engine *e, int64_t first, int64_t count, const H *pos3, co
   AFE_HIP(e, hipSetDevice(e->device));
   if (motor4 && (rc = materialize_motor(e))) return rc;   // the rest of the slab must be current
   if (e->precision == AFE_F64) {
-    if ((rc = set_field<double>(e, e->pos, 3, first, count, pos3))) return rc;
+    if ((rc = set_positions(e, first, count, pos3))) return rc;
     if ((rc = set_field<double>(e, e->vel, 3, first, count, vel3))) return rc;
     if ((rc = set_field<double>(e, e->att, 4, first, count, att4))) return rc;
     if ((rc = set_field<double>(e, e->ang_vel, 3, first, count, ang_vel3))) return rc;
     if ((rc = set_field<double>(e, e->motor, 4, first, count, motor4))) return rc;
   } else {
-    if ((rc = set_field<float>(e, e->pos, 3, first, count, pos3))) return rc;
+    if ((rc = set_positions(e, first, count, pos3))) return rc;
     if ((rc = set_field<float>(e, e->vel, 3, first, count, vel3))) return rc;
     if ((rc = set_field<float>(e, e->att, 4, first, count, att4))) return rc;
     if ((rc = set_field<float>(e, e->ang_vel, 3, first, count, ang_vel3))) return rc;
@@ -211,13 +265,13 @@ int get_state_any(afe_engine *e, int64_t first, int64_t count, H *pos3, H *vel3,
   AFE_HIP(e, hipSetDevice(e->device));
   if (motor4 && (rc = materialize_motor(e))) return rc;
   if (e->precision == AFE_F64) {
-    if ((rc = get_field<double>(e, e->pos, 3, first, count, pos3))) return rc;
+    if ((rc = get_positions(e, first, count, pos3))) return rc;
     if ((rc = get_field<double>(e, e->vel, 3, first, count, vel3))) return rc;
     if ((rc = get_field<double>(e, e->att, 4, first, count, att4))) return rc;
     if ((rc = get_field<double>(e, e->ang_vel, 3, first, count, ang_vel3))) return rc;
     if ((rc = get_field<double>(e, e->motor, 4, first, count, motor4))) return rc;
   } else {
-    if ((rc = get_field<float>(e, e->pos, 3, first, count, pos3))) return rc;
+    if ((rc = get_positions(e, first, count, pos3))) return rc;
     if ((rc = get_field<float>(e, e->vel, 3, first, count, vel3))) return rc;
     if ((rc = get_field<float>(e, e->att, 4, first, count, att4))) return rc;
     if ((rc = get_field<float>(e, e->ang_vel, 3, first, count, ang_vel3))) return rc;
@@ -326,8 +380,8 @@ void fill_view(const afe_engine *e, StepView<R> &v) {
   v.first_global = e->first_global;
   // one buffer resource spans the arena (pos is its first slab), another the logic arena (lpf first)
   const size_t lbytes = logic_arena_bytes(e);
-  const bool fits = !e->force_global_addressing && e->arena_bytes < 0xffff0000ull && lbytes < 0xffff0000ull;
-  v.buf_bytes = fits ? (uint32_t)e->arena_bytes : 0u;
+  const bool fits = !e->force_global_addressing && e->kernel_bytes < 0xffff0000ull && lbytes < 0xffff0000ull;
+  v.buf_bytes = fits ? (uint32_t)e->kernel_bytes : 0u;
   v.logic_buf_bytes = fits ? (uint32_t)lbytes : 0u;
 }
 
@@ -407,7 +461,7 @@ bool persist_eligible(const afe_engine *e) {
   if (e->step_mode == AFE_STEP_LAUNCH || e->p_failed) return false;
   if (e->step_mode == AFE_STEP_AUTO && e->n > (int64_t(1) << 20)) return false;   // measured: DESIGN.md section 6 (beyond the Infinity Cache the split launches are ahead)
   if (!e->types_uniform || e->has_ext_torque || e->stream != e->own_stream || e->force_global_addressing) return false;
-  return e->arena_bytes < 0xffff0000ull && logic_arena_bytes(e) < 0xffff0000ull;
+  return e->kernel_bytes < 0xffff0000ull && logic_arena_bytes(e) < 0xffff0000ull;
 }
 
 int persist_launch(afe_engine *e) {
@@ -591,7 +645,7 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
   // one arena, 256-B aligned slabs:
   //   state 17 comps + wrench 6 comps (elem size), cmd 4 + imu 6 floats, rng u32, type u8
   const size_t S = (size_t)e->stride, es = elem(e);
-  const size_t bytes = S * (17 + 6) * es + S * (4 + 6) * 4 + S * 4 + S + 256 * sizeof(DevParams<double>);
+  const size_t bytes = S * (17 + 6) * es + S * (4 + 6) * 4 + S * 4 + S + S * 2 * sizeof(double) + 256 * sizeof(DevParams<double>);
   if ((err = hipMalloc(&e->arena, bytes)) != hipSuccess) return bail("hipMalloc", err);
   e->arena_bytes = bytes;
   if ((err = hipMemsetAsync(e->arena, 0, bytes, main_stream(e))) != hipSuccess) return bail("hipMemset", err);
@@ -609,6 +663,8 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
   e->acc = (float *)carve(3 * S * 4);
   e->rng = (uint32_t *)carve(S * 4);
   e->type = (uint8_t *)carve(S);
+  e->kernel_bytes = (size_t)(p - (char *)e->arena);
+  e->anchor = (double *)carve(S * 2 * sizeof(double));
   e->dev_table = carve(256 * sizeof(DevParams<double>));
 
   // identity attitude (SimulationObject6DOF.hpp:17): w component = 1
@@ -1060,7 +1116,7 @@ extern "C" int afe_step_kernel_info(const afe_engine *e, int *record_path, int *
   if (!e) return AFE_ERR_INVALID_ARG;
   if (record_path) *record_path = e->types_uniform ? 0 : (e->types_wave_uniform ? 1 : 2);
   if (addressing) {
-    const bool fits = !e->force_global_addressing && e->arena_bytes < 0xffff0000ull && logic_arena_bytes(e) < 0xffff0000ull;
+    const bool fits = !e->force_global_addressing && e->kernel_bytes < 0xffff0000ull && logic_arena_bytes(e) < 0xffff0000ull;
     *addressing = fits ? 0 : 1;
   }
   return AFE_OK;
@@ -1168,6 +1224,7 @@ extern "C" int afe_get_device_view(afe_engine *e, afe_device_view *out) {
   out->ext_force = e->ext_force; out->ext_torque = e->ext_torque;
   out->motor_cmd = e->cmd; out->gyro = e->gyro; out->acc = e->acc;
   out->rng = e->rng; out->type_index = e->type;
+  out->pos_anchor_xy = e->anchor;
   return AFE_OK;
 }
 
@@ -1438,8 +1495,8 @@ extern "C" int afe_pack_positions(afe_engine *e, float *device_xyz) {
   AFE_HIP(e, hipSetDevice(e->device));
   engine_query_join(e);
   int rc = (e->precision == AFE_F64)
-               ? launch_pack_positions_f64((const double *)e->pos, e->stride, e->n, device_xyz, main_stream(e))
-               : launch_pack_positions_f32((const float *)e->pos, e->stride, e->n, device_xyz, main_stream(e));
+               ? launch_pack_positions_f64((const double *)e->pos, e->anchor, e->stride, e->n, device_xyz, main_stream(e))
+               : launch_pack_positions_f32((const float *)e->pos, e->anchor, e->stride, e->n, device_xyz, main_stream(e));
   if (rc) return fail(e, AFE_ERR_HIP, "pack kernel launch failed");
   return AFE_OK;
 }

@@ -1306,24 +1306,25 @@ int launch_stream_probe(float *base, int64_t stride, int64_t n, int n_read, int 
 // shared-world query support
 template <typename R>
 __global__ void __launch_bounds__(256)
-afe_pack_positions_kernel(const R *pos, int64_t stride, int64_t n, float *out) {
+afe_pack_positions_kernel(const R *pos, const double *anchor_xy, int64_t stride, int64_t n, float *out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  out[i] = (float)pos[i];
-  out[n + i] = (float)pos[stride + i];
+  // absolute x, y = set point + integrated offset, added in double (afe_engine.cpp set_positions)
+  out[i] = (float)(anchor_xy[i] + (double)pos[i]);
+  out[n + i] = (float)(anchor_xy[stride + i] + (double)pos[stride + i]);
   out[2 * n + i] = (float)pos[2 * stride + i];
 }
 
-int launch_pack_positions_f32(const float *pos, int64_t stride, int64_t n, float *out, void *stream) {
+int launch_pack_positions_f32(const float *pos, const double *anchor_xy, int64_t stride, int64_t n, float *out, void *stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(afe_pack_positions_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, pos, stride, n, out);
+                     (hipStream_t)stream, pos, anchor_xy, stride, n, out);
   return (int)hipGetLastError();
 }
-int launch_pack_positions_f64(const double *pos, int64_t stride, int64_t n, float *out, void *stream) {
+int launch_pack_positions_f64(const double *pos, const double *anchor_xy, int64_t stride, int64_t n, float *out, void *stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(afe_pack_positions_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, pos, stride, n, out);
+                     (hipStream_t)stream, pos, anchor_xy, stride, n, out);
   return (int)hipGetLastError();
 }
 

@@ -263,6 +263,7 @@ struct PoseArgs {
   int elem_size;              // 4 or 8
   double mount[4];
   double *poses;              // [count][12] = origin, row-major camera-to-world matrix
+  const double *anchor_xy;    // engine state: x, y are relative to this set point (afe_device_view::pos_anchor_xy); NULL: absolute
 };
 
 __global__ void afe_camera_pose_kernel(PoseArgs a) {
@@ -280,6 +281,7 @@ __global__ void afe_camera_pose_kernel(PoseArgs a) {
     for (int k = 0; k < 3; k++) p[k] = (double)P[k * a.stride + v];
     for (int k = 0; k < 4; k++) q[k] = (double)Q[k * a.stride + v];
   }
+  if (a.anchor_xy) { p[0] = a.anchor_xy[v] + p[0]; p[1] = a.anchor_xy[a.stride + v] + p[1]; }
   const double *m = a.mount;
   // att * mount, Rotation.hpp:124-131
   const double c0 = m[0] * q[0] - m[1] * q[1] - m[2] * q[2] - m[3] * q[3];
@@ -720,9 +722,10 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
   return rc;
 }
 
-int launch_poses(const void *pos, const void *att, int64_t stride, int64_t first, int64_t count, int elem_size,
+int launch_poses(const void *pos, const double *anchor_xy, const void *att, int64_t stride, int64_t first, int64_t count, int elem_size,
                  const double mount[4], double *poses, hipStream_t stream) {
   PoseArgs p;
+  p.anchor_xy = anchor_xy;
   p.pos = pos; p.att = att; p.stride = stride; p.first = first; p.count = count; p.elem_size = elem_size;
   static const double identity[4] = {1, 0, 0, 0};
   const double *m = mount ? mount : identity;
@@ -947,7 +950,7 @@ extern "C" int afe_render_depth(afe_scene *s, const afe_camera *cam, int64_t n_v
   if (!d_pos.upload(pos, (size_t)n_views * 24) || !d_att.upload(att, (size_t)n_views * 32) ||
       !d_pose.alloc((size_t)n_views * 96) || !d_out.alloc((size_t)n_views * px * 2))
     return AFE_ERR_HIP;
-  int rc = launch_poses(d_pos.p, d_att.p, n_views, 0, n_views, 8, mount, (double *)d_pose.p, nullptr);
+  int rc = launch_poses(d_pos.p, nullptr, d_att.p, n_views, 0, n_views, 8, mount, (double *)d_pose.p, nullptr);
   if (rc != AFE_OK) return rc;
   float ms = 0;
   rc = launch_render(s, cam, n_views, (const double *)d_pose.p, (uint16_t *)d_out.p, nullptr, &ms);
@@ -971,7 +974,7 @@ extern "C" int afe_render_depth_stats(afe_scene *s, const afe_camera *cam, int64
       !d_pose.alloc((size_t)n_views * 96) || !d_out.alloc((size_t)n_views * px * 2) || !d_cnt.alloc(64))
     return AFE_ERR_HIP;
   if (hipMemset(d_cnt.p, 0, 64) != hipSuccess) return AFE_ERR_HIP;
-  int rc = launch_poses(d_pos.p, d_att.p, n_views, 0, n_views, 8, mount, (double *)d_pose.p, nullptr);
+  int rc = launch_poses(d_pos.p, nullptr, d_att.p, n_views, 0, n_views, 8, mount, (double *)d_pose.p, nullptr);
   if (rc != AFE_OK) return rc;
   float ms = 0;
   rc = launch_render(s, cam, n_views, (const double *)d_pose.p, (uint16_t *)d_out.p, nullptr, &ms,
@@ -1005,7 +1008,7 @@ extern "C" int afe_render_depth_engine(afe_engine *e, afe_scene *s, const afe_ca
     if (!d_out.alloc((size_t)count * px * 2)) return AFE_ERR_HIP;
     out_dev = (uint16_t *)d_out.p;
   }
-  rc = launch_poses(view.pos, view.att, view.stride, first, count, view.state_elem_size, mount, (double *)d_pose.p,
+  rc = launch_poses(view.pos, view.pos_anchor_xy, view.att, view.stride, first, count, view.state_elem_size, mount, (double *)d_pose.p,
                     stream);
   if (rc != AFE_OK) return rc;
   float ms = 0;

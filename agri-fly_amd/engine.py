@@ -153,7 +153,7 @@ class DeviceView(C.Structure):
         ("ang_vel", C.c_void_p), ("motor_speed", C.c_void_p),
         ("ext_force", C.c_void_p), ("ext_torque", C.c_void_p),
         ("motor_cmd", C.c_void_p), ("gyro", C.c_void_p), ("acc", C.c_void_p),
-        ("rng", C.c_void_p), ("type_index", C.c_void_p),
+        ("rng", C.c_void_p), ("type_index", C.c_void_p), ("pos_anchor_xy", C.c_void_p),
     ]
 
 

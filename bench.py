@@ -351,7 +351,7 @@ def cpu_baseline(afa, budget_vehicle_steps=100_000_000):
         ticks, _ = afa.plan_ticks(LOGIC_PERIOD, 0, DT_US, k)
         t0 = time.perf_counter()
         oracle_py.step_counter(b, DT_US, k, ticks, counter_noise=True, seed=NOISE_SEED, first_global=0, tick_base=tick_base,
-                               gust_period_us=GUST_PERIOD_US, t0_us=t0_us, n_global=1 << 20, sigma_max=GUST_SIGMA_MAX)
+                               gust_seed=GUST_SEED, gust_period_us=GUST_PERIOD_US, t0_us=t0_us, n_global=1 << 20, sigma_max=GUST_SIGMA_MAX)
         return time.perf_counter() - t0, int(ticks.sum())
 
     run(10, 0, 0)  # warm

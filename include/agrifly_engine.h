@@ -561,6 +561,12 @@ typedef struct afe_device_view {
   uint8_t *type_index;   /* READ ONLY: the engine chooses its step kernel from a host mirror of this
                           * slab (afe_set_vehicle_types keeps both in step); writing it through this
                           * pointer desynchronises them */
+  /* pos holds x and y RELATIVE to where they were last set (SetPosition): absolute x = pos_anchor_xy[i] + pos[i],
+   * absolute y = pos_anchor_xy[stride + i] + pos[stride + i], added in double; z is absolute.  An fp32 x far from
+   * the origin cannot resolve a slow vehicle's motion (at 4 km one ulp is 0.24 mm), an offset from the set point
+   * can.  AFE_F64 engines keep absolute positions like the reference: their anchors are zero.  The getters,
+   * afe_pack_positions and the depth camera add the anchors themselves. */
+  const double *pos_anchor_xy; /* 2 components */
 } afe_device_view;
 int afe_get_device_view(afe_engine *e, afe_device_view *out);
 

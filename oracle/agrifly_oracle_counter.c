@@ -64,7 +64,7 @@ void ora_step_batch_counter(int64_t n, int n_steps, const ora_params *table, con
                             double *att, double *ang_vel, double *motor_speed, uint32_t *rng, const float *motor_cmd,
                             double *ext_force, const double *ext_torque, uint64_t dt_us, const uint8_t *tick_per_step,
                             float *gyro, float *acc, int use_counter_noise, uint64_t seed, uint64_t first_global,
-                            uint64_t tick_base, uint64_t gust_period_us, uint64_t t0_us, uint64_t n_global, double sigma_max) {
+                            uint64_t tick_base, uint64_t gust_seed, uint64_t gust_period_us, uint64_t t0_us, uint64_t n_global, double sigma_max) {
   const double dt = (double)((double)dt_us * 1e-6);     /* Timer::GetSeconds<double>, Timer.hpp:36-38 */
   const int threads = ora_get_batch_threads();
 #pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
@@ -82,7 +82,7 @@ void ora_step_batch_counter(int64_t n, int n_steps, const ora_params *table, con
     if (ext_torque) for (int k = 0; k < 3; k++) te[k] = ext_torque[k * n + i];
     uint64_t ticks = tick_base;
     for (int st = 0; st < n_steps; st++) {
-      if (gust_period_us) ora_gust_force(seed, first_global + (uint64_t)i, n_global, (t0_us + (uint64_t)st * dt_us) / gust_period_us, sigma_max, fe);
+      if (gust_period_us) ora_gust_force(gust_seed, first_global + (uint64_t)i, n_global, (t0_us + (uint64_t)st * dt_us) / gust_period_us, sigma_max, fe);
       const int tick = tick_per_step ? tick_per_step[st] : 0;
       float g[3], a[3];
       uint32_t keep = s.rng;

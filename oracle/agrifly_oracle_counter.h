@@ -46,14 +46,14 @@ void ora_gust_force(uint64_t seed, uint64_t index, uint64_t n_global, uint64_t e
 
 /* ora_step_batch (agrifly_oracle.h) with the counter policy: the six normals of a tick come from
  * ora_imu_normals(seed, first_global + i, tick_base + ticks so far) instead of the vehicle's libstdc++ stream, and --
- * when gust_period_us != 0 -- the external force of every step is ora_gust_force at epoch (t0_us + step * dt_us) /
+ * when gust_period_us != 0 -- the external force of every step is ora_gust_force(gust_seed, ...) at epoch (t0_us + step * dt_us) /
  * gust_period_us (ext_force is then an OUTPUT: the force of the last step).  use_counter_noise = 0 keeps the
  * libstdc++ stream (rng) and only adds the gusts. */
 void ora_step_batch_counter(int64_t n, int n_steps, const ora_params *table, const uint8_t *types, double *pos, double *vel,
                             double *att, double *ang_vel, double *motor_speed, uint32_t *rng, const float *motor_cmd,
                             double *ext_force, const double *ext_torque, uint64_t dt_us, const uint8_t *tick_per_step,
                             float *gyro, float *acc, int use_counter_noise, uint64_t seed, uint64_t first_global,
-                            uint64_t tick_base, uint64_t gust_period_us, uint64_t t0_us, uint64_t n_global, double sigma_max);
+                            uint64_t tick_base, uint64_t gust_seed, uint64_t gust_period_us, uint64_t t0_us, uint64_t n_global, double sigma_max);
 
 #ifdef __cplusplus
 }

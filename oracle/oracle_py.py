@@ -131,7 +131,7 @@ def lib():
         L.ora_gust_force.argtypes = [u64, u64, u64, u64, C.c_double, dp]
         L.ora_gust_force.restype = None
         L.ora_step_batch_counter.argtypes = [C.c_int64, C.c_int, C.POINTER(OraParams)] + [C.c_void_p] * 10 + [u64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_int, u64, u64, u64, u64, u64, u64, C.c_double]
+                                             C.c_int, u64, u64, u64, u64, u64, u64, u64, C.c_double]
         L.ora_step_batch_counter.restype = None
         _lib = L
     return _lib
@@ -247,7 +247,7 @@ def gust_forces(seed, first, count, n_global, epoch, sigma_max):
 
 
 def step_counter(b, dt_us, n_steps, ticks, counter_noise=True, seed=0, first_global=0, tick_base=0, gust_period_us=0, t0_us=0,
-                 n_global=None, sigma_max=0.0):
+                 n_global=None, sigma_max=0.0, gust_seed=None):
     """Batch.step with the counter policy / the gust process (ora_step_batch_counter); b.ext_force receives the last gust"""
     ticks = np.ascontiguousarray(ticks, dtype=np.uint8)
     assert ticks.shape == (n_steps,)
@@ -255,7 +255,7 @@ def step_counter(b, dt_us, n_steps, ticks, counter_noise=True, seed=0, first_glo
                                  b.ang_vel.ctypes.data, b.motor_speed.ctypes.data, b.rng.ctypes.data, b.motor_cmd.ctypes.data,
                                  b.ext_force.ctypes.data, b.ext_torque.ctypes.data, int(dt_us), ticks.ctypes.data, b.gyro.ctypes.data,
                                  b.acc.ctypes.data, int(bool(counter_noise)), int(seed), int(first_global), int(tick_base),
-                                 int(gust_period_us), int(t0_us), int(b.n if n_global is None else n_global), float(sigma_max))
+                                 int(seed if gust_seed is None else gust_seed), int(gust_period_us), int(t0_us), int(b.n if n_global is None else n_global), float(sigma_max))
 
 
 def clock_ticks(loop_dt, period, n_runs):

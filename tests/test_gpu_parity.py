@@ -333,6 +333,55 @@ def test_full_size_properties_1m_vehicles():
     assert abs(float(gyro[2].std()) - 0.1) < 2e-3
 
 
+def test_full_size_on_the_bench_workload_itself():
+    """The ensemble bench.py times, as bench.py builds it (bench.build_shard): 2^20 vehicles on the 4 m lattice out to
+    (4.1 km, 4.1 km) -- where an fp32 position ulp is 0.24-0.49 mm --, the on-device gust process, counter-based IMU noise,
+    the engine's automatic stepping (one resident grid).  150 steps (two gust epochs); a 512-vehicle subsample spread over
+    the whole lattice against the checker flown through the same process (ora_step_batch_counter)."""
+    import bench
+    from oracle import oracle_py as ora
+    n, steps = 1 << 20, 150
+    e = bench.build_shard(afa, n, 0, n, 0)
+    p0 = e.get_state()["pos"]
+    e.step(1000, steps)
+    st = e.get_state()
+    gyro, acc = e.get_imu()
+    force = e.get_external_force()
+    e.close()
+    assert p0[0].max() == 4092.0 and p0[1].max() == 4092.0
+    idx = np.sort((np.arange(512) * 2053 + 7) % n)        # every column and row band of the lattice
+    b = ora.Batch(len(idx), [ora.params_from_type(5)])
+    data = afa.scenarios.hover_ensemble(len(idx), afa.params_from_type(5))
+    b.pos[:], b.vel[:], b.att[:], b.ang_vel[:] = p0[:, idx], data.vel, data.att, data.ang_vel
+    b.motor_speed[:], b.motor_cmd[:] = data.motor_speed, data.motor_cmd
+    ticks = _ticks(afa, 1 / 500, 1000, steps)
+    # the checker's batch driver numbers vehicles first_global .. consecutively: fly the subsample one vehicle at a time
+    for k, g in enumerate(idx):
+        one = ora.Batch(1, [ora.params_from_type(5)])
+        for f in ("pos", "vel", "att", "ang_vel", "motor_speed", "motor_cmd"):
+            getattr(one, f)[:] = getattr(b, f)[:, k:k + 1]
+        ora.step_counter(one, 1000, steps, ticks, counter_noise=True, seed=bench.NOISE_SEED, first_global=int(g), tick_base=0,
+                         gust_seed=bench.GUST_SEED, gust_period_us=bench.GUST_PERIOD_US, t0_us=0, n_global=n, sigma_max=bench.GUST_SIGMA_MAX)
+        for f in ("pos", "vel", "att", "ang_vel", "ext_force", "gyro", "acc"):
+            getattr(b, f)[:, k:k + 1] = getattr(one, f)
+    for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, gyro=b.gyro, acc=b.acc).items():
+        got = dict(st, gyro=gyro, acc=acc)[k]
+        assert record_parity("bench workload: 2^20 vehicles on the 4 km lattice x 150 steps, 512-vehicle subsample", afa.AFE_F32, k, got[:, idx], ref,
+                             floor=0.1 if k in ("vel", "ang_vel", "gyro") else None) <= F32_TOL, k
+    assert np.abs(force[:, idx] - b.ext_force).max() <= 1e-6 * 0.5
+    # what fp32 positions cost out there, in metres: the displacement over the 150 steps against the checker's
+    moved_e, moved_o = st["pos"][:, idx] - p0[:, idx], b.pos - p0[:, idx]
+    worst = np.abs(moved_e - moved_o).max()
+    ulp = np.spacing(np.float32(4092.0))
+    far = (p0[0, idx] > 2048) | (p0[1, idx] > 2048)
+    assert far.sum() > 100
+    # x and y are integrated relative to where they were set (the slab holds the offset, an anchor in double the set
+    # point): the displacement is resolved to fp32 relative precision of the DISPLACEMENT, not of 4 km.  With absolute
+    # fp32 positions this figure was 1.1e-2 m (47 ulp of 4 km: the slow vehicles out there simply did not move).
+    assert worst <= 2e-5, worst                   # measured 1.2e-5 m (z is absolute at 3.5 m: 150 x half an ulp of that is 1.8e-5)
+    assert ulp > 10 * worst
+
+
 def test_device_normals_match_libstdcxx_known_answers(golden_dir):
     """the DEVICE generator against the committed libstdc++ fixture directly
     (not through the oracle): raw engine words bit-exact, normals to a few ulp"""

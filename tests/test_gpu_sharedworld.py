@@ -497,10 +497,23 @@ def test_device_view_matches_host_getters():
                 self.__cuda_array_interface__ = dict(shape=shape, typestr="<f4", data=(ptr, False), version=2,
                                                      strides=None)
         pos = torch.as_tensor(_Wrap(v.pos, (3, v.stride)), device="cuda")[:, :n]
-        np.testing.assert_array_equal(pos.cpu().numpy(), e.get_state(dtype=np.float32)["pos"])
+
+        class _Wrap64(_Wrap):
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = dict(shape=shape, typestr="<f8", data=(ptr, False), version=2, strides=None)
+        anchor = torch.as_tensor(_Wrap64(v.pos_anchor_xy, (2, v.stride)), device="cuda")[:, :n]
+
+        def absolute():
+            # x, y are kept relative to where they were set (afe_device_view::pos_anchor_xy); z is absolute
+            p = pos.cpu().numpy().astype(np.float64)
+            p[:2] += anchor.cpu().numpy()
+            return p
+        np.testing.assert_array_equal(absolute(), e.get_state()["pos"])
+        assert np.array_equal(anchor.cpu().numpy(), ens.data.pos[:2]) and not pos[:2].any()
         e.step(1000, 3)
         e.sync()
-        np.testing.assert_array_equal(pos.cpu().numpy(), e.get_state(dtype=np.float32)["pos"])
+        np.testing.assert_array_equal(absolute(), e.get_state()["pos"])
+        assert pos[:2].any()
 
 
 def test_wide_campaign_grid_equals_brute_force_on_every_query():
