@@ -42,6 +42,19 @@ struct PlannerBatch {
   int max_pyramids;
   PlanOutput *out;               // [n]
   uint8_t *flags;                // [n][n_candidates] or null
+  // Interruptible search (launch_rappids): in a round every unfinished planner works for at most `budget_ticks`
+  // (100 MHz ticks), then writes down where it stands -- the sequential loop's own variables, nothing else -- and
+  // leaves its slot; a later round picks it up.  Decisions, flags and counters are those of the uninterrupted loop by
+  // construction.  (Built against the launch's tail -- a launch lasts as long as its longest planner, and planners
+  // differ by two orders of magnitude --, measured slower than one launch, off by default: see launch_rappids.)
+  struct Resume {
+    int32_t done, base, lane;    // next candidate to look at = base + lane
+    int32_t best_index, n_cost, n_feasible, n_velocity, n_free, n_pyr, pad;
+    double best_cost;
+  };
+  Resume *resume;                // [n] or null (one uninterrupted launch)
+  uint32_t budget_ticks;         // 0: no limit
+  int32_t round;                 // 0: first round (nothing to resume)
 };
 
 int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream);

@@ -19,6 +19,7 @@
 // polynomial coefficients are bit-identical to a CPU evaluation; only acos/cos/pow differ
 // from libm by an ulp.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -1240,17 +1241,26 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
   int nPyr = 0;
   int n_cost = 0, n_feasible = 0, n_velocity = 0, n_free = 0, best_index = -1;
   double bestCost = 1.7976931348623157e308;
-  if (lane == 0) {                    // the "nothing found" answer; overwritten below
+  int start_base = 0, start_lane = 0;
+  PlannerBatch::Resume *rs = b.resume ? b.resume + i : nullptr;
+  if (rs && b.round > 0) {            // pick up where an earlier round left this planner
+    if (rs->done) return;
+    start_base = rs->base; start_lane = rs->lane;
+    best_index = rs->best_index; n_cost = rs->n_cost; n_feasible = rs->n_feasible; n_velocity = rs->n_velocity; n_free = rs->n_free;
+    nPyr = rs->n_pyr; bestCost = rs->best_cost;
+  } else if (lane == 0) {             // the "nothing found" answer; overwritten below
     out->tf = 0;
     for (int q = 0; q < 6; q++) for (int a = 0; a < 3; a++) out->coeffs[q][a] = 0;
   }
-  for (int base = 0; base < b.n_candidates; base += 64) {
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  for (int base = start_base; base < b.n_candidates; base += 64) {
     const int c = base + lane;
     const bool has = c < b.n_candidates;
     const double my_cost = has ? cand_cost[c] : 0.0;
     const unsigned my_bits = has ? cand_bits[c] : 0u;
     unsigned my_result = 0;
-    uint64_t todo = ~0ull;
+    const int first_lane = base == start_base ? start_lane : 0;     // lanes below it were settled by an earlier round
+    uint64_t todo = lanes_from(first_lane);
     for (;;) {
       // candidates of this chunk that beat the best cost so far; the first one is the next the
       // sequential loop would look into (the best cost only falls, so the others stay skipped)
@@ -1293,10 +1303,23 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
       }
       if (lane == l) my_result = result;
       todo = lanes_from(l + 1);
+      // out of budget for this round: everything up to candidate base + l is settled; write it down and leave
+      if (b.budget_ticks && __builtin_amdgcn_s_memrealtime() - t_begin > (unsigned long long)b.budget_ticks) {
+        if (b.flags && has && lane >= first_lane && lane <= l) b.flags[i * b.n_candidates + c] = (uint8_t)my_result;
+        if (lane == 0) {
+          rs->done = 0;
+          rs->base = l == 63 ? base + 64 : base;
+          rs->lane = l == 63 ? 0 : l + 1;
+          rs->best_index = best_index; rs->n_cost = n_cost; rs->n_feasible = n_feasible; rs->n_velocity = n_velocity; rs->n_free = n_free;
+          rs->n_pyr = nPyr; rs->best_cost = bestCost;
+        }
+        return;
+      }
     }
-    if (b.flags && has) b.flags[i * b.n_candidates + c] = (uint8_t)my_result;
+    if (b.flags && has && lane >= first_lane) b.flags[i * b.n_candidates + c] = (uint8_t)my_result;
   }
   if (lane == 0) {
+    if (rs) rs->done = 1;
     out->found = best_index >= 0;
     out->best_index = best_index;
     out->best_cost = bestCost;
@@ -1355,7 +1378,36 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   const int64_t n_cand = b.n * b.n_candidates;
   hipLaunchKernelGGL(afe_rappids_candidates_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      cfg, b);
-  hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, b);
+  // Rounds with doubling budgets (PlannerBatch::Resume) -- built to even out a launch that lasts as long as its longest
+  // planner, measured, and OFF by default: rounds make the long planners wait for every round's queue of short ones
+  // (65 536 cluttered planners: 210 ms in one launch, 245 ms in rounds of 1, 2, ... 32 ms, 218 ms in rounds of 4 and
+  // 16 ms; profiles/r03_planner_rounds.txt).  What the tail needs is the long planners STARTED first, i.e. a predictor of
+  // a planner's length, or parallelism inside one planner.  The interruptible search stays (exact by construction,
+  // tests/test_gpu_planner.py::test_search_in_budgeted_rounds_is_the_uninterrupted_search) for a host that time-slices
+  // planning against other work: AFE_PLANNER_ROUNDS_FROM=<planners> switches it on from that batch size.
+  PlannerBatch bb = b;
+  int64_t rounds_from = INT64_MAX;
+  if (const char *env = std::getenv("AFE_PLANNER_ROUNDS_FROM")) rounds_from = std::strtoll(env, nullptr, 10);
+  if (!b.resume || b.n <= rounds_from) {
+    bb.resume = nullptr; bb.budget_ticks = 0; bb.round = 0;
+    hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
+  } else {
+    unsigned budgets_us[16] = {1000, 2000, 4000, 8000, 16000, 32000};
+    int n_rounds = 6;
+    if (const char *env = std::getenv("AFE_PLANNER_ROUNDS_US")) {     // measurement aid: "500,1000,..." (a last unlimited round is always added)
+      n_rounds = 0;
+      for (const char *q = env; *q && n_rounds < 16;) {
+        budgets_us[n_rounds++] = (unsigned)std::strtoul(q, nullptr, 10);
+        while (*q && *q != ',') q++;
+        if (*q == ',') q++;
+      }
+    }
+    for (int r = 0; r <= n_rounds; r++) {
+      bb.round = r;
+      bb.budget_ticks = r < n_rounds ? budgets_us[r] * 100u : 0u;
+      hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
+    }
+  }
 #ifdef AFE_PLANNER_PROFILE
   unsigned long long prof[24];
   (void)hipDeviceSynchronize();

@@ -62,7 +62,7 @@ struct ScratchSlot {
   size_t cap = 0;
 };
 std::mutex g_scratch_mutex;
-ScratchSlot g_scratch[16];
+ScratchSlot g_scratch[17];
 int g_scratch_device = -1;
 
 void release_scratch_locked() {
@@ -140,7 +140,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   if (g_scratch_device != device) { release_scratch_locked(); (void)hipSetDevice(device); g_scratch_device = device; }
   const size_t px = (size_t)cfg->width * cfg->height;
   DevBuf d_img(0), d_imgT(1), d_cc(2), d_cb(3), d_cs(4), d_idx(5), d_v(6), d_a(7), d_g(8), d_c(9), d_s(10), d_t(11), d_pyr(12), d_out(13),
-      d_flags(14);
+      d_flags(14), d_resume(15);
   if ((!depth_on_device && !d_img.upload(depth_images, (size_t)n_images * px * 2)) || !d_v.upload(vel0, (size_t)n * 24) ||
       !d_a.upload(acc0, (size_t)n * 24) || !d_g.upload(grav, (size_t)n * 24) ||
       !d_s.upload(samples, (size_t)n_tables * n_candidates * 32))
@@ -153,6 +153,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
       !d_cb.alloc((size_t)n * n_candidates) || !d_cs.alloc((size_t)n * n_candidates * sizeof(CandSections)))
     return AFE_ERR_HIP;
   if (flags && !d_flags.alloc((size_t)n * n_candidates)) return AFE_ERR_HIP;
+  if (!d_resume.alloc((size_t)n * sizeof(PlannerBatch::Resume))) return AFE_ERR_HIP;
 
   PlannerBatch b;
   b.n = n;
@@ -172,6 +173,9 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   b.max_pyramids = cfg->max_pyramids;
   b.out = (PlanOutput *)d_out.p;
   b.flags = flags ? (uint8_t *)d_flags.p : nullptr;
+  b.resume = (PlannerBatch::Resume *)d_resume.p;
+  b.budget_ticks = 0;
+  b.round = 0;
 
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return AFE_ERR_HIP;

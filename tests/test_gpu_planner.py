@@ -59,6 +59,53 @@ def test_planner_matches_oracle_varied_states_and_images(ora):
     assert max(r[0].n_pyramids for r in refs) >= 3
 
 
+def test_search_in_budgeted_rounds_is_the_uninterrupted_search():
+    """Big batches are searched in rounds (launch_rappids: every unfinished planner works for a budget, writes down the
+    sequential loop's variables and leaves its slot; budgets double).  Forced here on a small batch with budgets of
+    20 .. 320 us -- most planners are interrupted several times, anywhere in their candidate list: outputs, every
+    candidate's flags and all counters must be those of one uninterrupted launch, bit for bit.  Child processes (the
+    hooks are environment variables read by the library)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+afa = importlib.import_module("agri-fly_amd")
+rng = np.random.default_rng(17)
+n, m, n_img = 1500, 256, 24
+scene = afa.Scene(afa.scenarios.orchard_mesh(rows=8, cols=8, seed=3))
+cam = afa.camera_default(320, 240)
+pos = np.stack([rng.uniform(-3, 25, n_img), rng.uniform(-3, 30, n_img), rng.uniform(0.8, 2.5, n_img)])
+yaw = rng.uniform(-np.pi, np.pi, n_img)
+att = np.stack([np.cos(yaw / 2), 0 * yaw, 0 * yaw, np.sin(yaw / 2)])
+images, _ = scene.render(cam, pos, att, afa.camera_default_mount())
+images = np.asarray(images).reshape(n_img, 240, 320)
+cfg = afa.planner_default_config(320, 240, 10.0 / 256.0, 160.0, 0.116, 0.174, 0.5)
+cfg.max_pyramids = 64
+idx = rng.integers(0, n_img, n).astype(np.int32)
+vel0 = np.stack([rng.normal(0, 0.4, n), rng.normal(0, 0.2, n), rng.uniform(0, 2.0, n)])
+acc0 = rng.normal(0, 0.3, (3, n))
+grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n))
+out, flags, ms = afa.rappids_plan(cfg, images, vel0, acc0, grav, afa.planner_samples(0, 320, 240, m), image_index=idx, want_flags=True)
+np.save(sys.argv[1], np.concatenate([np.frombuffer(bytes(out), np.uint8), flags.ravel()]))
+print(np.mean([o.n_pyramids for o in out]), np.mean([o.found for o in out]))
+""" % root
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        res = []
+        for name, env in (("whole", {}), ("rounds", {"AFE_PLANNER_ROUNDS_FROM": "0", "AFE_PLANNER_ROUNDS_US": "20,40,80,160,320"}),
+                          ("one tiny round", {"AFE_PLANNER_ROUNDS_FROM": "0", "AFE_PLANNER_ROUNDS_US": "5"})):
+            path = os.path.join(d, name.replace(" ", "_") + ".npy")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res.append(np.load(path))
+        pyr, found = [float(x) for x in r.stdout.split()]
+        assert pyr > 3 and 0.2 < found < 1.0            # cluttered enough to make the planners work
+        assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+
+
 def test_planner_exploration_cost_and_per_vehicle_directions(ora):
     rng = np.random.default_rng(8)
     n, m = 40, 200
