@@ -55,6 +55,12 @@ struct PlannerBatch {
   Resume *resume;                // [n] or null (one uninterrupted launch)
   uint32_t budget_ticks;         // 0: no limit
   int32_t round;                 // 0: first round (nothing to resume)
+  // Longest first (launch_rappids): a planner interrupted in the sizing round files itself under how many collision
+  // checks it may still have to make; the finishing round starts the planners bin by bin, most work first.
+  enum { kBins = 8 };
+  int32_t *bin_count;            // [kBins] (zeroed before the sizing round) or null
+  int32_t *bin_list;             // [kBins][n]
+  int32_t ordered;               // this launch takes its planner from the bins: block j = the j-th planner in bin order
 };
 
 int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream);

@@ -1221,7 +1221,18 @@ __global__ void __launch_bounds__(256) afe_rappids_candidates_kernel(const Plann
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFE_PLANNER_WAVES, AFE_PLANNER_WAVES)))
 afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
 #pragma clang fp contract(off)
-  const int64_t i = blockIdx.x;      // one wave per planner
+  int64_t i = blockIdx.x;            // one wave per planner
+  if (b.ordered) {                   // the finishing round: most remaining work first
+    int64_t j = blockIdx.x;
+    int k = 0;
+    for (; k < PlannerBatch::kBins; k++) {
+      const int64_t cnt = b.bin_count[k];
+      if (j < cnt) break;
+      j -= cnt;
+    }
+    if (k == PlannerBatch::kBins) return;
+    i = b.bin_list[(int64_t)k * b.n + j];
+  }
 #ifdef AFE_PLANNER_PROFILE
   if (threadIdx.x < 24) s_mine[threadIdx.x] = 0;
   __syncthreads();
@@ -1306,6 +1317,22 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
       // out of budget for this round: everything up to candidate base + l is settled; write it down and leave
       if (b.budget_ticks && __builtin_amdgcn_s_memrealtime() - t_begin > (unsigned long long)b.budget_ticks) {
         if (b.flags && has && lane >= first_lane && lane <= l) b.flags[i * b.n_candidates + c] = (uint8_t)my_result;
+        if (b.bin_count) {
+          // what may still lie ahead: candidates behind this one that are admissible and cheaper than the best so far
+          // (each costs a collision check unless a better one is found first) -- the planner's place in the finishing round
+          int est = 0;
+          for (int b2 = base; b2 < b.n_candidates; b2 += 64) {
+            const int c2 = b2 + lane;
+            const bool ahead = c2 < b.n_candidates && c2 > base + l &&
+                               (cand_bits[c2] & (CAND_INPUT_FEASIBLE | CAND_VELOCITY_OK)) == (CAND_INPUT_FEASIBLE | CAND_VELOCITY_OK) && cand_cost[c2] < bestCost;
+            est += __popcll(__ballot(ahead));
+          }
+          if (lane == 0) {
+            const int bin = est >= 160 ? 0 : est >= 96 ? 1 : est >= 48 ? 2 : est >= 24 ? 3 : est >= 12 ? 4 : est >= 6 ? 5 : est >= 1 ? 6 : 7;
+            const int at = atomicAdd(b.bin_count + bin, 1);
+            b.bin_list[(int64_t)bin * b.n + at] = (int32_t)i;
+          }
+        }
         if (lane == 0) {
           rs->done = 0;
           rs->base = l == 63 ? base + 64 : base;
@@ -1378,20 +1405,36 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   const int64_t n_cand = b.n * b.n_candidates;
   hipLaunchKernelGGL(afe_rappids_candidates_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      cfg, b);
-  // Rounds with doubling budgets (PlannerBatch::Resume) -- built to even out a launch that lasts as long as its longest
-  // planner, measured, and OFF by default: rounds make the long planners wait for every round's queue of short ones
-  // (65 536 cluttered planners: 210 ms in one launch, 245 ms in rounds of 1, 2, ... 32 ms, 218 ms in rounds of 4 and
-  // 16 ms; profiles/r03_planner_rounds.txt).  What the tail needs is the long planners STARTED first, i.e. a predictor of
-  // a planner's length, or parallelism inside one planner.  The interruptible search stays (exact by construction,
-  // tests/test_gpu_planner.py::test_search_in_budgeted_rounds_is_the_uninterrupted_search) for a host that time-slices
-  // planning against other work: AFE_PLANNER_ROUNDS_FROM=<planners> switches it on from that batch size.
+  // A launch lasts as long as its longest planner, and planners differ by two orders of magnitude.  Two uses of the
+  // interruptible search (PlannerBatch::Resume; exact by construction,
+  // tests/test_gpu_planner.py::test_search_in_budgeted_rounds_is_the_uninterrupted_search) against that tail were
+  // built and measured on 65 536 planners (profiles/r03_planner_rounds.txt, r03_planner_lpt.txt):
+  //   * rounds with doubling budgets: SLOWER than one launch (cluttered orchard views 245 against 210 ms) -- the long
+  //     planners wait for every round's queue of short ones.  Off; AFE_PLANNER_ROUNDS_FROM=<planners> switches it on
+  //     (a host that time-slices planning against other work).
+  //   * longest first (below): 210 -> 152 ms on the cluttered views, 50.6 -> 29 ms on the config-3 shape.
   PlannerBatch bb = b;
+  bb.ordered = 0;
   int64_t rounds_from = INT64_MAX;
   if (const char *env = std::getenv("AFE_PLANNER_ROUNDS_FROM")) rounds_from = std::strtoll(env, nullptr, 10);
-  if (!b.resume || b.n <= rounds_from) {
-    bb.resume = nullptr; bb.budget_ticks = 0; bb.round = 0;
+  // Longest first: a short sizing round (every planner works for at most `sizing` microseconds; most finish), then ONE
+  // finishing round that starts the interrupted planners in the order of the work they may still have -- the launch
+  // then ends when the work runs out, not when a long planner that happened to start late does.
+  int64_t lpt_from = 16384;           // beyond four times what the chip holds at once (4 096 waves); measured: profiles/r03_planner_lpt.txt
+  unsigned sizing_us = 400;
+  if (const char *env = std::getenv("AFE_PLANNER_LPT_FROM")) lpt_from = std::strtoll(env, nullptr, 10);
+  if (const char *env = std::getenv("AFE_PLANNER_SIZING_US")) sizing_us = (unsigned)std::strtoul(env, nullptr, 10);
+  if (b.resume && b.bin_count && b.n > lpt_from && b.n <= rounds_from) {
+    (void)hipMemsetAsync(b.bin_count, 0, PlannerBatch::kBins * sizeof(int32_t), (hipStream_t)stream);
+    bb.round = 0; bb.budget_ticks = sizing_us * 100u;
+    hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
+    bb.round = 1; bb.budget_ticks = 0; bb.ordered = 1;
+    hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
+  } else if (!b.resume || b.n <= rounds_from) {
+    bb.resume = nullptr; bb.budget_ticks = 0; bb.round = 0; bb.bin_count = nullptr;
     hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
   } else {
+    bb.bin_count = nullptr;
     unsigned budgets_us[16] = {1000, 2000, 4000, 8000, 16000, 32000};
     int n_rounds = 6;
     if (const char *env = std::getenv("AFE_PLANNER_ROUNDS_US")) {     // measurement aid: "500,1000,..." (a last unlimited round is always added)

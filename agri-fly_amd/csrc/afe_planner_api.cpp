@@ -62,7 +62,7 @@ struct ScratchSlot {
   size_t cap = 0;
 };
 std::mutex g_scratch_mutex;
-ScratchSlot g_scratch[17];
+ScratchSlot g_scratch[18];
 int g_scratch_device = -1;
 
 void release_scratch_locked() {
@@ -140,7 +140,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   if (g_scratch_device != device) { release_scratch_locked(); (void)hipSetDevice(device); g_scratch_device = device; }
   const size_t px = (size_t)cfg->width * cfg->height;
   DevBuf d_img(0), d_imgT(1), d_cc(2), d_cb(3), d_cs(4), d_idx(5), d_v(6), d_a(7), d_g(8), d_c(9), d_s(10), d_t(11), d_pyr(12), d_out(13),
-      d_flags(14), d_resume(15);
+      d_flags(14), d_resume(15), d_bins(16);
   if ((!depth_on_device && !d_img.upload(depth_images, (size_t)n_images * px * 2)) || !d_v.upload(vel0, (size_t)n * 24) ||
       !d_a.upload(acc0, (size_t)n * 24) || !d_g.upload(grav, (size_t)n * 24) ||
       !d_s.upload(samples, (size_t)n_tables * n_candidates * 32))
@@ -154,6 +154,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
     return AFE_ERR_HIP;
   if (flags && !d_flags.alloc((size_t)n * n_candidates)) return AFE_ERR_HIP;
   if (!d_resume.alloc((size_t)n * sizeof(PlannerBatch::Resume))) return AFE_ERR_HIP;
+  if (!d_bins.alloc(((size_t)n * PlannerBatch::kBins + 64) * sizeof(int32_t))) return AFE_ERR_HIP;
 
   PlannerBatch b;
   b.n = n;
@@ -176,6 +177,9 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   b.resume = (PlannerBatch::Resume *)d_resume.p;
   b.budget_ticks = 0;
   b.round = 0;
+  b.bin_count = (int32_t *)d_bins.p;
+  b.bin_list = (int32_t *)d_bins.p + 64;
+  b.ordered = 0;
 
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return AFE_ERR_HIP;

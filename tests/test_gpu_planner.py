@@ -60,11 +60,13 @@ def test_planner_matches_oracle_varied_states_and_images(ora):
 
 
 def test_search_in_budgeted_rounds_is_the_uninterrupted_search():
-    """Big batches are searched in rounds (launch_rappids: every unfinished planner works for a budget, writes down the
-    sequential loop's variables and leaves its slot; budgets double).  Forced here on a small batch with budgets of
-    20 .. 320 us -- most planners are interrupted several times, anywhere in their candidate list: outputs, every
-    candidate's flags and all counters must be those of one uninterrupted launch, bit for bit.  Child processes (the
-    hooks are environment variables read by the library)."""
+    """The search is interruptible (launch_rappids: a planner works for a budget, writes down the sequential loop's
+    variables and leaves its slot; a later launch picks it up).  Big batches use it to start their longest planners
+    first -- a short sizing round, then one finishing round in the order of the work still ahead.  Forced here on a
+    small batch, with budgets of 5 .. 400 us and with rounds of doubling budgets: most planners are interrupted, some
+    several times, anywhere in their candidate list, and resumed in another order -- outputs, every candidate's flags
+    and all counters must be those of one uninterrupted launch, bit for bit.  Child processes (the hooks are
+    environment variables read by the library)."""
     import os
     import subprocess
     import sys
@@ -96,14 +98,16 @@ print(np.mean([o.n_pyramids for o in out]), np.mean([o.found for o in out]))
     with tempfile.TemporaryDirectory() as d:
         res = []
         for name, env in (("whole", {}), ("rounds", {"AFE_PLANNER_ROUNDS_FROM": "0", "AFE_PLANNER_ROUNDS_US": "20,40,80,160,320"}),
-                          ("one tiny round", {"AFE_PLANNER_ROUNDS_FROM": "0", "AFE_PLANNER_ROUNDS_US": "5"})):
+                          ("one tiny round", {"AFE_PLANNER_ROUNDS_FROM": "0", "AFE_PLANNER_ROUNDS_US": "5"}),
+                          ("longest first", {"AFE_PLANNER_LPT_FROM": "0", "AFE_PLANNER_SIZING_US": "30"}),
+                          ("longest first, default sizing", {"AFE_PLANNER_LPT_FROM": "0"})):
             path = os.path.join(d, name.replace(" ", "_") + ".npy")
             r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             res.append(np.load(path))
         pyr, found = [float(x) for x in r.stdout.split()]
         assert pyr > 3 and 0.2 < found < 1.0            # cluttered enough to make the planners work
-        assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+        assert all(np.array_equal(res[0], r) for r in res[1:])
 
 
 def test_planner_exploration_cost_and_per_vehicle_directions(ora):
