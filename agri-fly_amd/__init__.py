@@ -20,6 +20,7 @@ from .engine import (  # noqa: F401
     AFE_STEP_AUTO,
     AFE_STEP_LAUNCH,
     AFE_STEP_PERSISTENT,
+    AFE_STEP_RESIDENT,
     AfeError,
     Camera,
     Comm,

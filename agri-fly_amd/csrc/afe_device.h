@@ -92,6 +92,7 @@ struct StepView {
 
 struct LaunchFlags {
   bool ext_force, ext_torque, noise, logic;
+  bool resident = false;        // persistent grid only: AFE_STEP_RESIDENT (fused batches, loads shared)
   bool counter_noise = false;   // noise from the counter-based generator (AFE_SEED_COUNTER) instead of the per-vehicle libstdc++ stream
   // heterogeneous ensemble whose type index is constant over every aligned run of 64 vehicles (fleets
   // laid out type by type): each wave then reads its one record by scalar loads -- no LDS table

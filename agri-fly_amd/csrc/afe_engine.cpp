@@ -445,6 +445,7 @@ LaunchFlags persist_flags(const afe_engine *e) {
   LaunchFlags f;
   f.ext_force = e->has_ext_force; f.ext_torque = false; f.noise = e->noise; f.logic = e->logic_on;
   f.counter_noise = e->seed_policy == AFE_SEED_COUNTER;
+  f.resident = e->step_mode == AFE_STEP_RESIDENT;
   return f;
 }
 
@@ -1079,7 +1080,7 @@ extern "C" int afe_get_external_force(afe_engine *e, int64_t first, int64_t coun
 }
 
 extern "C" int afe_set_step_mode(afe_engine *e, int mode) {
-  if (!e || mode < AFE_STEP_LAUNCH || mode > AFE_STEP_AUTO) return fail(e, AFE_ERR_INVALID_ARG, "step mode: 0 (launches), 1 (persistent) or 2 (automatic)");
+  if (!e || mode < AFE_STEP_LAUNCH || mode > AFE_STEP_RESIDENT) return fail(e, AFE_ERR_INVALID_ARG, "step mode: 0 (launches), 1 (persistent), 2 (automatic) or 3 (resident state)");
   AFE_HIP(e, hipSetDevice(e->device));
   const int rc = persist_park(e);
   if (rc) return rc;

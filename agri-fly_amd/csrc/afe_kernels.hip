@@ -548,7 +548,7 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
   else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), r, (int)voff, (int)soff, 0);
 }
 
-template <typename R, bool FEXT, bool TEXT, int NOISE, bool LOGIC, bool SINGLE, bool BUF>
+template <typename R, bool FEXT, bool TEXT, int NOISE, bool LOGIC, bool SINGLE, bool BUF, bool EACH = false>
 __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParams<R> &P, const DevLogic &G,
                                             const int64_t i, const unsigned long long tick_mask, const int n_steps_arg, const uint64_t tick_ordinal0) {
   // No implicit FMA contraction: every rounding is the one the source spells
@@ -808,6 +808,23 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
         for (int m = 0; m < 4; m++) { cmd[m] = (R)cmd_new[m]; if (cmd[m] < 0) cmd[m] = 0; }
       }
     }
+    // EACH (the resident grid's fused batches, AFE_STEP_RESIDENT): every sub-step's state goes to memory as it is made
+    // -- the step stays observable --, only the loads are shared by the batch.  The last sub-step is written below.
+    if (EACH && step + 1 < n_steps) {
+      AFE_ST(R, v.pos, 0, off, px); AFE_ST(R, v.pos, 1, off, py); AFE_ST(R, v.pos, 2, off, pz);
+      AFE_ST(R, v.vel, 0, off, vx); AFE_ST(R, v.vel, 1, off, vy); AFE_ST(R, v.vel, 2, off, vz);
+      AFE_ST(R, v.att, 0, off, q0); AFE_ST(R, v.att, 1, off, q1); AFE_ST(R, v.att, 2, off, q2); AFE_ST(R, v.att, 3, off, q3);
+      AFE_ST(R, v.ang_vel, 0, off, wx); AFE_ST(R, v.ang_vel, 1, off, wy); AFE_ST(R, v.ang_vel, 2, off, wz);
+      if (v.motor_write) { AFE_ST(R, v.motor, 0, off, ms[0]); AFE_ST(R, v.motor, 1, off, ms[1]); AFE_ST(R, v.motor, 2, off, ms[2]); AFE_ST(R, v.motor, 3, off, ms[3]); }
+      if (tick) {
+        AFE_ST(float, v.gyro, 0, off4, gx); AFE_ST(float, v.gyro, 1, off4, gy); AFE_ST(float, v.gyro, 2, off4, gz);
+        AFE_ST(float, v.acc, 0, off4, ax_m); AFE_ST(float, v.acc, 1, off4, ay_m); AFE_ST(float, v.acc, 2, off4, az_m);
+        if (LOGIC) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) AFE_ST(float, v.cmd_out, m, off4, cmd_new[m]);
+        }
+      }
+    }
   }
 
   // ---- write back (in place: same lines this lane just read) ----
@@ -982,7 +999,7 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
   }
 }
 
-template <typename R, bool FEXT, int NOISE, bool LOGIC>
+template <typename R, bool FEXT, int NOISE, bool LOGIC, bool RESIDENT>
 __global__ void __launch_bounds__(64)
 afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G, const PersistArgs a) {
   if (blockIdx.x == 0) { persist_pump(a); return; }
@@ -1019,7 +1036,43 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
     const u64_t low = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
     const u64_t ticks = __ballot(ready && (e & AFE_PERSIST_TICK)) & low;
     const u64_t parks = __ballot(ready && (e & AFE_PERSIST_PARK)) & low;
-    const int run = parks ? (int)__builtin_ctzll(parks) : cnt;             // steps in front of the park entry
+    int run = parks ? (int)__builtin_ctzll(parks) : cnt;                   // steps in front of the park entry
+    if (RESIDENT) {
+      // AFE_STEP_RESIDENT: every step already authorised is taken in ONE pass per chunk -- inputs loaded once, the state
+      // in registers from step to step, each step's state stored as it is made.  (The gust force is an input: a batch
+      // ends where the next gust epoch begins.)
+      if (a.gust_period_us && run > 0) {
+        while (t_us >= gust_next_us) { gust_epoch++; gust_next_us += a.gust_period_us; }
+        const u64_t left = (gust_next_us - t_us + a.dt_us - 1) / a.dt_us;  // steps that start inside this epoch (>= 1)
+        if ((u64_t)run > left) run = (int)left;
+        if (gust_epoch != gust_in_slab) {
+          for (int c = w; c < a.n_chunks; c += a.n_workers) {
+            const int64_t i = (int64_t)c * 64 + lane;
+            if (i < v.n) {
+              R f[3];
+              gust_force<R>(a.gust_seed, (uint64_t)(v.first_global + i), a.gust_n_global, gust_epoch, a.gust_sigma_max, f);
+              R *slab = const_cast<R *>(v.ext_force);
+              slab[i] = f[0]; slab[v.stride + i] = f[1]; slab[2 * v.stride + i] = f[2];
+            }
+          }
+          gust_in_slab = gust_epoch;
+        }
+        t_us += (u64_t)run * a.dt_us;
+      }
+      if (run > 0) {
+        const u64_t batch_ticks = ticks & (run == 64 ? ~0ull : ((1ull << run) - 1));
+        for (int c = w; c < a.n_chunks; c += a.n_workers) {
+          const int64_t i = (int64_t)c * 64 + lane;
+          if (i < v.n) run_vehicle<R, FEXT, false, NOISE, LOGIC, false, true, true>(v, P, G, i, batch_ticks, run, tick_no);
+        }
+        tick_no += (u64_t)__popcll(batch_ticks);
+      }
+      s += (u64_t)run;
+      if (lane == 0) st_agent(a.done + w, s);
+      if (parks && run == (int)__builtin_ctzll(parks)) return;             // everything in front of the park entry is done
+      t_wait = ticks100();
+      continue;
+    }
     for (int k = 0; k < run; k++) {
       const u64_t tick = (ticks >> k) & 1ull;                              // wave-uniform (scalar)
       if (a.gust_period_us) {
@@ -1081,21 +1134,23 @@ static int launch_persistent(const StepView<R> &v, const LaunchFlags &f, const D
   DevLogic no_logic = {};
   const DevLogic &G = uniform_logic ? *uniform_logic : no_logic;
   const dim3 grid((unsigned)(1 + a.n_workers)), block(64);
-#define AFE_PL(FE, NO, LO)                                                                                              \
+#define AFE_PL_R(FE, NO, LO, RE)                                                                                        \
   do {                                                                                                                  \
     if (occupancy) {                                                                                                    \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, afe_step_persistent_kernel<R, FE, NO, LO>, 64, 0) != hipSuccess) \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, afe_step_persistent_kernel<R, FE, NO, LO, RE>, 64, 0) != hipSuccess) \
         *occupancy = 0;                                                                                                 \
     } else {                                                                                                            \
-      hipLaunchKernelGGL((afe_step_persistent_kernel<R, FE, NO, LO>), grid, block, 0, st, v, uniform, G, a);            \
+      hipLaunchKernelGGL((afe_step_persistent_kernel<R, FE, NO, LO, RE>), grid, block, 0, st, v, uniform, G, a);        \
     }                                                                                                                   \
   } while (0)
+#define AFE_PL(FE, NO, LO) do { if (f.resident) AFE_PL_R(FE, NO, LO, true); else AFE_PL_R(FE, NO, LO, false); } while (0)
 #define AFE_PL_LO(FE, NO) do { if (f.logic) AFE_PL(FE, NO, true); else AFE_PL(FE, NO, false); } while (0)
 #define AFE_PL_NO(FE) do { if (!f.noise) AFE_PL_LO(FE, 0); else if (f.counter_noise) AFE_PL_LO(FE, 2); else AFE_PL_LO(FE, 1); } while (0)
   if (f.ext_force) AFE_PL_NO(true); else AFE_PL_NO(false);
 #undef AFE_PL_NO
 #undef AFE_PL_LO
 #undef AFE_PL
+#undef AFE_PL_R
   return (int)hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ _LIB = os.environ.get("AGRIFLY_ENGINE_LIB") or os.path.join(_HERE, "lib", "libag
 
 AFE_F32, AFE_F64 = 0, 1
 AFE_SEED_REFERENCE, AFE_SEED_DECORRELATED, AFE_SEED_COUNTER = 0, 1, 2
-AFE_STEP_LAUNCH, AFE_STEP_PERSISTENT, AFE_STEP_AUTO = 0, 1, 2
+AFE_STEP_LAUNCH, AFE_STEP_PERSISTENT, AFE_STEP_AUTO, AFE_STEP_RESIDENT = 0, 1, 2, 3
 
 # every symbol include/agrifly_engine.h declares (checked by tests/test_abi.py)
 ABI_FUNCTIONS = [

@@ -83,8 +83,8 @@ def uses_persistent(afa, mode, n):
 def time_steps(e, steps, per_launch, sync, barrier):
     """wall time of `steps` physics steps issued as afe_step calls of `per_launch` steps each, bracketed by
     barrier + synchronise on both sides (e.sync() first: it ends a resident grid after the last authorised step)"""
+    e.sync()          # no resident grid while the ranks meet (the collective's kernel wants CUs too)
     barrier()
-    e.sync()
     sync()
     t0 = time.perf_counter()
     done = 0
@@ -206,6 +206,18 @@ def companion_rows(afa, n_local, device, sync, barrier, split=False):
                                        "algorithmic_bytes_per_vehicle_step": bytes_step, "frac": n_local * bytes_step / (t / k) / 1e9 / HBM_PEAK_GBS,
                                        "stepping": "persistent" if uses_persistent(afa, None, n_local) else "launches",
                                        "note": "IMU noise from per-vehicle libstdc++-exact streams (seed 1 + global index) instead of the counter-based generator"}
+    e.close()
+    # the resident grid taking the steps that are already authorised together (AFE_STEP_RESIDENT): inputs once per batch,
+    # state in registers from step to step, every step's state stored as it is made
+    e = build_shard(afa, n_local, 0, n_local, device)
+    e.set_step_mode(afa.AFE_STEP_RESIDENT)
+    time_steps(e, 100, 1, sync, barrier)
+    k = 2000
+    t = median([time_steps(e, k, 1, sync, barrier) for _ in range(3)])
+    rows["resident_state"] = {"value": n_local * k / t, "unit": "vehicle-steps/s", "us_per_step": t / k * 1e6,
+                              "stored_bytes_per_vehicle_step": 52 + 12, "stored_GBs": n_local * 64 / (t / k) / 1e9,
+                              "note": "afe_set_step_mode(AFE_STEP_RESIDENT): bitwise the headline's trajectory; each step's state still lands in memory (52 B + "
+                                      "24 B of IMU sample every 2nd step), but is not read back between the steps a host has authorised ahead of the device"}
     e.close()
     e = build_shard(afa, n_local, 0, n_local, device, precision=afa.AFE_F64)      # stepping: automatic, like the headline
     time_steps(e, 50, 1, sync, barrier)

@@ -500,6 +500,13 @@ int afe_get_external_force(afe_engine *e, int64_t first, int64_t count, double *
 #define AFE_STEP_LAUNCH 0
 #define AFE_STEP_PERSISTENT 1
 #define AFE_STEP_AUTO 2
+/*   mode = AFE_STEP_RESIDENT (3): the resident grid with the steps that are ALREADY authorised taken together: a wave
+ *     that finds k steps waiting loads its vehicles' inputs once, keeps the state in registers from step to step and
+ *     stores each step's state as it is made -- every step still lands in memory (a host that authorises one step at a
+ *     time and watches afe_steps_completed sees exactly the persistent mode), but a host that runs ahead pays for the
+ *     stores only (~64 instead of ~143 bytes per vehicle-step).  Same bits.  Not what bench.py's headline measures
+ *     (that one reads the state back every step); reported beside it. */
+#define AFE_STEP_RESIDENT 3
 int afe_set_step_mode(afe_engine *e, int mode);
 int afe_steps_completed(afe_engine *e, uint64_t *steps);
 /* 1 while a resident grid is on the device, 0 otherwise (diagnostic; tests use it) */

@@ -148,7 +148,9 @@ def test_samples_do_not_depend_on_how_the_ensemble_is_stepped_or_sharded(precisi
     plan_fused = [(1000, 7), (1000, 64), (1000, 29), (1000, 160)]
     ref = roll(make(0, n, afa.AFE_STEP_LAUNCH), plan_single)
     for name, mode, plan in (("fused launches", afa.AFE_STEP_LAUNCH, plan_fused), ("resident grid, one call", afa.AFE_STEP_PERSISTENT, [(1000, 260)]),
-                             ("resident grid, step by step", afa.AFE_STEP_PERSISTENT, plan_single)):
+                             ("resident grid, step by step", afa.AFE_STEP_PERSISTENT, plan_single),
+                             ("resident state, one call", afa.AFE_STEP_RESIDENT, [(1000, 260)]),
+                             ("resident state, bursts", afa.AFE_STEP_RESIDENT, [(1000, 3), (1000, 100), (1000, 1), (1000, 156)])):
         got = roll(make(0, n, mode), plan)
         for k in ref:
             assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)

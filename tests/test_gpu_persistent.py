@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def make(n, precision, persistent, logic=False, seed=5, wrench=True):
+def make(n, precision, persistent, logic=False, seed=5, wrench=True, resident=False):
     ens = random_ensemble(n, seed=seed, with_wrench=wrench, type_ids=(5,))
     d = ens.data
     e = afa.Ensemble(n, precision=precision)
@@ -39,7 +39,7 @@ def make(n, precision, persistent, logic=False, seed=5, wrench=True):
         rng = np.random.default_rng(3)
         e.set_rates_commands(np.full(n, 9.5, np.float32), (0.2 * rng.standard_normal((3, n))).astype(np.float32))
     e.set_split_stepping(1)
-    e.set_step_mode(afa.AFE_STEP_PERSISTENT if persistent else afa.AFE_STEP_LAUNCH)
+    e.set_step_mode((afa.AFE_STEP_RESIDENT if resident else afa.AFE_STEP_PERSISTENT) if persistent else afa.AFE_STEP_LAUNCH)
     return e, d
 
 
@@ -57,10 +57,11 @@ def assert_same(a, b, what=""):
 
 @pytest.mark.parametrize("precision", [afa.AFE_F32, afa.AFE_F64])
 @pytest.mark.parametrize("logic", [False, True])
-def test_persistent_steps_are_bitwise_the_launched_steps(precision, logic):
+@pytest.mark.parametrize("resident", [False, True])
+def test_persistent_steps_are_bitwise_the_launched_steps(precision, logic, resident):
     n = 70001                      # 1 094 chunks, the last one ragged
     a, d = make(n, precision, False, logic)
-    b, _ = make(n, precision, True, logic)
+    b, _ = make(n, precision, True, logic, resident=resident)
     script = ([("step", 1000, 1)] * 6 + [("get",), ("step", 1000, 9), ("cmd",), ("step", 500, 3), ("step", 1000, 1), ("force",),
               ("step", 1000, 40), ("launch",), ("step", 1000, 3), ("persistent",), ("step", 2000, 7), ("noise_off",), ("step", 1000, 4),
               ("noise_on",), ("step", 1000, 5), ("get",)])
@@ -78,7 +79,7 @@ def test_persistent_steps_are_bitwise_the_launched_steps(precision, logic):
             elif op[0] == "launch" and e is b:
                 e.set_step_mode(afa.AFE_STEP_LAUNCH)
             elif op[0] == "persistent" and e is b:
-                e.set_step_mode(afa.AFE_STEP_PERSISTENT)
+                e.set_step_mode(afa.AFE_STEP_RESIDENT if resident else afa.AFE_STEP_PERSISTENT)
             elif op[0] == "noise_off":
                 e.set_imu_noise(False, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
             elif op[0] == "noise_on":

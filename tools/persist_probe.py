@@ -11,7 +11,7 @@ sizes = [int(x) for x in sys.argv[1:]] or [4096, 65536, 131072, 262144, 524288, 
 for n in sizes:
     steps = 4000 if n <= (1 << 18) else 2000
     row = {}
-    for name, mode, parts in (("launch", afa.AFE_STEP_LAUNCH, 1), ("split", afa.AFE_STEP_LAUNCH, 2), ("persistent", afa.AFE_STEP_PERSISTENT, 1)):
+    for name, mode, parts in (("launch", afa.AFE_STEP_LAUNCH, 1), ("split", afa.AFE_STEP_LAUNCH, 2), ("persistent", afa.AFE_STEP_PERSISTENT, 1), ("resident", afa.AFE_STEP_RESIDENT, 1)):
         e = bench.build_shard(afa, n, 0, n, 0)
         e.set_split_stepping(parts)
         e.set_step_mode(mode)
