@@ -190,8 +190,7 @@ def companion_rows(afa, n_local, device, sync, barrier, split=False):
                                   "kernel_us": t_launch * 1e6, "algorithmic_bytes_per_launch_per_vehicle": b,
                                   "achieved_GBs": n_local * b / t_launch / 1e9, "frac": n_local * b / t_launch / 1e9 / HBM_PEAK_GBS,
                                   "note": "bitwise the same trajectory as the headline (tests/test_gpu_parity.py::"
-                                          "test_fused_steps_equal_single_steps_bitwise); VALU-bound on the six libstdc++-exact "
-                                          "Gaussian draws, not on HBM"}
+                                          "test_fused_steps_equal_single_steps_bitwise); launched kernels (AFE_STEP_LAUNCH), two streams from 2^19 vehicles up"}
     e.destroy_event(ev0)
     e.destroy_event(ev1)
     e.close()
