@@ -56,7 +56,7 @@ def counter_per_launch(dirname):
 
 
 summary = {"build": note, "tag": tag, "script": "tools/profile_r03.sh %s %d" % (tag, N), "vehicles": N,
-           "kernel": "afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=1, LOGIC=0> (one launch per synchronised block of steps)"}
+           "kernel": "afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=2 (counter), LOGIC=0, RESIDENT=0> (one launch per synchronised block of steps)"}
 for src, dst in (("prof_%s" % tag, "%s_kernel_stats.csv" % tag), ("prof_k20_%s" % tag, "%s_k20_kernel_stats.csv" % tag),
                  ("prof_full_%s" % tag, "%s_full_kernel_stats.csv" % tag)):
     f = one(src + "/**/*_kernel_stats.csv")
