@@ -177,3 +177,57 @@ def test_ineligible_ensembles_fall_back_to_launches():
     assert_same(*engines)
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_host_behaviour_against_the_launches(seed):
+    """a host doing random things -- bursts of steps of random length and step size, pauses around the grid's patience
+    (so that it parks itself while entries may be arriving), getters, setters, configuration and mode changes, the
+    completion word, checkpoints -- on a launched engine and on a resident-grid engine side by side: whenever the state
+    is read it must be the same bits."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([3000, 20011, 140000]))
+    a, d = make(n, afa.AFE_F32, False, logic=bool(seed % 2))
+    b, _ = make(n, afa.AFE_F32, True, logic=bool(seed % 2), resident=bool(seed == 3))
+    issued = 0
+    blob = None
+    for op in range(160):
+        what = rng.choice(["step", "step", "step", "burst", "pause", "get", "cmd", "noise", "gust", "mode", "completed", "save", "load"])
+        if what == "step":
+            dt, k = int(rng.choice([1000, 1000, 500, 2000])), int(rng.integers(1, 40))
+            a.step(dt, k); b.step(dt, k); issued += k
+        elif what == "burst":
+            k = int(rng.integers(1, 400))
+            for _ in range(k):
+                b.step(1000, 1)
+            a.step(1000, k); issued += k
+        elif what == "pause":
+            time.sleep(float(rng.choice([0.00005, 0.0002, 0.0004, 0.002])))
+        elif what == "get":
+            assert_same(a, b, (seed, op))
+        elif what == "cmd":
+            for e in (a, b):
+                if seed % 2:
+                    e.set_rates_commands(np.full(n, 9.0 + op * 0.01, np.float32), np.zeros((3, n), np.float32))
+                else:
+                    e.set_motor_cmds(np.clip(d.motor_cmd * (1 + 0.001 * op), 0, None))
+        elif what == "noise":
+            pol = int(rng.choice([afa.AFE_SEED_DECORRELATED, afa.AFE_SEED_COUNTER]))
+            on = bool(rng.integers(0, 4))
+            for e in (a, b):
+                e.set_imu_noise(on, 0.1, 0.2, pol)
+        elif what == "gust":
+            on, per = bool(rng.integers(0, 2)), int(rng.choice([7000, 30000, 100000]))
+            for e in (a, b):
+                e.set_gust_process(on, seed=5, sigma_max=0.3, period_us=per)
+        elif what == "mode":
+            b.set_step_mode(int(rng.choice([afa.AFE_STEP_PERSISTENT, afa.AFE_STEP_RESIDENT, afa.AFE_STEP_AUTO, afa.AFE_STEP_LAUNCH])))
+        elif what == "completed":
+            assert b.steps_completed <= issued == a.steps_completed
+        elif what == "save":
+            blob = b.save_checkpoint()
+            blob_a = a.save_checkpoint()
+        elif what == "load" and blob is not None:
+            b.load_checkpoint(blob); a.load_checkpoint(blob_a)
+    assert_same(a, b, (seed, "end"))
+    a.close(); b.close()
