@@ -413,7 +413,7 @@ int persist_alloc(afe_engine *e) {
   AFE_HIP(e, hipHostMalloc((void **)&e->p_host, hbytes, hipHostMallocCoherent | hipHostMallocMapped));
   std::memset(e->p_host, 0, hbytes);
   AFE_HIP(e, hipHostGetDevicePointer((void **)&e->p_host_dev, e->p_host, 0));
-  const size_t dbytes = ((size_t)AFE_PERSIST_DEV_RING + (size_t)(chunks < most ? chunks : most)) * sizeof(unsigned long long);
+  const size_t dbytes = ((size_t)AFE_PERSIST_DEV_RING + (size_t)(chunks < most ? chunks : most) + 8) * sizeof(unsigned long long);   // + the workers' call-for-help word behind done[]
   AFE_HIP(e, hipMalloc((void **)&e->p_dev, dbytes));
   AFE_HIP(e, hipMemsetAsync(e->p_dev, 0, dbytes, e->stream));
   return AFE_OK;

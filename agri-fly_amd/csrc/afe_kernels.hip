@@ -946,6 +946,8 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
   u64_t park_pos;
   u64_t err = 0;
   u64_t m = a.start;                    // every worker has consumed at least this much (a lower bound: done[] only grows)
+  u64_t *const help = a.done + a.n_workers;   // a worker that has waited far too long asks for a park here (below)
+  if (lane == 0) st_agent(help, 0);
   u64_t acc = ~0ull;                    // this lane's minimum over the part of done[] swept so far in the current cycle
   int sw = 0;                           // where the next partial sweep starts
   for (;;) {
@@ -985,7 +987,7 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
     m_seen = m;
     // (3) nobody feeds us: park at p.  Slot p is free: p < min_done + ring by (2).
     const bool idle = now - t_fed > (u64_t)a.idle_ticks;
-    const bool gave_up = now - t_moving > (u64_t)a.give_up_ticks;   // entries waiting and the workers never made room
+    const bool gave_up = now - t_moving > (u64_t)a.give_up_ticks || ld_agent(help) != 0;   // entries waiting and the workers never made room, or a worker starved
     if (idle || gave_up) {
       if (lane == 0) st_agent(a.dev_ring + (p & a.dev_mask), entry_stamp(((p + 1) << 2) | AFE_PERSIST_PARK, a.epoch));
       park_pos = p;
@@ -1019,7 +1021,13 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
     const bool ready = entry_index(e) == idx + 1 && (!(e & AFE_PERSIST_PARK) || (unsigned)(e >> 48) == (a.epoch & 0xffffu));
     const int cnt = ones_from_bit0(__ballot(ready));
     if (cnt == 0) {
-      if (ticks100() - t_wait > (u64_t)a.give_up_ticks + 50000000ull) {   // the pump gives up first and parks us; this is the last resort
+      // Starved for half a second (the pump parks an idle grid after 200 us, so this is not a quiet host: the pump is
+      // not getting through, or part of the grid is not resident beside somebody else's kernels): ask the pump to park
+      // EVERYBODY at one step -- nothing is torn, the host starts a smaller grid -- and only after ten more seconds
+      // without an answer leave alone, with the error that says so.
+      const u64_t waited = ticks100() - t_wait;
+      if (waited > (u64_t)a.give_up_ticks + 50000000ull && lane == 0) st_agent(a.done + a.n_workers, 1);
+      if (waited > (u64_t)a.give_up_ticks + 1050000000ull) {
         if (lane == 0) st_system(a.host_status + 2, 2);
         return;
       }
