@@ -682,6 +682,10 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
   if (launch_seed_rng(e->rng, e->n, e->first_global, e->seed_policy, main_stream(e)) != 0)
     return bail("seed kernel launch (is the gfx950 code object present?)", hipGetLastError());
   if ((err = hipStreamSynchronize(main_stream(e))) != hipSuccess) return bail("seed kernel", err);
+  if (const char *fm = std::getenv("AFE_FORCE_STEP_MODE")) {   // test hook: every engine of this process steps by the resident grid where it can (1 persistent, 3 resident state)
+    const int m = std::atoi(fm);
+    if (m >= AFE_STEP_LAUNCH && m <= AFE_STEP_RESIDENT) e->step_mode = m;
+  }
   if (std::getenv("AFE_FORCE_SPLIT")) {   // test hook: every engine of this process steps split (tests/: the whole GPU suite runs this way once)
     const int src = afe_set_split_stepping(e, 2);
     if (src) { afe_destroy(e); return src; }

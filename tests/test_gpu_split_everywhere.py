@@ -26,3 +26,21 @@ def test_the_suite_does_not_notice_split_stepping():
     tail = "\n".join(out.stdout.strip().split("\n")[-15:])
     assert out.returncode == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
+
+
+@pytest.mark.parametrize("mode", ["1", "3"])
+def test_the_suite_does_not_notice_the_resident_grid(mode):
+    """the same argument for afe_set_step_mode: with AFE_FORCE_STEP_MODE every engine of a process starts in
+    AFE_STEP_PERSISTENT (1) or AFE_STEP_RESIDENT (3) -- homogeneous ensembles on the engine's own stream are then stepped
+    by the resident grid, which every other entry point has to park -- and the files that lean hardest on ordering,
+    plus the parity files, must not notice (the whole suite passes this way: AFE_FORCE_STEP_MODE=1 pytest -m gpu)."""
+    if os.environ.get("AFE_FORCE_STEP_MODE") or os.environ.get("AFE_FORCE_SPLIT"):
+        pytest.skip("already inside a forced run")
+    files = ["tests/test_gpu_logic.py", "tests/test_gpu_facade.py", "tests/test_gpu_sharedworld.py", "tests/test_gpu_config01.py",
+             "tests/test_gpu_orchard_flight.py", "tests/test_gpu_headless.py", "tests/test_gpu_parity.py"]
+    env = dict(os.environ, AFE_FORCE_STEP_MODE=mode)
+    out = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + files, cwd=ROOT, env=env,
+                         capture_output=True, text=True)
+    tail = "\n".join(out.stdout.strip().split("\n")[-15:])
+    assert out.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
