@@ -350,6 +350,26 @@ struct Shrink {
 // one cross-lane ordering this file relied on implicitly -- and with the helpers inlined again the campaign
 // still fails (plan 79 of 640: one candidate reported collision-free that is not).  So the barriers stay
 // because they are right, and `noinline` stays because it is needed.
+// Round 3 (tools/planner_inline_probe.sh, one helper force-inlined at a time): only side_scan's inlining breaks the
+// campaign, and only at the kernel's 128-VGPR budget -- the same source is correct at 168 or 256 VGPRs
+// (amdgpu_waves_per_eu 3 / 2).  The failing build is the one where the scans' wave-uniform state lives across vector
+// spills inside inflate_pyramid's divergent regions (planner section).
+// (each helper's attribute is a macro so that a build can inline them one at a time: tools/planner_inline_probe.sh)
+#ifndef AFE_NI_MASK
+#define AFE_NI_MASK __attribute__((noinline))
+#endif
+#ifndef AFE_NI_RING
+#define AFE_NI_RING __attribute__((noinline))
+#endif
+#ifndef AFE_NI_SIDE
+#define AFE_NI_SIDE __attribute__((noinline))
+#endif
+#ifndef AFE_NI_CORNER
+#define AFE_NI_CORNER __attribute__((noinline))
+#endif
+#ifndef AFE_NI_INFLATE
+#define AFE_NI_INFLATE __attribute__((noinline))
+#endif
 // ---- wave-cooperative pixel scans ------------------------------------------------
 // One wave runs one planner: everything outside the scans below is computed redundantly
 // (and therefore convergently) by all 64 lanes; inside a scan lane l looks at pixel
@@ -409,7 +429,7 @@ __device__ __forceinline__ unsigned range_bits8(const uint4 q, unsigned lo1, uns
 // WANT_MIN: also return the smallest marked depth (65535 if none) -- the shrink scans stop where
 // even that depth could not reach an edge any more
 template <bool WANT_MIN>
-__device__ __attribute__((noinline)) int build_mask(const uint16_t *__restrict__ img, int W, int H, int lane, uint64_t *mask, int WW, uint16_t lo,
+__device__ AFE_NI_MASK int build_mask(const uint16_t *__restrict__ img, int W, int H, int lane, uint64_t *mask, int WW, uint16_t lo,
                           uint16_t hi) {
   int lane_min = 65535;
   // The bit image is written by one set of lanes and read by others.  The block is a single wave,
@@ -534,7 +554,7 @@ __device__ __forceinline__ bool mask_bit(const uint64_t *mask, int WW, int x, in
 // advancing.  The first ring in which a free side meets a marked pixel is therefore the smallest
 // ring distance of any marked pixel inside the window the free sides can still reach; all rings
 // before it are clear and can be taken in one step.  Returns that ring index (>= 1) or INT_MAX.
-__device__ __attribute__((noinline)) int first_blocking_ring(const uint64_t *mask, int WW, int lane, int xlo, int xhi, int ylo, int yhi, int L,
+__device__ AFE_NI_RING int first_blocking_ring(const uint64_t *mask, int WW, int lane, int xlo, int xhi, int ylo, int yhi, int L,
                                    int R, int T, int B) {
   const int wa = xlo >> 6, nw = (xhi >> 6) - wa + 1, total = nw * (yhi - ylo + 1);
   const unsigned magic = div_magic(nw);
@@ -587,7 +607,7 @@ enum { SIDE_RIGHT = 0, SIDE_LEFT = 1, SIDE_TOP = 2, SIDE_BOTTOM = 3 };
 constexpr int kScanBatch = 4;
 
 template <int SIDE>
-__device__ __attribute__((noinline)) bool side_scan(const uint16_t *__restrict__ src, int sx, int sy, const uint64_t *mask, int WW, int lane,
+__device__ AFE_NI_SIDE bool side_scan(const uint16_t *__restrict__ src, int sx, int sy, const uint64_t *mask, int WW, int lane,
                           int total, int inner, int xa, int ya, int dxo, int dyo, int dxi, int dyi, int num, int buf,
                           int x0, int y0, int dmin, Shrink &s) {
   const unsigned magic = div_magic(inner);
@@ -702,7 +722,7 @@ enum { CORNER_TR = 0, CORNER_BR = 1, CORNER_TL = 2, CORNER_BL = 3 };
 // One of the four corner scans, DIP.cpp:794-940: rows outward from the top / bottom edge,
 // pixels outward from the right / left edge.
 template <int CORNER>
-__device__ __attribute__((noinline)) bool corner_scan(const uint16_t *__restrict__ img, int W, const uint64_t *mask, int WW, int lane, int rows,
+__device__ AFE_NI_CORNER bool corner_scan(const uint16_t *__restrict__ img, int W, const uint64_t *mask, int WW, int lane, int rows,
                             int inner, int xa, int ya, int num, int buf, int x0, int y0, int dmin, Shrink &s) {
   constexpr bool RIGHT = (CORNER == CORNER_TR || CORNER == CORNER_BR);
   constexpr bool TOP = (CORNER == CORNER_TR || CORNER == CORNER_TL);
@@ -780,7 +800,7 @@ __device__ __attribute__((noinline)) bool corner_scan(const uint16_t *__restrict
 }
 
 // DIP.cpp:456-970, executed by one wave (lane = 0..63, everything but the scans is uniform)
-__device__ __attribute__((noinline)) bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restrict__ img,
+__device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restrict__ img,
                                 const uint16_t *__restrict__ imgT, uint64_t *mask, int lane, int x0, int y0,
                                 double minimumDepth, PlannerPyramid &out) {
 #pragma clang fp contract(off)
