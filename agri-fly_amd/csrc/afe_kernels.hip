@@ -571,47 +571,69 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   // (built unconditionally: without BUF nothing uses them and they fold away)
   const __amdgpu_buffer_rsrc_t rs_main = __builtin_amdgcn_make_buffer_rsrc((void *)v.pos, 0, (int)v.buf_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_logic = __builtin_amdgcn_make_buffer_rsrc((void *)v.lpf, 0, (int)v.logic_buf_bytes, 0x00020000);
-#define AFE_SOFF(first, base, comp) ((uint32_t)(reinterpret_cast<const char *>((base) + (comp) * S) - reinterpret_cast<const char *>(first)))
-#define AFE_LD(T, base, comp, o) (BUF ? buf_ld<T>(rs_main, (o), AFE_SOFF(v.pos, base, comp)) \
-                                      : *reinterpret_cast<const T *>(reinterpret_cast<const char *>((base) + (comp) * S) + (o)))
-#define AFE_ST(T, base, comp, o, val) do { if (BUF) buf_st<T>(rs_main, (o), AFE_SOFF(v.pos, base, comp), (val)); \
-                                           else *reinterpret_cast<T *>(reinterpret_cast<char *>((base) + (comp) * S) + (o)) = (val); } while (0)
-#define AFE_LDL(T, base, comp, o) (BUF ? buf_ld<T>(rs_logic, (o), AFE_SOFF(v.lpf, base, comp)) \
-                                       : *reinterpret_cast<const T *>(reinterpret_cast<const char *>((base) + (comp) * S) + (o)))
-#define AFE_STL(T, base, comp, o, val) do { if (BUF) buf_st<T>(rs_logic, (o), AFE_SOFF(v.lpf, base, comp), (val)); \
-                                            else *reinterpret_cast<T *>(reinterpret_cast<char *>((base) + (comp) * S) + (o)) = (val); } while (0)
+  // A slab component's byte offset inside its arena is (its position in the arena's fixed order) x (one component's
+  // bytes): a compile-time constant times SE or S4, formed by the scalar ALU where it is used.  (It used to be
+  // the difference of two slab pointers -- ten pointer pairs and two dozen offsets that wanted scalar registers of
+  // their own for the whole body; inside the resident grid's loop that pushed the kernel over the scalar register file
+  // and a sixth of the body's vector instructions were v_readlane / v_writelane spill traffic.)  Arena order
+  // (afe_create): pos 3, vel 3, att 4, ang_vel 3, motor 4, ext_force 3, ext_torque 3 components of R; then cmd 4, gyro 3,
+  // acc 3, rng 1 of four bytes.  Logic arena (afe_set_rates_logic): lpf 12, rates_cmd 4 floats.
+  uint32_t SE = (uint32_t)S * (uint32_t)sizeof(R), S4 = (uint32_t)S * 4u;
+  asm volatile("" : "+s"(SE), "+s"(S4));     // opaque here: the products below are formed at their uses, not hoisted out of a caller's loop
+#define AFE_OFF_pos(c) ((uint32_t)(0 + (c)) * SE)
+#define AFE_OFF_vel(c) ((uint32_t)(3 + (c)) * SE)
+#define AFE_OFF_att(c) ((uint32_t)(6 + (c)) * SE)
+#define AFE_OFF_ang_vel(c) ((uint32_t)(10 + (c)) * SE)
+#define AFE_OFF_motor(c) ((uint32_t)(13 + (c)) * SE)
+#define AFE_OFF_ext_force(c) ((uint32_t)(17 + (c)) * SE)
+#define AFE_OFF_ext_torque(c) ((uint32_t)(20 + (c)) * SE)
+#define AFE_OFF_cmd(c) (23u * SE + (uint32_t)(0 + (c)) * S4)
+#define AFE_OFF_cmd_out(c) AFE_OFF_cmd(c)
+#define AFE_OFF_gyro(c) (23u * SE + (uint32_t)(4 + (c)) * S4)
+#define AFE_OFF_acc(c) (23u * SE + (uint32_t)(7 + (c)) * S4)
+#define AFE_OFF_rng(c) (23u * SE + (uint32_t)(10 + (c)) * S4)
+#define AFE_OFF_lpf(c) ((uint32_t)(c) * S4)
+#define AFE_OFF_rates_cmd(c) ((uint32_t)(12 + (c)) * S4)
+#define AFE_LD(T, name, comp, o) (BUF ? buf_ld<T>(rs_main, (o), AFE_OFF_##name(comp)) \
+                                      : *reinterpret_cast<const T *>(reinterpret_cast<const char *>((v.name) + (comp) * S) + (o)))
+#define AFE_ST(T, name, comp, o, val) do { if (BUF) buf_st<T>(rs_main, (o), AFE_OFF_##name(comp), (val)); \
+                                           else *reinterpret_cast<T *>(reinterpret_cast<char *>((v.name) + (comp) * S) + (o)) = (val); } while (0)
+#define AFE_LDL(T, name, comp, o) (BUF ? buf_ld<T>(rs_logic, (o), AFE_OFF_##name(comp)) \
+                                       : *reinterpret_cast<const T *>(reinterpret_cast<const char *>((v.name) + (comp) * S) + (o)))
+#define AFE_STL(T, name, comp, o, val) do { if (BUF) buf_st<T>(rs_logic, (o), AFE_OFF_##name(comp), (val)); \
+                                            else *reinterpret_cast<T *>(reinterpret_cast<char *>((v.name) + (comp) * S) + (o)) = (val); } while (0)
 
   // ---- issue every load up front (independent, coalesced) ----
   // The engine word goes first: loads return in order, so the Gaussian draws of
   // this launch's first logic tick (which need nothing else) run while the ~24
   // state loads behind it are still in flight.
   uint32_t rng = 0;
-  if (NOISE == 1 && tick_mask) rng = AFE_LD(uint32_t, v.rng, 0, off4);
+  if (NOISE == 1 && tick_mask) rng = AFE_LD(uint32_t, rng, 0, off4);
   uint64_t tick_ordinal = tick_ordinal0;   // NOISE == 2: the logic-tick number addresses the sample (wave-uniform)
-  R px = AFE_LD(R, v.pos, 0, off), py = AFE_LD(R, v.pos, 1, off), pz = AFE_LD(R, v.pos, 2, off);
-  R vx = AFE_LD(R, v.vel, 0, off), vy = AFE_LD(R, v.vel, 1, off), vz = AFE_LD(R, v.vel, 2, off);
-  R q0 = AFE_LD(R, v.att, 0, off), q1 = AFE_LD(R, v.att, 1, off), q2 = AFE_LD(R, v.att, 2, off), q3 = AFE_LD(R, v.att, 3, off);
-  R wx = AFE_LD(R, v.ang_vel, 0, off), wy = AFE_LD(R, v.ang_vel, 1, off), wz = AFE_LD(R, v.ang_vel, 2, off);
+  R px = AFE_LD(R, pos, 0, off), py = AFE_LD(R, pos, 1, off), pz = AFE_LD(R, pos, 2, off);
+  R vx = AFE_LD(R, vel, 0, off), vy = AFE_LD(R, vel, 1, off), vz = AFE_LD(R, vel, 2, off);
+  R q0 = AFE_LD(R, att, 0, off), q1 = AFE_LD(R, att, 1, off), q2 = AFE_LD(R, att, 2, off), q3 = AFE_LD(R, att, 3, off);
+  R wx = AFE_LD(R, ang_vel, 0, off), wy = AFE_LD(R, ang_vel, 1, off), wz = AFE_LD(R, ang_vel, 2, off);
   R ms[4] = {0, 0, 0, 0};
   if (!v.motor_stateless) {  // wave-uniform: with c_lag == 0 and J_m == 0 the old speed only ever meets a zero factor
-    ms[0] = AFE_LD(R, v.motor, 0, off); ms[1] = AFE_LD(R, v.motor, 1, off);
-    ms[2] = AFE_LD(R, v.motor, 2, off); ms[3] = AFE_LD(R, v.motor, 3, off);
+    ms[0] = AFE_LD(R, motor, 0, off); ms[1] = AFE_LD(R, motor, 1, off);
+    ms[2] = AFE_LD(R, motor, 2, off); ms[3] = AFE_LD(R, motor, 3, off);
   }
-  const float cmd_f[4] = {AFE_LD(float, v.cmd, 0, off4), AFE_LD(float, v.cmd, 1, off4), AFE_LD(float, v.cmd, 2, off4), AFE_LD(float, v.cmd, 3, off4)};
+  const float cmd_f[4] = {AFE_LD(float, cmd, 0, off4), AFE_LD(float, cmd, 1, off4), AFE_LD(float, cmd, 2, off4), AFE_LD(float, cmd, 3, off4)};
   R fex = 0, fey = 0, fez = 0, tex = 0, tey = 0, tez = 0;
-  if (FEXT) { fex = AFE_LD(R, v.ext_force, 0, off); fey = AFE_LD(R, v.ext_force, 1, off); fez = AFE_LD(R, v.ext_force, 2, off); }
-  if (TEXT) { tex = AFE_LD(R, v.ext_torque, 0, off); tey = AFE_LD(R, v.ext_torque, 1, off); tez = AFE_LD(R, v.ext_torque, 2, off); }
+  if (FEXT) { fex = AFE_LD(R, ext_force, 0, off); fey = AFE_LD(R, ext_force, 1, off); fez = AFE_LD(R, ext_force, 2, off); }
+  if (TEXT) { tex = AFE_LD(R, ext_torque, 0, off); tey = AFE_LD(R, ext_torque, 1, off); tez = AFE_LD(R, ext_torque, 2, off); }
   LogicRegs lg;
 #define AFE_LOAD_LOGIC_STATE()                                        \
   do {                                                                \
     _Pragma("unroll") for (int k = 0; k < 3; k++) {                   \
-      lg.xm0[k] = AFE_LDL(float, v.lpf, k, off4);                     \
-      lg.xm1[k] = AFE_LDL(float, v.lpf, 3 + k, off4);                 \
-      lg.ym0[k] = AFE_LDL(float, v.lpf, 6 + k, off4);                 \
-      lg.ym1[k] = AFE_LDL(float, v.lpf, 9 + k, off4);                 \
-      lg.wdes[k] = AFE_LDL(float, v.rates_cmd, 1 + k, off4);          \
+      lg.xm0[k] = AFE_LDL(float, lpf, k, off4);                     \
+      lg.xm1[k] = AFE_LDL(float, lpf, 3 + k, off4);                 \
+      lg.ym0[k] = AFE_LDL(float, lpf, 6 + k, off4);                 \
+      lg.ym1[k] = AFE_LDL(float, lpf, 9 + k, off4);                 \
+      lg.wdes[k] = AFE_LDL(float, rates_cmd, 1 + k, off4);          \
     }                                                                 \
-    lg.thrust_norm = AFE_LDL(float, v.rates_cmd, 0, off4);            \
+    lg.thrust_norm = AFE_LDL(float, rates_cmd, 0, off4);            \
     lg.imu_init = v.imu_init[(uint32_t)i];                            \
     lg.have_cmd = v.have_cmd[(uint32_t)i];                            \
   } while (0)
@@ -776,10 +798,10 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     // The one-step logic launch writes the rigid-body state back as soon as it is final instead of at the end:
     // the registers are then free for the logic's own state (AFE_LOGIC_LOADS_LATE).
     if (LOGIC && SINGLE && AFE_LOGIC_LOADS_LATE) {
-      AFE_ST(R, v.pos, 0, off, px); AFE_ST(R, v.pos, 1, off, py); AFE_ST(R, v.pos, 2, off, pz);
-      AFE_ST(R, v.vel, 0, off, vx); AFE_ST(R, v.vel, 1, off, vy); AFE_ST(R, v.vel, 2, off, vz);
-      AFE_ST(R, v.att, 0, off, q0); AFE_ST(R, v.att, 1, off, q1); AFE_ST(R, v.att, 2, off, q2); AFE_ST(R, v.att, 3, off, q3);
-      AFE_ST(R, v.ang_vel, 0, off, wx); AFE_ST(R, v.ang_vel, 1, off, wy); AFE_ST(R, v.ang_vel, 2, off, wz);
+      AFE_ST(R, pos, 0, off, px); AFE_ST(R, pos, 1, off, py); AFE_ST(R, pos, 2, off, pz);
+      AFE_ST(R, vel, 0, off, vx); AFE_ST(R, vel, 1, off, vy); AFE_ST(R, vel, 2, off, vz);
+      AFE_ST(R, att, 0, off, q0); AFE_ST(R, att, 1, off, q1); AFE_ST(R, att, 2, off, q2); AFE_ST(R, att, 3, off, q3);
+      AFE_ST(R, ang_vel, 0, off, wx); AFE_ST(R, ang_vel, 1, off, wy); AFE_ST(R, ang_vel, 2, off, wz);
     }
     // ---- onboard-logic gate fired on this sub-step: IMU synthesis ----
     if (tick) {
@@ -811,17 +833,17 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     // EACH (the resident grid's fused batches, AFE_STEP_RESIDENT): every sub-step's state goes to memory as it is made
     // -- the step stays observable --, only the loads are shared by the batch.  The last sub-step is written below.
     if (EACH && step + 1 < n_steps) {
-      AFE_ST(R, v.pos, 0, off, px); AFE_ST(R, v.pos, 1, off, py); AFE_ST(R, v.pos, 2, off, pz);
-      AFE_ST(R, v.vel, 0, off, vx); AFE_ST(R, v.vel, 1, off, vy); AFE_ST(R, v.vel, 2, off, vz);
-      AFE_ST(R, v.att, 0, off, q0); AFE_ST(R, v.att, 1, off, q1); AFE_ST(R, v.att, 2, off, q2); AFE_ST(R, v.att, 3, off, q3);
-      AFE_ST(R, v.ang_vel, 0, off, wx); AFE_ST(R, v.ang_vel, 1, off, wy); AFE_ST(R, v.ang_vel, 2, off, wz);
-      if (v.motor_write) { AFE_ST(R, v.motor, 0, off, ms[0]); AFE_ST(R, v.motor, 1, off, ms[1]); AFE_ST(R, v.motor, 2, off, ms[2]); AFE_ST(R, v.motor, 3, off, ms[3]); }
+      AFE_ST(R, pos, 0, off, px); AFE_ST(R, pos, 1, off, py); AFE_ST(R, pos, 2, off, pz);
+      AFE_ST(R, vel, 0, off, vx); AFE_ST(R, vel, 1, off, vy); AFE_ST(R, vel, 2, off, vz);
+      AFE_ST(R, att, 0, off, q0); AFE_ST(R, att, 1, off, q1); AFE_ST(R, att, 2, off, q2); AFE_ST(R, att, 3, off, q3);
+      AFE_ST(R, ang_vel, 0, off, wx); AFE_ST(R, ang_vel, 1, off, wy); AFE_ST(R, ang_vel, 2, off, wz);
+      if (v.motor_write) { AFE_ST(R, motor, 0, off, ms[0]); AFE_ST(R, motor, 1, off, ms[1]); AFE_ST(R, motor, 2, off, ms[2]); AFE_ST(R, motor, 3, off, ms[3]); }
       if (tick) {
-        AFE_ST(float, v.gyro, 0, off4, gx); AFE_ST(float, v.gyro, 1, off4, gy); AFE_ST(float, v.gyro, 2, off4, gz);
-        AFE_ST(float, v.acc, 0, off4, ax_m); AFE_ST(float, v.acc, 1, off4, ay_m); AFE_ST(float, v.acc, 2, off4, az_m);
+        AFE_ST(float, gyro, 0, off4, gx); AFE_ST(float, gyro, 1, off4, gy); AFE_ST(float, gyro, 2, off4, gz);
+        AFE_ST(float, acc, 0, off4, ax_m); AFE_ST(float, acc, 1, off4, ay_m); AFE_ST(float, acc, 2, off4, az_m);
         if (LOGIC) {
 #pragma unroll
-          for (int m = 0; m < 4; m++) AFE_ST(float, v.cmd_out, m, off4, cmd_new[m]);
+          for (int m = 0; m < 4; m++) AFE_ST(float, cmd_out, m, off4, cmd_new[m]);
         }
       }
     }
@@ -829,29 +851,29 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 
   // ---- write back (in place: same lines this lane just read) ----
   if (!(LOGIC && SINGLE && AFE_LOGIC_LOADS_LATE)) {
-    AFE_ST(R, v.pos, 0, off, px); AFE_ST(R, v.pos, 1, off, py); AFE_ST(R, v.pos, 2, off, pz);
-    AFE_ST(R, v.vel, 0, off, vx); AFE_ST(R, v.vel, 1, off, vy); AFE_ST(R, v.vel, 2, off, vz);
-    AFE_ST(R, v.att, 0, off, q0); AFE_ST(R, v.att, 1, off, q1); AFE_ST(R, v.att, 2, off, q2); AFE_ST(R, v.att, 3, off, q3);
-    AFE_ST(R, v.ang_vel, 0, off, wx); AFE_ST(R, v.ang_vel, 1, off, wy); AFE_ST(R, v.ang_vel, 2, off, wz);
+    AFE_ST(R, pos, 0, off, px); AFE_ST(R, pos, 1, off, py); AFE_ST(R, pos, 2, off, pz);
+    AFE_ST(R, vel, 0, off, vx); AFE_ST(R, vel, 1, off, vy); AFE_ST(R, vel, 2, off, vz);
+    AFE_ST(R, att, 0, off, q0); AFE_ST(R, att, 1, off, q1); AFE_ST(R, att, 2, off, q2); AFE_ST(R, att, 3, off, q3);
+    AFE_ST(R, ang_vel, 0, off, wx); AFE_ST(R, ang_vel, 1, off, wy); AFE_ST(R, ang_vel, 2, off, wz);
   }
   if (v.motor_write) {  // wave-uniform; off for stateless motors driven by held commands (see afe_motor_from_cmd_kernel)
-    AFE_ST(R, v.motor, 0, off, ms[0]); AFE_ST(R, v.motor, 1, off, ms[1]); AFE_ST(R, v.motor, 2, off, ms[2]); AFE_ST(R, v.motor, 3, off, ms[3]);
+    AFE_ST(R, motor, 0, off, ms[0]); AFE_ST(R, motor, 1, off, ms[1]); AFE_ST(R, motor, 2, off, ms[2]); AFE_ST(R, motor, 3, off, ms[3]);
   }
   if (have_imu) {
-    AFE_ST(float, v.gyro, 0, off4, gx); AFE_ST(float, v.gyro, 1, off4, gy); AFE_ST(float, v.gyro, 2, off4, gz);
-    AFE_ST(float, v.acc, 0, off4, ax_m); AFE_ST(float, v.acc, 1, off4, ay_m); AFE_ST(float, v.acc, 2, off4, az_m);
-    if (NOISE == 1) AFE_ST(uint32_t, v.rng, 0, off4, rng);
+    AFE_ST(float, gyro, 0, off4, gx); AFE_ST(float, gyro, 1, off4, gy); AFE_ST(float, gyro, 2, off4, gz);
+    AFE_ST(float, acc, 0, off4, ax_m); AFE_ST(float, acc, 1, off4, ay_m); AFE_ST(float, acc, 2, off4, az_m);
+    if (NOISE == 1) AFE_ST(uint32_t, rng, 0, off4, rng);
     if (LOGIC) {
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        AFE_STL(float, v.lpf, k, off4, lg.xm0[k]);
-        AFE_STL(float, v.lpf, 3 + k, off4, lg.xm1[k]);
-        AFE_STL(float, v.lpf, 6 + k, off4, lg.ym0[k]);
-        AFE_STL(float, v.lpf, 9 + k, off4, lg.ym1[k]);
+        AFE_STL(float, lpf, k, off4, lg.xm0[k]);
+        AFE_STL(float, lpf, 3 + k, off4, lg.xm1[k]);
+        AFE_STL(float, lpf, 6 + k, off4, lg.ym0[k]);
+        AFE_STL(float, lpf, 9 + k, off4, lg.ym1[k]);
       }
       v.imu_init[(uint32_t)i] = lg.imu_init;
 #pragma unroll
-      for (int m = 0; m < 4; m++) AFE_ST(float, v.cmd_out, m, off4, cmd_new[m]);
+      for (int m = 0; m < 4; m++) AFE_ST(float, cmd_out, m, off4, cmd_new[m]);
     }
   }
 #undef AFE_LD
@@ -859,7 +881,6 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #undef AFE_LDL
 #undef AFE_LOAD_LOGIC_STATE
 #undef AFE_STL
-#undef AFE_SOFF
 }
 
 #ifndef AFE_LB_WAVES
