@@ -120,7 +120,10 @@ int main(int argc, char **argv) {
   double const timeDelayOffboardControlLoopTrue = 0.03;   // :178
 
   afe_engine *quad = 0;
-  die(0, afe_create(&quad, nVehicles, precision, -1, 0), "afe_create");
+  // the offboard loop below visits the ensemble every few steps (mocap at 200 Hz, commands at 100 Hz, the log every step):
+  // small ensembles keep their state in host-visible memory, so that those visits are host copies beside a resident grid
+  if (nVehicles <= 4096) die(0, afe_create_host_visible(&quad, nVehicles, precision, -1, 0), "afe_create_host_visible");
+  else die(0, afe_create(&quad, nVehicles, precision, -1, 0), "afe_create");
   die(quad, afe_set_type_table(quad, &vehConsts, 1), "afe_set_type_table");
   die(quad, afe_set_logic_period(quad, periodOnboardLogic), "afe_set_logic_period");
   die(quad, afe_set_imu_noise(quad, 1, 0.1, 0.2, seeds), "afe_set_imu_noise");       // Quadcopter_T.cpp:5-6

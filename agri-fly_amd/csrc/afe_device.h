@@ -121,12 +121,13 @@ struct PersistArgs {
   int n_chunks;                          // aligned runs of 64 vehicles; worker w steps chunks w, w + n_workers, ...
   unsigned int idle_ticks;               // 100 MHz ticks (s_memrealtime)
   unsigned int give_up_ticks;
-  unsigned int epoch;                    // launch counter (stamps the device ring's entries)
+  unsigned int epoch;                    // bits 0-15: launch counter (stamps the device ring's entries); AFE_PERSIST_HOST_IO: the arena is host memory
   // gust process (afe_set_gust_process; gust_period_us == 0: off).  A step's start time is t0_us + (its index - start) * dt_us;
   // its epoch floor(time / period) is tracked incrementally from gust_epoch0 = epoch of t0_us.
   unsigned long long gust_period_us, gust_seed, gust_n_global, gust_epoch0, gust_epoch_applied, t0_us, dt_us;
   double gust_sigma_max;
 };
+#define AFE_PERSIST_HOST_IO 0x10000u   /* PersistArgs::epoch */
 #define AFE_PERSIST_TICK 1ull
 #define AFE_PERSIST_PARK 2ull
 #define AFE_PERSIST_HOST_RING 4096

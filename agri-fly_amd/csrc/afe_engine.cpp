@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,13 @@ struct afe_engine {
   float *cmd = nullptr, *gyro = nullptr, *acc = nullptr;
   uint32_t *rng = nullptr;
   uint8_t *type = nullptr;
+  // afe_create_host_visible: the arena lives in pinned, coherent host memory that the device addresses over the bus;
+  // getters and setters are plain host copies once the authorised steps are done (no transfer call, no parked grid)
+  bool host_arena = false;
+  char *arena_host = nullptr;   // the arena as the host addresses it
+  char *logic_arena_host = nullptr;
+  size_t logic_arena_alloc = 0;
+  bool stream_pending = false;  // something may be queued on the stream since the last synchronisation
   double *anchor = nullptr;   // [2][stride]: where each vehicle's x, y were last set; the pos slab holds x, y RELATIVE to it (fp32 engine)
   void *dev_table = nullptr;  // n_types DevParams<R>
   std::vector<DevParams<float>> table_f32;   // host copies of the device table
@@ -117,6 +125,7 @@ namespace {
 void join_streams(afe_engine *e);
 hipStream_t main_stream(afe_engine *e);
 int persist_park(afe_engine *e);
+int quiesce(afe_engine *e);
 int gust_resample(afe_engine *e, uint64_t epoch);
 }  // namespace
 
@@ -146,8 +155,28 @@ int check_range(afe_engine *e, int64_t first, int64_t count) {
 }
 
 // host planar [comps][count] <-> device planar [comps][stride] at offset first
+inline bool in_span(const void *p, const void *base, size_t bytes) { return base && (const char *)p >= (const char *)base && (const char *)p < (const char *)base + bytes; }
+inline bool in_host_arena(const afe_engine *e, const void *dev) {
+  return e->host_arena && (in_span(dev, e->arena, e->arena_bytes) || in_span(dev, e->logic_arena, e->logic_arena_alloc));
+}
+inline char *host_of(const afe_engine *e, const void *dev) {
+  if (in_span(dev, e->arena, e->arena_bytes)) return e->arena_host + ((const char *)dev - (const char *)e->arena);
+  return e->logic_arena_host + ((const char *)dev - (const char *)e->logic_arena);
+}
+
 int copy_in(afe_engine *e, void *dev, size_t esz, int comps, int64_t first, int64_t count, const void *host) {
   if (!host || count == 0) return AFE_OK;
+  if (in_host_arena(e, dev)) {
+    // the slab is host memory: wait until nothing on the device is stepping (a resident grid stays where it is -- its
+    // workers touch the slabs only between a ring entry and their completion mark), then write
+    const int rc = quiesce(e);
+    if (rc) return rc;
+    char *d = host_of(e, dev);
+    for (int c = 0; c < comps; c++)
+      std::memcpy(d + ((size_t)c * e->stride + first) * esz, (const char *)host + (size_t)c * count * esz, (size_t)count * esz);
+    __atomic_thread_fence(__ATOMIC_RELEASE);   // ahead of the ring entry / the launch that lets the device read it
+    return AFE_OK;
+  }
   AFE_HIP(e, hipMemcpy2DAsync((char *)dev + first * esz, e->stride * esz, host, count * esz,
                               count * esz, comps, hipMemcpyHostToDevice, main_stream(e)));
   AFE_HIP(e, hipStreamSynchronize(main_stream(e)));  // host buffer may be reused by the caller
@@ -155,9 +184,32 @@ int copy_in(afe_engine *e, void *dev, size_t esz, int comps, int64_t first, int6
 }
 int copy_out(afe_engine *e, const void *dev, size_t esz, int comps, int64_t first, int64_t count, void *host) {
   if (!host || count == 0) return AFE_OK;
+  if (in_host_arena(e, dev)) {
+    const int rc = quiesce(e);
+    if (rc) return rc;
+    const char *d = host_of(e, dev);
+    for (int c = 0; c < comps; c++)
+      std::memcpy((char *)host + (size_t)c * count * esz, d + ((size_t)c * e->stride + first) * esz, (size_t)count * esz);
+    return AFE_OK;
+  }
   AFE_HIP(e, hipMemcpy2DAsync(host, count * esz, (const char *)dev + first * esz, e->stride * esz,
                               count * esz, comps, hipMemcpyDeviceToHost, main_stream(e)));
   AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
+  return AFE_OK;
+}
+
+// `byte` into rows [first, first + count) of `comps` planar components
+int fill_rows(afe_engine *e, void *dev, size_t esz, int comps, int64_t first, int64_t count, int byte) {
+  if (count == 0) return AFE_OK;
+  if (in_host_arena(e, dev)) {
+    const int rc = quiesce(e);
+    if (rc) return rc;
+    char *d = host_of(e, dev);
+    for (int c = 0; c < comps; c++) std::memset(d + ((size_t)c * e->stride + first) * esz, byte, (size_t)count * esz);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    return AFE_OK;
+  }
+  AFE_HIP(e, hipMemset2DAsync((char *)dev + first * esz, e->stride * esz, byte, count * esz, comps, main_stream(e)));
   return AFE_OK;
 }
 
@@ -285,9 +337,7 @@ int set_wrench(afe_engine *e, void *dev, bool &flag, int64_t first, int64_t coun
   if (rc) return rc;
   AFE_HIP(e, hipSetDevice(e->device));
   if (!w3) {
-    const size_t esz = elem(e);
-    AFE_HIP(e, hipMemset2DAsync((char *)dev + first * esz, e->stride * esz, 0, count * esz, 3, main_stream(e)));
-    return AFE_OK;
+    return fill_rows(e, dev, elem(e), 3, first, count, 0);
   }
   flag = true;
   if (e->precision == AFE_F64) return set_field<double>(e, dev, 3, first, count, w3);
@@ -340,7 +390,9 @@ bool motors_stateless(const afe_engine *e) {
 }
 // the step kernel may skip the rotor-speed store: the speed is clamp(cmd) and the commands
 // stay what they were during the step (the on-device logic rewrites them at every tick)
-bool motor_lazy(const afe_engine *e) { return motors_stateless(e) && !e->logic_on; }
+// (a host-visible arena is for small ensembles with the host in the loop: there the sixteen bytes are written and
+// nothing ever has to be rebuilt by a launch)
+bool motor_lazy(const afe_engine *e) { return motors_stateless(e) && !e->logic_on && !e->host_arena; }
 
 // rebuild the rotor-speed slab from the commands of the last step, if it was skipped
 int materialize_motor(afe_engine *e) {
@@ -396,6 +448,7 @@ void join_streams(afe_engine *e) {
 hipStream_t main_stream(afe_engine *e) {
   join_streams(e);
   if (e->p_running) (void)persist_park(e);   // a failure is sticky (p_failed) and reported by the next afe_step / afe_sync
+  e->stream_pending = true;                  // whoever asks is about to queue something
   return e->stream;
 }
 
@@ -462,6 +515,9 @@ bool persist_eligible(const afe_engine *e) {
   if (e->step_mode == AFE_STEP_LAUNCH || e->p_failed) return false;
   if (e->step_mode == AFE_STEP_AUTO && e->n > (int64_t(1) << 20)) return false;   // measured: DESIGN.md section 6 (beyond the Infinity Cache the split launches are ahead)
   if (!e->types_uniform || e->has_ext_torque || e->stream != e->own_stream || e->force_global_addressing) return false;
+  // a host-visible arena is streamed over the bus by every step: beyond a few thousand vehicles a step takes longer than
+  // the grid's patience with itself (measured: 2^18 vehicles stall it), and the launches are no slower there
+  if (e->host_arena && e->n > 16384) return false;
   return e->kernel_bytes < 0xffff0000ull && logic_arena_bytes(e) < 0xffff0000ull;
 }
 
@@ -481,7 +537,7 @@ int persist_launch(afe_engine *e) {
   a.n_chunks = (int)((e->n + 63) / 64);
   a.idle_ticks = 20000;         // 200 us
   a.give_up_ticks = 5000000;    // 50 ms without any progress while steps are waiting
-  a.epoch = ++e->p_epoch;
+  a.epoch = (++e->p_epoch & 0xffffu) | (e->host_arena ? AFE_PERSIST_HOST_IO : 0u);
   // The books at step p_resume, where this grid starts (the host's own clock, tick count and gust epoch are already
   // those of step p_next, the end of everything authorised): its start time is linear in the step index since
   // p_seg_start; the ticks before it are the engine's count less the tick flags of the entries still ahead of it;
@@ -552,6 +608,36 @@ int persist_park(afe_engine *e) {
   }
 }
 
+// Host-visible arenas: every authorised step has run and nothing is queued -- but a resident grid STAYS (its workers
+// read and write the slabs only between seeing a ring entry and publishing their completion mark, and the pump's
+// completion word is written after the marks it summarises: once it stands at p_next the slabs are the host's).
+int quiesce(afe_engine *e) {
+  join_streams(e);
+  if (e->p_running) {
+    volatile unsigned long long *st = p_status(e);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+      if (st[0] != 0) {                          // it has parked (idle host, or a stall): collect, finish what is left
+        int rc = persist_collect(e);
+        if (rc) return rc;
+        if (e->p_resume > e->p_next) { e->p_failed = true; return fail(e, AFE_ERR_HIP, "persistent step kernel ran past the authorised steps"); }
+        if (e->p_resume == e->p_next) break;
+        if ((rc = persist_launch(e))) return rc;
+        continue;
+      }
+      if (st[1] >= e->p_next) break;
+      if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+        return fail(e, AFE_ERR_HIP, "persistent step kernel makes no progress");
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  if (!e->p_running && e->stream_pending) {
+    AFE_HIP(e, hipStreamSynchronize(e->stream));
+    e->stream_pending = false;
+  }
+  return AFE_OK;
+}
+
 // afe_step in persistent mode: n_steps more ring entries; a grid is started if none is resident
 int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   int rc = persist_alloc(e);
@@ -602,8 +688,7 @@ int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
 
 // ---------------------------------------------------------------------------
 
-extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, int device,
-                          int64_t first_global_index) {
+static int create_engine(afe_engine **out, int64_t n_vehicles, int precision, int device, int64_t first_global_index, bool host_arena) {
   if (!out || n_vehicles <= 0 || (precision != AFE_F32 && precision != AFE_F64) || first_global_index < 0)
     return AFE_ERR_INVALID_ARG;
   // the kernels address a slab component as base + 32-bit byte offset
@@ -647,7 +732,15 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
   //   state 17 comps + wrench 6 comps (elem size), cmd 4 + imu 6 floats, rng u32, type u8
   const size_t S = (size_t)e->stride, es = elem(e);
   const size_t bytes = S * (17 + 6) * es + S * (4 + 6) * 4 + S * 4 + S + S * 2 * sizeof(double) + 256 * sizeof(DevParams<double>);
-  if ((err = hipMalloc(&e->arena, bytes)) != hipSuccess) return bail("hipMalloc", err);
+  if (host_arena) {
+    // pinned, coherent, device-mapped host memory: the kernels address it over the bus (a step of a small ensemble is a
+    // handful of bus reads in flight at once), the host reads and writes it in place
+    void *hp = nullptr;
+    if ((err = hipHostMalloc(&hp, bytes, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess) return bail("hipHostMalloc", err);
+    e->arena_host = (char *)hp;
+    e->host_arena = true;
+    if ((err = hipHostGetDevicePointer(&e->arena, hp, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", err);
+  } else if ((err = hipMalloc(&e->arena, bytes)) != hipSuccess) return bail("hipMalloc", err);
   e->arena_bytes = bytes;
   if ((err = hipMemsetAsync(e->arena, 0, bytes, main_stream(e))) != hipSuccess) return bail("hipMemset", err);
   char *p = (char *)e->arena;
@@ -686,12 +779,22 @@ extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, i
     const int m = std::atoi(fm);
     if (m >= AFE_STEP_LAUNCH && m <= AFE_STEP_RESIDENT) e->step_mode = m;
   }
+  if (e->host_arena) e->step_mode = AFE_STEP_AUTO;   // what such an engine is for: the host in the loop of a small ensemble
   if (std::getenv("AFE_FORCE_SPLIT")) {   // test hook: every engine of this process steps split (tests/: the whole GPU suite runs this way once)
     const int src = afe_set_split_stepping(e, 2);
     if (src) { afe_destroy(e); return src; }
   }
   *out = e;
   return AFE_OK;
+}
+
+extern "C" int afe_create(afe_engine **out, int64_t n_vehicles, int precision, int device, int64_t first_global_index) {
+  // test hook: every engine of this process up to 16 384 vehicles keeps its arena in host memory (tests/: the GPU suite
+  // runs this way once; the large ensembles of the suite would spend the day on the bus)
+  return create_engine(out, n_vehicles, precision, device, first_global_index, n_vehicles <= 16384 && std::getenv("AFE_FORCE_HOST_ARENA") != nullptr);
+}
+extern "C" int afe_create_host_visible(afe_engine **out, int64_t n_vehicles, int precision, int device, int64_t first_global_index) {
+  return create_engine(out, n_vehicles, precision, device, first_global_index, true);
 }
 
 extern "C" int afe_destroy(afe_engine *e) {
@@ -711,8 +814,10 @@ extern "C" int afe_destroy(afe_engine *e) {
   if (e->query_stream) (void)hipStreamDestroy(e->query_stream);
   if (e->world) world_destroy(e->world);
   if (e->pack_scratch) (void)hipFree(e->pack_scratch);
-  if (e->logic_arena) (void)hipFree(e->logic_arena);
-  if (e->arena) (void)hipFree(e->arena);
+  if (e->host_arena) { if (e->logic_arena_host) (void)hipHostFree(e->logic_arena_host); }
+  else if (e->logic_arena) (void)hipFree(e->logic_arena);
+  if (e->host_arena) { if (e->arena_host) (void)hipHostFree(e->arena_host); }
+  else if (e->arena) (void)hipFree(e->arena);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
   return AFE_OK;
@@ -784,8 +889,7 @@ extern "C" int afe_set_vehicle_types(afe_engine *e, int64_t first, int64_t count
       return fail(e, AFE_ERR_INVALID_ARG, "type index " + std::to_string(type_index[k]) + " of vehicle " +
                                               std::to_string(first + k) + " is outside the type table");
   AFE_HIP(e, hipSetDevice(e->device));
-  AFE_HIP(e, hipMemcpyAsync(e->type + first, type_index, (size_t)count, hipMemcpyHostToDevice, main_stream(e)));
-  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
+  if ((rc = copy_in(e, e->type, 1, 1, first, count, type_index))) return rc;
   if (e->type_host.size() != (size_t)e->n) e->type_host.assign((size_t)e->n, 0);
   std::memcpy(e->type_host.data() + first, type_index, (size_t)count);
   refresh_type_flags(e, first, count);
@@ -842,18 +946,14 @@ extern "C" int afe_set_rng_state(afe_engine *e, int64_t first, int64_t count, co
   for (int64_t k = 0; k < count; k++)
     if (state[k] == 0 || state[k] >= 2147483647u) return fail(e, AFE_ERR_INVALID_ARG, "minstd_rand0 state must be in [1, 2^31-2]");
   AFE_HIP(e, hipSetDevice(e->device));
-  AFE_HIP(e, hipMemcpyAsync(e->rng + first, state, (size_t)count * 4, hipMemcpyHostToDevice, main_stream(e)));
-  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
-  return AFE_OK;
+  return copy_in(e, e->rng, 4, 1, first, count, state);
 }
 extern "C" int afe_get_rng_state(afe_engine *e, int64_t first, int64_t count, uint32_t *state) {
   int rc = check_range(e, first, count);
   if (rc) return rc;
   if (!state) return fail(e, AFE_ERR_INVALID_ARG, "state is NULL");
   AFE_HIP(e, hipSetDevice(e->device));
-  AFE_HIP(e, hipMemcpyAsync(state, e->rng + first, (size_t)count * 4, hipMemcpyDeviceToHost, main_stream(e)));
-  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
-  return AFE_OK;
+  return copy_out(e, e->rng, 4, 1, first, count, state);
 }
 
 extern "C" int afe_set_motor_cmds(afe_engine *e, int64_t first, int64_t count, const float *cmd4) {
@@ -892,7 +992,13 @@ extern "C" int afe_set_rates_logic(afe_engine *e, const afe_rates_logic_params *
   const size_t S = (size_t)e->stride;
   if (!e->logic_arena) {
     const size_t bytes = S * 12 * 4 + S * 4 * 4 + S * 2 + 256 * sizeof(DevLogic);
-    AFE_HIP(e, hipMalloc(&e->logic_arena, bytes));
+    if (e->host_arena) {
+      void *hp = nullptr;
+      AFE_HIP(e, hipHostMalloc(&hp, bytes, hipHostMallocCoherent | hipHostMallocMapped));
+      e->logic_arena_host = (char *)hp;
+      AFE_HIP(e, hipHostGetDevicePointer(&e->logic_arena, hp, 0));
+    } else AFE_HIP(e, hipMalloc(&e->logic_arena, bytes));
+    e->logic_arena_alloc = bytes;
     char *p = (char *)e->logic_arena;
     e->lpf = (float *)p; p += S * 12 * 4;
     e->rates_cmd = (float *)p; p += S * 4 * 4;
@@ -901,10 +1007,13 @@ extern "C" int afe_set_rates_logic(afe_engine *e, const afe_rates_logic_params *
     e->imu_init = (uint8_t *)p;
   }
   // QuadcopterLogic::Initialise: filters at 0 (QuadcopterLogic.cpp:38,133), _kf.Reset(), FS_IDLE
-  AFE_HIP(e, hipMemsetAsync(e->lpf, 0, S * 12 * 4, main_stream(e)));
-  AFE_HIP(e, hipMemsetAsync(e->rates_cmd, 0, S * 4 * 4, main_stream(e)));
-  AFE_HIP(e, hipMemsetAsync(e->have_cmd, 0, S * 2, main_stream(e)));
-  AFE_HIP(e, hipMemsetAsync(e->cmd, 0, S * 4 * 4, main_stream(e)));
+  {
+    int frc;
+    if ((frc = fill_rows(e, e->lpf, 4, 12, 0, (int64_t)S, 0)) || (frc = fill_rows(e, e->rates_cmd, 4, 4, 0, (int64_t)S, 0)) ||
+        (frc = fill_rows(e, e->have_cmd, 1, 1, 0, (int64_t)S, 0)) || (frc = fill_rows(e, e->imu_init, 1, 1, 0, (int64_t)S, 0)) ||
+        (frc = fill_rows(e, e->cmd, 4, 4, 0, (int64_t)S, 0)))
+      return frc;
+  }
   e->logic_params.assign(table, table + n_types);
   e->logic_table_period = -1.0f;
   e->logic_on = true;
@@ -920,8 +1029,7 @@ extern "C" int afe_set_rates_commands(afe_engine *e, int64_t first, int64_t coun
   AFE_HIP(e, hipSetDevice(e->device));
   if ((rc = copy_in(e, e->rates_cmd, 4, 1, first, count, thrust_norm))) return rc;
   if ((rc = copy_in(e, e->rates_cmd + e->stride, 4, 3, first, count, ang_vel3))) return rc;
-  AFE_HIP(e, hipMemsetAsync(e->have_cmd + first, 1, (size_t)count, main_stream(e)));
-  return AFE_OK;
+  return fill_rows(e, e->have_cmd, 1, 1, first, count, 1);
 }
 
 extern "C" int afe_set_commands_from_radio(afe_engine *e, int64_t first, int64_t count, const uint8_t *raw_packets) {
@@ -947,9 +1055,7 @@ extern "C" int afe_set_commands_from_radio(afe_engine *e, int64_t first, int64_t
   }
   AFE_HIP(e, hipSetDevice(e->device));
   if ((rc = copy_in(e, e->rates_cmd, 4, 4, first, count, cmd.data()))) return rc;
-  AFE_HIP(e, hipMemcpyAsync(e->have_cmd + first, have.data(), (size_t)count, hipMemcpyHostToDevice, main_stream(e)));
-  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
-  return AFE_OK;
+  return copy_in(e, e->have_cmd, 1, 1, first, count, have.data());
 }
 
 extern "C" int afe_set_external_force(afe_engine *e, int64_t first, int64_t count, const double *force3) {
@@ -1042,6 +1148,7 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
       }
     }
     if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+    e->stream_pending = true;
     if (motor_lazy(e)) e->motor_stale = true;
     done += chunk;
     e->steps_issued += (uint64_t)chunk;
@@ -1387,9 +1494,11 @@ extern "C" int afe_save_checkpoint(afe_engine *e, void *host_buffer, uint64_t by
   char *p = (char *)host_buffer;
   std::memcpy(p, &h, sizeof(h));
   p += sizeof(h);
-  AFE_HIP(e, hipMemcpy(p, e->arena, e->arena_bytes, hipMemcpyDeviceToHost));
+  if (e->host_arena) std::memcpy(p, e->arena_host, e->arena_bytes);
+  else AFE_HIP(e, hipMemcpy(p, e->arena, e->arena_bytes, hipMemcpyDeviceToHost));
   p += e->arena_bytes;
-  if (h.logic_bytes) AFE_HIP(e, hipMemcpy(p, e->logic_arena, h.logic_bytes, hipMemcpyDeviceToHost));
+  if (h.logic_bytes && e->host_arena) std::memcpy(p, e->logic_arena_host, h.logic_bytes);
+  else if (h.logic_bytes) AFE_HIP(e, hipMemcpy(p, e->logic_arena, h.logic_bytes, hipMemcpyDeviceToHost));
   return AFE_OK;
 }
 
@@ -1436,9 +1545,11 @@ extern "C" int afe_load_checkpoint(afe_engine *e, const void *host_buffer, uint6
   e->table_dirty = true;
   e->logic_table_period = -1.0f;
   const char *p = (const char *)host_buffer + sizeof(h);
-  AFE_HIP(e, hipMemcpy(e->arena, p, e->arena_bytes, hipMemcpyHostToDevice));
+  if (e->host_arena) std::memcpy(e->arena_host, p, e->arena_bytes);
+  else AFE_HIP(e, hipMemcpy(e->arena, p, e->arena_bytes, hipMemcpyHostToDevice));
   p += e->arena_bytes;
-  if (h.logic_bytes) AFE_HIP(e, hipMemcpy(e->logic_arena, p, h.logic_bytes, hipMemcpyHostToDevice));
+  if (h.logic_bytes && e->host_arena) std::memcpy(e->logic_arena_host, p, h.logic_bytes);
+  else if (h.logic_bytes) AFE_HIP(e, hipMemcpy(e->logic_arena, p, h.logic_bytes, hipMemcpyHostToDevice));
   e->now_us = h.now_us;
   e->logic_elapsed_us = h.logic_elapsed_us;
   e->n_ticks = h.n_ticks;

@@ -20,7 +20,7 @@ AFE_STEP_LAUNCH, AFE_STEP_PERSISTENT, AFE_STEP_AUTO, AFE_STEP_RESIDENT = 0, 1, 2
 
 # every symbol include/agrifly_engine.h declares (checked by tests/test_abi.py)
 ABI_FUNCTIONS = [
-    "afe_params_from_type", "afe_type_from_id", "afe_create", "afe_destroy",
+    "afe_params_from_type", "afe_type_from_id", "afe_create", "afe_create_host_visible", "afe_destroy",
     "afe_last_error", "afe_status_string", "afe_abi_version", "afe_set_stream",
     "afe_set_type_table", "afe_set_vehicle_types", "afe_set_logic_period",
     "afe_set_imu_noise", "afe_set_state", "afe_get_state", "afe_set_state_f32",
@@ -250,6 +250,7 @@ def library():
         "afe_params_from_type": [ci, C.POINTER(VehicleParams)],
         "afe_type_from_id": [C.c_uint],
         "afe_create": [C.POINTER(vp), i64, ci, ci, i64],
+        "afe_create_host_visible": [C.POINTER(vp), i64, ci, ci, i64],
         "afe_destroy": [eng],
         "afe_abi_version": [],
         "afe_set_stream": [eng, vp],
@@ -639,7 +640,9 @@ def _planar(a, comps, count, dtype):
 class Ensemble:
     """One engine = one vehicle ensemble (or one rank's shard of it) on one GPU."""
 
-    def __init__(self, n_vehicles, precision=AFE_F32, device=-1, first_global_index=0, _borrowed=None):
+    def __init__(self, n_vehicles, precision=AFE_F32, device=-1, first_global_index=0, _borrowed=None, host_visible=False):
+        """host_visible: afe_create_host_visible -- the state arena in pinned host memory (small ensembles with the host in
+        the loop of every step: getters and setters become host copies and leave a resident grid where it is)."""
         self._L = library()
         self._owned = _borrowed is None
         if _borrowed is not None:   # a shard of a Group: the group owns the engine
@@ -649,8 +652,8 @@ class Ensemble:
             self.first_global_index = int(first_global_index)
             return
         self._h = C.c_void_p()
-        rc = self._L.afe_create(C.byref(self._h), int(n_vehicles), int(precision), int(device),
-                                int(first_global_index))
+        create = self._L.afe_create_host_visible if host_visible else self._L.afe_create
+        rc = create(C.byref(self._h), int(n_vehicles), int(precision), int(device), int(first_global_index))
         if rc:
             self._h = None
             raise AfeError(rc, self._L.afe_status_string(rc).decode() +

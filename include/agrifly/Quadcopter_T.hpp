@@ -102,7 +102,10 @@ class Fleet {
         int device = -1, float battVoltage = 0.0f)
       : _master(masterTimer), _integrationTimer(masterTimer), _n(nVehicles), _period(onboardLogicPeriod),
         _battVoltage(battVoltage), _battCurrent(-1.0f) {  // Quadcopter_T.cpp:72-73
-    check(0, afe_create(&_e, nVehicles, precision, device, 0), "afe_create");
+    // the onboard logic runs on the host at every tick (Run() below): up to a few thousand vehicles the state arena
+    // lives in host-visible memory, so that a Run() and the accessors after it cost bus latency, not transfer calls
+    if (nVehicles <= 16384) check(0, afe_create_host_visible(&_e, nVehicles, precision, device, 0), "afe_create_host_visible");
+    else check(0, afe_create(&_e, nVehicles, precision, device, 0), "afe_create");
     check(_e, afe_set_type_table(_e, typeTable.data(), (int)typeTable.size()), "afe_set_type_table");
     if (!typeIndex.empty()) check(_e, afe_set_vehicle_types(_e, 0, nVehicles, typeIndex.data()), "afe_set_vehicle_types");
     check(_e, afe_set_logic_period(_e, onboardLogicPeriod), "afe_set_logic_period");

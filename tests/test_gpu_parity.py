@@ -780,7 +780,8 @@ def test_rotor_speeds_are_those_of_the_last_step_even_though_they_are_not_stored
     e.set_state(np.zeros((3, n)), np.zeros((3, n)), np.tile([[1.0], [0], [0], [0]], (1, n)), np.zeros((3, n)),
                 np.full((4, n), 123.0))
     es = 4 if precision == afa.AFE_F32 else 8
-    assert e.algorithmic_bytes_per_step(False) == 13 * es * 2 + 16           # state r/w + commands, no rotor speeds
+    # state r/w + commands, no rotor speeds (a host-visible arena -- the AFE_FORCE_HOST_ARENA run of the suite -- writes them)
+    assert e.algorithmic_bytes_per_step(False) == 13 * es * 2 + 16 + (4 * es if os.environ.get("AFE_FORCE_HOST_ARENA") else 0)
     cmd_a = rng.uniform(-200, 1.3 * p.motor_max_speed, (4, n)).astype(np.float32)
     cmd_b = rng.uniform(0, p.motor_max_speed, (4, n)).astype(np.float32)
     want_a = np.clip(np.maximum(cmd_a.astype(np.float64), 0), p.motor_min_speed, p.motor_max_speed)
