@@ -829,7 +829,10 @@ def main():
                 t1 = median([time_steps(es, k, 1, sync, barrier) for _ in range(3)])
                 es.set_step_mode(afa.AFE_STEP_LAUNCH)
                 t10 = median([time_steps(es, k, 10, sync, barrier) for _ in range(3)])
-                closed.append({"vehicles": n, "vsteps_per_s": n * k / t1, "vsteps_per_s_fused10": n * k / t10})
+                b_mean, _ = mean_bytes_per_step(es, afa, k)   # state, force, commands; on ticks IMU, filter state, rate commands
+                closed.append({"vehicles": n, "vsteps_per_s": n * k / t1, "us_per_step": t1 / k * 1e6,
+                               "algorithmic_bytes_per_vehicle_step": b_mean, "achieved_GBs": n * b_mean / (t1 / k) / 1e9,
+                               "frac": n * b_mean / (t1 / k) / 1e9 / HBM_PEAK_GBS, "vsteps_per_s_fused10": n * k / t10})
                 es.close()
             out["closed_loop_on_device"] = closed
             out["disturbance_sweep"] = disturbance_sweep(afa, local_rank)
