@@ -498,7 +498,10 @@ int afe_get_external_force(afe_engine *e, int64_t first, int64_t count, double *
  * The grid leaves the device ("parks") when any other entry point needs the stream or the state (afe_sync, getters,
  * setters, events, queries, checkpoints ...: they all do it implicitly and the next afe_step starts a new grid), and
  * by itself when the host has not authorised a step for ~200 us, so nothing -- not even a device-wide
- * synchronisation issued elsewhere -- can wait on it for ever.
+ * synchronisation issued elsewhere -- can wait on it for ever.  A grid of a large ensemble occupies every wave slot of
+ * the device while it is resident: another engine's grid, or any other kernel of the process, starts when it has left
+ * (two such engines stepped alternately take turns, each handing over after its 200 us of idling -- correct, slow:
+ * tests/test_gpu_persistent.py; one process, one large resident grid per device is the intended use).
  *   mode = AFE_STEP_LAUNCH (0, default): one kernel launch per step (or per afe_set_max_fused_steps chunk).
  *   mode = AFE_STEP_PERSISTENT (1): as above, whenever the ensemble qualifies -- every vehicle on type record 0,
  *     no external torque, the engine's own stream, an arena below 4 GiB; otherwise the launches, silently.

@@ -231,3 +231,25 @@ def test_random_host_behaviour_against_the_launches(seed):
             b.load_checkpoint(blob); a.load_checkpoint(blob_a)
     assert_same(a, b, (seed, "end"))
     a.close(); b.close()
+
+
+def test_two_resident_grids_on_one_device_take_turns():
+    """Two engines of one process, both in persistent mode, stepped alternately: a full-size grid occupies every wave
+    slot of the device, so the second engine's grid becomes resident only when the first has left (by itself after
+    200 us without work, or parked by any call that needs the stream).  Nothing may hang or tear; the bits are those of
+    the launches.  (Small ensembles -- grids that do not fill the device -- run side by side.)"""
+    for n in (3000, 500000):
+        a1, _ = make(n, afa.AFE_F32, False, seed=1)
+        a2, _ = make(n, afa.AFE_F32, False, seed=2)
+        b1, _ = make(n, afa.AFE_F32, True, seed=1)
+        b2, _ = make(n, afa.AFE_F32, True, seed=2)
+        t0 = time.perf_counter()
+        for k in (1, 3, 1, 20, 2, 1, 1, 5):
+            for e in (a1, b1, a2, b2):
+                e.step(1000, k)
+        b1.sync(); b2.sync()
+        assert time.perf_counter() - t0 < 20.0
+        assert_same(a1, b1, n)
+        assert_same(a2, b2, n)
+        for e in (a1, a2, b1, b2):
+            e.close()
