@@ -319,6 +319,8 @@ struct RenderArgs {
   const PairNode *pairs;    // eight copies of n_pairs records: [0] as built, [c] mirrored along the axes in c
   int64_t n_pairs;
   const TriRec *tris;       // leaf order
+  const float *tribox;      // eight copies of n_tri x {lo, hi} x 3 (+ 2 pad): the triangles' boxes mirrored like the node boxes
+  int64_t n_tri;
   const double *poses;
   uint16_t *out;
   unsigned long long *counters;   // counting build only: see afe_render_depth_stats
@@ -432,14 +434,20 @@ __device__ __forceinline__ bool node_box_reached(f32x2 bx, f32x2 by, f32x2 bz, c
 // first, in fp32 -- a ray that misses it, or enters it no nearer than its best hit so far, cannot gain
 // anything from this triangle, and when that holds for all 64 rays of the tile the double-precision
 // test is skipped altogether
-template <bool COUNT>
-__device__ __forceinline__ void leaf_triangles(const RenderArgs &a, RayState &ray, uint32_t first, unsigned count,
-                                               uint64_t m, WalkCounters &cnt) {
+template <bool COUNT, bool ORDERED>
+__device__ __forceinline__ void leaf_triangles(const RenderArgs &a, RayState &ray, const BoxRay &br, const float *__restrict__ tribox,
+                                               uint32_t first, unsigned count, uint64_t m, WalkCounters &cnt) {
 #pragma clang fp contract(off)
   for (unsigned k = 0; k < count; k++) {
     const TriRec &T = a.tris[first + k];
-    const bool in_box = box_reached((f32x2){T.box[0], T.box[1]}, (f32x2){T.box[2], T.box[3]},
-                                    (f32x2){T.box[4], T.box[5]}, ray.oi, ray.inv, ray.best_f);
+    bool in_box;
+    if (ORDERED) {
+      // the mirrored copy of the triangle's box (32 B, one scalar load): near faces are `lo`, the 9-instruction test of the nodes
+      const float *B = tribox + (size_t)(first + k) * 8;
+      in_box = node_box_reached<true>((f32x2){B[0], B[1]}, (f32x2){B[2], B[3]}, (f32x2){B[4], B[5]}, br, ray.best_f);
+    } else {
+      in_box = box_reached((f32x2){T.box[0], T.box[1]}, (f32x2){T.box[2], T.box[3]}, (f32x2){T.box[4], T.box[5]}, ray.oi, ray.inv, ray.best_f);
+    }
     const uint64_t reach = __ballot(in_box) & m;
     if (COUNT) { cnt.tri_lane_box += __builtin_amdgcn_inverse_ballot_w64(m) ? 1 : 0; cnt.tri_wave_box += 1; }
     if (reach) {
@@ -467,7 +475,7 @@ __device__ __forceinline__ void leaf_triangles(const RenderArgs &a, RayState &ra
 // minimum over the triangles each ray reaches, each value computed in double exactly as the checker
 // does, so the result does not depend on the order.
 template <bool COUNT, bool ORDERED>
-__device__ __forceinline__ void walk(const RenderArgs &a, const PairNode *tree, RayState &ray, const BoxRay &br,
+__device__ __forceinline__ void walk(const RenderArgs &a, const PairNode *tree, const float *__restrict__ tribox, RayState &ray, const BoxRay &br,
                                      bool in_image, unsigned neg, WalkCounters &cnt) {
   int sp = 0;
   int st_node = 0, st_lo = 0, st_hi = 0;
@@ -488,16 +496,17 @@ __device__ __forceinline__ void walk(const RenderArgs &a, const PairNode *tree, 
     const uint32_t ref1 = right_first ? R[13] : R[12], ref2 = right_first ? R[12] : R[13];
     const unsigned c1 = (right_first ? (meta >> 16) : (meta >> 8)) & 255u;
     const unsigned c2 = (right_first ? (meta >> 8) : (meta >> 16)) & 255u;
-    if (m1 && c1) leaf_triangles<COUNT>(a, ray, ref1, c1, m1, cnt);
-    if (m2 && c2) leaf_triangles<COUNT>(a, ray, ref2, c2, m2, cnt);
+    if (m1 && c1) leaf_triangles<COUNT, ORDERED>(a, ray, br, tribox, ref1, c1, m1, cnt);
+    if (m2 && c2) leaf_triangles<COUNT, ORDERED>(a, ray, br, tribox, ref2, c2, m2, cnt);
     const bool inner1 = m1 && !c1, inner2 = m2 && !c2;
+    // the far child goes into slot sp at EVERY visit and sp advances only when it is really pushed: a conditional
+    // write makes the compiler carry the three stack registers through copies on both paths (six v_mov per visit,
+    // an eighth of the kernel's vector instructions); what an unadvanced slot holds is never read
+    st_node = afe_writelane((int)ref2, sp, st_node);
+    st_lo = afe_writelane((int)(uint32_t)m2, sp, st_lo);
+    st_hi = afe_writelane((int)(uint32_t)(m2 >> 32), sp, st_hi);
     if (inner1) {
-      if (inner2) {
-        st_node = afe_writelane((int)ref2, sp, st_node);
-        st_lo = afe_writelane((int)(uint32_t)m2, sp, st_lo);
-        st_hi = afe_writelane((int)(uint32_t)(m2 >> 32), sp, st_hi);
-        sp++;
-      }
+      sp += inner2 ? 1 : 0;
       cur = ref1; act = m1;
       continue;
     }
@@ -574,13 +583,13 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
       br.scale[k] = (f32x2){ai * 0.99999f, ai * 1.00001f};
       br.shift[k] = (f32x2){-ray.oi[k] * 0.99999f, -ray.oi[k] * 1.00001f};
     }
-    walk<COUNT, true>(a, a.pairs + (int64_t)neg * a.n_pairs, ray, br, in_image, neg, cnt);
+    walk<COUNT, true>(a, a.pairs + (int64_t)neg * a.n_pairs, a.tribox + (int64_t)neg * a.n_tri * 8, ray, br, in_image, neg, cnt);
   } else {
     for (int k = 0; k < 3; k++) {
       br.scale[k] = (f32x2){ray.inv[k], ray.inv[k]};
       br.shift[k] = (f32x2){-ray.oi[k], -ray.oi[k]};
     }
-    walk<COUNT, false>(a, a.pairs, ray, br, in_image, neg, cnt);
+    walk<COUNT, false>(a, a.pairs, a.tribox, ray, br, in_image, neg, cnt);
   }
   const double best = ray.best;
   const unsigned c_top = cnt.top, c_nodes = cnt.nodes, c_tri_wave_box = cnt.tri_wave_box, c_tri_wave_mt = cnt.tri_wave_mt,
@@ -629,6 +638,7 @@ struct afe_scene {
   PairNode *pairs = nullptr;   // 8 x n_pairs (Builder::pairs)
   int64_t n_pairs = 0;
   TriRec *tris = nullptr;
+  float *tribox = nullptr;     // 8 x n_tri x 8 floats
   // pixel-ray tables, one per camera geometry this scene has been rendered with (kept until the scene goes:
   // a launch still in flight on some stream may be reading one)
   struct RayTable { int width, height; double cx, cy, focal; double *uv; };
@@ -684,7 +694,7 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
     }
     r.uv = uv;
   }
-  r.pairs = s->pairs; r.n_pairs = s->n_pairs; r.tris = s->tris; r.counters = dev_counters;
+  r.pairs = s->pairs; r.n_pairs = s->n_pairs; r.tris = s->tris; r.tribox = s->tribox; r.n_tri = s->n_tri; r.counters = dev_counters;
   r.width = cam->width; r.height = cam->height;
   r.tiles_x = (cam->width + kTileW - 1) / kTileW;
   r.tiles_per_view = r.tiles_x * ((cam->height + kTileH - 1) / kTileH);
@@ -810,7 +820,21 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
     const std::vector<PairNode> mirrored = b.pairs(octant);
     pairs.insert(pairs.end(), mirrored.begin(), mirrored.end());
   }
+  // the triangles' boxes once more, mirrored like the node boxes of each octant copy ({lo, hi} -> {-hi, -lo})
+  std::vector<float> tribox((size_t)8 * n_tri * 8, 0.0f);
+  for (unsigned octant = 0; octant < 8; octant++)
+    for (int64_t i = 0; i < n_tri; i++) {
+      float *B = tribox.data() + ((size_t)octant * n_tri + i) * 8;
+      const float *src = packed[(size_t)i].box;
+      for (int k = 0; k < 3; k++) {
+        const bool mirrored = (octant >> k) & 1u;
+        B[2 * k] = mirrored ? -src[2 * k + 1] : src[2 * k];
+        B[2 * k + 1] = mirrored ? -src[2 * k] : src[2 * k + 1];
+      }
+    }
   if (hipMalloc((void **)&s->pairs, pairs.size() * sizeof(PairNode)) != hipSuccess ||
+      hipMalloc((void **)&s->tribox, tribox.size() * sizeof(float)) != hipSuccess ||
+      hipMemcpy(s->tribox, tribox.data(), tribox.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc((void **)&s->tris, packed.size() * sizeof(TriRec)) != hipSuccess ||
       hipMemcpy(s->pairs, pairs.data(), pairs.size() * sizeof(PairNode), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(s->tris, packed.data(), packed.size() * sizeof(TriRec), hipMemcpyHostToDevice) != hipSuccess) {
@@ -923,6 +947,7 @@ extern "C" void afe_scene_destroy(afe_scene *s) {
   for (const afe_scene::RayTable &t : s->ray_tables) (void)hipFree(t.uv);
   if (s->pairs) (void)hipFree(s->pairs);
   if (s->tris) (void)hipFree(s->tris);
+  if (s->tribox) (void)hipFree(s->tribox);
   delete s;
 }
 
