@@ -128,6 +128,7 @@ struct PersistArgs {
   double gust_sigma_max;
 };
 #define AFE_PERSIST_HOST_IO 0x10000u   /* PersistArgs::epoch */
+#define AFE_PERSIST_HOST_MARKS 64      /* host-visible arenas: grids of up to this many workers also write their marks to host_status[8 + w] */
 #define AFE_PERSIST_TICK 1ull
 #define AFE_PERSIST_PARK 2ull
 #define AFE_PERSIST_HOST_RING 4096

@@ -462,7 +462,7 @@ int persist_alloc(afe_engine *e) {
   e->p_cus = prop.multiProcessorCount;
   const int64_t chunks = (e->n + 63) / 64;
   const int64_t most = (int64_t)e->p_cus * 32;      // a CU has 32 wave slots: done[] never needs more
-  const size_t hbytes = (AFE_PERSIST_HOST_RING + 8) * sizeof(unsigned long long);
+  const size_t hbytes = (AFE_PERSIST_HOST_RING + 8 + AFE_PERSIST_HOST_MARKS) * sizeof(unsigned long long);
   AFE_HIP(e, hipHostMalloc((void **)&e->p_host, hbytes, hipHostMallocCoherent | hipHostMallocMapped));
   std::memset(e->p_host, 0, hbytes);
   AFE_HIP(e, hipHostGetDevicePointer((void **)&e->p_host_dev, e->p_host, 0));
@@ -524,8 +524,9 @@ bool persist_eligible(const afe_engine *e) {
 int persist_launch(afe_engine *e) {
   volatile unsigned long long *st = p_status(e);
   st[0] = 0; st[1] = e->p_resume; st[2] = 0;
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);
   persist_size_grid(e);
+  for (int w = 0; w < AFE_PERSIST_HOST_MARKS; w++) st[8 + w] = w < e->p_workers ? e->p_resume : ~0ull;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
   PersistArgs a;
   a.host_ring = e->p_host_dev;
   a.host_status = e->p_host_dev + AFE_PERSIST_HOST_RING;
@@ -626,6 +627,11 @@ int quiesce(afe_engine *e) {
         continue;
       }
       if (st[1] >= e->p_next) break;
+      if (e->host_arena && e->p_workers <= AFE_PERSIST_HOST_MARKS) {   // small grids write their marks here themselves: no wait for the pump's sweep
+        unsigned long long low = ~0ull;
+        for (int w = 0; w < e->p_workers; w++) { const unsigned long long d = st[8 + w]; low = d < low ? d : low; }
+        if (low >= e->p_next) break;
+      }
       if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
         return fail(e, AFE_ERR_HIP, "persistent step kernel makes no progress");
     }

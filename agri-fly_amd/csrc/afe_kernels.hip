@@ -1105,7 +1105,10 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
         tick_no += (u64_t)__popcll(batch_ticks);
       }
       s += (u64_t)run;
-      if (a.epoch & AFE_PERSIST_HOST_IO) AFE_HOST_RELEASE();   // the slabs are in host memory before the mark says so
+      if (a.epoch & AFE_PERSIST_HOST_IO) {                     // the slabs are in host memory before the mark says so
+        AFE_HOST_RELEASE();
+        if (lane == 0 && a.n_workers <= AFE_PERSIST_HOST_MARKS) st_system(a.host_status + 8 + w, s);   // small grids: the host reads the marks themselves
+      }
       if (lane == 0) st_agent(a.done + w, s);
       if (parks && run == (int)__builtin_ctzll(parks)) return;             // everything in front of the park entry is done
       t_wait = ticks100();
@@ -1136,7 +1139,10 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
       tick_no += tick;
     }
     s += (u64_t)run;
-    if (a.epoch & AFE_PERSIST_HOST_IO) AFE_HOST_RELEASE();
+    if (a.epoch & AFE_PERSIST_HOST_IO) {
+      AFE_HOST_RELEASE();
+      if (lane == 0 && a.n_workers <= AFE_PERSIST_HOST_MARKS) st_system(a.host_status + 8 + w, s);
+    }
     if (lane == 0) st_agent(a.done + w, s);
     if (parks) return;
     t_wait = ticks100();

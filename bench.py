@@ -245,6 +245,35 @@ def committed_traffic(n_local):
     return None, None
 
 
+def config1_row():
+    """BASELINE config 1 / configs[0] -- the reference's own CPU-runnable case: ONE vehicle flown by the offboard loop of
+    Simulator/Rappids_Simulator/main.cpp (mocap 200 Hz, control 100 Hz, 30 ms radio delay, the log every step) for
+    simulated seconds at dt = 1 ms, through the C ABI by agri-fly_amd/bin/rappids_headless (host-visible engine, resident
+    grid).  Two run lengths, so that process start and HIP initialisation cancel."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "agri-fly_amd", "bin", "rappids_headless")
+    if not os.path.exists(exe):
+        return {"error": "agri-fly_amd/bin/rappids_headless is not built (__graft_entry__.build() makes it)"}
+    wall = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for seconds in (2, 12):
+            best = 1e30
+            for _ in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "--seconds", str(seconds), "--dt-us", "1000", "--out", os.path.join(tmp, "sim.csv")],
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+                if r.returncode != 0:
+                    return {"error": "rappids_headless exit %d: %s" % (r.returncode, r.stderr.decode()[-300:])}
+                best = min(best, time.perf_counter() - t0)
+            wall[seconds] = best
+    us = (wall[12] - wall[2]) / 10000 * 1e6
+    return {"vehicles": 1, "dt_ms": 1.0, "steps_timed": 10000, "wall_s_12s_run": wall[12], "wall_s_2s_run": wall[2], "us_per_step": us,
+            "vsteps_per_s": 1e6 / us, "realtime_factor": 1000.0 / us,
+            "note": "one vehicle with the host in the loop of every step (state read back and logged every step, mocap estimator and "
+                    "controller on the host); the reference's CPU loop does this in ~0.5 us per step, a device-arena engine in ~74"}
+
+
 def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
     """SURVEY 8f rows f4 + f3 on the config-5 / config-3 shapes, bounded to a fraction of a second:
     depth camera over a procedural orchard, then the RAPPIDS planner on those images (kept in HBM)."""
@@ -838,6 +867,7 @@ def main():
             out["disturbance_sweep"] = disturbance_sweep(afa, local_rank)
             out["companions"] = companion_rows(afa, n_local, local_rank, sync, barrier, split)
             out["perception_rows"] = perception_rows(afa)
+            out["config1_host_in_loop"] = config1_row()
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             out["cpu_baseline"] = cpu_baseline(afa)
     # The headline is measured.  What follows (the shared-world exchange: a second communicator, collectives at

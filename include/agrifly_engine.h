@@ -118,7 +118,8 @@ int afe_create(afe_engine **out, int64_t n_vehicles, int precision, int device,
  * Simulator/Rappids_Simulator/main.cpp:330-392; the onboard logic of Quadcopter_T.cpp:159-189 on the host).  Getters
  * and setters of state, commands, wrench and IMU are then plain copies inside host memory once the steps authorised so
  * far are done: no transfer call, and a resident grid (the engine starts in AFE_STEP_AUTO) is NOT parked by them.
- * A step's loads and stores cross the bus (~1.5 us of latency per step, all in flight together), so this is the wrong
+ * One step of that loop then costs ~9 us instead of ~75 (one vehicle, MI355X).  A step's loads and stores cross the bus
+ * (~1.5 us of latency, all in flight together), so this is the wrong
  * choice for ensembles that step many times between host visits or hold more than a few thousand vehicles.
  * Same results, bit for bit, as afe_create; every other entry point behaves the same. */
 int afe_create_host_visible(afe_engine **out, int64_t n_vehicles, int precision, int device,
