@@ -1084,7 +1084,12 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   if (rc) return rc;
   if (e->logic_on && (rc = refresh_logic(e))) return rc;
   if (e->p_failed) return fail(e, AFE_ERR_HIP, "a persistent step kernel failed earlier (" + e->err + "); create a new engine");
-  if (persist_eligible(e)) return persist_step(e, dt_us, n_steps);
+  // AFE_STEP_AUTO and a call that asks for several steps at once: nobody can look at the steps in between, so the fused
+  // launch (state in registers from step to step, one load and one store per call) is the faster way to the same bits --
+  // from 2 steps per call at 2^19 vehicles and more, from 8 at any size (measured: bench.py sweep, fused2 / fused50
+  // against the resident grid).  One step per call stays with the resident grid.
+  const bool fuse = e->step_mode == AFE_STEP_AUTO && e->max_fused > 1 && (n_steps >= 8 || (n_steps >= 2 && e->n >= (int64_t(1) << 19)));
+  if (!fuse && persist_eligible(e)) return persist_step(e, dt_us, n_steps);
   if (e->p_running && (rc = persist_park(e))) return rc;
   LaunchFlags f;
   f.ext_force = e->has_ext_force;

@@ -543,12 +543,13 @@ def shared_world(afa, n_local, rank, world, local_rank, dist, torch, sync, barri
             e.destroy_event(ev1)
 
         # physics with a query every 10 steps (100 Hz at dt = 1 ms) vs physics alone
-        def run(k_steps, every, asynchronous=False):
+        def run(k_steps, every, asynchronous=False, per_call=10):
             barrier()
             e.query_sync(); e.sync(); sync()
             t0 = time.perf_counter()
             for s in range(0, k_steps, 10):
-                e.step(DT_US, 10)
+                for _ in range(10 // per_call):
+                    e.step(DT_US, per_call)   # ten steps per call: nobody looks in between, the engine (AFE_STEP_AUTO) fuses them
                 if every:
                     query(asynchronous)     # (the UWB read-back would serialise the host; timed above on its own)
             e.query_sync(); e.sync(); sync()
@@ -557,6 +558,7 @@ def shared_world(afa, n_local, rank, world, local_rank, dist, torch, sync, barri
         k = 400
         run(50, 10)
         t_without = reduce_max(median([run(k, 0) for _ in range(3)]))
+        t_single = reduce_max(median([run(k, 0, per_call=1) for _ in range(3)]))   # the headline's protocol: every step its own call
         t_sync = reduce_max(median([run(k, 10) for _ in range(3)]))
         run(50, 10, True)
         t_async = reduce_max(median([run(k, 10, True) for _ in range(3)]))
@@ -565,6 +567,7 @@ def shared_world(afa, n_local, rank, world, local_rank, dist, torch, sync, barri
         w = dict(parts)
         w.update({"query_ms": parts["allgather_ms"] + parts["nearest_neighbour_ms"],
                   "vsteps_per_s_physics_only": n_all * k / t_without,
+                  "vsteps_per_s_physics_only_one_step_per_call": n_all * k / t_single,
                   "vsteps_per_s_query_in_stream": n_all * k / t_sync, "fraction_query_in_stream": t_without / t_sync,
                   "vsteps_per_s_query_on_own_stream": n_all * k / t_async, "fraction_query_on_own_stream": t_without / t_async,
                   "neighbour_grid": {"dims": list(info["dims"]), "cell_size_m": info["cell_size"], "queries_finished_by_brute_force": info["n_bruteforce"]},
@@ -572,9 +575,12 @@ def shared_world(afa, n_local, rank, world, local_rank, dist, torch, sync, barri
         out["worlds"][world_name] = w
         out["rccl_ranks"] = comm.info()[1]
         e.close()
-    out["note"] = ("a query = all-gather + exact nearest neighbour of every local vehicle among all gathered ones.  Both the steps and the query live on the "
-                   "memory system: running the query beside the next ten steps (own stream) hides its launch gaps and little else -- fraction_* = rate with "
-                   "queries / rate without")
+    out["note"] = ("a query = all-gather + exact nearest neighbour of every local vehicle among all gathered ones, every 10 steps; the ten steps between two "
+                   "queries are ONE afe_step call (nothing is observable in between, so AFE_STEP_AUTO runs them as a fused launch: state in registers, "
+                   "~9 us per step at 2^20 vehicles instead of the ~19 of one observable step per call -- vsteps_per_s_physics_only_one_step_per_call is the "
+                   "headline's protocol on the same engine).  fraction_* = rate with queries / rate without, both with ten steps per call: the query's "
+                   "~0.1-0.15 ms now stand against ~0.09 ms of physics.  Both live on the memory system: running the query beside the next ten steps "
+                   "(own stream) hides its launch gaps and little else")
     net.close()
     with stdout_to_stderr():
         comm.close()
