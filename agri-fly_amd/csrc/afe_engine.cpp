@@ -1685,6 +1685,13 @@ extern "C" int afe_set_neighbour_grid_refresh(afe_engine *e, int every_n_queries
   return world_set_refresh(e->world, every_n_queries);
 }
 
+extern "C" int afe_set_neighbour_sort_reuse(afe_engine *e, int every_n_queries) {
+  if (!e || every_n_queries < 1) return fail(e, AFE_ERR_INVALID_ARG, "sort interval must be >= 1");
+  AFE_HIP(e, hipSetDevice(e->device));
+  if (!e->world) { const int rc = world_create(e->device, &e->world); if (rc) return fail(e, rc, "shared-world scratch"); }
+  return world_set_sort_reuse(e->world, every_n_queries);
+}
+
 extern "C" int afe_neighbour_grid_info(const afe_engine *e, int dims[3], float *cell_size, int64_t *n_cells, int64_t *n_bruteforce) {
   if (!e || !e->world) return AFE_ERR_NOT_CONFIGURED;
   return world_grid_info(e->world, dims, cell_size, n_cells, n_bruteforce);

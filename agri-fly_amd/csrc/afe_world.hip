@@ -209,14 +209,72 @@ __global__ void __launch_bounds__(256) world_scan_add_kernel(uint32_t *__restric
 }
 
 // counting sort, pass 2: points into cell order as (x, y, z, global index)
+// (slot[i] becomes the point's place in the cell order and ref keeps where it was: a later query may keep the order
+// and only refresh the positions, world_regather_kernel)
 __global__ void __launch_bounds__(256) world_scatter_kernel(const float *__restrict__ xyz, int64_t n, const uint32_t *__restrict__ starts,
-                                                            const uint32_t *__restrict__ cell, const uint32_t *__restrict__ slot,
-                                                            uint4 *__restrict__ sorted) {
+                                                            const uint32_t *__restrict__ cell, uint32_t *__restrict__ slot,
+                                                            uint4 *__restrict__ sorted, float *__restrict__ ref, int64_t ref_stride) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const float x = xyz[i], y = xyz[n + i], z = xyz[2 * n + i];
+  ref[i] = x; ref[ref_stride + i] = y; ref[2 * ref_stride + i] = z;
   const uint32_t c = cell[i];
   if (c == AFE_WORLD_DROPPED) return;
-  sorted[starts[c] + slot[i]] = make_uint4(__float_as_uint(xyz[i]), __float_as_uint(xyz[n + i]), __float_as_uint(xyz[2 * n + i]), (uint32_t)i);
+  const uint32_t at = starts[c] + slot[i];
+  slot[i] = at;
+  sorted[at] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), (uint32_t)i);
+}
+
+// A query that KEEPS the cell order of an earlier one (afe_set_neighbour_sort_reuse): every point's current position
+// goes to the place the sort gave it, and words[0] becomes an upper bound of how far any point -- sorted or dropped --
+// has moved since the sort (float bits; non-negative floats order like their bit patterns).  The query -- which looks
+// around the cell its position of TODAY falls into -- then trusts a ring only up to (r - 0.05) h less that bound: a point
+// listed outside the rings was at least r h away from anywhere in the query's cell when it was sorted.  A point that was non-finite at the sort (dead bin, never scanned) and
+// is finite now would be missed: the bound becomes infinite -- no ring settles anything, the brute force answers --
+// and the host is told to sort again (host_flag, pinned memory).
+__global__ void __launch_bounds__(256) world_regather_kernel(const float *__restrict__ xyz, int64_t n, const uint32_t *__restrict__ cell,
+                                                             const uint32_t *__restrict__ slot, const float *__restrict__ ref, int64_t ref_stride,
+                                                             uint4 *__restrict__ sorted, float *__restrict__ partial) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float moved = 0.0f;
+  if (i < n) {
+    const float x = xyz[i], y = xyz[n + i], z = xyz[2 * n + i];
+    const float rx = ref[i], ry = ref[ref_stride + i], rz = ref[2 * ref_stride + i];
+    const bool fin = finite3(x, y, z), was = finite3(rx, ry, rz);
+    if (fin && was) {
+      const float dx = x - rx, dy = y - ry, dz = z - rz;
+      moved = sqrtf((dx * dx + dy * dy) + dz * dz) * 1.000001f + 1e-30f;   // rounded up
+      if (!(moved < 3.0e38f)) moved = __builtin_inff();
+    } else if (fin && !was) {
+      moved = __builtin_inff();
+    }
+    const uint32_t c = cell[i];
+    if (c != AFE_WORLD_DROPPED) sorted[slot[i]] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), (uint32_t)i);
+  }
+  // one partial maximum per workgroup, reduced by world_moved_kernel (thousands of waves taking an atomic maximum on one
+  // word serialise at the memory side: measured, that alone made the kept order slower than the sort)
+  __shared__ float wave_max[4];
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) moved = fmaxf(moved, __shfl_xor(moved, s));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = moved;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+}
+__global__ void __launch_bounds__(256) world_moved_kernel(const float *__restrict__ partial, int64_t n_partial, uint32_t *__restrict__ words,
+                                                          uint32_t *host_flag) {
+  __shared__ float wave_max[4];
+  float moved = 0.0f;
+  for (int64_t k = threadIdx.x; k < n_partial; k += 256) moved = fmaxf(moved, partial[k]);
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) moved = fmaxf(moved, __shfl_xor(moved, s));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = moved;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    moved = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+    words[0] = __float_as_uint(moved);
+    if (moved > 3.0e38f) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // squared distance exactly as the brute-force definition rounds it (three products, two sums, fp32)
@@ -267,7 +325,7 @@ __device__ __forceinline__ float clearance(const GridDesc &g, float x, float y, 
 
 // rings r_first, r_first + 1, ... around cell (cx, cy, cz) through the cache; true if the query is settled
 __device__ bool ring_search(const uint4 *__restrict__ sorted, const uint32_t *__restrict__ starts, const GridDesc &g, float qx, float qy,
-                            float qz, int me, int cx, int cy, int cz, float clear, int r_first, float &best, int &best_j) {
+                            float qz, int me, int cx, int cy, int cz, float clear, float moved, int r_first, float &best, int &best_j) {
   const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
   bool done = false;
   for (int r = r_first; r <= AFE_WORLD_MAX_RING && !done; r++) {
@@ -288,9 +346,11 @@ __device__ bool ring_search(const uint4 *__restrict__ sorted, const uint32_t *__
         }
       }
     }
-    const float reach = fminf(((float)r - 0.05f) * g.h, clear);   // 0.05 h: slack for the fp32 cell coordinates (<= 65536 per axis)
+    // 0.05 h: slack for the fp32 cell coordinates (<= 65536 per axis).  moved: the cell order may be an earlier query's
+    // (world_regather_kernel) -- whatever is listed outside the rings has come at most that much closer since
+    const float reach = fminf(((float)r - 0.05f) * g.h - moved, clear);
     const bool covers_all = cx - r <= 0 && cx + r >= nx - 1 && cy - r <= 0 && cy + r >= ny - 1 && cz - r <= 0 && cz + r >= nz - 1;
-    done = (covers_all && !g.filtered) || best < reach * reach;
+    done = (covers_all && !g.filtered && moved < 3.0e38f) || (reach > 0.0f && best < reach * reach);
     if (covers_all) break;
   }
   return done;
@@ -316,7 +376,8 @@ __device__ __forceinline__ void finish_query(bool done, int64_t local, float bes
 __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restrict__ sorted, int64_t n_all, const uint32_t *__restrict__ starts,
                                                           GridDesc g, int64_t first_global, int64_t n_self, float *__restrict__ dist2_out,
                                                           int32_t *__restrict__ index_out, uint32_t *__restrict__ leftover_count,
-                                                          int32_t *__restrict__ leftover, uint64_t *__restrict__ leftover_keys) {
+                                                          int32_t *__restrict__ leftover, uint64_t *__restrict__ leftover_keys,
+                                                          const uint32_t *__restrict__ words) {
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= n_all || s >= (int64_t)starts[g.n_cells + 1]) return;   // the end sentinel: how many points were sorted
   const uint4 qb = sorted[s];
@@ -330,8 +391,9 @@ __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restric
   int cx, cy, cz;
   cell_of(g, q.x, q.y, q.z, cx, cy, cz);
   bool done = false;
-  const float clear = clearance(g, q.x, q.y, q.z);
-  if (clear > 0.0f) done = ring_search(sorted, starts, g, q.x, q.y, q.z, me, cx, cy, cz, clear, 1, best, best_j);
+  const float moved = __uint_as_float(words[0]);   // 0 unless the cell order is an earlier query's
+  const float clear = clearance(g, q.x, q.y, q.z) - moved;   // a dropped vehicle may have come that much closer
+  if (clear > 0.0f) done = ring_search(sorted, starts, g, q.x, q.y, q.z, me, cx, cy, cz, clear, moved, 1, best, best_j);
   finish_query(done, local, best, best_j, dist2_out, index_out, leftover_count, leftover, leftover_keys);
 }
 
@@ -438,6 +500,14 @@ struct afe_world {
   float grid_cell_arg = 0;      // and the caller's cell size then
   int refresh_every = 1;        // re-shape the grid every this many queries (1: always)
   int since_refresh = 0;
+  // keeping the cell ORDER over several queries (world_set_sort_reuse): positions are refreshed in place, the query's
+  // stopping rule allows for how far anybody has moved since the sort
+  int resort_every = 1;         // sort every this many queries (1: always)
+  int since_sort = 0;
+  bool sort_valid = false;
+  float *ref = nullptr;         // [3][cap_points]: positions at the last sort, original order
+  uint32_t *words = nullptr;    // device: [0] bound on the movement since the sort (float bits)
+  uint32_t *host_flag = nullptr;   // pinned: a kernel asks for a new sort
   uint32_t last_leftover = 0;
   std::string err;
 };
@@ -459,6 +529,8 @@ void free_points(afe_world *w) {
   if (w->cell) (void)hipFree(w->cell);
   if (w->slot) (void)hipFree(w->slot);
   if (w->sorted) (void)hipFree(w->sorted);
+  if (w->ref) (void)hipFree(w->ref);
+  w->ref = nullptr; w->sort_valid = false;
   if (w->leftover) (void)hipFree(w->leftover);
   if (w->leftover_keys) (void)hipFree(w->leftover_keys);
   w->cell = w->slot = nullptr; w->sorted = nullptr; w->leftover = nullptr; w->leftover_keys = nullptr;
@@ -537,6 +609,7 @@ int ensure_capacity(afe_world *w, int64_t n_all, int64_t n_cells_total) {
     W_HIP(w, hipMalloc((void **)&w->cell, (size_t)cap * 4));
     W_HIP(w, hipMalloc((void **)&w->slot, (size_t)cap * 4));
     W_HIP(w, hipMalloc((void **)&w->sorted, (size_t)cap * sizeof(uint4)));
+    W_HIP(w, hipMalloc((void **)&w->ref, (size_t)cap * 3 * sizeof(float)));
     W_HIP(w, hipMalloc((void **)&w->leftover, (size_t)cap * 4));
     W_HIP(w, hipMalloc((void **)&w->leftover_keys, (size_t)cap * 8));
     w->cap_points = cap;
@@ -551,6 +624,8 @@ int ensure_capacity(afe_world *w, int64_t n_all, int64_t n_cells_total) {
     w->cap_cells = cap;
   }
   if (!w->lohi) W_HIP(w, hipMalloc((void **)&w->lohi, 8 * sizeof(int)));
+  if (!w->words) { W_HIP(w, hipMalloc((void **)&w->words, 4 * sizeof(uint32_t))); W_HIP(w, hipMemset(w->words, 0, 4 * sizeof(uint32_t))); }
+  if (!w->host_flag) { W_HIP(w, hipHostMalloc((void **)&w->host_flag, 64, hipHostMallocCoherent | hipHostMallocMapped)); *w->host_flag = 0; }
   if (!w->bounds_part) W_HIP(w, hipMalloc((void **)&w->bounds_part, AFE_WORLD_BOUNDS_BLOCKS * sizeof(BoundsPartial)));
   return AFE_OK;
 }
@@ -579,6 +654,8 @@ void afe::world_destroy(afe_world *w) {
   if (w->lohi) (void)hipFree(w->lohi);
   if (w->bounds_part) (void)hipFree(w->bounds_part);
   if (w->self_scratch) (void)hipFree(w->self_scratch);
+  if (w->words) (void)hipFree(w->words);
+  if (w->host_flag) (void)hipHostFree(w->host_flag);
   delete w;
 }
 
@@ -633,20 +710,36 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   }
   const GridDesc g = w->grid;
   const int64_t m = g.n_cells + 2;   // cells, the dead bin, and the end sentinel
+  const int64_t cap_before = w->cap_points;
   if ((rc = ensure_capacity(w, n_all, m))) return rc;
-  // 2. counting sort by cell
-  W_HIP(w, hipMemsetAsync(w->counts, 0, (size_t)m * 4, st));
   const unsigned pb = (unsigned)((n_all + 255) / 256);
-  hipLaunchKernelGGL(world_count_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, g, w->counts, w->cell, w->slot);
-  const int64_t nb = (m + 1023) / 1024;
-  hipLaunchKernelGGL(world_scan_local_kernel, dim3((unsigned)nb), dim3(256), 0, st, w->counts, w->counts, w->block_sums, m);
-  hipLaunchKernelGGL(world_scan_blocks_kernel, dim3(1), dim3(256), 0, st, w->block_sums, nb);
-  hipLaunchKernelGGL(world_scan_add_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w->counts, w->block_sums, m);
-  hipLaunchKernelGGL(world_scatter_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, w->counts, w->cell, w->slot, w->sorted);
+  if (*(volatile uint32_t *)w->host_flag) { w->sort_valid = false; *(volatile uint32_t *)w->host_flag = 0; }   // a regather met a vehicle the sort never listed
+  const bool keep_order = !reshape && w->sort_valid && cap_before == w->cap_points && w->since_sort + 1 < w->resort_every;
+  if (keep_order) {
+    // 2'. the cell order of the last sort, today's positions (vehicles move centimetres between two queries, cells are
+    // metres wide): one pass instead of the five of a sort
+    w->since_sort++;
+    // (the partial maxima live in the leftover-key scratch: the brute force behind the query is the next to touch it)
+    float *partial = (float *)w->leftover_keys;
+    hipLaunchKernelGGL(world_regather_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, w->cell, w->slot, w->ref, w->cap_points, w->sorted, partial);
+    hipLaunchKernelGGL(world_moved_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)pb, w->words, w->host_flag);
+  } else {
+    // 2. counting sort by cell
+    W_HIP(w, hipMemsetAsync(w->counts, 0, (size_t)m * 4, st));
+    W_HIP(w, hipMemsetAsync(w->words, 0, 4, st));
+    hipLaunchKernelGGL(world_count_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, g, w->counts, w->cell, w->slot);
+    const int64_t nb = (m + 1023) / 1024;
+    hipLaunchKernelGGL(world_scan_local_kernel, dim3((unsigned)nb), dim3(256), 0, st, w->counts, w->counts, w->block_sums, m);
+    hipLaunchKernelGGL(world_scan_blocks_kernel, dim3(1), dim3(256), 0, st, w->block_sums, nb);
+    hipLaunchKernelGGL(world_scan_add_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w->counts, w->block_sums, m);
+    hipLaunchKernelGGL(world_scatter_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, w->counts, w->cell, w->slot, w->sorted, w->ref, w->cap_points);
+    w->sort_valid = true;
+    w->since_sort = 0;
+  }
   // 3. queries in cell order; isolated vehicles finish in the brute-force kernel
   uint32_t *left_count = (uint32_t *)(w->lohi + 6);
   hipLaunchKernelGGL(world_query_kernel, dim3(pb), dim3(256), 0, st, w->sorted, n_all, w->counts, g, first_global, n_self, dist2_out,
-                     index_out, left_count, w->leftover, w->leftover_keys);
+                     index_out, left_count, w->leftover, w->leftover_keys, w->words);
   hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(1024), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global,
                      (unsigned long long *)w->leftover_keys);
   hipLaunchKernelGGL(world_brute_finish_kernel, dim3(64), dim3(256), 0, st, w->leftover, left_count, w->leftover_keys, dist2_out, index_out);
@@ -657,6 +750,12 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
 int afe::world_set_refresh(afe_world *w, int every_n_queries) {
   if (!w || every_n_queries < 1) return AFE_ERR_INVALID_ARG;
   w->refresh_every = every_n_queries;
+  return AFE_OK;
+}
+
+int afe::world_set_sort_reuse(afe_world *w, int every_n_queries) {
+  if (!w || every_n_queries < 1) return AFE_ERR_INVALID_ARG;
+  w->resort_every = every_n_queries;
   return AFE_OK;
 }
 

@@ -43,7 +43,7 @@ ABI_FUNCTIONS = [
     "afe_comm_unique_id", "afe_comm_create", "afe_comm_info", "afe_comm_destroy", "afe_comm_last_error",
     "afe_gather_positions", "afe_group_create", "afe_group_destroy", "afe_group_size", "afe_group_shard",
     "afe_group_step", "afe_group_sync", "afe_group_gather_positions", "afe_group_last_error",
-    "afe_nearest_neighbour_grid", "afe_neighbour_grid_info", "afe_set_neighbour_grid_refresh", "afe_nearest_neighbour_bruteforce",
+    "afe_nearest_neighbour_grid", "afe_neighbour_grid_info", "afe_set_neighbour_grid_refresh", "afe_set_neighbour_sort_reuse", "afe_nearest_neighbour_bruteforce",
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
     "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running", "afe_stream_probe",
     "afe_set_noise_seed", "afe_set_gust_process", "afe_get_external_force", "afe_nearest_neighbour_async", "afe_query_sync",
@@ -348,6 +348,7 @@ def library():
         "afe_neighbour_grid_info": [eng, vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64)],
         "afe_nearest_neighbour_bruteforce": [eng, vp, i64, vp, i64, vp, vp],
         "afe_set_neighbour_grid_refresh": [eng, ci],
+        "afe_set_neighbour_sort_reuse": [eng, ci],
         "afe_uwb_create": [C.POINTER(vp)],
         "afe_uwb_set_noise": [vp, C.c_double, C.c_double, C.c_double],
         "afe_uwb_draw": [vp, i64, vp, vp],
@@ -960,6 +961,11 @@ class Ensemble:
 
     def set_neighbour_grid_refresh(self, every_n_queries):
         self._ck(self._L.afe_set_neighbour_grid_refresh(self._h, int(every_n_queries)))
+
+    def set_neighbour_sort_reuse(self, every_n_queries):
+        """sort the vehicles into the grid's cells every n-th query only; in between the order is kept and the positions
+        refreshed (exact all the same: the device bounds the movement since the sort)"""
+        self._ck(self._L.afe_set_neighbour_sort_reuse(self._h, int(every_n_queries)))
 
     def neighbour_grid_info(self):
         dims = (C.c_int * 3)()

@@ -718,6 +718,13 @@ int afe_query_sync(afe_engine *e);
  * the stream; in between, queries are fully asynchronous.  Results do not depend on it (the query is
  * exact for any grid; vehicles that have left the grid's core are clamped into its boundary cells). */
 int afe_set_neighbour_grid_refresh(afe_engine *e, int every_n_queries);
+/* How often the vehicles are sorted into the grid's cells: every `every_n_queries` queries (default 1).  In between a
+ * query keeps the cell ORDER of the last sort and only refreshes the positions in it (one pass instead of the five of a
+ * counting sort); the device keeps a bound on how far any vehicle has moved since the sort and the search stops a ring
+ * only where that bound allows -- the answers are exactly the sorted query's whatever the vehicles did (vehicles moving
+ * centimetres between queries through cells metres wide cost nothing; an ensemble that has moved by cells searches wider
+ * rings, and one that has jumped is answered by the brute force until the next sort).  A grid re-shape sorts anyway. */
+int afe_set_neighbour_sort_reuse(afe_engine *e, int every_n_queries);
 /* shape of the grid the last query used, and how many of its queries fell through to brute force
  * (isolated vehicles; reading that count synchronises the device).  Any pointer may be NULL. */
 int afe_neighbour_grid_info(const afe_engine *e, int dims[3], float *cell_size, int64_t *n_cells, int64_t *n_bruteforce);

@@ -531,3 +531,78 @@ def test_wide_campaign_grid_equals_brute_force_on_every_query():
     from tests.scenarios import MEASUREMENTS
     MEASUREMENTS["neighbour_query_campaign"] = r
     assert r["mismatching_worlds"] == 0 and r["queries"] > 100000
+
+
+def test_a_kept_cell_order_is_still_exact(ora):
+    """afe_set_neighbour_sort_reuse: between two sorts a query keeps the cell ORDER and only refreshes the positions; the
+    device bounds how far anybody has moved since the sort and the rings stop only where that allows.  Every answer must
+    be the definition's whatever happens in between: centimetre drifts (the intended use), drifts by a cell and more,
+    pairs that swap places, a jump of everybody, vehicles turning non-finite and -- the case the order cannot know --
+    vehicles that were non-finite at the sort coming back."""
+    import torch
+    n = 6000
+    rng = np.random.default_rng(41)
+    base = np.stack([rng.uniform(0, 120, n), rng.uniform(0, 120, n), rng.uniform(0, 3, n)])
+    base[:, :7] = np.nan                                  # dead at the sort
+    with afa.Ensemble(n) as e:
+        e.set_type_table([afa.params_from_type(5)])
+        e.set_neighbour_grid_refresh(1000)
+        e.set_neighbour_sort_reuse(1000)
+        w = base.copy()
+        sorts_only = 0
+        for k in range(14):
+            if k in (1, 2, 3):
+                w = w + rng.normal(0, 0.02, w.shape)      # centimetres
+            elif k == 4:
+                w = w + rng.normal(0, 1.5, w.shape)       # about a cell
+            elif k == 5:
+                w[:, 100:200], w[:, 200:300] = w[:, 200:300].copy(), w[:, 100:200].copy()   # swaps across the field
+            elif k == 6:
+                w[:, 1000:1010] = np.inf                  # some die
+            elif k == 7:
+                w = w + np.array([[35.0], [-20.0], [0.5]])   # everybody jumps
+            elif k == 8:
+                w[:, :7] = np.array([[10.0], [10.0], [1.0]]) + rng.normal(0, 0.3, (3, 7))   # the dead come back: only a new sort lists them
+            elif k == 9:
+                w = w + rng.normal(0, 0.02, w.shape)
+            elif k == 10:
+                w[:, 1000:1010] = np.array([[60.0], [60.0], [1.0]]) + rng.normal(0, 0.5, (3, 10))
+            elif k >= 11:
+                w = w * 0.5
+            pos = w.astype(np.float32)
+            t = torch.from_numpy(np.ascontiguousarray(pos)).cuda()
+            d2, idx = _nn(e, t, n)
+            ref_d, ref_i = ora.nearest_neighbour(pos)
+            np.testing.assert_array_equal(idx, ref_i, err_msg="query %d, %r" % (k, e.neighbour_grid_info()))
+            np.testing.assert_array_equal(d2, ref_d)
+            if k in (1, 2, 3):
+                assert e.neighbour_grid_info()["n_bruteforce"] == 0      # the rings settle everything after a small drift
+
+
+def test_a_kept_cell_order_in_a_sharded_world(ora):
+    """the same with a filtered sort (a shard's block of a gathered ensemble): vehicles the sort dropped come closer"""
+    rng = np.random.default_rng(42)
+    n_all, first, n = 9000, 3000, 3000
+    base = np.stack([np.concatenate([rng.uniform(40 * k, 40 * (k + 1), 3000) for k in range(3)]), rng.uniform(0, 40, n_all),
+                     rng.uniform(0, 4, n_all)])
+    base[0, 6000:6500] += 400.0                                      # other shards' vehicles far outside the keep box: dropped
+    with afa.Ensemble(n, first_global_index=first) as e:
+        e.set_neighbour_sort_reuse(1000)
+        w = base.copy()
+        for k in range(8):
+            if k in (1, 2):
+                w = w + rng.normal(0, 0.03, w.shape)
+            elif k == 3:
+                w[0, 6000:6500] -= 150.0                              # the dropped ones approach ...
+            elif k == 4:
+                w[0, 6000:6500] -= 250.0                              # ... and arrive among ours
+            elif k == 5:
+                w[0, first:first + n] += 30.0                         # ours move into the next strip
+            elif k == 6:
+                w[:, 100:140] = np.nan
+            elif k == 7:
+                w = w + rng.normal(0, 0.03, w.shape)
+            d2, idx, info = _shard_query(w, first, n, refresh=1000, e=e)
+            ref_d, ref_i = ora.nearest_neighbour(w.astype(np.float32), first, n)
+            np.testing.assert_array_equal(idx, ref_i, err_msg="query %d, %r" % (k, info))
+            np.testing.assert_array_equal(d2, ref_d)

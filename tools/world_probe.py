@@ -22,6 +22,19 @@ for refresh in (1, 16):
     e.record(b); ms = e.elapsed_ms(a, b) / 32
     print("refresh every %2d queries: %.3f ms per query on the stream, %.3f ms of host time to submit one" % (refresh, ms, t_submit / 32 * 1e3))
 print(e.neighbour_grid_info())
+# the cell order kept over several queries (afe_set_neighbour_sort_reuse) while the ensemble flies on
+e.set_neighbour_grid_refresh(16)
+for reuse in (1, 4, 8, 16):
+    e.set_neighbour_sort_reuse(reuse)
+    for _ in range(3): e.nearest_neighbour(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr())
+    e.sync()
+    a, b = e.event(), e.event(); tq = 0.0
+    for _ in range(32):
+        e.step(1000, 10); e.pack_positions(xyz.data_ptr())
+        e.record(a); e.nearest_neighbour(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr()); e.record(b); e.sync()
+        tq += e.elapsed_ms(a, b)
+    print("sort every %2d queries, ten steps of flight between queries: %.3f ms per query on the stream  %s" % (reuse, tq / 32, e.neighbour_grid_info()))
+e.set_neighbour_sort_reuse(1)
 e.set_neighbour_grid_refresh(16)
 for cs in (6.0, 8.0, 10.0, 11.0, 12.0, 14.0, 17.0):
     for _ in range(3): e.nearest_neighbour(xyz.data_ptr(), n, d2.data_ptr(), idx.data_ptr(), cell_size=cs)
