@@ -209,6 +209,9 @@ extern "C" int afe_gather_positions(afe_engine *e, afe_comm *c, const int64_t *c
   int64_t first = 0, n = 0;
   engine_shard(e, &first, &n);
   if (counts && counts[c->rank] != n) { c->err = "counts[rank] differs from the engine's vehicle count"; return AFE_ERR_INVALID_ARG; }
+  // one rank: the gathered buffer IS the packed block -- straight into it, no copy through the communicator (three
+  // device-to-device copies of 4 MB at 2^20 vehicles, 16 us of every query cycle)
+  if (c->n_ranks == 1) return afe_pack_positions(e, dev_xyz_all);
   float *scratch = nullptr;
   int rc = engine_pack_to_scratch(e, &scratch);
   if (rc) return rc;

@@ -127,8 +127,9 @@ __device__ __forceinline__ void cell_of(const GridDesc &g, float x, float y, flo
 // counting sort, pass 1: cell of every point, histogram, slot of the point inside its cell
 __global__ void __launch_bounds__(256) world_count_kernel(const float *__restrict__ xyz, int64_t n, GridDesc g,
                                                           uint32_t *__restrict__ counts, uint32_t *__restrict__ cell,
-                                                          uint32_t *__restrict__ slot) {
+                                                          uint32_t *__restrict__ slot, uint32_t *__restrict__ left_count, uint32_t *__restrict__ words) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) { left_count[0] = 0; left_count[1] = 0; words[0] = 0; }   // this query's leftover counter; a fresh sort: nobody has moved
   if (i >= n) return;
   const float x = xyz[i], y = xyz[n + i], z = xyz[2 * n + i];
   uint32_t c = (uint32_t)g.n_cells;
@@ -234,9 +235,10 @@ __global__ void __launch_bounds__(256) world_scatter_kernel(const float *__restr
 // and the host is told to sort again (host_flag, pinned memory).
 __global__ void __launch_bounds__(256) world_regather_kernel(const float *__restrict__ xyz, int64_t n, const uint32_t *__restrict__ cell,
                                                              const uint32_t *__restrict__ slot, const float *__restrict__ ref, int64_t ref_stride,
-                                                             uint4 *__restrict__ sorted, float *__restrict__ partial) {
+                                                             uint4 *__restrict__ sorted, float *__restrict__ partial, uint32_t *__restrict__ left_count) {
 #pragma clang fp contract(off)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) { left_count[0] = 0; left_count[1] = 0; }   // this query's leftover counter
   float moved = 0.0f;
   if (i < n) {
     const float x = xyz[i], y = xyz[n + i], z = xyz[2 * n + i];
@@ -674,7 +676,7 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   // The shape may be kept for a few queries: the query is exact for ANY grid (positions outside it clamp
   // into its boundary cells), a stale shape only costs speed, and without the read-back the whole query is
   // asynchronous on the stream (afe_set_neighbour_grid_refresh).
-  W_HIP(w, hipMemsetAsync(w->lohi + 6, 0, 8, st));   // leftover counter (a device-side fill: a copy from pageable host memory would make the host wait for the stream)
+  // (the leftover counter is zeroed by the first kernel of the sort / of the regather)
   // A shard that queries for its own block of a larger gathered ensemble shapes the grid on ITS vehicles and sorts
   // only what can matter to them (see GridDesc::filtered): the cost of a query then follows the shard, not the
   // ensemble -- on 8 GPUs every rank would otherwise sort all 8 x 2^20 gathered positions for its 2^20 queries.
@@ -721,13 +723,13 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
     w->since_sort++;
     // (the partial maxima live in the leftover-key scratch: the brute force behind the query is the next to touch it)
     float *partial = (float *)w->leftover_keys;
-    hipLaunchKernelGGL(world_regather_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, w->cell, w->slot, w->ref, w->cap_points, w->sorted, partial);
+    hipLaunchKernelGGL(world_regather_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, w->cell, w->slot, w->ref, w->cap_points, w->sorted, partial,
+                       (uint32_t *)(w->lohi + 6));
     hipLaunchKernelGGL(world_moved_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)pb, w->words, w->host_flag);
   } else {
     // 2. counting sort by cell
     W_HIP(w, hipMemsetAsync(w->counts, 0, (size_t)m * 4, st));
-    W_HIP(w, hipMemsetAsync(w->words, 0, 4, st));
-    hipLaunchKernelGGL(world_count_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, g, w->counts, w->cell, w->slot);
+    hipLaunchKernelGGL(world_count_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, g, w->counts, w->cell, w->slot, (uint32_t *)(w->lohi + 6), w->words);
     const int64_t nb = (m + 1023) / 1024;
     hipLaunchKernelGGL(world_scan_local_kernel, dim3((unsigned)nb), dim3(256), 0, st, w->counts, w->counts, w->block_sums, m);
     hipLaunchKernelGGL(world_scan_blocks_kernel, dim3(1), dim3(256), 0, st, w->block_sums, nb);
