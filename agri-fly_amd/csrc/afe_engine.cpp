@@ -111,6 +111,9 @@ struct afe_engine {
   int p_workers = 0;
   int p_cus = 0;
   int p_shrink_num = 16;    // sixteenths of the computed capacity still trusted (a stalled grid takes one off)
+  int p_capacity = 0;       // resident one-wave workgroups per CU of the current configuration's kernel (p_capacity_key)
+  unsigned p_capacity_key = 0;
+  bool p_balanced = false;
   uint64_t p_next = 0;      // ring entries written so far == index of the next step to authorise
   uint64_t p_resume = 0;    // where the next grid starts (every worker's done[] stands there while none runs)
   uint64_t p_dt_us = 0;     // what the resident grid was launched with
@@ -475,9 +478,19 @@ int persist_alloc(afe_engine *e) {
 // worker waves of the grid about to be launched: one per chunk if the device keeps that many resident, else
 // every resident slot but the pump's (the instantiation's occupancy x CUs), less whatever earlier stalls took off
 void persist_size_grid(afe_engine *e) {
-  int per_cu = e->precision == AFE_F64 ? persistent_capacity_f64(e->p_flags) : persistent_capacity_f32(e->p_flags);
-  if (per_cu < 1) per_cu = 1;
-  if (const char *s = std::getenv("AFE_PERSIST_WAVES_PER_CU")) { const int k = std::atoi(s); if (k >= 1 && k <= 32) per_cu = k; }
+  // (the occupancy query and the environment are asked once per configuration, not at every launch: a grid is started
+  // after every synchronisation of a host that steps in short blocks)
+  const unsigned key = 1u | (e->p_flags.ext_force ? 2u : 0u) | (e->p_flags.noise ? 4u : 0u) | (e->p_flags.logic ? 8u : 0u) |
+                       (e->p_flags.counter_noise ? 16u : 0u) | (e->p_flags.resident ? 32u : 0u);
+  if (e->p_capacity_key != key) {
+    int cap = e->precision == AFE_F64 ? persistent_capacity_f64(e->p_flags) : persistent_capacity_f32(e->p_flags);
+    if (cap < 1) cap = 1;
+    if (const char *s = std::getenv("AFE_PERSIST_WAVES_PER_CU")) { const int k = std::atoi(s); if (k >= 1 && k <= 32) cap = k; }
+    e->p_capacity = cap;
+    e->p_capacity_key = key;
+    e->p_balanced = std::getenv("AFE_PERSIST_BALANCED") != nullptr;
+  }
+  const int per_cu = e->p_capacity;
   const int64_t chunks = (e->n + 63) / 64;
   int64_t cap = (int64_t)e->p_cus * per_cu - 1;     // the pump takes one slot
   cap = cap * e->p_shrink_num / 16;
@@ -487,7 +500,7 @@ void persist_size_grid(afe_engine *e) {
   // the waves with less to do run ahead into the ring's window and wait there with backed-off polls, costing nothing,
   // while equal shares on fewer waves (5 462 x 3) leave memory parallelism unused: 19.4 against 21.0 us per step.
   e->p_workers = (int)(chunks < cap ? chunks : cap);
-  if (std::getenv("AFE_PERSIST_BALANCED")) {      // measurement aid: the fewest waves with equal shares
+  if (e->p_balanced) {      // AFE_PERSIST_BALANCED, measurement aid: the fewest waves with equal shares
     const int64_t per_wave = (chunks + cap - 1) / cap;
     e->p_workers = (int)((chunks + per_wave - 1) / per_wave);
   }
