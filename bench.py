@@ -239,10 +239,10 @@ def committed_traffic(n_local):
         t = json.load(open(path))
         w = t["workload"]
         if w["vehicles_per_gpu"] == n_local and w["dt_us"] == DT_US and w["fext"] and w["noise"]:
-            return t.get("traffic_bytes_per_step", t["traffic_bytes_per_launch"]), t["source"]
+            return t.get("traffic_bytes_per_step", t["traffic_bytes_per_launch"]), t["source"], t.get("rocprof_kernel_us_per_step")
     except (OSError, KeyError, ValueError):
         pass
-    return None, None
+    return None, None, None
 
 
 def config1_row():
@@ -733,7 +733,7 @@ def main():
             time_steps(e, 100, 1, sync, lambda: None)
             t_launch = median([kernel_time_events(e, long_steps) for _ in range(3)])
             e.set_step_mode(mode)
-        traffic, traffic_src = committed_traffic(n_local)
+        traffic, traffic_src, rocprof_us = committed_traffic(n_local)
         # what the box streams in this launch shape, in this run (measured figure next to the nominal peak)
         probe = None
         if not args.headline_only:
@@ -788,11 +788,15 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "kernel": ("afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=2 (counter), LOGIC=0>: one launch serves every step between two "
-                           "synchronisations; its rocprofv3 duration / the steps it served = kernel_us" if persistent else
+                           "synchronisations; its rocprofv3 duration / the steps it served = kernel_us_rocprof, the HIP events around a block = kernel_us" if persistent else
                            "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, LOGIC=0, SINGLE=1>, 64-lane workgroups -- the timed region "
                            "alternates NOISE=0 (no logic tick) and NOISE=1 (tick: IMU + six Gaussian draws) launches"),
                 "kernel_us": t_kernel * 1e6,
                 "kernel_us_min": t_kmin * 1e6, "kernel_us_max": t_kmax * 1e6, "kernel_repeats": k_rep,
+                # the committed rocprofv3 kernel trace of this command: the resident grid's own duration per step.  The events
+                # above bracket the whole block on the stream -- dispatch of the grid, its ramp-up and the park hand-shake
+                # included (about 25 us per block, i.e. 1.3 us per step in blocks of 20) -- so they read higher than the kernel
+                "kernel_us_rocprof": rocprof_us,
                 "steps_per_event_block": args.steps,
                 "algorithmic_bytes_per_vehicle_step": bytes_step,
                 "algorithmic_bytes_per_step": n_local * bytes_step,

@@ -86,6 +86,10 @@ if fetch.get("FETCH_SIZE") and write.get("WRITE_SIZE"):
         json.dump({"workload": {"vehicles_per_gpu": N, "fext": True, "noise": True, "dt_us": 1000, "logic_period_s": 0.002},
                    "traffic_bytes_per_step": per_step,
                    "traffic_bytes_per_launch": per_step,
+                   "rocprof_kernel_us_per_step": {"blocks_of_20_steps": summary.get("blocks_of_20_steps", {}).get("us_per_step"),
+                                                  "blocks_of_2000_steps": summary.get("blocks_of_2000_steps", {}).get("us_per_step"),
+                                                  "source": "profiles/%s_k20_kernel_stats.csv, profiles/%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats; "
+                                                            "median duration of the resident grid's launches / the steps each served)" % (tag, tag)},
                    "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over resident-grid launches of %d steps, separate passes, "
                              "FETCH_SIZE x2 gfx950 correction)" % (tag, steps)}, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 if sq.get("SQ_WAVES"):
