@@ -94,8 +94,9 @@ def time_steps(e, steps, per_launch, sync, barrier):
         done += k
     e.sync()
     sync()
-    barrier()
-    return time.perf_counter() - t0
+    t1 = time.perf_counter()      # this rank's own finish; the caller takes the MAX over ranks (the closing barrier's own
+    barrier()                     # latency is not part of anybody's K steps)
+    return t1 - t0
 
 
 def timed_blocks(e, steps, per_launch, sync, barrier, reduce_max, min_total_s=0.05, min_blocks=5, max_blocks=2000):
