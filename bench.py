@@ -502,7 +502,7 @@ def shared_world(afa, n_local, rank, world, local_rank, dist, torch, sync, barri
     def reduce_max(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if one_device else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -654,7 +654,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if torch.cuda.device_count() < world:
+    # test hook (tools/bench_two_ranks_one_gpu.sh): every rank on device 0 and gloo instead of RCCL, so that the N > 1
+    # control flow -- shard bookkeeping, the strong-scaling row, the MAX over ranks -- can be run on a one-GPU box.
+    # RCCL refuses two ranks on one device, so the shared-world part needs --no-shared-world there; no number is meant.
+    one_device = os.environ.get("AFE_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
+    if torch.cuda.device_count() < world and not one_device:
         raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
@@ -664,7 +670,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with stdout_to_stderr():     # RCCL's banner must not land on stdout
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if one_device:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
 
