@@ -469,7 +469,7 @@ int persist_alloc(afe_engine *e) {
   AFE_HIP(e, hipHostMalloc((void **)&e->p_host, hbytes, hipHostMallocCoherent | hipHostMallocMapped));
   std::memset(e->p_host, 0, hbytes);
   AFE_HIP(e, hipHostGetDevicePointer((void **)&e->p_host_dev, e->p_host, 0));
-  const size_t dbytes = ((size_t)AFE_PERSIST_DEV_RING + (size_t)(chunks < most ? chunks : most) + 8) * sizeof(unsigned long long);   // + the workers' call-for-help word behind done[]
+  const size_t dbytes = (8 + (size_t)AFE_PERSIST_DEV_RING + (size_t)(chunks < most ? chunks : most) + 8) * sizeof(unsigned long long);   // [8 words: the workers' call-for-help word is the last of them][ring][done[]]
   AFE_HIP(e, hipMalloc((void **)&e->p_dev, dbytes));
   AFE_HIP(e, hipMemsetAsync(e->p_dev, 0, dbytes, e->stream));
   return AFE_OK;
@@ -543,8 +543,8 @@ int persist_launch(afe_engine *e) {
   PersistArgs a;
   a.host_ring = e->p_host_dev;
   a.host_status = e->p_host_dev + AFE_PERSIST_HOST_RING;
-  a.dev_ring = e->p_dev;
-  a.done = e->p_dev + AFE_PERSIST_DEV_RING;
+  a.dev_ring = e->p_dev + 8;
+  a.done = e->p_dev + 8 + AFE_PERSIST_DEV_RING;
   a.start = e->p_resume;
   a.host_mask = AFE_PERSIST_HOST_RING - 1; a.dev_mask = AFE_PERSIST_DEV_RING - 1;
   a.n_workers = e->p_workers;
@@ -581,6 +581,9 @@ int persist_launch(afe_engine *e) {
     lrc = launch_persistent_f32(v, f, e->table_f32[0], ulogic, a, e->stream);
   }
   if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("persistent step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+  static const bool debug = std::getenv("AFE_PERSIST_DEBUG") != nullptr;   // development aid: one line per grid
+  if (debug) std::fprintf(stderr, "agrifly_engine: grid %u: %d workers (%d per CU allowed) for %lld chunks, from step %llu, resident-state %d noise %d logic %d force %d\n",
+                          e->p_epoch, e->p_workers, e->p_capacity, (long long)a.n_chunks, (unsigned long long)a.start, (int)f.resident, (int)f.noise + (int)f.counter_noise, (int)f.logic, (int)f.ext_force);
   e->p_running = true;
   return AFE_OK;
 }
@@ -595,8 +598,10 @@ int persist_collect(afe_engine *e) {
     // started held the ring's window shut).  It parked at st[0] - 1 and every workgroup, late ones included, stopped
     // there: nothing is torn.  The next grid is cut smaller.
     e->p_shrink_num--;
-    std::fprintf(stderr, "agrifly_engine: a resident grid of %d worker waves stalled; continuing with %d/16 of the computed capacity\n",
-                 e->p_workers, e->p_shrink_num);
+    std::fprintf(stderr, "agrifly_engine: a resident grid of %d worker waves stalled; continuing with %d/16 of the computed capacity "
+                         "(the pump had republished up to step %llu; the slowest worker, #%u, and %u with it stood at %llu; help word %llu)\n",
+                 e->p_workers, e->p_shrink_num, (unsigned long long)st[4], (unsigned)(st[5] >> 32), (unsigned)(st[5] & 0xffffffffu),
+                 (unsigned long long)st[3], (unsigned long long)(st[6] >> 32));
   } else if (herr != hipSuccess || st[0] == 0 || st[2] != 0) {
     e->p_failed = true;
     return fail(e, AFE_ERR_HIP, herr != hipSuccess ? std::string("persistent step kernel: ") + hipGetErrorString(herr)

@@ -967,7 +967,7 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
   u64_t park_pos;
   u64_t err = 0;
   u64_t m = a.start;                    // every worker has consumed at least this much (a lower bound: done[] only grows)
-  u64_t *const help = a.done + a.n_workers;   // a worker that has waited far too long asks for a park here (below)
+  u64_t *const help = a.dev_ring - 1;   // a worker that has waited far too long asks for a park here (below): a word of its own in front of the ring
   if (lane == 0) st_agent(help, 0);
   u64_t acc = ~0ull;                    // this lane's minimum over the part of done[] swept so far in the current cycle
   int sw = 0;                           // where the next partial sweep starts
@@ -1016,6 +1016,31 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
       break;
     }
   }
+  if (err) {
+    // what the pump saw when it gave up, for the host's message: the slowest worker, how many stand with it, where the
+    // republishing stood, whether a worker had called for help
+    u64_t low = ~0ull;
+    int who = -1, with = 0;
+    for (int w0 = 0; w0 < a.n_workers; w0 += 64) {
+      const int w = w0 + lane;
+      const u64_t d = w < a.n_workers ? ld_agent(a.done + w) : ~0ull;
+      if (d < low) { low = d; who = w; with = 0; }
+      if (d == low && w < a.n_workers) with++;
+    }
+    u64_t glow = low;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u64_t other = __shfl_xor(glow, o, 64); glow = other < glow ? other : glow; }
+    const u64_t holders = __ballot(low == glow);
+    int total = low == glow ? with : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    if (lane == (int)__builtin_ctzll(holders)) {
+      st_system(a.host_status + 3, glow);
+      st_system(a.host_status + 4, p);
+      st_system(a.host_status + 5, ((u64_t)(unsigned)who << 32) | (u64_t)(unsigned)total);
+      st_system(a.host_status + 6, (ld_agent(help) << 32) | (u64_t)(unsigned)a.n_workers);
+    }
+  }
   if (lane == 0) {
     if (err) st_system(a.host_status + 2, err);
     st_system(a.host_status + 0, park_pos + 1);
@@ -1033,6 +1058,11 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
   if (blockIdx.x == 0) { persist_pump(a); return; }
   const int lane = (int)threadIdx.x;
   const int w = (int)blockIdx.x - 1;
+  // this worker's mark stands where the grid starts.  (Not a formality: a grid with MORE workers than the last one --
+  // another configuration's kernel keeps more waves resident -- would otherwise find the marks of the additional
+  // workers where an older grid left them; the pump would take them for stragglers a thousand steps behind, never open
+  // the ring's window, and park the grid as stalled after 50 ms.  Found by tools/handshake_soak.py.)
+  if (lane == 0) st_agent(a.done + w, a.start);
   u64_t s = a.start;
   u64_t t_wait = ticks100();
   u64_t tick_no = v.tick_base;                       // logic ticks so far (the counter policy's sample address)
@@ -1052,7 +1082,7 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
       // EVERYBODY at one step -- nothing is torn, the host starts a smaller grid -- and only after ten more seconds
       // without an answer leave alone, with the error that says so.
       const u64_t waited = ticks100() - t_wait;
-      if (waited > (u64_t)a.give_up_ticks + 50000000ull && lane == 0) st_agent(a.done + a.n_workers, 1);
+      if (waited > (u64_t)a.give_up_ticks + 50000000ull && lane == 0) st_agent(a.dev_ring - 1, 1);
       if (waited > (u64_t)a.give_up_ticks + 1050000000ull) {
         if (lane == 0) st_system(a.host_status + 2, 2);
         return;

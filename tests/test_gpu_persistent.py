@@ -253,3 +253,29 @@ def test_two_resident_grids_on_one_device_take_turns():
         assert_same(a2, b2, n)
         for e in (a1, a2, b1, b2):
             e.close()
+
+
+def test_a_grid_with_more_workers_than_the_last_one_starts_at_once(capfd):
+    """Configurations differ in how many waves their kernel keeps resident (fp64 at 140 000 vehicles = 2 188 chunks: 2 047
+    workers with the IMU noise on, 2 188 with it off).  A grid that has MORE workers than the one before it finds, for
+    the additional workers, completion marks that no grid of this run has written: they must not count as stragglers
+    (every worker sets its mark to the grid's start when it arrives).  Right bits, no 50 ms hiccup, no complaint."""
+    n = 140000
+    a, _ = make(n, afa.AFE_F64, False)
+    b, _ = make(n, afa.AFE_F64, True)
+    for _ in range(40):                       # more steps than the device ring holds: the old marks are far behind now
+        a.step(1000, 40); b.step(1000, 40)
+    for e in (a, b):
+        e.set_imu_noise(False, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+    b.sync()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        b.step(1000, 1)
+    b.sync()
+    took = time.perf_counter() - t0
+    a.step(1000, 10)
+    assert_same(a, b)
+    err = capfd.readouterr().err
+    assert "stalled" not in err, err
+    assert took < 0.03, "ten steps after the change took %.1f ms" % (took * 1e3)
+    a.close(); b.close()
