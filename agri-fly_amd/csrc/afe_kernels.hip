@@ -1034,6 +1034,18 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
     int total = low == glow ? with : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    // (and who they are, up to 32 of them: host_status[8 + k] -- the slots of the host-visible marks, free here)
+    if (!(a.epoch & AFE_PERSIST_HOST_IO)) {
+      int slot = 0;
+      for (int w0 = 0; w0 < a.n_workers && slot < 32; w0 += 64) {
+        const int w = w0 + lane;
+        const bool is = w < a.n_workers && ld_agent(a.done + w) == glow;
+        const u64_t mask = __ballot(is);
+        const int my = slot + (int)__popcll(mask & ((1ull << lane) - 1));
+        if (is && my < 32) st_system(a.host_status + 8 + my, (u64_t)(unsigned)w);
+        slot += (int)__popcll(mask);
+      }
+    }
     if (lane == (int)__builtin_ctzll(holders)) {
       st_system(a.host_status + 3, glow);
       st_system(a.host_status + 4, p);
@@ -1077,12 +1089,13 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
     const bool ready = entry_index(e) == idx + 1 && (!(e & AFE_PERSIST_PARK) || (unsigned)(e >> 48) == (a.epoch & 0xffffu));
     const int cnt = ones_from_bit0(__ballot(ready));
     if (cnt == 0) {
-      // Starved for half a second (the pump parks an idle grid after 200 us, so this is not a quiet host: the pump is
-      // not getting through, or part of the grid is not resident beside somebody else's kernels): ask the pump to park
-      // EVERYBODY at one step -- nothing is torn, the host starts a smaller grid -- and only after ten more seconds
-      // without an answer leave alone, with the error that says so.
+      // Starved for 60 ms (the pump parks an idle grid after 200 us, so this is not a quiet host: the pump is not
+      // getting through, or part of the grid is not resident beside somebody else's kernels -- seen by the soak: the
+      // last few workgroups of an fp64 grid beside a second engine's launches, whose host thread was waiting for
+      // exactly those launches): ask the pump to park EVERYBODY at one step -- nothing is torn, the host starts a
+      // smaller grid -- and only after ten more seconds without an answer leave alone, with the error that says so.
       const u64_t waited = ticks100() - t_wait;
-      if (waited > (u64_t)a.give_up_ticks + 50000000ull && lane == 0) st_agent(a.dev_ring - 1, 1);
+      if (waited > (u64_t)a.give_up_ticks + 1000000ull && lane == 0) st_agent(a.dev_ring - 1, 1);
       if (waited > (u64_t)a.give_up_ticks + 1050000000ull) {
         if (lane == 0) st_system(a.host_status + 2, 2);
         return;
