@@ -502,7 +502,9 @@ int afe_get_external_force(afe_engine *e, int64_t first, int64_t count, double *
  * synchronisation issued elsewhere -- can wait on it for ever.  A grid of a large ensemble occupies every wave slot of
  * the device while it is resident: another engine's grid, or any other kernel of the process, starts when it has left
  * (two such engines stepped alternately take turns, each handing over after its 200 us of idling -- correct, slow:
- * tests/test_gpu_persistent.py; one process, one large resident grid per device is the intended use).
+ * tests/test_gpu_persistent.py; one process, one large resident grid per device is the intended use).  A grid that starts
+ * while another engine's launch is running may find the register file fragmented and a few of its workgroups without a
+ * slot; the grid notices (60 ms), parks at one step and is started again -- results are unaffected, stderr says so.
  *   mode = AFE_STEP_LAUNCH (0, default): one kernel launch per step (or per afe_set_max_fused_steps chunk).
  *   mode = AFE_STEP_PERSISTENT (1): as above, whenever the ensemble qualifies -- every vehicle on type record 0,
  *     no external torque, the engine's own stream, an arena below 4 GiB; otherwise the launches, silently.
