@@ -602,12 +602,6 @@ int persist_collect(afe_engine *e) {
                          "(the pump had republished up to step %llu; the slowest worker, #%u, and %u with it stood at %llu; help word %llu)\n",
                  e->p_workers, e->p_shrink_num, (unsigned long long)st[4], (unsigned)(st[5] >> 32), (unsigned)(st[5] & 0xffffffffu),
                  (unsigned long long)st[3], (unsigned long long)(st[6] >> 32));
-    if (!e->host_arena) {
-      const unsigned cnt = std::min<unsigned>((unsigned)(st[5] & 0xffffffffu), 32u);
-      std::fprintf(stderr, "agrifly_engine:   the workers that stood there:");
-      for (unsigned k = 0; k < cnt; k++) std::fprintf(stderr, " %llu", (unsigned long long)st[8 + k]);
-      std::fprintf(stderr, "\n");
-    }
   } else if (herr != hipSuccess || st[0] == 0 || st[2] != 0) {
     e->p_failed = true;
     return fail(e, AFE_ERR_HIP, herr != hipSuccess ? std::string("persistent step kernel: ") + hipGetErrorString(herr)

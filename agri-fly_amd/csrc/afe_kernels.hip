@@ -969,6 +969,12 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
   u64_t m = a.start;                    // every worker has consumed at least this much (a lower bound: done[] only grows)
   u64_t *const help = a.dev_ring - 1;   // a worker that has waited far too long asks for a park here (below): a word of its own in front of the ring
   if (lane == 0) st_agent(help, 0);
+  // every worker's mark stands where the grid starts, before any entry is republished.  (Not a formality: a grid with
+  // MORE workers than the last one -- another configuration's kernel keeps more waves resident -- would otherwise find
+  // the marks of the additional workers where an older grid left them and take them for stragglers a thousand steps
+  // behind.  Done here and not by the workers themselves: four more vector registers in the worker's path are the
+  // difference between six and five resident waves per SIMD, 19.3 and 20.8 us per step at 2^20 vehicles -- measured.)
+  for (int w = lane; w < a.n_workers; w += 64) st_agent(a.done + w, a.start);
   u64_t acc = ~0ull;                    // this lane's minimum over the part of done[] swept so far in the current cycle
   int sw = 0;                           // where the next partial sweep starts
   for (;;) {
@@ -1034,18 +1040,6 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
     int total = low == glow ? with : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
-    // (and who they are, up to 32 of them: host_status[8 + k] -- the slots of the host-visible marks, free here)
-    if (!(a.epoch & AFE_PERSIST_HOST_IO)) {
-      int slot = 0;
-      for (int w0 = 0; w0 < a.n_workers && slot < 32; w0 += 64) {
-        const int w = w0 + lane;
-        const bool is = w < a.n_workers && ld_agent(a.done + w) == glow;
-        const u64_t mask = __ballot(is);
-        const int my = slot + (int)__popcll(mask & ((1ull << lane) - 1));
-        if (is && my < 32) st_system(a.host_status + 8 + my, (u64_t)(unsigned)w);
-        slot += (int)__popcll(mask);
-      }
-    }
     if (lane == (int)__builtin_ctzll(holders)) {
       st_system(a.host_status + 3, glow);
       st_system(a.host_status + 4, p);
@@ -1064,17 +1058,17 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
 // the L2 on this device, a step then reads what the host wrote two setters ago.)
 #define AFE_HOST_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "")
 #define AFE_HOST_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "")
+// fp32 instantiations that keep one step's state only are held to the 80 vector registers of six resident waves per
+// SIMD: the on-device logic's kernels sit at 81-82 on their own, one register over (five waves, 5 119 workers instead
+// of 6 143)
+template <typename R, bool LOGIC, bool RESIDENT>
+constexpr int persistent_min_waves() { return (sizeof(R) == 4 && !RESIDENT) ? 6 : 1; }
 template <typename R, bool FEXT, int NOISE, bool LOGIC, bool RESIDENT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(persistent_min_waves<R, LOGIC, RESIDENT>())))
 afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G, const PersistArgs a) {
   if (blockIdx.x == 0) { persist_pump(a); return; }
   const int lane = (int)threadIdx.x;
   const int w = (int)blockIdx.x - 1;
-  // this worker's mark stands where the grid starts.  (Not a formality: a grid with MORE workers than the last one --
-  // another configuration's kernel keeps more waves resident -- would otherwise find the marks of the additional
-  // workers where an older grid left them; the pump would take them for stragglers a thousand steps behind, never open
-  // the ring's window, and park the grid as stalled after 50 ms.  Found by tools/handshake_soak.py.)
-  if (lane == 0) st_agent(a.done + w, a.start);
   u64_t s = a.start;
   u64_t t_wait = ticks100();
   u64_t tick_no = v.tick_base;                       // logic ticks so far (the counter policy's sample address)
