@@ -110,7 +110,8 @@ struct afe_engine {
   unsigned long long *p_dev = nullptr;       // device memory: ring[AFE_PERSIST_DEV_RING] + done[p_workers]
   int p_workers = 0;
   int p_cus = 0;
-  int p_shrink_num = 16;    // sixteenths of the computed capacity still trusted (a stalled grid takes one off)
+  int p_shrink_num = 16;    // sixteenths of the computed capacity still trusted (two stalled grids in a row take one off)
+  int p_stall_streak = 0;
   int p_capacity = 0;       // resident one-wave workgroups per CU of the current configuration's kernel (p_capacity_key)
   unsigned p_capacity_key = 0;
   bool p_balanced = false;
@@ -597,7 +598,9 @@ int persist_collect(afe_engine *e) {
     // The pump saw steps waiting and no worker moving for 50 ms: the grid was not co-resident (workgroups that never
     // started held the ring's window shut).  It parked at st[0] - 1 and every workgroup, late ones included, stopped
     // there: nothing is torn.  The next grid is cut smaller.
-    e->p_shrink_num--;
+    // (once: the same size again -- beside another engine's launches a grid can find the register file fragmented, which
+    // says nothing about the next start; twice in a row: the capacity is wrong, take a sixteenth off)
+    if (++e->p_stall_streak >= 2) { e->p_shrink_num--; e->p_stall_streak = 0; }
     std::fprintf(stderr, "agrifly_engine: a resident grid of %d worker waves stalled; continuing with %d/16 of the computed capacity "
                          "(the pump had republished up to step %llu; the slowest worker, #%u, and %u with it stood at %llu; help word %llu)\n",
                  e->p_workers, e->p_shrink_num, (unsigned long long)st[4], (unsigned)(st[5] >> 32), (unsigned)(st[5] & 0xffffffffu),
@@ -608,6 +611,7 @@ int persist_collect(afe_engine *e) {
                                    : st[2] ? "persistent step kernel gave up waiting (code " + std::to_string(st[2]) + "); the ensemble may be torn between two steps"
                                            : std::string("persistent step kernel ended without parking"));
   }
+  else e->p_stall_streak = 0;     // (a grid that parked in the ordinary way)
   e->p_resume = st[0] - 1;
   return AFE_OK;
 }
