@@ -1060,9 +1060,10 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
 #define AFE_HOST_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "")
 // fp32 instantiations that keep one step's state only are held to the 80 vector registers of six resident waves per
 // SIMD: the on-device logic's kernels sit at 81-82 on their own, one register over (five waves, 5 119 workers instead
-// of 6 143)
+// of 6 143).  The resident-state ones without logic are held to five waves (96 registers; 101-104 on their own, a few
+// dwords of scratch instead): measured 3.1 -> 2.7 us per step at 262 144 vehicles, 11.0 -> 10.7 at 2^20
 template <typename R, bool LOGIC, bool RESIDENT>
-constexpr int persistent_min_waves() { return (sizeof(R) == 4 && !RESIDENT) ? 6 : 1; }
+constexpr int persistent_min_waves() { return sizeof(R) != 4 ? 1 : (!RESIDENT ? 6 : (LOGIC ? 1 : 5)); }
 template <typename R, bool FEXT, int NOISE, bool LOGIC, bool RESIDENT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(persistent_min_waves<R, LOGIC, RESIDENT>())))
 afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G, const PersistArgs a) {
