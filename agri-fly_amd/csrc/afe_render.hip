@@ -496,21 +496,26 @@ __device__ __forceinline__ void walk(const RenderArgs &a, const PairNode *tree, 
     const uint32_t ref1 = right_first ? R[13] : R[12], ref2 = right_first ? R[12] : R[13];
     const unsigned c1 = (right_first ? (meta >> 16) : (meta >> 8)) & 255u;
     const unsigned c2 = (right_first ? (meta >> 8) : (meta >> 16)) & 255u;
-    if (m1 && c1) leaf_triangles<COUNT, ORDERED>(a, ray, br, tribox, ref1, c1, m1, cnt);
-    if (m2 && c2) leaf_triangles<COUNT, ORDERED>(a, ray, br, tribox, ref2, c2, m2, cnt);
-    const bool inner1 = m1 && !c1, inner2 = m2 && !c2;
     // the far child goes into slot sp at EVERY visit and sp advances only when it is really pushed: a conditional
     // write makes the compiler carry the three stack registers through copies on both paths (six v_mov per visit,
     // an eighth of the kernel's vector instructions); what an unadvanced slot holds is never read
     st_node = afe_writelane((int)ref2, sp, st_node);
     st_lo = afe_writelane((int)(uint32_t)m2, sp, st_lo);
     st_hi = afe_writelane((int)(uint32_t)(m2 >> 32), sp, st_hi);
-    if (inner1) {
-      sp += inner2 ? 1 : 0;
-      cur = ref1; act = m1;
-      continue;
+    // (nested tests on the masks and counts themselves: every one is a scalar compare and branch; the same decisions
+    // written as booleans that are combined and reused cost twice the scalar instructions)
+    uint32_t nxt = 0xffffffffu;
+    uint64_t nact = 0;
+    if (m1 != 0) {
+      if (c1 != 0) leaf_triangles<COUNT, ORDERED>(a, ray, br, tribox, ref1, c1, m1, cnt);
+      else { nxt = ref1; nact = m1; }
     }
-    if (inner2) { cur = ref2; act = m2; continue; }
+    if (m2 != 0) {
+      if (c2 != 0) leaf_triangles<COUNT, ORDERED>(a, ray, br, tribox, ref2, c2, m2, cnt);
+      else if (nxt == 0xffffffffu) { nxt = ref2; nact = m2; }
+      else sp++;                     // both inner: the nearer one next, the farther one is in its slot already
+    }
+    if (nxt != 0xffffffffu) { cur = nxt; act = nact; continue; }
     if (sp == 0) break;
     --sp;
     cur = (uint32_t)__builtin_amdgcn_readlane(st_node, sp);
