@@ -256,6 +256,10 @@ struct Builder {
 #define AFE_TILE_H 8
 #endif
 constexpr int kTileW = AFE_TILE_W, kTileH = AFE_TILE_H, kStack = 32;
+#ifndef AFE_ENTRY_GROUP
+#define AFE_ENTRY_GROUP 2
+#endif
+constexpr int kEntryGroup = AFE_ENTRY_GROUP;
 
 struct PoseArgs {
   const void *pos, *att;      // planar, `stride` elements between components
@@ -321,6 +325,12 @@ struct RenderArgs {
   const TriRec *tris;       // leaf order
   const float *tribox;      // eight copies of n_tri x {lo, hi} x 3 (+ 2 pad): the triangles' boxes mirrored like the node boxes
   int64_t n_tri;
+  // triangles whose box spans a good part of the scene (a ground plane's two) are kept OUT of the tree -- every tile
+  // tests them first, which also gives every ray that looks down its pruning distance before the walk -- so that the
+  // tree's top levels separate space: records [big_first, big_first + n_big) of tris
+  uint32_t big_first, n_big;
+  int groups_x, groups_per_view;   // tiles in groups of kEntryGroup x kEntryGroup for the entry table
+  const uint32_t *entry;    // per tile group of this launch: byte offset of the PairNode its walk starts at (afe_tile_entry_kernel); NULL: the root
   const double *poses;
   uint16_t *out;
   unsigned long long *counters;   // counting build only: see afe_render_depth_stats
@@ -481,10 +491,10 @@ __device__ __forceinline__ void leaf_triangles(const RenderArgs &a, RayState &ra
 // does, so the result does not depend on the order.
 template <bool COUNT, bool ORDERED>
 __device__ __forceinline__ void walk(const RenderArgs &a, const PairNode *tree, const float *__restrict__ tribox, RayState &ray, const BoxRay &br,
-                                     bool in_image, unsigned neg, WalkCounters &cnt) {
+                                     bool in_image, unsigned neg, WalkCounters &cnt, uint32_t start) {
   int sp = 0;
   int st_node = 0, st_lo = 0, st_hi = 0;
-  uint32_t cur = 0;   // byte offset of the PairNode
+  uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);   // byte offset of the PairNode (wave-uniform: one tile, one entry)
   uint64_t act = __ballot(in_image);
   for (;;) {
     const u32x16 R = *reinterpret_cast<const u32x16 *>(reinterpret_cast<const char *>(tree) + cur);
@@ -504,9 +514,6 @@ __device__ __forceinline__ void walk(const RenderArgs &a, const PairNode *tree, 
     // the far child goes into slot sp at EVERY visit and sp advances only when it is really pushed: a conditional
     // write makes the compiler carry the three stack registers through copies on both paths (six v_mov per visit,
     // an eighth of the kernel's vector instructions); what an unadvanced slot holds is never read
-    st_node = afe_writelane((int)ref2, sp, st_node);
-    st_lo = afe_writelane((int)(uint32_t)m2, sp, st_lo);
-    st_hi = afe_writelane((int)(uint32_t)(m2 >> 32), sp, st_hi);
     // (nested tests on the masks and counts themselves: every one is a scalar compare and branch; the same decisions
     // written as booleans that are combined and reused cost twice the scalar instructions)
     uint32_t nxt = 0xffffffffu;
@@ -518,7 +525,12 @@ __device__ __forceinline__ void walk(const RenderArgs &a, const PairNode *tree, 
     if (m2 != 0) {
       if (c2 != 0) leaf_triangles<COUNT, ORDERED>(a, ray, br, tribox, ref2, c2, m2, cnt);
       else if (nxt == 0xffffffffu) { nxt = ref2; nact = m2; }
-      else sp++;                     // both inner: the nearer one next, the farther one is in its slot already
+      else {                         // both inner: the nearer one next, the farther one onto the stack
+        st_node = afe_writelane((int)ref2, sp, st_node);
+        st_lo = afe_writelane((int)(uint32_t)m2, sp, st_lo);
+        st_hi = afe_writelane((int)(uint32_t)(m2 >> 32), sp, st_hi);
+        sp++;
+      }
     }
     if (nxt != 0xffffffffu) { cur = nxt; act = nact; continue; }
     if (sp == 0) break;
@@ -533,6 +545,65 @@ __global__ void __launch_bounds__(256) afe_pixel_ray_table_kernel(double *uv, in
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < nx) uv[i] = (i - cx) / focal;
   else if (i < nx + ny) uv[i] = ((i - nx) - cy) / focal;
+}
+
+// Where a tile's walk may start.  One lane per tile: the four corner rays of the tile bound its 64 (the direction is
+// linear in the pixel, so every component of every ray lies between the corners' and, where the corners agree on its
+// sign, so does its reciprocal); a child box that the bundle cannot reach within the camera's range -- per axis the
+// earliest any ray can enter and the latest any can leave, the slab test on intervals -- holds nothing any ray of the
+// tile can hit.  From the root, as long as exactly ONE child is reachable and it is an inner node, go there: the walk
+// of the tile starts at the node where that stops.  In double, with a margin; an axis on which the corners do not
+// agree (or a component is nearly zero) constrains nothing.  Conservative, so the images cannot change; what it saves
+// is the visits of the top levels, whose other child is a part of the scene the tile's 10 m cannot reach.
+__global__ void __launch_bounds__(64) afe_tile_entry_kernel(RenderArgs a, uint32_t *entry) {
+#pragma clang fp contract(off)
+  // (one lane per GROUP of kEntryGroup x kEntryGroup tiles: a quarter of the lanes, entries half a level higher)
+  const int64_t logical = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (logical >= a.n_views * a.groups_per_view) return;
+  const int64_t view = logical / a.groups_per_view;
+  const int group = (int)(logical - view * a.groups_per_view);
+  const int px0 = (group % a.groups_x) * kTileW * kEntryGroup, py0 = (group / a.groups_x) * kTileH * kEntryGroup;
+  const int px1 = min(px0 + kTileW * kEntryGroup - 1, a.width - 1), py1 = min(py0 + kTileH * kEntryGroup - 1, a.height - 1);
+  const double *pose = a.poses + 12 * view;
+  const double us[2] = {a.uv[px0], a.uv[px1]}, vs[2] = {a.uv[a.tiles_x * kTileW + py0], a.uv[a.tiles_x * kTileW + py1]};
+  // (single precision with margins a hundred times its rounding: the boxes are inflated by 3e-4 m and more, the test
+  // only has to be conservative, and this kernel's time is not the images')
+  float inv[3][4];
+  int sign[3];          // +1 / -1: every corner agrees; 0: no constraint from this axis
+  for (int k = 0; k < 3; k++) {
+    int pos = 0, neg = 0;
+    for (int c = 0; c < 4; c++) {
+      const double d = pose[3 + 3 * k] * us[c & 1] + pose[4 + 3 * k] * vs[c >> 1] + pose[5 + 3 * k];
+      pos += d > 1e-6; neg += d < -1e-6;
+      inv[k][c] = __builtin_amdgcn_rcpf((float)d);
+    }
+    sign[k] = pos == 4 ? 1 : (neg == 4 ? -1 : 0);
+  }
+  const float o[3] = {(float)pose[0], (float)pose[1], (float)pose[2]};
+  const float t_limit = (float)((double)a.max_count * a.depth_scale * 1.001);
+  auto reachable = [&](const float *box) {
+    float tmin = 0.0f, tmax = t_limit;
+    for (int k = 0; k < 3; k++) {
+      if (sign[k] == 0) continue;
+      const float near = (sign[k] > 0 ? box[2 * k] : box[2 * k + 1]) - o[k];
+      const float far = (sign[k] > 0 ? box[2 * k + 1] : box[2 * k]) - o[k];
+      float tn = near * inv[k][0], tf = far * inv[k][0];
+      for (int c = 1; c < 4; c++) { tn = fminf(tn, near * inv[k][c]); tf = fmaxf(tf, far * inv[k][c]); }
+      tmin = fmaxf(tmin, tn - 1e-4f * (1.0f + fabsf(tn)));
+      tmax = fminf(tmax, tf + 1e-4f * (1.0f + fabsf(tf)));
+    }
+    return tmin <= tmax;
+  };
+  uint32_t cur = 0;
+  for (int level = 0; level < kStack; level++) {
+    const PairNode &P = *reinterpret_cast<const PairNode *>(reinterpret_cast<const char *>(a.pairs) + cur);
+    const bool hl = reachable(P.box_l), hr = reachable(P.box_r);
+    const unsigned cl = (P.meta >> 8) & 255u, cr = (P.meta >> 16) & 255u;
+    if (hl && !hr && cl == 0) cur = P.left;
+    else if (hr && !hl && cr == 0) cur = P.right;
+    else break;
+  }
+  entry[logical] = cur;
 }
 
 template <bool COUNT>
@@ -595,13 +666,17 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
       br.scale[k] = (f32x2){ai * 0.99999f, ai * 1.00001f};
       br.shift[k] = (f32x2){-ray.oi[k] * 0.99999f, -ray.oi[k] * 1.00001f};
     }
-    walk<COUNT, true>(a, a.pairs + (int64_t)neg * a.n_pairs, a.tribox + (int64_t)neg * a.n_tri * 8, ray, br, in_image, neg, cnt);
+    const float *tb = a.tribox + (int64_t)neg * a.n_tri * 8;
+    if (a.n_big) leaf_triangles<COUNT, true>(a, ray, br, tb, a.big_first, a.n_big, __ballot(in_image), cnt);
+    const int64_t group = view * a.groups_per_view + (int64_t)((tile / a.tiles_x) / kEntryGroup) * a.groups_x + (tile % a.tiles_x) / kEntryGroup;
+    walk<COUNT, true>(a, a.pairs + (int64_t)neg * a.n_pairs, tb, ray, br, in_image, neg, cnt, a.entry ? a.entry[group] : 0u);
   } else {
     for (int k = 0; k < 3; k++) {
       br.scale[k] = (f32x2){ray.inv[k], ray.inv[k]};
       br.shift[k] = (f32x2){-ray.oi[k], -ray.oi[k]};
     }
-    walk<COUNT, false>(a, a.pairs, a.tribox, ray, br, in_image, neg, cnt);
+    if (a.n_big) leaf_triangles<COUNT, false>(a, ray, br, a.tribox, a.big_first, a.n_big, __ballot(in_image), cnt);
+    walk<COUNT, false>(a, a.pairs, a.tribox, ray, br, in_image, neg, cnt, 0u);
   }
   const double best = ray.best;
   const unsigned c_top = cnt.top, c_nodes = cnt.nodes, c_tri_wave_box = cnt.tri_wave_box, c_tri_wave_mt = cnt.tri_wave_mt,
@@ -651,6 +726,7 @@ struct afe_scene {
   int64_t n_pairs = 0;
   TriRec *tris = nullptr;
   float *tribox = nullptr;     // 8 x n_tri x 8 floats
+  uint32_t big_first = 0, n_big = 0;   // the triangles kept out of the tree (RenderArgs)
   // pixel-ray tables, one per camera geometry this scene has been rendered with (kept until the scene goes:
   // a launch still in flight on some stream may be reading one)
   struct RayTable { int width, height; double cx, cy, focal; double *uv; };
@@ -707,9 +783,12 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
     r.uv = uv;
   }
   r.pairs = s->pairs; r.n_pairs = s->n_pairs; r.tris = s->tris; r.tribox = s->tribox; r.n_tri = s->n_tri; r.counters = dev_counters;
+  r.big_first = s->big_first; r.n_big = s->n_big; r.entry = nullptr;
   r.width = cam->width; r.height = cam->height;
   r.tiles_x = (cam->width + kTileW - 1) / kTileW;
   r.tiles_per_view = r.tiles_x * ((cam->height + kTileH - 1) / kTileH);
+  r.groups_x = (r.tiles_x + kEntryGroup - 1) / kEntryGroup;
+  r.groups_per_view = r.groups_x * (((cam->height + kTileH - 1) / kTileH + kEntryGroup - 1) / kEntryGroup);
   r.focal = cam->focal_length; r.cx = cam->cx; r.cy = cam->cy; r.depth_scale = cam->depth_scale;
   r.max_count = cam->max_count;
   r.plain_walk_only = s->plain_walk_only;
@@ -731,9 +810,19 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
     r.n_blocks = nv * r.tiles_per_view;
     r.blocks_per_xcd = (r.n_blocks + 7) / 8;
     const int64_t grid = r.blocks_per_xcd * 8;
+    uint32_t *entry = nullptr;
+    if (!s->plain_walk_only) {     // (the plain walk stays the independent formulation: from the root)
+      // the table lives for this launch only, allocated and freed in stream order (several streams may render one scene)
+      const int64_t n_groups = nv * r.groups_per_view;
+      if (hipMallocAsync((void **)&entry, (size_t)n_groups * sizeof(uint32_t), stream) != hipSuccess) { rc = AFE_ERR_HIP; break; }
+      r.entry = nullptr;
+      hipLaunchKernelGGL(afe_tile_entry_kernel, dim3((unsigned)((n_groups + 63) / 64)), dim3(64), 0, stream, r, entry);
+      r.entry = entry;
+    }
     if (dev_counters) hipLaunchKernelGGL(afe_render_depth_kernel<true>, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
     else hipLaunchKernelGGL(afe_render_depth_kernel<false>, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
     rc = hipGetLastError() == hipSuccess ? AFE_OK : AFE_ERR_HIP;
+    if (entry) (void)hipFreeAsync(entry, stream);
   }
   if (kernel_ms) {
     (void)hipEventRecord(e1, stream);
@@ -789,19 +878,44 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
   const int rc = pick_device(device, &dev);
   if (rc != AFE_OK) return rc;
 
+  // Triangles whose own box is a good part of the scene's (a ground plane's two) stay out of the tree: inside it they
+  // sit at the bottom of a chain of scene-wide nodes, and every one of those is a visit for every tile.  At most 16 of
+  // them, and only if something is left for the tree; the kernel tests them before the walk.
+  std::vector<int64_t> small_ix, big_ix;
+  {
+    Box all; all.reset();
+    for (int64_t i = 0; i < 3 * n_tri; i++) all.grow(triangles + 3 * i);
+    const float scene_area = all.half_area();
+    for (int64_t i = 0; i < n_tri; i++) {
+      Box tb; tb.reset();
+      for (int v = 0; v < 3; v++) tb.grow(triangles + 9 * i + 3 * v);
+      (tb.half_area() > 0.25f * scene_area ? big_ix : small_ix).push_back(i);
+    }
+    if (big_ix.size() > 16 || small_ix.empty()) {
+      small_ix.resize((size_t)n_tri);
+      for (int64_t i = 0; i < n_tri; i++) small_ix[(size_t)i] = i;
+      big_ix.clear();
+    }
+  }
+  const int64_t n_small = (int64_t)small_ix.size();
+  std::vector<float> small_tris;
+  if (!big_ix.empty()) {
+    small_tris.resize((size_t)9 * n_small);
+    for (int64_t i = 0; i < n_small; i++) std::memcpy(small_tris.data() + 9 * i, triangles + 9 * small_ix[(size_t)i], 9 * sizeof(float));
+  }
   Builder b;
-  b.tri = triangles;
-  b.build(n_tri);
+  b.tri = big_ix.empty() ? triangles : small_tris.data();
+  b.build(n_small);
   if (b.max_depth > kStack) {   // degenerate input (e.g. many coincident centroids): balanced tree instead
     b.median_only = true;
-    b.build(n_tri);
+    b.build(n_small);
     if (b.max_depth > kStack) return AFE_ERR_OUT_OF_RANGE;
   }
-  // triangles in leaf order: vertex 0 and the edges in double (the checker's own expressions,
-  // oracle: e = (double)v_k - (double)v_0), and the triangle's box inflated like a node's
+  // triangles in leaf order (then the ones kept out of the tree): vertex 0 and the edges in double (the checker's own
+  // expressions, oracle: e = (double)v_k - (double)v_0), and the triangle's box inflated like a node's
   std::vector<TriRec> packed((size_t)n_tri);
   for (int64_t i = 0; i < n_tri; i++) {
-    const float *src = triangles + 9 * (int64_t)b.order[(size_t)i];
+    const float *src = triangles + 9 * (i < n_small ? small_ix[(size_t)b.order[(size_t)i]] : big_ix[(size_t)(i - n_small)]);
     TriRec &T = packed[(size_t)i];
     Box tb; tb.reset();
     for (int v = 0; v < 3; v++) tb.grow(src + 3 * v);
@@ -823,7 +937,10 @@ extern "C" int afe_scene_create(int device, const float *triangles, int64_t n_tr
   s->n_tri = n_tri;
   s->n_nodes = (int64_t)b.nodes.size();
   s->depth = b.max_depth;
-  Box all = b.range_box(0, n_tri);
+  s->big_first = (uint32_t)n_small;
+  s->n_big = (uint32_t)big_ix.size();
+  Box all; all.reset();
+  for (int64_t i = 0; i < 3 * n_tri; i++) all.grow(triangles + 3 * i);
   for (int k = 0; k < 3; k++) { s->bounds[k] = all.lo[k]; s->bounds[3 + k] = all.hi[k]; }
   std::vector<PairNode> pairs = b.pairs(0);
   s->n_pairs = (int64_t)pairs.size();
