@@ -354,7 +354,7 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
     fp64_flops = st["tri_fp64_tests_per_ray"] * mt_flops + rays * ray_flops
     node_bytes = st["nodes_per_wave"] * 64.0 + st["tri_box_tests_per_wave"] * 96.0   # scalar loads, served by L2
     render_roofline = {
-        "bound": "vector-instruction issue (SQ_ACTIVE_INST_VALU x 4 / SIMD = 92 % of busy cycles, scalar unit 81 %: profiles/r02d_render_pmc.json), not HBM and not fp64 throughput",
+        "bound": "vector-instruction issue (SQ_ACTIVE_INST_VALU x 4 / SIMD = 93 % of busy cycles, scalar unit 65 %: profiles/r03_render_pmc.json; 768 vector instructions and 14.9 node visits per wave of 64 rays), not HBM and not fp64 throughput",
         "per_ray": {"triangle_box_tests": st["tri_box_tests_per_ray"] / rays, "fp64_triangle_tests": st["tri_fp64_tests_per_ray"] / rays},
         "per_wave_of_64_rays": {"nodes_visited": st["nodes_per_wave"] / waves, "triangle_box_tests": st["tri_box_tests_per_wave"] / waves,
                                 "fp64_triangle_tests_executed": st["tri_fp64_tests_per_wave"] / waves},
