@@ -36,6 +36,7 @@
 // --print-seconds: the logged vehicle's true state on stdout after every whole second of Run() calls
 //   ("t=1.000 pos=x y z vel=... q=... f0=..."), the line format SURVEY.md Appendix B quotes for the reference.
 // Defaults are the reference's own: 1 vehicle, dt = 1/500 s, 8 s, 6 significant digits (ofstream default).
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -215,6 +216,7 @@ int main(int argc, char **argv) {
   agrifly_cli::Estimate estLogged;
   estLogged.att = Rotationd::Identity();
   Vec3d desiredPositionLogged(desiredPosition), desiredVelocityLogged(desiredVelocity);
+  const std::chrono::steady_clock::time_point wall0 = std::chrono::steady_clock::now();   // (host wall clock of the loop itself: process start and HIP initialisation are outside)
   while (t.GetSeconds<double>() < endTime) {                                  // :330
     if (scene && requestNewImage) {                                            // :331-389: one DepthVis image per vehicle
       die(quad, afe_render_depth_engine(quad, scene, &cam, 0, nVehicles, depthCamAtt, depthImages, 1, 0), "afe_render_depth_engine");
@@ -427,6 +429,8 @@ int main(int argc, char **argv) {
     }
   }
   die(quad, afe_sync(quad), "afe_sync");
+  const double loopWall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+  std::printf("Loop wall time %.6f s for %ld steps\n", loopWall, steps);
   uint64_t ticks = 0, now = 0;
   afe_logic_ticks(quad, &ticks);
   afe_time_us(quad, &now);

@@ -234,6 +234,7 @@ struct afe_group {
   std::vector<hipEvent_t> packed;     // per shard: its scratch is ready
   std::vector<hipEvent_t> pulled;     // per shard: it has pulled every block it needs
   int64_t n_total = 0;
+  bool peer_ok = true;                // every pair of distinct devices reads the other's memory directly
   std::string err;
 };
 
@@ -266,27 +267,29 @@ extern "C" int afe_group_create(afe_group **out, int64_t n_vehicles, int precisi
     g->pulled.push_back(ev2);
     first += cnt;
   }
-  // every device reads every other one's memory directly (xGMI): afe_group_gather_positions issues device-to-device
-  // copies between the shards' scratch buffers.  A pair without peer access cannot serve them -- say so here, with
-  // the pair, instead of failing in the middle of a gather later.
+  // Every device reads every other one's memory directly where it can (xGMI): afe_group_gather_positions issues
+  // device-to-device copies between the shards' scratch buffers.  A pair without peer access (IOMMU, a VM, a restricted
+  // container) is still served -- the runtime stages such copies through the host -- only slower: say so once, with the
+  // pair, remember it (afe_group_peer_access) and go on.  A copy that really fails is reported by the gather itself.
+  const bool assume_none = std::getenv("AFE_GROUP_ASSUME_NO_PEER") != nullptr;    // test hook: as if no pair had peer access
   for (int a = 0; a < n_devices; a++)
     for (int b = 0; b < n_devices; b++) {
-      if (devices[a] == devices[b]) continue;
+      if (devices[a] == devices[b] && !assume_none) continue;
       int can = 0;
-      hipError_t perr = hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
+      hipError_t perr = assume_none ? hipSuccess : hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
       if (perr == hipSuccess && can) {
         (void)hipSetDevice(devices[a]);
         perr = hipDeviceEnablePeerAccess(devices[b], 0);
         if (perr == hipErrorPeerAccessAlreadyEnabled) perr = hipSuccess;
-        (void)hipGetLastError();
       } else if (perr == hipSuccess) {
         perr = hipErrorPeerAccessUnsupported;
       }
+      (void)hipGetLastError();
       if (perr != hipSuccess) {
-        std::fprintf(stderr, "agrifly_engine: afe_group_create: device %d cannot access device %d's memory (%s); a group needs peer access between all its devices\n",
-                     devices[a], devices[b], hipGetErrorString(perr));
-        afe_group_destroy(g);
-        return AFE_ERR_HIP;
+        if (g->peer_ok)
+          std::fprintf(stderr, "agrifly_engine: afe_group_create: device %d cannot access device %d's memory directly (%s); the group's position "
+                               "gather falls back to copies staged by the runtime\n", devices[a], devices[b], hipGetErrorString(perr));
+        g->peer_ok = false;
       }
     }
   *out = g;
@@ -322,6 +325,12 @@ extern "C" int afe_group_shard(afe_group *g, int shard, afe_engine **engine, int
 }
 
 extern "C" const char *afe_group_last_error(const afe_group *g) { return g ? g->err.c_str() : "null group"; }
+
+extern "C" int afe_group_peer_access(const afe_group *g, int *all_pairs) {
+  if (!g || !all_pairs) return AFE_ERR_INVALID_ARG;
+  *all_pairs = g->peer_ok ? 1 : 0;
+  return AFE_OK;
+}
 
 // for (v : vehicles) v->Run(); timer.Advance(dt) over every shard: the launches go to each device's
 // own stream and run concurrently; nothing is exchanged (the step reads no other vehicle)

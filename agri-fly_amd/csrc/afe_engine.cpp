@@ -105,6 +105,7 @@ struct afe_engine {
   int step_mode = AFE_STEP_LAUNCH;
   bool p_running = false;   // a resident grid is on the device
   bool p_failed = false;    // a resident grid gave up: the ensemble may be torn between two steps, stepping is refused
+  std::string p_fail_msg;   // what it said when it did (kept apart from err, which every later refusal rewrites)
   unsigned long long *p_host = nullptr;      // pinned host memory: ring[AFE_PERSIST_HOST_RING] + status[8]
   unsigned long long *p_host_dev = nullptr;  // the same memory as the device addresses it
   unsigned long long *p_dev = nullptr;       // device memory: ring[AFE_PERSIST_DEV_RING] + done[p_workers]
@@ -460,19 +461,29 @@ hipStream_t main_stream(afe_engine *e) {
 inline volatile unsigned long long *p_status(afe_engine *e) { return e->p_host + AFE_PERSIST_HOST_RING; }
 
 int persist_alloc(afe_engine *e) {
-  if (e->p_host) return AFE_OK;
+  if (e->p_host && e->p_host_dev && e->p_dev) return AFE_OK;
   hipDeviceProp_t prop;
   AFE_HIP(e, hipGetDeviceProperties(&prop, e->device));
   e->p_cus = prop.multiProcessorCount;
   const int64_t chunks = (e->n + 63) / 64;
   const int64_t most = (int64_t)e->p_cus * 32;      // a CU has 32 wave slots: done[] never needs more
   const size_t hbytes = (AFE_PERSIST_HOST_RING + 8 + AFE_PERSIST_HOST_MARKS) * sizeof(unsigned long long);
-  AFE_HIP(e, hipHostMalloc((void **)&e->p_host, hbytes, hipHostMallocCoherent | hipHostMallocMapped));
-  std::memset(e->p_host, 0, hbytes);
-  AFE_HIP(e, hipHostGetDevicePointer((void **)&e->p_host_dev, e->p_host, 0));
   const size_t dbytes = (8 + (size_t)AFE_PERSIST_DEV_RING + (size_t)(chunks < most ? chunks : most) + 8) * sizeof(unsigned long long);   // [8 words: the workers' call-for-help word is the last of them][ring][done[]]
-  AFE_HIP(e, hipMalloc((void **)&e->p_dev, dbytes));
-  AFE_HIP(e, hipMemsetAsync(e->p_dev, 0, dbytes, e->stream));
+  // all three or none: a half-made set (the second or third call failing) must not look complete to the next afe_step
+  hipError_t herr = e->p_host ? hipSuccess : hipHostMalloc((void **)&e->p_host, hbytes, hipHostMallocCoherent | hipHostMallocMapped);
+  if (herr == hipSuccess) {
+    std::memset(e->p_host, 0, hbytes);
+    herr = hipHostGetDevicePointer((void **)&e->p_host_dev, e->p_host, 0);
+  }
+  if (herr == hipSuccess && !e->p_dev) herr = hipMalloc((void **)&e->p_dev, dbytes);
+  if (herr == hipSuccess) herr = hipMemsetAsync(e->p_dev, 0, dbytes, e->stream);
+  if (herr != hipSuccess) {
+    if (e->p_dev) (void)hipFree(e->p_dev);
+    if (e->p_host) (void)hipHostFree(e->p_host);
+    e->p_dev = nullptr; e->p_host = nullptr; e->p_host_dev = nullptr;
+    (void)hipGetLastError();
+    return fail(e, AFE_ERR_HIP, std::string("persistent stepping: allocating the rings: ") + hipGetErrorString(herr));
+  }
   return AFE_OK;
 }
 
@@ -537,7 +548,7 @@ bool persist_eligible(const afe_engine *e) {
 
 int persist_launch(afe_engine *e) {
   volatile unsigned long long *st = p_status(e);
-  st[0] = 0; st[1] = e->p_resume; st[2] = 0;
+  st[0] = 0; st[1] = e->p_resume; st[2] = 0; st[7] = 0;
   persist_size_grid(e);
   for (int w = 0; w < AFE_PERSIST_HOST_MARKS; w++) st[8 + w] = w < e->p_workers ? e->p_resume : ~0ull;
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -666,6 +677,30 @@ int quiesce(afe_engine *e) {
   return AFE_OK;
 }
 
+// The pump parks itself after 200 us without news.  If it decides to while entries are being written, they would wait
+// for a grid nobody starts before the next engine call -- a host that synchronises outside the engine
+// (hipDeviceSynchronize) would see state short of the steps it asked for.  The pump announces where it means to park
+// (status word 7) before it looks at that slot one last time; the host writes its entries before it looks at the
+// announcement: one of the two sees the other.  Seen here: wait (microseconds) for the pump to take the entry after
+// all or to leave, and in the second case start the grid that finishes the rest.
+int persist_settle(afe_engine *e) {
+  if (!e->p_running) return AFE_OK;
+  volatile unsigned long long *st = p_status(e);
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    const unsigned long long intent = st[7];
+    if (st[0] != 0) break;                                        // it has left
+    if (intent == 0 || intent - 1 >= e->p_next) return AFE_OK;    // not leaving, or leaving behind everything authorised
+    if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;   // (collect below reports what is wrong)
+  }
+  int rc = persist_collect(e);
+  if (rc) return rc;
+  if (e->p_resume > e->p_next) { e->p_failed = true; return fail(e, AFE_ERR_HIP, "persistent step kernel ran past the authorised steps"); }
+  if (e->p_resume < e->p_next) return persist_launch(e);
+  return AFE_OK;
+}
+
 // afe_step in persistent mode: n_steps more ring entries; a grid is started if none is resident
 int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   int rc = persist_alloc(e);
@@ -708,6 +743,7 @@ int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     e->steps_issued++;
   }
   if (!e->p_running && (rc = persist_launch(e))) return rc;
+  if ((rc = persist_settle(e))) return rc;
   if (motor_lazy(e)) e->motor_stale = true;
   return AFE_OK;
 }
@@ -1105,7 +1141,10 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   int rc = refresh_table(e, dt);
   if (rc) return rc;
   if (e->logic_on && (rc = refresh_logic(e))) return rc;
-  if (e->p_failed) return fail(e, AFE_ERR_HIP, "a persistent step kernel failed earlier (" + e->err + "); create a new engine");
+  if (e->p_failed) {
+    if (e->p_fail_msg.empty()) e->p_fail_msg = e->err;      // the first refusal after the failure: err still holds its text
+    return fail(e, AFE_ERR_HIP, "a persistent step kernel failed earlier (" + e->p_fail_msg + "); create a new engine");
+  }
   // AFE_STEP_AUTO and a call that asks for several steps at once: nobody can look at the steps in between, so the fused
   // launch (state in registers from step to step, one load and one store per call) is the faster way to the same bits --
   // from 2 steps per call at 2^19 vehicles and more, from 8 at any size (measured: bench.py sweep, fused2 / fused50
@@ -1360,16 +1399,25 @@ int engine_pack_to_scratch(afe_engine *e, float **scratch) {
 
 extern "C" int afe_get_device_view(afe_engine *e, afe_device_view *out) {
   if (!e || !out) return AFE_ERR_INVALID_ARG;
+  const size_t have = out->struct_bytes;
+  if (have < offsetof(afe_device_view, pos_anchor_xy))
+    return fail(e, AFE_ERR_INVALID_ARG, "afe_device_view::struct_bytes must be set to sizeof(afe_device_view) before the call (ABI version 2)");
+  AFE_HIP(e, hipSetDevice(e->device));
+  (void)main_stream(e);            // a resident grid ends here (its last stores are the caller's to read); split streams are joined
+  if (e->p_failed) return fail(e, AFE_ERR_HIP, e->err);
   { const int mrc = materialize_motor(e); if (mrc) return mrc; }   // motor_speed is current as of this call
-  out->n_vehicles = e->n;
-  out->stride = e->stride;
-  out->state_elem_size = (int)elem(e);
-  out->pos = e->pos; out->vel = e->vel; out->att = e->att; out->ang_vel = e->ang_vel;
-  out->motor_speed = e->motor;
-  out->ext_force = e->ext_force; out->ext_torque = e->ext_torque;
-  out->motor_cmd = e->cmd; out->gyro = e->gyro; out->acc = e->acc;
-  out->rng = e->rng; out->type_index = e->type;
-  out->pos_anchor_xy = e->anchor;
+  afe_device_view v;
+  v.struct_bytes = have < sizeof(v) ? have : sizeof(v);
+  v.n_vehicles = e->n;
+  v.stride = e->stride;
+  v.state_elem_size = (int)elem(e);
+  v.pos = e->pos; v.vel = e->vel; v.att = e->att; v.ang_vel = e->ang_vel;
+  v.motor_speed = e->motor;
+  v.ext_force = e->ext_force; v.ext_torque = e->ext_torque;
+  v.motor_cmd = e->cmd; v.gyro = e->gyro; v.acc = e->acc;
+  v.rng = e->rng; v.type_index = e->type;
+  v.pos_anchor_xy = e->anchor;
+  std::memcpy(out, &v, v.struct_bytes);      // never past what the caller has
   return AFE_OK;
 }
 

@@ -1015,6 +1015,20 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
     // (3) nobody feeds us: park at p.  Slot p is free: p < min_done + ring by (2).
     const bool idle = now - t_fed > (u64_t)a.idle_ticks;
     const bool gave_up = now - t_moving > (u64_t)a.give_up_ticks || ld_agent(help) != 0;   // entries waiting and the workers never made room, or a worker starved
+    if (idle && !gave_up) {
+      // Leaving because the host is quiet must not race with a host that speaks at this very moment (an entry written
+      // between our last look at slot p and the status word below would wait for a grid nobody starts): say where we
+      // mean to park, THEN look at slot p once more.  The host does the mirror image (entry, then this word;
+      // afe_engine.cpp persist_settle), so one of the two always sees the other.
+      if (lane == 0) st_system(a.host_status + 7, p + 1);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+      const u64_t again = ld_system(a.host_ring + (p & a.host_mask));
+      if (entry_index(again) == p + 1) {
+        if (lane == 0) st_system(a.host_status + 7, 0);
+        t_fed = ticks100();
+        continue;
+      }
+    }
     if (idle || gave_up) {
       if (lane == 0) st_agent(a.dev_ring + (p & a.dev_mask), entry_stamp(((p + 1) << 2) | AFE_PERSIST_PARK, a.epoch));
       park_pos = p;

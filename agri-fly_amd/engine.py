@@ -42,7 +42,7 @@ ABI_FUNCTIONS = [
     "afe_device_alloc", "afe_device_free", "afe_device_download", "afe_scene_check_hierarchy",
     "afe_comm_unique_id", "afe_comm_create", "afe_comm_info", "afe_comm_destroy", "afe_comm_last_error",
     "afe_gather_positions", "afe_group_create", "afe_group_destroy", "afe_group_size", "afe_group_shard",
-    "afe_group_step", "afe_group_sync", "afe_group_gather_positions", "afe_group_last_error",
+    "afe_group_step", "afe_group_sync", "afe_group_gather_positions", "afe_group_last_error", "afe_group_peer_access",
     "afe_nearest_neighbour_grid", "afe_neighbour_grid_info", "afe_set_neighbour_grid_refresh", "afe_set_neighbour_sort_reuse", "afe_nearest_neighbour_bruteforce",
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
     "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running", "afe_stream_probe",
@@ -148,7 +148,7 @@ def plans_as_array(out):
 
 class DeviceView(C.Structure):
     _fields_ = [
-        ("n_vehicles", C.c_int64), ("stride", C.c_int64), ("state_elem_size", C.c_int),
+        ("struct_bytes", C.c_size_t), ("n_vehicles", C.c_int64), ("stride", C.c_int64), ("state_elem_size", C.c_int),
         ("pos", C.c_void_p), ("vel", C.c_void_p), ("att", C.c_void_p),
         ("ang_vel", C.c_void_p), ("motor_speed", C.c_void_p),
         ("ext_force", C.c_void_p), ("ext_torque", C.c_void_p),
@@ -338,6 +338,7 @@ def library():
         "afe_comm_destroy": [vp],
         "afe_gather_positions": [eng, vp, vp, vp],
         "afe_group_create": [C.POINTER(vp), i64, ci, vp, ci],
+        "afe_group_peer_access": [vp, C.POINTER(ci)],
         "afe_group_destroy": [vp],
         "afe_group_size": [vp, C.POINTER(ci), C.POINTER(i64)],
         "afe_group_shard": [vp, ci, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)],
@@ -876,6 +877,7 @@ class Ensemble:
 
     def device_view(self):
         v = DeviceView()
+        v.struct_bytes = C.sizeof(DeviceView)
         self._ck(self._L.afe_get_device_view(self._h, C.byref(v)))
         return v
 
@@ -1042,6 +1044,12 @@ class Group:
 
     def ranges(self):
         return [(s.first_global_index, s.n) for s in self.shards]
+
+    def peer_access(self):
+        """True if every pair of the group's devices reads the other's memory directly"""
+        ok = C.c_int(0)
+        self._ck(self._L.afe_group_peer_access(self._h, C.byref(ok)))
+        return bool(ok.value)
 
     def step(self, dt_us, n_steps=1):
         self._ck(self._L.afe_group_step(self._h, int(dt_us), int(n_steps)))

@@ -12,10 +12,13 @@ beyond that one launch per step and half of the shard.  The timed region is
 repeated -- blocks of exactly K steps, each bracketed by barrier + synchronise --
 until 50 ms have been timed; the line carries the median block.  Workload: the
 config-4 shape of BASELINE.json -- a hovering MINIQUAD ensemble with a
-per-vehicle wind-gust force through the SetExternalForce port, IMU synthesis
-with on-device libstdc++-compatible noise at the 500 Hz onboard-logic cadence --
-1,048,576 vehicles PER GPU (weak scaling; inputs resident in HBM before the
-timed region).  For N > 1 there is one rank process per GPU: either the caller
+per-vehicle wind-gust force from the on-device gust process (the
+SetExternalForce port), IMU synthesis at the 500 Hz onboard-logic cadence with
+Gaussian noise from the counter-based generator (AFE_SEED_COUNTER; the same
+workload on the reference's own std::minstd_rand0 / std::normal_distribution
+streams is measured with the same protocol and printed beside it as
+`reference_noise_streams`) -- 1,048,576 vehicles PER GPU (weak scaling; inputs
+resident in HBM before the timed region).  For N > 1 there is one rank process per GPU: either the caller
 starts them (python -m torch.distributed.run ... bench.py --gpus N: RANK /
 WORLD_SIZE are in the environment) or `python bench.py --gpus N` starts them
 itself (child processes, before this process has touched a GPU) and relays
@@ -25,15 +28,20 @@ the path has -- the shared-world query: RCCL all-gather of positions + the
 neighbour / UWB-ranging consumers, at 100 Hz of simulated time -- is timed
 separately in `shared_world`.
 
-Prints ONE JSON line on rank 0 (see the repo task contract), including
+Prints ONE JSON line on rank 0 (see the repo task contract), kept below 6 kB
+(compact_line; tests/test_bench_line.py holds the bound), including
   roofline     -- algorithmic HBM bytes / measured kernel time vs 8 TB/s
   cpu_baseline -- the CPU oracle (port of the reference's algorithm) timed on
                   one host core over a bounded sample (rank 0, N = 1 only)
+Everything else that is measured (size sweep, perception rows, disturbance
+bins, shared-world worlds, notes) goes to the side file bench_detail.json
+(and gpurun_out/bench_detail.json where that directory exists).
 """
 import argparse
 import importlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -195,18 +203,6 @@ def companion_rows(afa, n_local, device, sync, barrier, split=False):
     e.destroy_event(ev0)
     e.destroy_event(ev1)
     e.close()
-    # the headline's workload with the reference's own noise machinery: per-vehicle std::minstd_rand0 + std::normal_distribution
-    # streams (AFE_SEED_DECORRELATED), bit-exact engine words and polar-method decisions
-    e = build_shard(afa, n_local, 0, n_local, device, exact_stream=True)
-    time_steps(e, 100, 1, sync, barrier)
-    k = 2000
-    t = median([time_steps(e, k, 1, sync, barrier) for _ in range(3)])
-    bytes_step, _ = mean_bytes_per_step(e, afa, k)
-    rows["libstdcxx_noise_streams"] = {"value": n_local * k / t, "unit": "vehicle-steps/s", "us_per_step": t / k * 1e6,
-                                       "algorithmic_bytes_per_vehicle_step": bytes_step, "frac": n_local * bytes_step / (t / k) / 1e9 / HBM_PEAK_GBS,
-                                       "stepping": "persistent" if uses_persistent(afa, None, n_local) else "launches",
-                                       "note": "IMU noise from per-vehicle libstdc++-exact streams (seed 1 + global index) instead of the counter-based generator"}
-    e.close()
     # the resident grid taking the steps that are already authorised together (AFE_STEP_RESIDENT): inputs once per batch,
     # state in registers from step to step, every step's state stored as it is made
     e = build_shard(afa, n_local, 0, n_local, device)
@@ -250,29 +246,30 @@ def config1_row():
     """BASELINE config 1 / configs[0] -- the reference's own CPU-runnable case: ONE vehicle flown by the offboard loop of
     Simulator/Rappids_Simulator/main.cpp (mocap 200 Hz, control 100 Hz, 30 ms radio delay, the log every step) for
     simulated seconds at dt = 1 ms, through the C ABI by agri-fly_amd/bin/rappids_headless (host-visible engine, resident
-    grid).  Two run lengths, so that process start and HIP initialisation cancel."""
+    grid).  The program times its own loop (steady_clock), so process start and HIP initialisation are outside."""
     import subprocess
     import tempfile
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "agri-fly_amd", "bin", "rappids_headless")
     if not os.path.exists(exe):
         return {"error": "agri-fly_amd/bin/rappids_headless is not built (__graft_entry__.build() makes it)"}
-    wall = {}
+    seconds, us = 10, None
     with tempfile.TemporaryDirectory() as tmp:
-        for seconds in (2, 12):
-            best = 1e30
-            for _ in range(2):
-                t0 = time.perf_counter()
-                r = subprocess.run([exe, "--seconds", str(seconds), "--dt-us", "1000", "--out", os.path.join(tmp, "sim.csv")],
-                                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
-                if r.returncode != 0:
-                    return {"error": "rappids_headless exit %d: %s" % (r.returncode, r.stderr.decode()[-300:])}
-                best = min(best, time.perf_counter() - t0)
-            wall[seconds] = best
-    us = (wall[12] - wall[2]) / 10000 * 1e6
-    return {"vehicles": 1, "dt_ms": 1.0, "steps_timed": 10000, "wall_s_12s_run": wall[12], "wall_s_2s_run": wall[2], "us_per_step": us,
+        best = 1e30
+        for _ in range(2):
+            r = subprocess.run([exe, "--seconds", str(seconds), "--dt-us", "1000", "--out", os.path.join(tmp, "sim.csv")],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            if r.returncode != 0:
+                return {"error": "rappids_headless exit %d: %s" % (r.returncode, r.stderr.decode()[-300:])}
+            m = re.search(r"Loop wall time ([0-9.eE+-]+) s for (\d+) steps", r.stdout.decode())
+            if not m:
+                return {"error": "rappids_headless printed no loop wall time"}
+            best = min(best, float(m.group(1)) / int(m.group(2)))
+        us = best * 1e6
+    return {"vehicles": 1, "dt_ms": 1.0, "steps_timed": seconds * 1000, "us_per_step": us,
             "vsteps_per_s": 1e6 / us, "realtime_factor": 1000.0 / us,
             "note": "one vehicle with the host in the loop of every step (state read back and logged every step, mocap estimator and "
-                    "controller on the host); the reference's CPU loop does this in ~0.5 us per step, a device-arena engine in ~74"}
+                    "controller on the host); the program's own steady_clock around its loop (process start and HIP initialisation outside); "
+                    "the reference's CPU loop does this in ~0.5 us per step, a device-arena engine in ~74"}
 
 
 def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
@@ -386,9 +383,10 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
                     "bit-identical to the CPU checkers in tests/test_gpu_render.py / test_gpu_planner.py"}
 
 
-def cpu_baseline(afa, budget_vehicle_steps=100_000_000):
+def cpu_baseline(afa, budget_vehicle_steps=24_000_000):
     """the oracle (double, scalar C, 1 thread) on a bounded sample of the same
-    workload; test infrastructure used here only as the reported baseline"""
+    workload; test infrastructure used here only as the reported baseline.  Both legs together stay below ~10 s (the
+    driver's run is mostly this otherwise): ~6 s on one thread, ~3 s on all host cores"""
     from oracle import oracle_py
     n, steps = 16384, max(10, budget_vehicle_steps // 16384)
     p = afa.params_from_type(5)
@@ -415,7 +413,7 @@ def cpu_baseline(afa, budget_vehicle_steps=100_000_000):
     if threads > 1:
         oracle_py.lib().ora_set_batch_threads(threads)
         run(10, 0, 0)
-        steps_mt = steps * min(threads, 32) // 4
+        steps_mt = max(10, steps * min(threads, 32) // 8)
         dt_mt, _ = run(steps_mt, 0, 0)
         oracle_py.lib().ora_set_batch_threads(1)
         out["all_cores"] = {"value": n * steps_mt / dt_mt, "unit": "vehicle-steps/s", "cores": threads,
@@ -617,16 +615,139 @@ def shard_row(afa, n, device, sync, barrier, reduce_max, block_steps, mode=None,
     return e, row
 
 
+LINE_LIMIT = 6000            # bytes of the printed JSON line (the driver's parser lost a 20 kB line in round 3)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _r(x, sig=6):
+    """numbers rounded to `sig` significant digits (the line is for reading and parsing, the side file keeps full precision)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return None if d is None else {k: d[k] for k in keys if k in d and d[k] is not None}
+
+
+def compact_line(full):
+    """The ONE printed line: the contract keys, a one-sentence workload, a compact roofline, cpu_baseline, the strong row
+    (config 4 as stated), the north-star shard, the reference-exact noise row and {name: value} companions.  Everything
+    else stays in `full`, which goes to bench_detail.json.  Never longer than LINE_LIMIT: if a caller's strings push it
+    over, the optional objects are dropped one by one (least important first) until it fits."""
+    cfg = full.get("config", {})
+    roof = full.get("roofline") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg.get("workload_short", cfg.get("workload", ""))[:400],
+                      "vehicles_per_gpu": cfg.get("vehicles_per_gpu"), "vehicles_total": cfg.get("vehicles_total"),
+                      "dt_us": cfg.get("dt_us"), "steps_per_call": cfg.get("steps_per_call"), "stepping": cfg.get("stepping"),
+                      "noise": cfg.get("noise"), "parallelism": cfg.get("parallelism_short", cfg.get("parallelism"))}
+    line.update(_pick(full, ("repeats", "ms_per_step_min", "ms_per_step_max")) or {})
+    r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel_us", "kernel_us_min", "kernel_us_max",
+                     "kernel_us_rocprof", "algorithmic_bytes_per_vehicle_step")) or {}
+    kr = roof.get("kernel_us_rocprof")
+    if isinstance(kr, dict):      # the committed trace holds one figure per block length: the line carries this run's
+        nums = {k: v for k, v in kr.items() if isinstance(v, (int, float))}
+        r["kernel_us_rocprof"] = nums.get("blocks_of_%s_steps" % full.get("steps"), next(iter(nums.values()), None))
+    r["kernel"] = (roof.get("kernel_short") or roof.get("kernel") or "")[:120]
+    if roof.get("traffic_source"):
+        r["traffic_source"] = str(roof["traffic_source"])[:100]
+    pm = roof.get("peak_measured")
+    if pm:
+        r["peak_measured"] = [pm.get("GBs_164B"), pm.get("GBs_132B")]
+    if roof.get("steady_state"):
+        r["steady_state"] = _pick(roof["steady_state"], ("steps", "kernel_us", "frac"))
+    if roof.get("launch_mode"):
+        r["launch_mode"] = _pick(roof["launch_mode"], ("kernel_us", "frac"))
+    if roof.get("beyond_cache"):
+        r["beyond_cache"] = _pick(roof["beyond_cache"], ("vehicles", "us_per_step", "frac", "frac_of_6290", "stepping"))
+    line["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind"))
+        c["sample"] = str(cb.get("sample", ""))[:200]
+        if cb.get("all_cores"):
+            c["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+        line["cpu_baseline"] = c
+    st = full.get("config4_as_stated")
+    if st:
+        c4 = _pick(st, ("scaling", "vehicles_total", "vehicles_per_gpu", "n_gpus", "value", "unit", "ms_per_step", "frac_per_gpu", "stepping"))
+        if st.get("steady_state"):
+            c4["steady_state"] = _pick(st["steady_state"], ("steps", "ms_per_step", "value", "frac_per_gpu"))
+        line["config4_as_stated"] = c4
+    ns = full.get("north_star_shard")
+    if ns:
+        line["north_star_shard"] = _pick(ns, ("vehicles_per_gpu", "us_per_step", "us_per_step_k_blocks", "vsteps_per_s_per_gpu", "frac", "launch_mode_frac"))
+    rn = full.get("reference_noise_streams")
+    if rn:
+        line["reference_noise_streams"] = _pick(rn, ("value", "unit", "ms_per_step", "algorithmic_bytes_per_vehicle_step", "kernel_us", "frac", "stepping", "seed_policy"))
+    comp = full.get("companions")
+    if comp:
+        line["companions"] = {k: v.get("value") for k, v in comp.items() if isinstance(v, dict) and "value" in v}
+    cl = full.get("closed_loop_on_device")
+    if cl:
+        line["closed_loop_on_device"] = [_pick(c, ("vehicles", "us_per_step", "vsteps_per_s", "frac")) for c in cl]
+    pr = full.get("perception_rows")
+    if pr and "depth_camera" in pr:
+        line["perception"] = {"depth_ms_per_%d_views" % pr["depth_camera"]["views"]: pr["depth_camera"]["kernel_ms"],
+                              "plan_ms_65536_planners": pr["rappids_planner"]["config3_size"]["kernel_ms"],
+                              "frame_ms_4096_vehicles": pr["closed_perception_loop_frame"]["frame_ms"]}
+    sw = full.get("shared_world")
+    if sw:
+        if "error" in sw:
+            line["shared_world"] = {"error": str(sw["error"])[:200]}
+        else:
+            line["shared_world"] = {"rccl_ranks": sw.get("rccl_ranks"),
+                                    "fraction_query_in_stream": {k: w.get("fraction_query_in_stream") for k, w in sw.get("worlds", {}).items()},
+                                    "vsteps_per_s_query_in_stream": {k: w.get("vsteps_per_s_query_in_stream") for k, w in sw.get("worlds", {}).items()}}
+    c1 = full.get("config1_host_in_loop")
+    if c1:
+        line["config1_host_in_loop"] = _pick(c1, ("us_per_step", "realtime_factor", "error"))
+    line["detail"] = full.get("detail", DETAIL_FILE)
+    line = _r(line)
+    for victim in ("config1_host_in_loop", "perception", "closed_loop_on_device", "shared_world", "companions", "reference_noise_streams",
+                   "north_star_shard", "config4_as_stated"):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(victim, None)
+    return line
+
+
+def write_detail(full):
+    """the whole measurement record, full precision, next to bench.py (and under gpurun_out/ where that exists, so that a
+    gpurun call brings it home); returns the name the line carries"""
+    text = json.dumps(full, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    f.write(text + "\n")
+            except OSError as ex:
+                sys.stderr.write("bench.py: could not write %s: %s\n" % (os.path.join(d, DETAIL_FILE), ex))
+    return DETAIL_FILE
+
+
 _REAL_STDOUT = os.dup(1)       # the line goes here whatever fd 1 points at when it is printed
 _PRINTED = __import__("threading").Lock()
 
 
 def print_line_once(out):
-    """exactly one JSON line on the real stdout, whoever gets here first (main thread or the watchdog)"""
+    """exactly one JSON line on the real stdout, whoever gets here first (main thread or the watchdog): the compact
+    line; the full record goes to the side file"""
     if not _PRINTED.acquire(blocking=False):
         return False
     sys.stdout.flush()
-    os.write(_REAL_STDOUT, (json.dumps(out) + "\n").encode())
+    out["detail"] = write_detail(out)
+    os.write(_REAL_STDOUT, (json.dumps(compact_line(out)) + "\n").encode())
     return True
 
 
@@ -727,6 +848,26 @@ def main():
                                    "frac_per_gpu": n_strong * sbytes / tl / 1e9 / HBM_PEAK_GBS}}
         es.close()
 
+    # ---- the same workload on the reference's own noise machinery (per-vehicle std::minstd_rand0 + std::normal_distribution
+    # streams, bit-exact words and polar-method decisions: Quadcopter_T.cpp:165-180), the headline's protocol ----
+    exact = None
+    if not args.headline_only:
+        ex = build_shard(afa, n_local, rank * n_local, n_global, local_rank, exact_stream=True)
+        ex.set_step_mode(mode)
+        time_steps(ex, max(args.warmup, 50), 1, sync, barrier)
+        xblocks = timed_blocks(ex, args.steps, 1, sync, barrier, reduce_max)
+        xbytes, _ = mean_bytes_per_step(ex, afa, args.steps)
+        tx = median(xblocks) / args.steps
+        tx_kernel = event_blocks(ex, args.steps)[0] if rank == 0 else None
+        exact = {"value": n_global / tx, "unit": "vehicle-steps/s", "ms_per_step": tx * 1e3, "steps": args.steps, "repeats": len(xblocks),
+                 "algorithmic_bytes_per_vehicle_step": xbytes, "kernel_us": None if tx_kernel is None else tx_kernel * 1e6,
+                 "frac": None if tx_kernel is None else n_local * xbytes / tx_kernel / 1e9 / HBM_PEAK_GBS,
+                 "frac_wall": n_local * xbytes / tx / 1e9 / HBM_PEAK_GBS,
+                 "stepping": "persistent" if uses_persistent(afa, mode, n_local) else "launches", "seed_policy": "AFE_SEED_DECORRELATED",
+                 "note": "IMU noise from per-vehicle libstdc++-exact streams (seed 1 + global index) instead of the counter-based generator; same "
+                         "timing protocol as the headline (median of bracketed K-step blocks), frac from HIP events like roofline.frac"}
+        ex.close()
+
     out = None
     if rank == 0:
         bytes_step, tick_frac = mean_bytes_per_step(e, afa, args.steps)
@@ -771,6 +912,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
+                "workload_short": "BASELINE config 4 per GPU: %d hovering CF_MINIQUAD vehicles, per-vehicle wind gusts (on-device gust process, sigma 0..0.5 N, "
+                                  "100 ms epochs), IMU synthesis + Gaussian noise at the 500 Hz logic gate, one afe_step call per 1 ms step, state "
+                                  "through memory every step (no temporal fusion)" % n_local,
+                "noise": "AFE_SEED_COUNTER (Philox4x32-10 + Box-Muller); the reference's libstdc++ streams: reference_noise_streams",
+                "parallelism_short": "contiguous shards, %d rank(s), no data-path collective" % world,
                 "workload": "config 4: hovering CF_MINIQUAD ensemble, per-vehicle wind gusts from the on-device gust process (sigma swept 0..0.5 N over "
                             "the global index, piecewise constant, resampled every 100 ms; afe_set_gust_process), IMU synthesis with Gaussian noise from the "
                             "counter-based generator (AFE_SEED_COUNTER: Philox4x32-10 + Box-Muller per vehicle and tick) at the 500 Hz logic gate, "
@@ -797,6 +943,7 @@ def main():
                 "frac_of_measured": None if probe is None else achieved / probe["GBs_164B"],
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "kernel_short": "afe_step_persistent_kernel<float,FEXT,NOISE=counter>" if persistent else "afe_step_kernel<float,FEXT,NOISE 0/1,SINGLE>",
                 "kernel": ("afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=2 (counter), LOGIC=0>: one launch serves every step between two "
                            "synchronisations; its rocprofv3 duration / the steps it served = kernel_us_rocprof, the HIP events around a block = kernel_us" if persistent else
                            "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, LOGIC=0, SINGLE=1>, 64-lane workgroups -- the timed region "
@@ -825,6 +972,7 @@ def main():
                         "committed rocprofv3 PMC summary" % (args.steps, n_local * bytes_step / 1e6),
             },
             "config4_as_stated": strong,
+            "reference_noise_streams": exact,
         }
         if world == 1 and not args.no_sweep and not args.headline_only:
             # beyond the Infinity Cache: 2^22 vehicles (620 MB per step)
@@ -836,6 +984,7 @@ def main():
             rowb["achieved_GBs"] = rowb["frac"] * HBM_PEAK_GBS
             rowb["peak_measured_GBs_164B"] = nb * 164 / usb / 1e3
             rowb["frac_of_measured"] = rowb["achieved_GBs"] / rowb["peak_measured_GBs_164B"]
+            rowb["frac_of_6290"] = rowb["achieved_GBs"] / 6290.0      # the guide's achievable-from-HBM figure
             out["roofline"]["beyond_cache"] = rowb
             # the north-star shard: one GPU's share of config 4 on eight (131,072 vehicles), and its neighbours
             sweep = []
@@ -867,7 +1016,10 @@ def main():
                                  "50 steps per launch (fused50: state in registers, open-loop commands).  131,072 vehicles is one GPU's shard of BASELINE "
                                  "config 4 on 8 GPUs")
             ns = [r for r in sweep if r["vehicles"] == 131072][0]
+            ek, rowk = shard_row(afa, 131072, local_rank, sync, barrier, reduce_max, args.steps)
+            ek.close()
             out["north_star_shard"] = {"vehicles_per_gpu": 131072, "us_per_step": ns["us_per_step"], "vsteps_per_s_per_gpu": ns["vsteps_per_s"],
+                                       "us_per_step_k_blocks": rowk["us_per_step"], "k": args.steps,
                                        "frac": ns["frac"], "launch_mode_frac": ns["launches"]["frac"],
                                        "note": "one GPU's shard of the 1M-vehicle ensemble on 8 GPUs, measured on this one GPU; shards do not communicate while stepping "
                                                "(no data-path collective), so 8 ranks deliver 8x this rate up to barrier skew -- a projection until the driver's --gpus 8 run.  "

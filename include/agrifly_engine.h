@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define AFE_ABI_VERSION 1
+/* 2: afe_device_view starts with `struct_bytes` (set by the caller; the engine never writes past it) and carries
+ *    pos_anchor_xy -- AFE_F32 engines keep x and y in `pos` RELATIVE to the last set point (round 3 changed the meaning of
+ *    view.pos without changing this number: a host built against version 1 must be rebuilt, afe_abi_version() tells). */
+#define AFE_ABI_VERSION 2
 
 typedef struct afe_engine afe_engine; /* opaque */
 
@@ -573,8 +576,17 @@ int afe_plan_ticks(double logic_period_s, uint64_t *elapsed_us, uint64_t dt_us,
  * motor_speed is current as of this call: for stateless motors (tau_m = J_m =
  * 0) driven by held commands the step kernel does not store the rotor speeds
  * (they are clamp(max(0, cmd))); ask for the view again, or use afe_get_state,
- * after further steps. */
+ * after further steps.
+ * The caller sets struct_bytes = sizeof(afe_device_view) BEFORE the call: the
+ * engine fills the members that fit and nothing beyond (a host compiled against
+ * an older, shorter struct keeps working); less than the members up to
+ * type_index is AFE_ERR_INVALID_ARG.  The call ends a resident step grid first
+ * (afe_set_step_mode) and leaves the engine's stream with every authorised
+ * step queued before anything the caller orders behind it: slabs read by the
+ * caller's own kernels after a stream-ordered wait (or after afe_sync) hold the
+ * state after the last afe_step. */
 typedef struct afe_device_view {
+  size_t struct_bytes;   /* IN: sizeof(afe_device_view) as the caller was compiled */
   int64_t n_vehicles;
   int64_t stride;
   int state_elem_size;
@@ -688,6 +700,11 @@ int afe_group_sync(afe_group *g);
  * dev_xyz_all_out[i] (optional) = shard i's planar [3][n_vehicles] buffer, owned by the group */
 int afe_group_gather_positions(afe_group *g, float **dev_xyz_all_out);
 const char *afe_group_last_error(const afe_group *g);
+/* *all_pairs = 1 if every pair of the group's devices has direct peer access; 0 if some pair has none
+ * (IOMMU, VMs, restricted containers): such a group still works -- the runtime stages those copies through
+ * the host -- afe_group_create says so once on stderr and the gather is slower.  (The reference's analogue is
+ * one address space for all vehicles: nothing to ask.) */
+int afe_group_peer_access(const afe_group *g, int *all_pairs);
 
 /* ---- shared-world consumers of the gathered buffer -----------------------
  * Nearest neighbour (collision / separation monitoring): for each local vehicle

@@ -516,6 +516,56 @@ def test_device_view_matches_host_getters():
         assert pos[:2].any()
 
 
+def test_device_view_never_writes_past_the_callers_struct():
+    """ABI version 2 (round-3 advisor): the caller states the size of ITS afe_device_view; a host built against a shorter
+    struct gets the members that fit and not a byte more; a struct_bytes that was never set is refused"""
+    import ctypes as C
+    L = afa.library()
+    assert L.afe_abi_version() == 2
+    ens = random_ensemble(256, seed=3)
+    with ens.to_engine(afa.AFE_F32) as e:
+        full = e.device_view()
+        short = afa.DeviceView.pos_anchor_xy.offset            # an older header: everything up to type_index
+        buf = (C.c_ubyte * (C.sizeof(afa.DeviceView) + 16))(*([0xA5] * (C.sizeof(afa.DeviceView) + 16)))
+        v = afa.DeviceView.from_buffer(buf)
+        v.struct_bytes = short
+        assert L.afe_get_device_view(e._h, C.byref(v)) == 0
+        assert v.pos == full.pos and v.type_index == full.type_index and v.struct_bytes == short
+        assert all(b == 0xA5 for b in bytes(buf)[short:])
+        v.struct_bytes = 0
+        assert L.afe_get_device_view(e._h, C.byref(v)) == 1          # AFE_ERR_INVALID_ARG
+        # a resident grid is ended by the view: what a consumer's own kernel reads is the state after the last step
+        e.set_step_mode(afa.AFE_STEP_PERSISTENT)
+        for _ in range(5):
+            e.step(1000, 1)
+        e.device_view()
+        assert not e.persistent_running
+
+
+def test_group_without_peer_access_still_gathers(monkeypatch):
+    """round-3 advisor: a pair of devices without peer access must not refuse the group -- the runtime stages the copies.
+    AFE_GROUP_ASSUME_NO_PEER makes afe_group_create treat every pair as peerless (one-GPU box: logical shards)."""
+    n = 5000
+    ens = random_ensemble(n, seed=77)
+    d = ens.data
+    monkeypatch.setenv("AFE_GROUP_ASSUME_NO_PEER", "1")
+    with afa.Group(n, afa.AFE_F32, devices=[0, 0, 0]) as grp:
+        assert grp.peer_access() is False
+        for s in grp.shards:
+            _configure(s, d.slice(s.first_global_index, s.n), afa.AFE_SEED_DECORRELATED, False)
+        grp.step(1000, 5)
+        ptrs = grp.gather_positions()
+        grp.sync()
+        want = np.concatenate([s.get_state(dtype=np.float32)["pos"] for s in grp.shards], axis=1)
+        for p in ptrs:
+            got = np.empty((3, n), np.float32)
+            assert afa.library().afe_device_download(got.ctypes.data, p, got.nbytes) == 0
+            assert np.array_equal(got, want)
+    monkeypatch.delenv("AFE_GROUP_ASSUME_NO_PEER")
+    with afa.Group(64, afa.AFE_F32, devices=[0, 0]) as grp:
+        assert grp.peer_access() is True
+
+
 def test_wide_campaign_grid_equals_brute_force_on_every_query():
     """tests/campaigns/world_campaign.py: 150 random worlds -- boxes at three scales, flats, clusters, lines, duplicates,
     lattices (all ties), two densities 1e5 apart, shells; 1 to 60 000 vehicles; non-finite positions and fly-aways;
