@@ -1,0 +1,77 @@
+"""What of the multi-GPU path can run on a ONE-GPU box (SCALE_r0x has been skipped every round: no 8-GPU node):
+bench.py's N > 1 control flow with two rank processes sharing device 0, and RCCL collectives beside a resident grid."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    assert len(lines[0]) < 6000
+    return json.loads(lines[0])
+
+
+def test_bench_with_two_ranks_on_one_gpu_prints_one_consistent_line(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` exactly as the driver starts it, with
+    both ranks on device 0 and gloo for the timing collectives (AFE_BENCH_ONE_DEVICE: RCCL refuses two ranks on one
+    device, hence --no-shared-world).  The two ranks' grids take turns on the device, so no number means anything; the
+    line's bookkeeping does: one line, n_gpus 2, weak row over 2 x the shard, strong row = config 4 as stated cut in
+    two, value = vehicles / the MAX-over-ranks time."""
+    env = dict(os.environ, AFE_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--vehicles", "131072", "--no-shared-world"], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 20 and d["warmup"] == 5
+    assert d["config"]["vehicles_per_gpu"] == 131072 and d["config"]["vehicles_total"] == 262144
+    assert d["value"] == pytest.approx(262144 / (d["ms_per_step"] * 1e-3), rel=1e-4)      # whole-job rate over the slowest rank's time
+    assert d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    s = d["config4_as_stated"]
+    assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["vehicles_per_gpu"] == 524288 and s["vehicles_total"] == 1048576
+    assert s["value"] == pytest.approx(1048576 / (s["ms_per_step"] * 1e-3), rel=1e-4)
+    assert d["reference_noise_streams"]["value"] > 0
+    assert "cpu_baseline" not in d                     # rank 0 at N = 1 only
+    detail = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert detail["ms_per_step_rank0_own"] <= detail["ms_per_step_max"] * (1 + 1e-9)
+    assert detail["config"]["vehicles_total"] == 262144
+
+
+def test_self_launched_ranks_relay_one_line():
+    """`python bench.py --gpus 2` without a launcher: bench.py starts its own rank processes (agri-fly_amd/launch.py) and
+    relays rank 0's line"""
+    env = dict(os.environ, AFE_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--vehicles", "65536",
+                        "--no-shared-world", "--headline-only"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["vehicles_total"] == 131072
+
+
+def test_rccl_collectives_beside_a_full_size_resident_grid():
+    """one-rank RCCL group + a 2^20-vehicle resident grid that fills every wave slot: an all-reduce on torch's stream and
+    the product's afe_gather_positions complete within 5 ms each (the grid makes room: it parks when the host goes quiet
+    / when an entry point needs the stream) and the trajectory's bits are those of an undisturbed run"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_resident_probe.py"), str(1 << 20), str(_free_port())],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["resident_before_collective"] and d["resident_before_gather"]
+    assert d["all_reduce_ok"] and d["gathered_equals_state"] and d["bits_identical"]
+    assert d["all_reduce_ms"] < 5.0 and d["gather_ms"] < 5.0, d

@@ -192,3 +192,65 @@ def test_bench_parent_stays_off_the_gpu_when_it_launches():
     assert "import torch" not in top
     launch_src = open(os.path.join(ROOT, "agri-fly_amd", "launch.py")).read()
     assert "import torch" not in launch_src and "hip" not in launch_src.replace("HIP call", "")
+
+
+class _StubEngine:
+    """what bench.time_steps needs of an engine: step and sync; a rank-dependent cost per step"""
+
+    def __init__(self, seconds_per_step):
+        self.cost, self.steps, self.syncs = seconds_per_step, 0, 0
+
+    def step(self, dt_us, k):
+        import time
+        time.sleep(self.cost * k)
+        self.steps += k
+
+    def sync(self):
+        self.syncs += 1
+
+
+def _bench_flow_worker(rank, world, port, q):
+    """bench.py's timing protocol for N > 1 -- time_steps / timed_blocks with a barrier and a MAX over ranks -- on a stub
+    engine over gloo: every rank must run the same number of blocks (or a barrier never completes) and see the same,
+    slowest-rank, time for each"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        def reduce_max(x):
+            t = torch.tensor([x], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        e = _StubEngine(0.0002 * (1 + 4 * rank))       # rank 1 is five times slower
+        own = []
+        blocks = bench.timed_blocks(e, 5, 1, lambda: None, dist.barrier, reduce_max, min_total_s=0.03, min_blocks=3, own=own)
+        # a second protocol on the same group right behind it: nobody is left behind in a collective of the first
+        blocks2 = bench.timed_blocks(e, 2, 2, lambda: None, dist.barrier, reduce_max, min_total_s=0.0, min_blocks=2)
+        q.put((rank, blocks, own, blocks2, e.steps))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_timing_protocol_with_two_ranks_over_gloo():
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_flow_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, own0, b20, steps0), (_, b1, own1, b21, steps1) = results
+    assert b0 == b1 and b20 == b21                     # the reduced times are the same numbers on every rank ...
+    assert len(own0) == len(own1) == len(b0) >= 3      # ... so both ran the same number of blocks
+    assert steps0 == steps1 == 5 * len(b0) + 2 * len(b20)
+    for t, o0, o1 in zip(b0, own0, own1):
+        assert t == max(o0, o1)                        # MAX over ranks, block by block
+    assert sum(own1) > 2 * sum(own0)                   # and it is the slow rank's time that counts
+    assert sum(b0) >= 0.03 or len(b0) == 2000
