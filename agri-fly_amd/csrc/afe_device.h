@@ -97,6 +97,9 @@ struct LaunchFlags {
   // heterogeneous ensemble whose type index is constant over every aligned run of 64 vehicles (fleets
   // laid out type by type): each wave then reads its one record by scalar loads -- no LDS table
   bool wave_uniform_types = false;
+  // cache-policy bits of the one-step launches' slab accesses (afe_kernels.hip run_vehicle, CP): 0 default, 1 inputs and
+  // outputs nt, 2 everything nt, 3 everything nt + one contiguous range per XCD.  Hints only: never a different bit.
+  int cache_policy = 0;
 };
 
 // ---------------------------------------------------------------------------

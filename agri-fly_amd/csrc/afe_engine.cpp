@@ -99,6 +99,7 @@ struct afe_engine {
   uint64_t logic_elapsed_us = 0;
   uint64_t n_ticks = 0;
   int max_fused = 64;
+  int cache_policy = -1;       // afe_set_cache_policy: -1 automatic, 0..3 as LaunchFlags::cache_policy
   uint64_t steps_issued = 0;   // afe_steps_completed
 
   // persistent stepping (afe_set_step_mode; afe_device.h PersistArgs)
@@ -701,6 +702,24 @@ int persist_settle(afe_engine *e) {
   return AFE_OK;
 }
 
+// Cache policy of the one-step launches (LaunchFlags::cache_policy).  Automatic: by what the Infinity Cache (256 MiB) can
+// hold from one step to the next.  Everything the step touches fits: default policy, the whole working set is served
+// on-die.  Only the state fits: inputs and outputs stream past it (nt).  Not even the state: everything nt, one contiguous
+// range per XCD.  (Thresholds measured: tools/cache_policy_probe.py)
+int resolve_cache_policy(const afe_engine *e) {
+  static const int forced = [] { const char *s = std::getenv("AFE_CACHE_POLICY"); return s && *s ? std::atoi(s) : -1; }();
+  const int asked = forced >= 0 && forced <= 3 ? forced : e->cache_policy;
+  if (asked >= 0) return asked;
+  if (e->host_arena) return 0;        // host memory: the policy bits mean nothing the bus honours
+  const double es = (double)elem(e), n = (double)e->n;
+  double state = 13 * es + (motor_lazy(e) ? 0 : 4 * es) + (e->noise && e->seed_policy != AFE_SEED_COUNTER ? 4 : 0) + (e->logic_on ? 12 * 4 + 4 * 4 : 0);
+  double streams = (e->logic_on ? 4 * 4 : 4 * 4) + (e->has_ext_force ? 3 * es : 0) + (e->has_ext_torque ? 3 * es : 0) + 6 * 4;
+  const double MiB = 1048576.0;
+  if ((state + streams) * n <= 200 * MiB) return 0;
+  if (state * n <= 224 * MiB) return 1;
+  return 3;
+}
+
 // afe_step in persistent mode: n_steps more ring entries; a grid is started if none is resident
 int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   int rc = persist_alloc(e);
@@ -1182,6 +1201,7 @@ extern "C" int afe_step(afe_engine *e, uint64_t dt_us, int n_steps) {
     f.counter_noise = e->seed_policy == AFE_SEED_COUNTER;
     f.logic = e->logic_on && mask != 0;
     f.wave_uniform_types = !e->types_uniform && e->types_wave_uniform;
+    f.cache_policy = resolve_cache_policy(e);
     const DevLogic *ulogic = (e->logic_on && e->types_uniform) ? &e->logic_table[0] : nullptr;
     // split stepping: vehicles [0, half) on the main stream, [half, n) on the side stream -- the two chains of launches
     // never wait for each other, so each one's drain-and-dispatch gap is covered by the other's streaming
@@ -1317,6 +1337,12 @@ extern "C" int afe_set_split_stepping(afe_engine *e, int parts) {
   AFE_HIP(e, hipSetDevice(e->device));
   join_streams(e);
   e->split_parts = parts;
+  return AFE_OK;
+}
+
+extern "C" int afe_set_cache_policy(afe_engine *e, int policy) {
+  if (!e || policy < -1 || policy > 3) return fail(e, AFE_ERR_INVALID_ARG, "cache policy: -1 (automatic), 0 (default), 1 (inputs and outputs nt), 2 (everything nt) or 3 (everything nt, one range per XCD)");
+  e->cache_policy = policy;
   return AFE_OK;
 }
 

@@ -536,19 +536,27 @@ __device__ __forceinline__ void rates_logic_tick(const DevLogic &G, LogicRegs &s
 // VGPRs) or this lane's record in the LDS-staged type table.
 // slab access through a buffer resource: address = resource base + 32-bit per-lane offset + scalar offset
 // (buffer_load_dword v, voff, s[rsrc:4], soff offen)
-template <typename T>
+// AUX: the instruction's cache-policy bits (0 default, 2 = nt: a line nobody re-reads within the caches' reach)
+template <typename T, int AUX = 0>
 __device__ __forceinline__ T buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-  if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
-  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+  if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, AUX));
+  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX));
 }
-template <typename T>
+template <typename T, int AUX = 0>
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, T val) {
   if constexpr (sizeof(T) == 8)
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0)), val), r, (int)voff, (int)soff, 0);
-  else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0)), val), r, (int)voff, (int)soff, AUX);
+  else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), r, (int)voff, (int)soff, AUX);
 }
 
-template <typename R, bool FEXT, bool TEXT, int NOISE, bool LOGIC, bool SINGLE, bool BUF, bool EACH = false>
+// CP -- cache policy of the slab accesses (afe_set_cache_policy; memory hints only, never a different bit):
+//   0  default everywhere: an ensemble whose whole working set lives in the 256 MiB Infinity Cache (up to ~2^20 fp32 vehicles);
+//   1  the streams nobody re-reads soon -- inputs (commands, wrench) and outputs (IMU samples) -- are nt, the state is
+//      default: the state of up to ~4 M fp32 vehicles (52 B each) then stays in the Infinity Cache from step to step while
+//      the inputs and outputs stream past it (tools/hbm_probe.hip);
+//   2  everything nt: beyond that nothing survives a step anyway, and lines that do not wait in the caches for a re-read
+//      that never comes make the write-backs cheaper (+6 % at 2^23, +10 % with one contiguous range per XCD = policy 3).
+template <typename R, bool FEXT, bool TEXT, int NOISE, bool LOGIC, bool SINGLE, bool BUF, bool EACH = false, int CP = 0>
 __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParams<R> &P, const DevLogic &G,
                                             const int64_t i, const unsigned long long tick_mask, const int n_steps_arg, const uint64_t tick_ordinal0) {
   // No implicit FMA contraction: every rounding is the one the source spells
@@ -594,13 +602,30 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #define AFE_OFF_rng(c) (23u * SE + (uint32_t)(10 + (c)) * S4)
 #define AFE_OFF_lpf(c) ((uint32_t)(c) * S4)
 #define AFE_OFF_rates_cmd(c) ((uint32_t)(12 + (c)) * S4)
-#define AFE_LD(T, name, comp, o) (BUF ? buf_ld<T>(rs_main, (o), AFE_OFF_##name(comp)) \
+  constexpr int AUX_STATE = (BUF && CP >= 2) ? 2 : 0, AUX_IN = (BUF && CP >= 1) ? 2 : 0, AUX_OUT = (BUF && CP >= 1) ? 2 : 0;
+  constexpr int AUX_CMD = LOGIC ? AUX_STATE : AUX_IN;    // with the on-device logic the commands are state (rewritten at every tick)
+  (void)AUX_STATE; (void)AUX_IN; (void)AUX_OUT; (void)AUX_CMD;
+#define AFE_AUX_pos AUX_STATE
+#define AFE_AUX_vel AUX_STATE
+#define AFE_AUX_att AUX_STATE
+#define AFE_AUX_ang_vel AUX_STATE
+#define AFE_AUX_motor AUX_STATE
+#define AFE_AUX_rng AUX_STATE
+#define AFE_AUX_lpf AUX_STATE
+#define AFE_AUX_cmd AUX_CMD
+#define AFE_AUX_cmd_out AUX_CMD
+#define AFE_AUX_ext_force AUX_IN
+#define AFE_AUX_ext_torque AUX_IN
+#define AFE_AUX_rates_cmd AUX_IN
+#define AFE_AUX_gyro AUX_OUT
+#define AFE_AUX_acc AUX_OUT
+#define AFE_LD(T, name, comp, o) (BUF ? buf_ld<T, AFE_AUX_##name>(rs_main, (o), AFE_OFF_##name(comp)) \
                                       : *reinterpret_cast<const T *>(reinterpret_cast<const char *>((v.name) + (comp) * S) + (o)))
-#define AFE_ST(T, name, comp, o, val) do { if (BUF) buf_st<T>(rs_main, (o), AFE_OFF_##name(comp), (val)); \
+#define AFE_ST(T, name, comp, o, val) do { if (BUF) buf_st<T, AFE_AUX_##name>(rs_main, (o), AFE_OFF_##name(comp), (val)); \
                                            else *reinterpret_cast<T *>(reinterpret_cast<char *>((v.name) + (comp) * S) + (o)) = (val); } while (0)
-#define AFE_LDL(T, name, comp, o) (BUF ? buf_ld<T>(rs_logic, (o), AFE_OFF_##name(comp)) \
+#define AFE_LDL(T, name, comp, o) (BUF ? buf_ld<T, AFE_AUX_##name>(rs_logic, (o), AFE_OFF_##name(comp)) \
                                        : *reinterpret_cast<const T *>(reinterpret_cast<const char *>((v.name) + (comp) * S) + (o)))
-#define AFE_STL(T, name, comp, o, val) do { if (BUF) buf_st<T>(rs_logic, (o), AFE_OFF_##name(comp), (val)); \
+#define AFE_STL(T, name, comp, o, val) do { if (BUF) buf_st<T, AFE_AUX_##name>(rs_logic, (o), AFE_OFF_##name(comp), (val)); \
                                             else *reinterpret_cast<T *>(reinterpret_cast<char *>((v.name) + (comp) * S) + (o)) = (val); } while (0)
 
   // ---- issue every load up front (independent, coalesced) ----
@@ -891,12 +916,16 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
 #endif
 
 // homogeneous ensemble: the one parameter record rides in the kernel arguments
-template <typename R, bool FEXT, bool TEXT, int NOISE, bool LOGIC, bool SINGLE, bool BUF>
+template <typename R, bool FEXT, bool TEXT, int NOISE, bool LOGIC, bool SINGLE, bool BUF, int CP = 0>
 __global__ void __launch_bounds__(AFE_BLOCK, AFE_LB_WAVES)
 afe_step_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G) {
-  const int64_t i = v.first + (int64_t)blockIdx.x * AFE_BLOCK + threadIdx.x;
+  // policy 3: workgroups are dealt to the eight XCDs round-robin (blockIdx % 8); XCD x takes the x-th contiguous eighth
+  // of the launch, so each XCD's L2 -- and each memory channel group behind it -- streams ONE range instead of every
+  // eighth line of all of them (the host asks for it only when the grid is a multiple of 8)
+  const unsigned b = CP == 3 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int64_t i = v.first + (int64_t)b * AFE_BLOCK + threadIdx.x;
   if (i >= v.end) return;
-  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE, BUF>(v, P, G, i, v.tick_mask, v.n_steps, v.tick_base);
+  run_vehicle<R, FEXT, TEXT, NOISE, LOGIC, SINGLE, BUF, false, (CP > 2 ? 2 : CP)>(v, P, G, i, v.tick_mask, v.n_steps, v.tick_base);
 }
 
 // heterogeneous ensemble: type tables staged into LDS, one record per lane
@@ -1291,8 +1320,15 @@ static int launch_step(const StepView<R> &v, const LaunchFlags &f, const DevPara
   const DevLogic &G = uniform_logic ? *uniform_logic : no_logic;
 #define AFE_LAUNCH_B(FE, TE, NO, LO, BU)                                                                   \
   do {                                                                                                     \
-    if (uniform && v.n_steps == 1)                                                                         \
-      hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true, BU>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
+    if (uniform && v.n_steps == 1) {                                                                       \
+      /* cache policy (LaunchFlags::cache_policy): buffer addressing, no external torque; otherwise the default kernel */ \
+      constexpr bool CPOK = (BU) && !(TE);                                                                 \
+      const int cp = !CPOK ? 0 : (f.cache_policy == 3 && (grid_u & 7u) ? 2 : f.cache_policy);             \
+      if (cp == 1) hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true, BU, CPOK ? 1 : 0>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
+      else if (cp == 2) hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true, BU, CPOK ? 2 : 0>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
+      else if (cp == 3) hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true, BU, CPOK ? 3 : 0>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
+      else hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, true, BU>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
+    }                                                                                                      \
     else if (uniform)                                                                                      \
       hipLaunchKernelGGL((afe_step_kernel<R, FE, TE, NO, LO, false, BU>), dim3(grid_u), dim3(AFE_BLOCK), 0, st, v, *uniform, G); \
     else if (f.wave_uniform_types && AFE_BLOCK == 64)                                                      \

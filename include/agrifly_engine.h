@@ -533,6 +533,13 @@ int afe_steps_completed(afe_engine *e, uint64_t *steps);
 /* 1 while a resident grid is on the device, 0 otherwise (diagnostic; tests use it) */
 int afe_persistent_running(const afe_engine *e, int *running);
 
+/* Cache-policy hints of the one-step launches' slab accesses (`nt` bits on the buffer instructions; never a different
+ * result bit).  -1 automatic (default): by what the 256 MiB Infinity Cache can keep from one step to the next --
+ * everything (up to ~2^20 fp32 vehicles): default policy; only the state (up to ~4 M): inputs (commands, wrench) and
+ * outputs (IMU samples) are streamed past it; not even the state: everything is streamed, one contiguous range per XCD.
+ * 0 / 1 / 2 / 3 force one of these.  Replaces nothing in the reference (a CPU's caches decide for themselves). */
+int afe_set_cache_policy(afe_engine *e, int policy);
+
 /* How many sub-steps afe_step may fuse into one kernel launch (1..64, default
  * 64).  1 = one launch per step (state goes through HBM every step: the
  * per-step-observable mode bench.py reports); results are bitwise identical
