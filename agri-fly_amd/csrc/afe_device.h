@@ -129,9 +129,21 @@ struct PersistArgs {
   // its epoch floor(time / period) is tracked incrementally from gust_epoch0 = epoch of t0_us.
   unsigned long long gust_period_us, gust_seed, gust_n_global, gust_epoch0, gust_epoch_applied, t0_us, dt_us;
   double gust_sigma_max;
+  // "tell me when step S - 1 is done" without ending the grid (afe_sync on a grid that stays resident): the host writes S
+  // into host_status[AFE_PERSIST_SYNCREQ_WORD]; the pump forwards it to sync_area[0]; a worker whose own count stands at S
+  // says so ONCE -- one atomic on its shard's counter (64 shards, a line each, sync_area[16 * (1 + shard)]), the shard's
+  // last arrival one more on the top counter (sync_area[16 * 65]), the last of those writes S to
+  // host_status[AFE_PERSIST_SYNC_WORD].  Counters are cumulative within a launch (the k-th request completes a shard at
+  // k x its workers); the pump zeroes them before it republishes anything.  One request at a time: the host waits.
+  unsigned long long *sync_area;
 };
+#define AFE_PERSIST_SYNC_SHARDS 64
+#define AFE_PERSIST_SYNC_AREA_WORDS (16 * (AFE_PERSIST_SYNC_SHARDS + 2))
 #define AFE_PERSIST_HOST_IO 0x10000u   /* PersistArgs::epoch */
 #define AFE_PERSIST_HOST_MARKS 64      /* host-visible arenas: grids of up to this many workers also write their marks to host_status[8 + w] */
+#define AFE_PERSIST_SYNC_WORD (8 + AFE_PERSIST_HOST_MARKS)      /* host_status: the step count the last sync request was answered for */
+#define AFE_PERSIST_SYNCREQ_WORD (9 + AFE_PERSIST_HOST_MARKS)   /* host_status: the host's sync request (a step count) */
+#define AFE_PERSIST_STATUS_WORDS (16 + AFE_PERSIST_HOST_MARKS)
 #define AFE_PERSIST_TICK 1ull
 #define AFE_PERSIST_PARK 2ull
 #define AFE_PERSIST_HOST_RING 4096
@@ -150,6 +162,9 @@ int launch_persistent_f32(const StepView<float> &v, const LaunchFlags &f, const 
                           const DevLogic *uniform_logic, const PersistArgs &a, void *stream);
 int launch_persistent_f64(const StepView<double> &v, const LaunchFlags &f, const DevParams<double> &uniform,
                           const DevLogic *uniform_logic, const PersistArgs &a, void *stream);
+// the host address of that instantiation (for the engine's own AQL queue, afe_aql.h)
+const void *persistent_kernel_fn_f32(const LaunchFlags &f);
+const void *persistent_kernel_fn_f64(const LaunchFlags &f);
 // one-wave workgroups of that instantiation a CU keeps resident (0: the query failed)
 int persistent_capacity_f32(const LaunchFlags &f);
 int persistent_capacity_f64(const LaunchFlags &f);

@@ -9,9 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
+#include "afe_aql.h"
 #include "afe_host.h"
 #include "afe_render.h"
 #include "afe_world.h"
@@ -123,6 +125,16 @@ struct afe_engine {
   unsigned p_epoch = 0;     // launches so far
   uint64_t p_seg_start = 0, p_seg_t0_us = 0, p_seg_gust_applied = ~0ull;   // the current run of equally long steps: its first index, the engine time and the slab's gust epoch there
   LaunchFlags p_flags = {};
+  // The resident grid on a queue of the engine's own (afe_aql.h): hipDeviceSynchronize does not wait for it, afe_sync
+  // waits for the steps and lets it live.  Falls back to a launch on the HIP stream when the runtime cannot be reached.
+  afe::AqlQueue *aql = nullptr;
+  bool aql_tried = false;
+  bool p_on_aql = false;            // the grid now resident was dispatched there
+  std::map<unsigned, afe::AqlKernel> aql_kernels;    // by configuration key (persist_size_grid's) | precision << 8
+  unsigned long long *p_sync_area = nullptr;         // device: PersistArgs::sync_area
+  bool view_exported = false;       // afe_get_device_view has handed the slabs to somebody: afe_sync must leave them readable
+  uint64_t p_grid_ns = 0, p_grid_steps = 0;          // device time and steps of the grids collected so far (afe_grid_time)
+  uint64_t p_launch_start = 0;                       // the step the grid now resident started from
 
   std::string err;
 };
@@ -468,8 +480,9 @@ int persist_alloc(afe_engine *e) {
   e->p_cus = prop.multiProcessorCount;
   const int64_t chunks = (e->n + 63) / 64;
   const int64_t most = (int64_t)e->p_cus * 32;      // a CU has 32 wave slots: done[] never needs more
-  const size_t hbytes = (AFE_PERSIST_HOST_RING + 8 + AFE_PERSIST_HOST_MARKS) * sizeof(unsigned long long);
-  const size_t dbytes = (8 + (size_t)AFE_PERSIST_DEV_RING + (size_t)(chunks < most ? chunks : most) + 8) * sizeof(unsigned long long);   // [8 words: the workers' call-for-help word is the last of them][ring][done[]]
+  const size_t hbytes = (AFE_PERSIST_HOST_RING + AFE_PERSIST_STATUS_WORDS) * sizeof(unsigned long long);
+  const size_t dwords = 8 + (size_t)AFE_PERSIST_DEV_RING + (((size_t)(chunks < most ? chunks : most) + 8 + 15) & ~(size_t)15);
+  const size_t dbytes = (dwords + AFE_PERSIST_SYNC_AREA_WORDS) * sizeof(unsigned long long);   // [8 words: the workers' call-for-help word is the last of them][ring][done[]][sync area, a line per counter]
   // all three or none: a half-made set (the second or third call failing) must not look complete to the next afe_step
   hipError_t herr = e->p_host ? hipSuccess : hipHostMalloc((void **)&e->p_host, hbytes, hipHostMallocCoherent | hipHostMallocMapped);
   if (herr == hipSuccess) {
@@ -478,6 +491,7 @@ int persist_alloc(afe_engine *e) {
   }
   if (herr == hipSuccess && !e->p_dev) herr = hipMalloc((void **)&e->p_dev, dbytes);
   if (herr == hipSuccess) herr = hipMemsetAsync(e->p_dev, 0, dbytes, e->stream);
+  if (herr == hipSuccess) e->p_sync_area = e->p_dev + dwords;
   if (herr != hipSuccess) {
     if (e->p_dev) (void)hipFree(e->p_dev);
     if (e->p_host) (void)hipHostFree(e->p_host);
@@ -547,9 +561,62 @@ bool persist_eligible(const afe_engine *e) {
   return e->kernel_bytes < 0xffff0000ull && logic_arena_bytes(e) < 0xffff0000ull;
 }
 
+// The engine's own AQL queue and the descriptor of the kernel of the current configuration, or nullptr: this grid goes to
+// the HIP stream (AFE_PERSIST_AQL=0; a caller's stream; the runtime out of reach -- said once on stderr).
+const afe::AqlKernel *aql_kernel_for(afe_engine *e) {
+  static const bool off = [] { const char *s = std::getenv("AFE_PERSIST_AQL"); return s && s[0] == '0'; }();
+  if (off || e->stream != e->own_stream) return nullptr;
+  if (!e->aql_tried) {
+    e->aql_tried = true;
+    std::string why;
+    e->aql = afe::aql_open(e->device, &why);
+    if (!e->aql) std::fprintf(stderr, "agrifly_engine: no AQL queue for the resident grid (%s); it is launched on the HIP stream and parked at every synchronisation\n", why.c_str());
+  }
+  if (!e->aql) return nullptr;
+  const unsigned key = (e->p_flags.ext_force ? 2u : 0u) | (e->p_flags.noise ? 4u : 0u) | (e->p_flags.logic ? 8u : 0u) | (e->p_flags.counter_noise ? 16u : 0u) |
+                       (e->p_flags.resident ? 32u : 0u) | ((unsigned)e->precision << 8);
+  auto it = e->aql_kernels.find(key);
+  if (it == e->aql_kernels.end()) {
+    afe::AqlKernel k;
+    std::string why;
+    const void *fn = e->precision == AFE_F64 ? persistent_kernel_fn_f64(e->p_flags) : persistent_kernel_fn_f32(e->p_flags);
+    if (!afe::aql_find_kernel(e->aql, fn, &k, &why)) {
+      std::fprintf(stderr, "agrifly_engine: resident grid stays on the HIP stream (%s)\n", why.c_str());
+      k = afe::AqlKernel();       // object 0: remembered as not available
+    }
+    it = e->aql_kernels.emplace(key, k).first;
+  }
+  return it->second.object ? &it->second : nullptr;
+}
+
+// kernel-argument segment as the code object lays it out: the four by-value arguments, each at its own alignment
+template <typename R>
+bool aql_launch(afe_engine *e, const afe::AqlKernel &k, const StepView<R> &v, const DevParams<R> &P, const DevLogic &G, const PersistArgs &a) {
+  alignas(16) char buf[2048];
+  size_t o = 0;
+  auto put = [&](const void *p, size_t bytes, size_t align) { o = (o + align - 1) / align * align; std::memcpy(buf + o, p, bytes); o += bytes; };
+  std::memset(buf, 0, sizeof(buf));
+  put(&v, sizeof(v), alignof(StepView<R>));
+  put(&P, sizeof(P), alignof(DevParams<R>));
+  put(&G, sizeof(G), alignof(DevLogic));
+  put(&a, sizeof(a), alignof(PersistArgs));
+  // the queue is not ordered behind the HIP stream: whatever the stream still holds (setters, a memset) finishes first
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+  e->stream_pending = false;
+  std::string why;
+  if (!afe::aql_dispatch(e->aql, k, buf, o, (uint32_t)(1 + a.n_workers), 64, &why)) {
+    static bool said = false;
+    if (!said) std::fprintf(stderr, "agrifly_engine: AQL dispatch of the resident grid refused (%s); using the HIP stream\n", why.c_str());
+    said = true;
+    return false;
+  }
+  return true;
+}
+
 int persist_launch(afe_engine *e) {
   volatile unsigned long long *st = p_status(e);
   st[0] = 0; st[1] = e->p_resume; st[2] = 0; st[7] = 0;
+  st[AFE_PERSIST_SYNC_WORD] = 0; st[AFE_PERSIST_SYNCREQ_WORD] = 0;
   persist_size_grid(e);
   for (int w = 0; w < AFE_PERSIST_HOST_MARKS; w++) st[8 + w] = w < e->p_workers ? e->p_resume : ~0ull;
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -578,22 +645,31 @@ int persist_launch(afe_engine *e) {
   a.gust_seed = e->gust_seed; a.gust_n_global = e->gust_n_global; a.gust_sigma_max = e->gust_sigma_max;
   a.gust_epoch0 = e->gust_on ? t0 / e->gust_period_us : 0;
   a.gust_epoch_applied = !e->gust_on ? 0 : (e->p_resume > e->p_seg_start ? (t0 - e->p_dt_us) / e->gust_period_us : e->p_seg_gust_applied);
+  a.sync_area = e->p_sync_area;
   const double dt = us_to_seconds(e->p_dt_us);
   const LaunchFlags &f = e->p_flags;
   const DevLogic *ulogic = e->logic_on ? &e->logic_table[0] : nullptr;
-  int lrc;
+  static const DevLogic no_logic = {};
+  const afe::AqlKernel *ak = aql_kernel_for(e);      // nullptr: launch on the HIP stream
+  int lrc = 0;
+  bool on_aql = false;
   if (e->precision == AFE_F64) {
     StepView<double> v;
     fill_view(e, v);
     v.dt = dt; v.inv_dt = 1.0 / dt; v.n_steps = 1; v.tick_mask = 0; v.tick_base = ticks0;
-    lrc = launch_persistent_f64(v, f, e->table_f64[0], ulogic, a, e->stream);
+    if (ak) on_aql = aql_launch(e, *ak, v, e->table_f64[0], ulogic ? *ulogic : no_logic, a);
+    if (!on_aql) lrc = launch_persistent_f64(v, f, e->table_f64[0], ulogic, a, e->stream);
   } else {
     StepView<float> v;
     fill_view(e, v);
     v.dt = (float)dt; v.inv_dt = (float)(1.0 / dt); v.n_steps = 1; v.tick_mask = 0; v.tick_base = ticks0;
-    lrc = launch_persistent_f32(v, f, e->table_f32[0], ulogic, a, e->stream);
+    if (ak) on_aql = aql_launch(e, *ak, v, e->table_f32[0], ulogic ? *ulogic : no_logic, a);
+    if (!on_aql) lrc = launch_persistent_f32(v, f, e->table_f32[0], ulogic, a, e->stream);
   }
   if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("persistent step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+  e->p_on_aql = on_aql;
+  e->p_launch_start = e->p_resume;
+  if (!on_aql) e->stream_pending = true;
   static const bool debug = std::getenv("AFE_PERSIST_DEBUG") != nullptr;   // development aid: one line per grid
   if (debug) std::fprintf(stderr, "agrifly_engine: grid %u: %d workers (%d per CU allowed) for %lld chunks, from step %llu, resident-state %d noise %d logic %d force %d\n",
                           e->p_epoch, e->p_workers, e->p_capacity, (long long)a.n_chunks, (unsigned long long)a.start, (int)f.resident, (int)f.noise + (int)f.counter_noise, (int)f.logic, (int)f.ext_force);
@@ -603,7 +679,20 @@ int persist_launch(afe_engine *e) {
 
 // The resident grid has left the device (or is leaving: the stream says when): where did it stop?
 int persist_collect(afe_engine *e) {
-  const hipError_t herr = hipStreamSynchronize(e->stream);
+  hipError_t herr = hipSuccess;
+  const bool was_aql = e->p_on_aql;
+  if (e->p_on_aql) {
+    std::string why;
+    const int w = afe::aql_wait(e->aql, 120000000ull, &why);     // (the grid's own patience ends long before: 50 ms without progress)
+    if (w != 0) {
+      e->p_running = false; e->p_on_aql = false; e->p_failed = true;
+      return fail(e, AFE_ERR_HIP, "persistent step kernel on the engine's AQL queue: " + (w > 0 ? std::string("still running after 120 s") : why));
+    }
+    e->p_grid_ns += afe::aql_last_duration_ns(e->aql);
+    e->p_on_aql = false;
+  } else {
+    herr = hipStreamSynchronize(e->stream);
+  }
   e->p_running = false;
   volatile unsigned long long *st = p_status(e);
   if (herr == hipSuccess && st[0] != 0 && st[2] == 1 && e->p_shrink_num > 1) {
@@ -625,6 +714,7 @@ int persist_collect(afe_engine *e) {
   }
   else e->p_stall_streak = 0;     // (a grid that parked in the ordinary way)
   e->p_resume = st[0] - 1;
+  if (was_aql && e->p_resume >= e->p_launch_start) e->p_grid_steps += e->p_resume - e->p_launch_start;
   return AFE_OK;
 }
 
@@ -661,6 +751,10 @@ int quiesce(afe_engine *e) {
         continue;
       }
       if (st[1] >= e->p_next) break;
+      // ask the workers themselves (PersistArgs::sync_area): the pump's sweep over thousands of marks is tens of
+      // microseconds old, a worker answers the moment its own count stands at the request
+      if (st[AFE_PERSIST_SYNCREQ_WORD] != e->p_next) __atomic_store_n(&e->p_host[AFE_PERSIST_HOST_RING + AFE_PERSIST_SYNCREQ_WORD], (unsigned long long)e->p_next, __ATOMIC_RELEASE);
+      if (st[AFE_PERSIST_SYNC_WORD] >= e->p_next) break;
       if (e->host_arena && e->p_workers <= AFE_PERSIST_HOST_MARKS) {   // small grids write their marks here themselves: no wait for the pump's sweep
         unsigned long long low = ~0ull;
         for (int w = 0; w < e->p_workers; w++) { const unsigned long long d = st[8 + w]; low = d < low ? d : low; }
@@ -703,9 +797,12 @@ int persist_settle(afe_engine *e) {
 }
 
 // Cache policy of the one-step launches (LaunchFlags::cache_policy).  Automatic: by what the Infinity Cache (256 MiB) can
-// hold from one step to the next.  Everything the step touches fits: default policy, the whole working set is served
-// on-die.  Only the state fits: inputs and outputs stream past it (nt).  Not even the state: everything nt, one contiguous
-// range per XCD.  (Thresholds measured: tools/cache_policy_probe.py)
+// hold from one step to the next.  The distinct bytes a step touches (state + inputs + outputs: 104 B per fp32 vehicle of
+// the bench workload) fit: default policy, the whole working set is served on-die.  The state alone fits, or nearly (the
+// part that does still hits): inputs and outputs stream past it (nt).  Beyond: everything nt, one contiguous range per
+// XCD.  Measured on the bench workload, two streams, us per step by policy 0 / 1 / 2 / 3 (tools/cache_policy_probe.py,
+// profiles/r04_cache_policy.txt): 2^21 vehicles 42.3 / 46.1 / 53.6 / 54.7; 3 x 2^20 74.8 / 66.6 / 82.2 / 89.7; 2^22
+// 115.8 / 91.3 / 108.4 / 106.4; 6 x 2^20 173.7 / 158.0 / 165.0 / 177.1; 2^23 231.7 / 225.9 / 219.6 / 214.8.
 int resolve_cache_policy(const afe_engine *e) {
   static const int forced = [] { const char *s = std::getenv("AFE_CACHE_POLICY"); return s && *s ? std::atoi(s) : -1; }();
   const int asked = forced >= 0 && forced <= 3 ? forced : e->cache_policy;
@@ -715,8 +812,8 @@ int resolve_cache_policy(const afe_engine *e) {
   double state = 13 * es + (motor_lazy(e) ? 0 : 4 * es) + (e->noise && e->seed_policy != AFE_SEED_COUNTER ? 4 : 0) + (e->logic_on ? 12 * 4 + 4 * 4 : 0);
   double streams = (e->logic_on ? 4 * 4 : 4 * 4) + (e->has_ext_force ? 3 * es : 0) + (e->has_ext_torque ? 3 * es : 0) + 6 * 4;
   const double MiB = 1048576.0;
-  if ((state + streams) * n <= 200 * MiB) return 0;
-  if (state * n <= 224 * MiB) return 1;
+  if ((state + streams) * n <= 240 * MiB) return 0;
+  if (state * n <= 384 * MiB) return 1;
   return 3;
 }
 
@@ -884,6 +981,7 @@ extern "C" int afe_destroy(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   (void)hipSetDevice(e->device);
   if (e->p_running) (void)persist_park(e);
+  if (e->aql) { afe::aql_close(e->aql); e->aql = nullptr; }     // (waits for a grid that did not take the park: nothing is freed under it)
   if (e->p_dev) (void)hipFree(e->p_dev);
   if (e->p_host) (void)hipHostFree(e->p_host);
   if (e->side_stream) (void)hipStreamSynchronize(e->side_stream);
@@ -1369,8 +1467,30 @@ extern "C" int afe_steps_until_tick(const afe_engine *e, uint64_t dt_us, int *n_
 extern "C" int afe_sync(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
+  if (e->p_running && e->p_on_aql && !e->view_exported) {
+    // Every authorised step has run and its stores are acknowledged; the grid STAYS (it lives on the engine's own queue,
+    // which no HIP synchronisation waits for) and takes the next afe_step without a launch.  Whoever reads the state does
+    // so through an entry point of the engine, which ends the grid first (kernel end = the caches written back).  Once
+    // afe_get_device_view has handed the slabs out, afe_sync ends the grid as it always did: a reader the engine does
+    // not know about must find them in memory.
+    const int rc = quiesce(e);
+    if (rc) return rc;
+    if (e->p_failed) return fail(e, AFE_ERR_HIP, e->err);
+    return AFE_OK;
+  }
   AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
   if (e->p_failed) return fail(e, AFE_ERR_HIP, e->err);
+  return AFE_OK;
+}
+
+extern "C" int afe_grid_time(afe_engine *e, uint64_t *device_ns, uint64_t *steps) {
+  if (!e || !device_ns || !steps) return AFE_ERR_INVALID_ARG;
+  AFE_HIP(e, hipSetDevice(e->device));
+  const int rc = persist_park(e);      // the grid now resident is counted too
+  if (rc) return rc;
+  *device_ns = e->p_grid_ns;
+  *steps = e->p_grid_steps;
+  e->p_grid_ns = 0; e->p_grid_steps = 0;
   return AFE_OK;
 }
 
@@ -1423,7 +1543,13 @@ int engine_pack_to_scratch(afe_engine *e, float **scratch) {
 }
 }  // namespace afe
 
-extern "C" int afe_get_device_view(afe_engine *e, afe_device_view *out) {
+static int device_view(afe_engine *e, afe_device_view *out, bool exported);
+extern "C" int afe_get_device_view(afe_engine *e, afe_device_view *out) { return device_view(e, out, true); }
+namespace afe {
+// the library's own consumers (depth camera): stream-ordered behind the steps, nothing leaves the engine
+int engine_device_view(afe_engine *e, afe_device_view *out) { return device_view(e, out, false); }
+}
+static int device_view(afe_engine *e, afe_device_view *out, bool exported) {
   if (!e || !out) return AFE_ERR_INVALID_ARG;
   const size_t have = out->struct_bytes;
   if (have < offsetof(afe_device_view, pos_anchor_xy))
@@ -1431,6 +1557,7 @@ extern "C" int afe_get_device_view(afe_engine *e, afe_device_view *out) {
   AFE_HIP(e, hipSetDevice(e->device));
   (void)main_stream(e);            // a resident grid ends here (its last stores are the caller's to read); split streams are joined
   if (e->p_failed) return fail(e, AFE_ERR_HIP, e->err);
+  if (exported) e->view_exported = true;   // from now on afe_sync leaves the slabs readable (it ends a resident grid)
   { const int mrc = materialize_motor(e); if (mrc) return mrc; }   // motor_speed is current as of this call
   afe_device_view v;
   v.struct_bytes = have < sizeof(v) ? have : sizeof(v);

@@ -1004,6 +1004,12 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
   // behind.  Done here and not by the workers themselves: four more vector registers in the worker's path are the
   // difference between six and five resident waves per SIMD, 19.3 and 20.8 us per step at 2^20 vehicles -- measured.)
   for (int w = lane; w < a.n_workers; w += 64) st_agent(a.done + w, a.start);
+  // the sync counters (PersistArgs::sync_area) start a launch at zero, and no request is forwarded yet; all of it is in
+  // memory before the first entry is republished (nothing a worker does can come before that)
+  st_agent(a.sync_area + 16 * (1 + lane), 0);
+  if (lane == 0) { st_agent(a.sync_area + 16 * (1 + AFE_PERSIST_SYNC_SHARDS), 0); st_agent(a.sync_area, 0); }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  u64_t req_forwarded = 0;
   u64_t acc = ~0ull;                    // this lane's minimum over the part of done[] swept so far in the current cycle
   int sw = 0;                           // where the next partial sweep starts
   for (;;) {
@@ -1013,6 +1019,7 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
     // most ~30 us old -- `m` errs low, which only makes the ring's window and the patience below conservative.
     const u64_t idx = p + (u64_t)lane;
     const u64_t h = ld_system(a.host_ring + (idx & a.host_mask));
+    const u64_t req = ld_system(a.host_status + AFE_PERSIST_SYNCREQ_WORD);     // (in flight with the ring read: no iteration gets longer)
     u64_t d[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { const int w = sw + lane + 64 * j; d[j] = w < a.n_workers ? ld_agent(a.done + w) : ~0ull; }
@@ -1025,6 +1032,10 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
       for (int o = 32; o > 0; o >>= 1) { const u64_t other = __shfl_xor(r, o, 64); r = other < r ? other : r; }
       m = r; acc = ~0ull; sw = 0;
       if (lane == 0) st_system(a.host_status + 1, m);
+    }
+    if (req != req_forwarded) {            // a sync request: the workers read it beside the ring
+      if (lane == 0) st_agent(a.sync_area, req);
+      req_forwarded = req;
     }
     // (2) up to 64 new entries, in order, never more than a device ring (less one sweep) ahead of the slowest worker
     const bool ready = entry_index(h) == idx + 1;
@@ -1121,9 +1132,31 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
   // rewrites ITS vehicles' entries when a step starts in an epoch other than the one the slab holds
   u64_t gust_in_slab = a.gust_epoch_applied, gust_epoch = a.gust_epoch0;
   u64_t gust_next_us = (a.gust_epoch0 + 1) * a.gust_period_us, t_us = a.t0_us;
+  u64_t sync_answered = 0;                           // the request this wave has already answered
+  unsigned sync_count = 0;                           // how many it has answered in this launch
   for (;;) {
     const u64_t idx = s + (u64_t)lane;
     const u64_t e = ld_agent(a.dev_ring + (idx & a.dev_mask));
+    const u64_t req_v = ld_agent(a.sync_area);       // (issued with the ring read; wave-uniform, kept in scalar registers)
+    const u64_t req = (u64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(req_v & 0xffffffffu)) |
+                      ((u64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(req_v >> 32)) << 32);
+    if (req == s && req != sync_answered) {
+      // the host waits for step s - 1 and this wave has done it: say so once (PersistArgs::sync_area).  The stores of the
+      // step are acknowledged first; the counters are cumulative, so the k-th request completes at k x the arrivals.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      sync_answered = req;
+      sync_count++;
+      if (lane == 0) {
+        const unsigned shard = (unsigned)w & (AFE_PERSIST_SYNC_SHARDS - 1);
+        const unsigned in_shard = ((unsigned)a.n_workers - shard + AFE_PERSIST_SYNC_SHARDS - 1) / AFE_PERSIST_SYNC_SHARDS;
+        const unsigned shards = (unsigned)a.n_workers < AFE_PERSIST_SYNC_SHARDS ? (unsigned)a.n_workers : AFE_PERSIST_SYNC_SHARDS;
+        const u64_t got = __hip_atomic_fetch_add(a.sync_area + 16 * (1 + shard), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        if (got == (u64_t)sync_count * in_shard) {
+          const u64_t top = __hip_atomic_fetch_add(a.sync_area + 16 * (1 + AFE_PERSIST_SYNC_SHARDS), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+          if (top == (u64_t)sync_count * shards) st_system(a.host_status + AFE_PERSIST_SYNC_WORD, req);
+        }
+      }
+    }
     const bool ready = entry_index(e) == idx + 1 && (!(e & AFE_PERSIST_PARK) || (unsigned)(e >> 48) == (a.epoch & 0xffffu));
     const int cnt = ones_from_bit0(__ballot(ready));
     if (cnt == 0) {
@@ -1256,13 +1289,15 @@ int launch_gust_f64(double *ext_force, int64_t stride, int64_t n, int64_t first_
 // occupancy != 0: do not launch, report how many of the instantiation's one-wave workgroups a CU holds
 template <typename R>
 static int launch_persistent(const StepView<R> &v, const LaunchFlags &f, const DevParams<R> &uniform,
-                             const DevLogic *uniform_logic, const PersistArgs &a, hipStream_t st, int *occupancy) {
+                             const DevLogic *uniform_logic, const PersistArgs &a, hipStream_t st, int *occupancy, const void **fn_out = nullptr) {
   DevLogic no_logic = {};
   const DevLogic &G = uniform_logic ? *uniform_logic : no_logic;
   const dim3 grid((unsigned)(1 + a.n_workers)), block(64);
 #define AFE_PL_R(FE, NO, LO, RE)                                                                                        \
   do {                                                                                                                  \
-    if (occupancy) {                                                                                                    \
+    if (fn_out) {                                                                                                       \
+      *fn_out = reinterpret_cast<const void *>(&afe_step_persistent_kernel<R, FE, NO, LO, RE>);                         \
+    } else if (occupancy) {                                                                                             \
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, afe_step_persistent_kernel<R, FE, NO, LO, RE>, 64, 0) != hipSuccess) \
         *occupancy = 0;                                                                                                 \
     } else {                                                                                                            \
@@ -1296,6 +1331,17 @@ static int persistent_capacity(const LaunchFlags &f) {
   const int sgpr_bound = 6 * 4;
   return per_cu < sgpr_bound ? per_cu : sgpr_bound;
 }
+template <typename R>
+static const void *persistent_kernel_fn(const LaunchFlags &f) {
+  StepView<R> v = {};
+  DevParams<R> P = {};
+  PersistArgs a = {};
+  const void *fn = nullptr;
+  (void)launch_persistent<R>(v, f, P, nullptr, a, nullptr, nullptr, &fn);
+  return fn;
+}
+const void *persistent_kernel_fn_f32(const LaunchFlags &f) { return persistent_kernel_fn<float>(f); }
+const void *persistent_kernel_fn_f64(const LaunchFlags &f) { return persistent_kernel_fn<double>(f); }
 int persistent_capacity_f32(const LaunchFlags &f) { return persistent_capacity<float>(f); }
 int persistent_capacity_f64(const LaunchFlags &f) { return persistent_capacity<double>(f); }
 

@@ -29,5 +29,7 @@ static_assert(sizeof(PairNode) == 64, "one visit = one 64-byte scalar load");
 
 // implemented in afe_engine.cpp: the stream the engine launches on and its device
 void engine_stream_device(afe_engine *e, void **stream, int *device);
+// afe_get_device_view for the library's own consumers (the slabs do not leave the engine: afe_sync keeps its short form)
+int engine_device_view(afe_engine *e, struct afe_device_view *out);
 
 }  // namespace afe

@@ -1147,7 +1147,7 @@ extern "C" int afe_render_depth_engine(afe_engine *e, afe_scene *s, const afe_ca
   if (!e || !s || !camera_ok(cam) || count <= 0 || first < 0 || !depth_out) return AFE_ERR_INVALID_ARG;
   afe_device_view view;
   view.struct_bytes = sizeof(view);
-  int rc = afe_get_device_view(e, &view);
+  int rc = engine_device_view(e, &view);
   if (rc != AFE_OK) return rc;
   if (first + count > view.n_vehicles) return AFE_ERR_OUT_OF_RANGE;
   hipStream_t stream = nullptr;

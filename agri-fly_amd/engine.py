@@ -47,7 +47,7 @@ ABI_FUNCTIONS = [
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
     "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running", "afe_stream_probe",
     "afe_set_noise_seed", "afe_set_gust_process", "afe_get_external_force", "afe_nearest_neighbour_async", "afe_query_sync",
-    "afe_gather_exchange", "afe_set_cache_policy",
+    "afe_gather_exchange", "afe_set_cache_policy", "afe_grid_time",
 ]
 
 
@@ -340,6 +340,7 @@ def library():
         "afe_group_create": [C.POINTER(vp), i64, ci, vp, ci],
         "afe_group_peer_access": [vp, C.POINTER(ci)],
         "afe_set_cache_policy": [eng, ci],
+        "afe_grid_time": [eng, C.POINTER(u64), C.POINTER(u64)],
         "afe_group_destroy": [vp],
         "afe_group_size": [vp, C.POINTER(ci), C.POINTER(i64)],
         "afe_group_shard": [vp, ci, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)],
@@ -881,6 +882,12 @@ class Ensemble:
         v.struct_bytes = C.sizeof(DeviceView)
         self._ck(self._L.afe_get_device_view(self._h, C.byref(v)))
         return v
+
+    def grid_time(self):
+        """(device seconds, steps) of the resident grids since the last call; ends the grid now resident"""
+        ns, steps = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.afe_grid_time(self._h, C.byref(ns), C.byref(steps)))
+        return ns.value * 1e-9, steps.value
 
     def set_cache_policy(self, policy):
         """-1 automatic, 0 default, 1 inputs / outputs nt, 2 everything nt, 3 everything nt + one range per XCD"""

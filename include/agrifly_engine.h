@@ -532,6 +532,11 @@ int afe_set_step_mode(afe_engine *e, int mode);
 int afe_steps_completed(afe_engine *e, uint64_t *steps);
 /* 1 while a resident grid is on the device, 0 otherwise (diagnostic; tests use it) */
 int afe_persistent_running(const afe_engine *e, int *running);
+/* Device time spent by the resident grids since the last call (begin / end timestamps of each grid's dispatch on the
+ * engine's own queue) and the steps they served: what rocprofv3 --kernel-trace reports as the kernel's duration,
+ * measured in the run.  Ends the grid now resident (it is counted).  Both 0 when the grids ran on the HIP stream
+ * (AFE_PERSIST_AQL=0, a caller's stream): use afe_event_record there.  Replaces nothing in the reference. */
+int afe_grid_time(afe_engine *e, uint64_t *device_ns, uint64_t *steps);
 
 /* Cache-policy hints of the one-step launches' slab accesses (`nt` bits on the buffer instructions; never a different
  * result bit).  -1 automatic (default): by what the 256 MiB Infinity Cache can keep from one step to the next --
