@@ -1127,7 +1127,7 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
   u64_t s = a.start;
   u64_t t_wait = ticks100();
   u64_t tick_no = v.tick_base;                       // logic ticks so far (the counter policy's sample address)
-  int idle_polls = 0;
+  int idle_polls = 0, idle_count = 0;
   // gust process (afe_set_gust_process): the force of epoch floor(t / period) lives in the ext_force slab; this wave
   // rewrites ITS vehicles' entries when a step starts in an epoch other than the one the slab holds
   u64_t gust_in_slab = a.gust_epoch_applied, gust_epoch = a.gust_epoch0;
@@ -1175,12 +1175,15 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
       // the working waves live on -- thousands of waves polling every 60 ns cost the others 10 % of their bandwidth.
       // 0.06, 0.12, ... up to ~2 us between polls (a step of a large ensemble takes tens of microseconds; a small one is
       // never more than a few polls behind)
-      if (idle_polls < 5 && !(a.epoch & AFE_PERSIST_HOST_IO)) idle_polls++;   // (a host-visible arena means few waves and a host waiting on every step: they keep polling)
+      // (the first ~30 us of a wait stop at ~0.5 us between polls: a host that synchronises after every block of steps
+      // comes back within microseconds, and the first step of its next block should not wait 2 us for each wave to look)
+      if (idle_polls < (idle_count < 64 ? 3 : 5) && !(a.epoch & AFE_PERSIST_HOST_IO)) idle_polls++;   // (a host-visible arena means few waves and a host waiting on every step: they keep polling)
+      if (idle_count < 64) idle_count++;
       __builtin_amdgcn_s_sleep(2);
       for (int b = 1; b < (1 << idle_polls); b++) __builtin_amdgcn_s_sleep(2);
       continue;
     }
-    idle_polls = 0;
+    idle_polls = 0; idle_count = 0;
     // host-visible arena (afe_create_host_visible): what the host wrote before it authorised these steps is read from
     // host memory, not from a cache line of an earlier step
     if (a.epoch & AFE_PERSIST_HOST_IO) AFE_HOST_ACQUIRE();

@@ -128,11 +128,13 @@ def median(xs):
 
 
 def kernel_time_events(e, launches):
-    """device time per step: HIP events on the engine's stream bracketing a back-to-back run of `launches` single-step
-    afe_step calls (launch mode: that many kernel launches; persistent mode: one resident grid serving them all, from
-    its launch to its exit)"""
+    """device time per step of a back-to-back run of `launches` single-step afe_step calls.  Launch mode: HIP events on the
+    engine's stream around that many kernel launches.  Resident grid: it runs on the engine's own AQL queue (no HIP stream
+    sees it), so its time is the begin / end device timestamps of its dispatch (afe_grid_time: what rocprofv3
+    --kernel-trace reports as the kernel's duration) -- one grid from its first wave to its exit, serving all the steps."""
     ev0, ev1 = e.event(), e.event()
     e.sync()
+    e.grid_time()             # ends a resident grid and clears the account
     e.record(ev0)
     for _ in range(launches):
         e.step(DT_US, 1)
@@ -140,6 +142,9 @@ def kernel_time_events(e, launches):
     ms = e.elapsed_ms(ev0, ev1)
     e.destroy_event(ev0)
     e.destroy_event(ev1)
+    grid_s, grid_steps = e.grid_time()
+    if grid_steps == launches and grid_s > 0:
+        return grid_s / launches
     return ms * 1e-3 / launches
 
 
