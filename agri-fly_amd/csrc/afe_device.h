@@ -129,16 +129,15 @@ struct PersistArgs {
   // its epoch floor(time / period) is tracked incrementally from gust_epoch0 = epoch of t0_us.
   unsigned long long gust_period_us, gust_seed, gust_n_global, gust_epoch0, gust_epoch_applied, t0_us, dt_us;
   double gust_sigma_max;
-  // "tell me when step S - 1 is done" without ending the grid (afe_sync on a grid that stays resident): the host writes S
-  // into host_status[AFE_PERSIST_SYNCREQ_WORD]; the pump forwards it to sync_area[0]; a worker whose own count stands at S
-  // says so ONCE -- one atomic on its shard's counter (64 shards, a line each, sync_area[16 * (1 + shard)]), the shard's
-  // last arrival one more on the top counter (sync_area[16 * 65]), the last of those writes S to
-  // host_status[AFE_PERSIST_SYNC_WORD].  Counters are cumulative within a launch (the k-th request completes a shard at
-  // k x its workers); the pump zeroes them before it republishes anything.  One request at a time: the host waits.
-  unsigned long long *sync_area;
 };
+// "tell me when step S - 1 is done" without ending the grid (afe_sync on a grid that stays resident): the host writes S
+// into host_status[AFE_PERSIST_SYNCREQ_WORD]; once everything before S is republished the pump puts a MARKER into slot S of
+// the device ring (the index of an entry for step S, both flags set: neither a step nor a park); a worker that finds the
+// marker under its own count says so ONCE -- one atomic on its shard's counter (64 shards, a line each, behind done[]),
+// the shard's last arrival one more on the top counter, the last of those writes S to host_status[AFE_PERSIST_SYNC_WORD].
+// Arrivals of two requests never interleave (the host waits for each): a counter is complete at every multiple of its size.
 #define AFE_PERSIST_SYNC_SHARDS 64
-#define AFE_PERSIST_SYNC_AREA_WORDS (16 * (AFE_PERSIST_SYNC_SHARDS + 2))
+#define AFE_PERSIST_SYNC_AREA_WORDS (16 * (AFE_PERSIST_SYNC_SHARDS + 3))   /* a pad line, 64 shard lines, the top line, slack */
 #define AFE_PERSIST_HOST_IO 0x10000u   /* PersistArgs::epoch */
 #define AFE_PERSIST_HOST_MARKS 64      /* host-visible arenas: grids of up to this many workers also write their marks to host_status[8 + w] */
 #define AFE_PERSIST_SYNC_WORD (8 + AFE_PERSIST_HOST_MARKS)      /* host_status: the step count the last sync request was answered for */

@@ -131,7 +131,6 @@ struct afe_engine {
   bool aql_tried = false;
   bool p_on_aql = false;            // the grid now resident was dispatched there
   std::map<unsigned, afe::AqlKernel> aql_kernels;    // by configuration key (persist_size_grid's) | precision << 8
-  unsigned long long *p_sync_area = nullptr;         // device: PersistArgs::sync_area
   bool view_exported = false;       // afe_get_device_view has handed the slabs to somebody: afe_sync must leave them readable
   uint64_t p_grid_ns = 0, p_grid_steps = 0;          // device time and steps of the grids collected so far (afe_grid_time)
   uint64_t p_launch_start = 0;                       // the step the grid now resident started from
@@ -491,7 +490,6 @@ int persist_alloc(afe_engine *e) {
   }
   if (herr == hipSuccess && !e->p_dev) herr = hipMalloc((void **)&e->p_dev, dbytes);
   if (herr == hipSuccess) herr = hipMemsetAsync(e->p_dev, 0, dbytes, e->stream);
-  if (herr == hipSuccess) e->p_sync_area = e->p_dev + dwords;
   if (herr != hipSuccess) {
     if (e->p_dev) (void)hipFree(e->p_dev);
     if (e->p_host) (void)hipHostFree(e->p_host);
@@ -645,7 +643,6 @@ int persist_launch(afe_engine *e) {
   a.gust_seed = e->gust_seed; a.gust_n_global = e->gust_n_global; a.gust_sigma_max = e->gust_sigma_max;
   a.gust_epoch0 = e->gust_on ? t0 / e->gust_period_us : 0;
   a.gust_epoch_applied = !e->gust_on ? 0 : (e->p_resume > e->p_seg_start ? (t0 - e->p_dt_us) / e->gust_period_us : e->p_seg_gust_applied);
-  a.sync_area = e->p_sync_area;
   const double dt = us_to_seconds(e->p_dt_us);
   const LaunchFlags &f = e->p_flags;
   const DevLogic *ulogic = e->logic_on ? &e->logic_table[0] : nullptr;
@@ -751,7 +748,7 @@ int quiesce(afe_engine *e) {
         continue;
       }
       if (st[1] >= e->p_next) break;
-      // ask the workers themselves (PersistArgs::sync_area): the pump's sweep over thousands of marks is tens of
+      // ask the workers themselves (afe_device.h, sync marker): the pump's sweep over thousands of marks is tens of
       // microseconds old, a worker answers the moment its own count stands at the request
       if (st[AFE_PERSIST_SYNCREQ_WORD] != e->p_next) __atomic_store_n(&e->p_host[AFE_PERSIST_HOST_RING + AFE_PERSIST_SYNCREQ_WORD], (unsigned long long)e->p_next, __ATOMIC_RELEASE);
       if (st[AFE_PERSIST_SYNC_WORD] >= e->p_next) break;

@@ -983,6 +983,9 @@ __device__ __forceinline__ int ones_from_bit0(u64_t m) { return m == ~0ull ? 64 
 __device__ __forceinline__ u64_t entry_index(u64_t e) { return (e >> 2) & ((1ull << 46) - 1); }
 __device__ __forceinline__ u64_t entry_stamp(u64_t e, unsigned epoch) { return (e & ((1ull << 48) - 1)) | ((u64_t)(epoch & 0xffffu) << 48); }
 
+// the sync counters of a launch: 64 shard counters and a top one, a line (16 words) each, behind done[]
+__device__ __forceinline__ u64_t *persist_sync_counters(const PersistArgs &a) { return a.done + ((a.n_workers + 15) & ~15) + 16; }
+
 // Workgroup 0.  Keeps three things moving, one sweep after the other: the workers' progress (the minimum over
 // done[] -> flow control of the device ring and the host's `completed` word), new host entries -> device ring, and
 // the two ways out: a park entry from the host, or one of its own when the host has gone quiet.
@@ -1004,12 +1007,12 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
   // behind.  Done here and not by the workers themselves: four more vector registers in the worker's path are the
   // difference between six and five resident waves per SIMD, 19.3 and 20.8 us per step at 2^20 vehicles -- measured.)
   for (int w = lane; w < a.n_workers; w += 64) st_agent(a.done + w, a.start);
-  // the sync counters (PersistArgs::sync_area) start a launch at zero, and no request is forwarded yet; all of it is in
-  // memory before the first entry is republished (nothing a worker does can come before that)
-  st_agent(a.sync_area + 16 * (1 + lane), 0);
-  if (lane == 0) { st_agent(a.sync_area + 16 * (1 + AFE_PERSIST_SYNC_SHARDS), 0); st_agent(a.sync_area, 0); }
+  // the sync counters (behind done[], see persist_sync_counters) start a launch at zero; all of it is in memory before the
+  // first entry is republished (nothing a worker does can come before that)
+  st_agent(persist_sync_counters(a) + 16 * lane, 0);
+  if (lane == 0) st_agent(persist_sync_counters(a) + 16 * AFE_PERSIST_SYNC_SHARDS, 0);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  u64_t req_forwarded = 0;
+  u64_t req_marked = 0;
   u64_t acc = ~0ull;                    // this lane's minimum over the part of done[] swept so far in the current cycle
   int sw = 0;                           // where the next partial sweep starts
   for (;;) {
@@ -1033,10 +1036,6 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
       m = r; acc = ~0ull; sw = 0;
       if (lane == 0) st_system(a.host_status + 1, m);
     }
-    if (req != req_forwarded) {            // a sync request: the workers read it beside the ring
-      if (lane == 0) st_agent(a.sync_area, req);
-      req_forwarded = req;
-    }
     // (2) up to 64 new entries, in order, never more than a device ring (less one sweep) ahead of the slowest worker
     const bool ready = entry_index(h) == idx + 1;
     const bool room = idx + 64 < m + (u64_t)a.dev_mask + 1;
@@ -1046,6 +1045,15 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
     if (lane < cnt) st_agent(a.dev_ring + (idx & a.dev_mask), entry_stamp(h, a.epoch));
     p += (u64_t)cnt;
     if (parks) { park_pos = p - 1; break; }
+    // a sync request (afe_sync on a grid that stays): "tell me when step req - 1 is done".  Once everything up to there is
+    // republished, slot `req` -- the one every worker polls when it has caught up -- gets a marker: an entry with the right
+    // index and BOTH flags, which no step and no park ever carries.  A worker that finds it under its own count answers
+    // once (persistent kernel below); the next real entry for that slot simply overwrites it.  (Slot p is free: as for a
+    // park entry.)
+    if (req != req_marked && req == p) {
+      if (lane == 0) st_agent(a.dev_ring + (p & a.dev_mask), entry_stamp(((p + 1) << 2) | AFE_PERSIST_PARK | AFE_PERSIST_TICK, a.epoch));
+      req_marked = req;
+    }
     const u64_t now = ticks100();
     const bool fed = (__ballot(ready) & 1ull) != 0;       // the host is ahead of us (there may just be no room yet)
     if (fed || m < p) t_fed = now;                         // patience runs only while the workers have nothing left to do:
@@ -1127,39 +1135,38 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
   u64_t s = a.start;
   u64_t t_wait = ticks100();
   u64_t tick_no = v.tick_base;                       // logic ticks so far (the counter policy's sample address)
-  int idle_polls = 0, idle_count = 0;
+  int idle_polls = 0;
   // gust process (afe_set_gust_process): the force of epoch floor(t / period) lives in the ext_force slab; this wave
   // rewrites ITS vehicles' entries when a step starts in an epoch other than the one the slab holds
   u64_t gust_in_slab = a.gust_epoch_applied, gust_epoch = a.gust_epoch0;
   u64_t gust_next_us = (a.gust_epoch0 + 1) * a.gust_period_us, t_us = a.t0_us;
-  u64_t sync_answered = 0;                           // the request this wave has already answered
-  unsigned sync_count = 0;                           // how many it has answered in this launch
+  bool sync_answered = false;                        // this wave has answered the sync marker standing at its count
   for (;;) {
     const u64_t idx = s + (u64_t)lane;
     const u64_t e = ld_agent(a.dev_ring + (idx & a.dev_mask));
-    const u64_t req_v = ld_agent(a.sync_area);       // (issued with the ring read; wave-uniform, kept in scalar registers)
-    const u64_t req = (u64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(req_v & 0xffffffffu)) |
-                      ((u64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(req_v >> 32)) << 32);
-    if (req == s && req != sync_answered) {
-      // the host waits for step s - 1 and this wave has done it: say so once (PersistArgs::sync_area).  The stores of the
-      // step are acknowledged first; the counters are cumulative, so the k-th request completes at k x the arrivals.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      sync_answered = req;
-      sync_count++;
-      if (lane == 0) {
-        const unsigned shard = (unsigned)w & (AFE_PERSIST_SYNC_SHARDS - 1);
-        const unsigned in_shard = ((unsigned)a.n_workers - shard + AFE_PERSIST_SYNC_SHARDS - 1) / AFE_PERSIST_SYNC_SHARDS;
-        const unsigned shards = (unsigned)a.n_workers < AFE_PERSIST_SYNC_SHARDS ? (unsigned)a.n_workers : AFE_PERSIST_SYNC_SHARDS;
-        const u64_t got = __hip_atomic_fetch_add(a.sync_area + 16 * (1 + shard), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-        if (got == (u64_t)sync_count * in_shard) {
-          const u64_t top = __hip_atomic_fetch_add(a.sync_area + 16 * (1 + AFE_PERSIST_SYNC_SHARDS), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-          if (top == (u64_t)sync_count * shards) st_system(a.host_status + AFE_PERSIST_SYNC_WORD, req);
+    const bool ready = entry_index(e) == idx + 1 && (!(e & AFE_PERSIST_PARK) || (unsigned)(e >> 48) == (a.epoch & 0xffffu));
+    const bool marker = ready && (e & 3ull) == 3ull;                        // the pump's sync marker: not a step, not a park
+    const int cnt = ones_from_bit0(__ballot(ready && !marker));
+    if (cnt == 0) {
+      if (!sync_answered && (__ballot(marker) & 1ull)) {
+        // the host waits for everything before this slot and this wave has done it: say so once.  The stores of the last
+        // step are acknowledged first.  Arrivals never interleave between two requests (the host waits for each), so a
+        // shard is complete whenever its count is a multiple of its size: 64 shards, then one top counter, the last
+        // arrival there writes the host's word.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sync_answered = true;
+        if (lane == 0) {
+          u64_t *const cnts = persist_sync_counters(a);
+          const unsigned shard = (unsigned)w & (AFE_PERSIST_SYNC_SHARDS - 1);
+          const unsigned in_shard = ((unsigned)a.n_workers - shard + AFE_PERSIST_SYNC_SHARDS - 1) / AFE_PERSIST_SYNC_SHARDS;
+          const unsigned shards = (unsigned)a.n_workers < AFE_PERSIST_SYNC_SHARDS ? (unsigned)a.n_workers : AFE_PERSIST_SYNC_SHARDS;
+          const u64_t got = __hip_atomic_fetch_add(cnts + 16 * shard, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+          if (got % in_shard == 0) {
+            const u64_t top = __hip_atomic_fetch_add(cnts + 16 * AFE_PERSIST_SYNC_SHARDS, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            if (top % shards == 0) st_system(a.host_status + AFE_PERSIST_SYNC_WORD, s);
+          }
         }
       }
-    }
-    const bool ready = entry_index(e) == idx + 1 && (!(e & AFE_PERSIST_PARK) || (unsigned)(e >> 48) == (a.epoch & 0xffffu));
-    const int cnt = ones_from_bit0(__ballot(ready));
-    if (cnt == 0) {
       // Starved for 60 ms (the pump parks an idle grid after 200 us, so this is not a quiet host: the pump is not
       // getting through, or part of the grid is not resident beside somebody else's kernels -- seen by the soak: the
       // last few workgroups of an fp64 grid beside a second engine's launches, whose host thread was waiting for
@@ -1177,13 +1184,13 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
       // never more than a few polls behind)
       // (the first ~30 us of a wait stop at ~0.5 us between polls: a host that synchronises after every block of steps
       // comes back within microseconds, and the first step of its next block should not wait 2 us for each wave to look)
-      if (idle_polls < (idle_count < 64 ? 3 : 5) && !(a.epoch & AFE_PERSIST_HOST_IO)) idle_polls++;   // (a host-visible arena means few waves and a host waiting on every step: they keep polling)
-      if (idle_count < 64) idle_count++;
+      if (idle_polls < 64 && !(a.epoch & AFE_PERSIST_HOST_IO)) idle_polls++;   // (a host-visible arena means few waves and a host waiting on every step: they keep polling)
+      const int ex = idle_polls < 3 ? idle_polls : (idle_polls < 64 ? 3 : 5);
       __builtin_amdgcn_s_sleep(2);
-      for (int b = 1; b < (1 << idle_polls); b++) __builtin_amdgcn_s_sleep(2);
+      for (int b = 1; b < (1 << ex); b++) __builtin_amdgcn_s_sleep(2);
       continue;
     }
-    idle_polls = 0; idle_count = 0;
+    idle_polls = 0; sync_answered = false;
     // host-visible arena (afe_create_host_visible): what the host wrote before it authorised these steps is read from
     // host memory, not from a cache line of an earlier step
     if (a.epoch & AFE_PERSIST_HOST_IO) AFE_HOST_ACQUIRE();
