@@ -687,6 +687,15 @@ int persist_collect(afe_engine *e) {
     }
     e->p_grid_ns += afe::aql_last_duration_ns(e->aql);
     e->p_on_aql = false;
+    // AFE_GRID_LOG=<file> (profiling aid, tools/profile_r04.sh): one line per grid that has left the device -- the steps it
+    // served and its device time -- in dispatch order, to be laid beside rocprofv3's kernel trace of the same run
+    static FILE *const grid_log = [] { const char *p = std::getenv("AFE_GRID_LOG"); return p && *p ? std::fopen(p, "a") : (FILE *)nullptr; }();
+    if (grid_log) {
+      volatile unsigned long long *stl = p_status(e);
+      std::fprintf(grid_log, "%lld,%d,%llu,%llu\n", (long long)e->n, e->p_workers, (unsigned long long)(stl[0] ? stl[0] - 1 - e->p_launch_start : 0),
+                   (unsigned long long)afe::aql_last_duration_ns(e->aql));
+      std::fflush(grid_log);
+    }
   } else {
     herr = hipStreamSynchronize(e->stream);
   }

@@ -225,9 +225,9 @@ def _bench_flow_worker(rank, world, port, q):
             return float(t.item())
         e = _StubEngine(0.0002 * (1 + 4 * rank))       # rank 1 is five times slower
         own = []
-        blocks = bench.timed_blocks(e, 5, 1, lambda: None, dist.barrier, reduce_max, min_total_s=0.03, min_blocks=3, own=own)
+        blocks = bench.timed_blocks(e, 5, 1, lambda: None, dist.barrier, reduce_max, min_total_s=0.03, min_blocks=3, own=own, settle_s=0.0)
         # a second protocol on the same group right behind it: nobody is left behind in a collective of the first
-        blocks2 = bench.timed_blocks(e, 2, 2, lambda: None, dist.barrier, reduce_max, min_total_s=0.0, min_blocks=2)
+        blocks2 = bench.timed_blocks(e, 2, 2, lambda: None, dist.barrier, reduce_max, min_total_s=0.0, min_blocks=2, settle_s=0.0)
         q.put((rank, blocks, own, blocks2, e.steps))
     finally:
         dist.destroy_process_group()
