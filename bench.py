@@ -670,7 +670,7 @@ def compact_line(full):
                       "noise": cfg.get("noise"), "parallelism": cfg.get("parallelism_short", cfg.get("parallelism"))}
     line.update(_pick(full, ("repeats", "ms_per_step_min", "ms_per_step_max")) or {})
     r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel_us", "kernel_us_min", "kernel_us_max",
-                     "kernel_us_rocprof", "algorithmic_bytes_per_vehicle_step")) or {}
+                     "kernel_us_rocprof", "kernel_us_dispatch_per_block", "algorithmic_bytes_per_vehicle_step")) or {}
     kr = roof.get("kernel_us_rocprof")
     if isinstance(kr, dict):      # the committed trace holds one figure per block length: the line carries this run's
         nums = {k: v for k, v in kr.items() if isinstance(v, (int, float))}
@@ -839,7 +839,12 @@ def main():
     # ---- the headline measurement: W warmup steps, then blocks of exactly K timed steps (median block) ----
     time_steps(e, args.warmup, 1, sync, barrier)
     own_blocks = []
+    e.grid_time()         # (ends a resident grid and clears its account: what follows is the timed region's own)
     blocks = timed_blocks(e, args.steps, 1, sync, barrier, reduce_max, own=own_blocks)
+    # device time of the resident grid over exactly that region (settling blocks included): the begin / end timestamps of
+    # its dispatch(es) on the engine's queue and the steps served -- what a rocprofv3 kernel trace of this command shows
+    # for the same dispatch (tools/profile_summary_r04.py).  (0, 0) when the steps were launched kernels.
+    grid_s, grid_steps = e.grid_time()
     persistent = uses_persistent(afa, mode, n_local)
     split = (not persistent) and n_local >= (1 << 19)
     elapsed = median(blocks)
@@ -873,10 +878,12 @@ def main():
         ex = build_shard(afa, n_local, rank * n_local, n_global, local_rank, exact_stream=True)
         ex.set_step_mode(mode)
         time_steps(ex, max(args.warmup, 50), 1, sync, barrier)
+        ex.grid_time()
         xblocks = timed_blocks(ex, args.steps, 1, sync, barrier, reduce_max)
+        xg_s, xg_steps = ex.grid_time()
         xbytes, _ = mean_bytes_per_step(ex, afa, args.steps)
         tx = median(xblocks) / args.steps
-        tx_kernel = event_blocks(ex, args.steps)[0] if rank == 0 else None
+        tx_kernel = (xg_s / xg_steps if xg_steps > 0 and xg_s > 0 else event_blocks(ex, args.steps)[0]) if rank == 0 else None
         exact = {"value": n_global / tx, "unit": "vehicle-steps/s", "ms_per_step": tx * 1e3, "steps": args.steps, "repeats": len(xblocks),
                  "algorithmic_bytes_per_vehicle_step": xbytes, "kernel_us": None if tx_kernel is None else tx_kernel * 1e6,
                  "frac": None if tx_kernel is None else n_local * xbytes / tx_kernel / 1e9 / HBM_PEAK_GBS,
@@ -890,7 +897,11 @@ def main():
     if rank == 0:
         bytes_step, tick_frac = mean_bytes_per_step(e, afa, args.steps)
         # device time per step over the timed cadence: HIP events on the engine's stream around K steps, repeated
-        t_kernel, t_kmin, t_kmax, k_rep = event_blocks(e, args.steps)
+        t_block, t_kmin, t_kmax, k_rep = event_blocks(e, args.steps)
+        # launch mode: HIP events around the K launches of a block.  Resident grid: one grid serves all the blocks of the
+        # timed region -- its device time / the steps it served; the one-block-per-dispatch figure (a grid started and
+        # parked around every block, as round 3 had to) stays in the record as kernel_us_dispatch_per_block
+        t_kernel = grid_s / grid_steps if grid_steps > 0 and grid_s > 0 else t_block
         achieved = n_local * bytes_step / t_kernel / 1e9
         # the same over a long run: a resident grid's launch and exit (and a stream's first launches) amortised away
         long_steps = max(args.steps, 2000)
@@ -968,6 +979,9 @@ def main():
                            "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, LOGIC=0, SINGLE=1>, 64-lane workgroups -- the timed region "
                            "alternates NOISE=0 (no logic tick) and NOISE=1 (tick: IMU + six Gaussian draws) launches"),
                 "kernel_us": t_kernel * 1e6,
+                "kernel_us_source": ("device timestamps of the resident grid's dispatch over the timed region / %d steps served (afe_grid_time)" % grid_steps
+                                     if grid_steps > 0 and grid_s > 0 else "HIP events on the engine's stream around the launches of a block"),
+                "kernel_us_dispatch_per_block": t_block * 1e6,
                 "kernel_us_min": t_kmin * 1e6, "kernel_us_max": t_kmax * 1e6, "kernel_repeats": k_rep,
                 # the committed rocprofv3 kernel trace of this command: the resident grid's own duration per step.  The events
                 # above bracket the whole block on the stream -- dispatch of the grid, its ramp-up and the park hand-shake
