@@ -536,7 +536,10 @@ LaunchFlags persist_flags(const afe_engine *e) {
   LaunchFlags f;
   f.ext_force = e->has_ext_force; f.ext_torque = false; f.noise = e->noise; f.logic = e->logic_on;
   f.counter_noise = e->seed_policy == AFE_SEED_COUNTER;
-  f.resident = e->step_mode == AFE_STEP_RESIDENT;
+  // AFE_STEP_AUTO takes the steps already authorised together (state in registers between them, every step stored): the
+  // same bits, and faster at every size measured (tools/small_n_probe.py: 4 096 vehicles 1.46 -> 0.94 us per step,
+  // 131 072 2.40 -> 1.56; bench.py companions at 2^20: 19.5 -> 10.9)
+  f.resident = e->step_mode == AFE_STEP_RESIDENT || e->step_mode == AFE_STEP_AUTO;
   return f;
 }
 

@@ -79,13 +79,21 @@ def build_shard(afa, n_local, first_global, n_global, device, fext=True, precisi
     e.set_motor_cmds(data.motor_cmd)
     if fext:
         e.set_gust_process(True, seed=GUST_SEED, sigma_max=GUST_SIGMA_MAX, period_us=GUST_PERIOD_US, n_global=n_global)
-    e.set_step_mode(afa.AFE_STEP_AUTO)      # one resident grid up to 2^20 vehicles, (split) launches beyond
+    e.set_step_mode(headline_mode(afa, n_local))      # one resident grid up to 2^20 vehicles, (split) launches beyond
     return e
 
 
+def headline_mode(afa, n):
+    """the stepping the headline and its rows are measured with: the resident grid in its per-step-observable form
+    (AFE_STEP_PERSISTENT: every step reads the state from memory and writes it back -- SURVEY 8d's accounting) up to 2^20
+    vehicles, launches beyond.  (AFE_STEP_AUTO itself would take the resident-state form, which does not read the state
+    back between steps authorised ahead: the `resident_state` companion.)"""
+    return afa.AFE_STEP_PERSISTENT if n <= (1 << 20) else afa.AFE_STEP_AUTO
+
+
 def uses_persistent(afa, mode, n):
-    mode = afa.AFE_STEP_AUTO if mode is None else mode
-    return mode == afa.AFE_STEP_PERSISTENT or (mode == afa.AFE_STEP_AUTO and n <= (1 << 20))
+    mode = headline_mode(afa, n) if mode is None else mode
+    return mode in (afa.AFE_STEP_PERSISTENT, afa.AFE_STEP_RESIDENT) or (mode == afa.AFE_STEP_AUTO and n <= (1 << 20))
 
 
 def time_steps(e, steps, per_launch, sync, barrier):
@@ -445,6 +453,7 @@ def disturbance_sweep(afa, device, n=1 << 20, seconds=10.0):
     vehicle under piecewise-constant white acceleration (Var x(T) = (sigma/m)^2 tau^4 sum_j (j + 1/2)^2)."""
     p = afa.params_from_type(5)
     e = build_shard(afa, n, 0, n, device)
+    e.set_step_mode(afa.AFE_STEP_AUTO)
     e.set_rates_logic([afa.rates_logic_params_from_type(5)])
     e.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
     p0 = e.get_state()["pos"]
@@ -526,6 +535,7 @@ def shared_world(afa, n_local, rank, world, local_rank, dist, torch, sync, barri
            "vehicles_sorted_into_cells_every_n_queries": 8, "worlds": {}}
     for world_name, age in (("lattice_as_started", 0), ("after_3000_steps_of_gusts", 3000)):
         e = build_shard(afa, n_local, rank * n_local, n_all, local_rank)
+        e.set_step_mode(afa.AFE_STEP_AUTO)               # ten steps per call: the engine fuses them
         with stdout_to_stderr():
             e.gather_positions(comm, xyz.data_ptr())     # RCCL's first call on this communicator
             e.sync()
@@ -712,7 +722,7 @@ def compact_line(full):
         line["companions"] = {k: v.get("value") for k, v in comp.items() if isinstance(v, dict) and "value" in v}
     cl = full.get("closed_loop_on_device")
     if cl:
-        line["closed_loop_on_device"] = [_pick(c, ("vehicles", "us_per_step", "vsteps_per_s", "frac")) for c in cl]
+        line["closed_loop_on_device"] = [_pick(c, ("vehicles", "us_per_step", "us_per_step_auto", "vsteps_per_s", "frac")) for c in cl]
     pr = full.get("perception_rows")
     if pr and "depth_camera" in pr:
         line["perception"] = {"depth_ms_per_%d_views" % pr["depth_camera"]["views"]: pr["depth_camera"]["kernel_ms"],
@@ -830,8 +840,8 @@ def main():
         return float(t.item())
 
     afa = importlib.import_module("agri-fly_amd")
-    mode = {"auto": afa.AFE_STEP_AUTO, "launch": afa.AFE_STEP_LAUNCH, "persistent": afa.AFE_STEP_PERSISTENT}[args.step_mode]
     n_local = args.vehicles
+    mode = {"auto": headline_mode(afa, n_local), "launch": afa.AFE_STEP_LAUNCH, "persistent": afa.AFE_STEP_PERSISTENT}[args.step_mode]
     n_global = n_local * world
     e = build_shard(afa, n_local, rank * n_local, n_global, local_rank)
     e.set_step_mode(mode)
@@ -1024,9 +1034,14 @@ def main():
             for n in (1024, 4096, 65536, 131072, 262144, 524288, 1 << 20, 2 << 20):
                 es, row = shard_row(afa, n, local_rank, sync, barrier, reduce_max, 400)
                 bytes_n, _ = mean_bytes_per_step(es, afa, 400)
+                k = 400
+                tr = None
+                if n <= (1 << 20):
+                    es.set_step_mode(afa.AFE_STEP_AUTO)
+                    tr = median(timed_blocks(es, k, 1, sync, barrier, reduce_max, min_total_s=0.02, settle_s=0.005))
+                    row["auto_resident_state"] = {"us_per_step": tr / k * 1e6, "vsteps_per_s": n * k / tr}
                 es.set_step_mode(afa.AFE_STEP_LAUNCH)
                 es.set_split_stepping(1)
-                k = 400
                 time_steps(es, 50, 1, sync, barrier)
                 t1 = median([time_steps(es, k, 1, sync, barrier) for _ in range(3)])
                 es.set_split_stepping(2)
@@ -1065,14 +1080,17 @@ def main():
                 es.set_rates_logic([afa.rates_logic_params_from_type(5)])
                 es.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
                 k = 400
-                time_steps(es, 50, 1, sync, barrier)
-                t1 = median([time_steps(es, k, 1, sync, barrier) for _ in range(3)])
+                t1 = median(timed_blocks(es, k, 1, sync, barrier, reduce_max, min_total_s=0.02)) 
+                es.set_step_mode(afa.AFE_STEP_AUTO)          # one step per call: the resident-state form (state not read back between steps authorised ahead)
+                ta = median(timed_blocks(es, k, 1, sync, barrier, reduce_max, min_total_s=0.02, settle_s=0.005))
                 es.set_step_mode(afa.AFE_STEP_LAUNCH)
                 t10 = median([time_steps(es, k, 10, sync, barrier) for _ in range(3)])
                 b_mean, _ = mean_bytes_per_step(es, afa, k)   # state, force, commands; on ticks IMU, filter state, rate commands
                 closed.append({"vehicles": n, "vsteps_per_s": n * k / t1, "us_per_step": t1 / k * 1e6,
                                "algorithmic_bytes_per_vehicle_step": b_mean, "achieved_GBs": n * b_mean / (t1 / k) / 1e9,
-                               "frac": n * b_mean / (t1 / k) / 1e9 / HBM_PEAK_GBS, "vsteps_per_s_fused10": n * k / t10})
+                               "frac": n * b_mean / (t1 / k) / 1e9 / HBM_PEAK_GBS, "vsteps_per_s_fused10": n * k / t10,
+                               "us_per_step_auto": ta / k * 1e6, "vsteps_per_s_auto": n * k / ta,
+                               "bound": "latency (state in the XCDs' L2s)" if n * b_mean < 32e6 else "memory"})
                 es.close()
             out["closed_loop_on_device"] = closed
             out["disturbance_sweep"] = disturbance_sweep(afa, local_rank)

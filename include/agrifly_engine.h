@@ -511,8 +511,9 @@ int afe_get_external_force(afe_engine *e, int64_t first, int64_t count, double *
  *   mode = AFE_STEP_LAUNCH (0, default): one kernel launch per step (or per afe_set_max_fused_steps chunk).
  *   mode = AFE_STEP_PERSISTENT (1): as above, whenever the ensemble qualifies -- every vehicle on type record 0,
  *     no external torque, the engine's own stream, an arena below 4 GiB; otherwise the launches, silently.
- *   mode = AFE_STEP_AUTO (2): the engine picks per call.  One step per call: persistent for ensembles of up to 2^20
- *     vehicles, launches (split, see above) beyond.  Several steps per call (nothing is observable in between): from
+ *   mode = AFE_STEP_AUTO (2): the engine picks per call.  One step per call: the resident grid in its resident-state
+ *     form (AFE_STEP_RESIDENT below: the same bits, fewer bytes) for ensembles of up to 2^20 vehicles, launches (split,
+ *     see above; cache-policy hints by size, afe_set_cache_policy) beyond.  Several steps per call (nothing is observable in between): from
  *     8 steps, or from 2 at 2^19 vehicles and more, fused launches -- the state stays in registers from step to step --
  *     which is the fastest way to the same bits there (measured table: DESIGN.md section 6).
  * afe_steps_completed: the number of steps (since afe_create) that EVERY vehicle has been advanced through -- the
