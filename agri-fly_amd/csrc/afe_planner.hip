@@ -335,8 +335,11 @@ __device__ void deproject(const PlannerConfig &c, double x, double y, double dep
 }
 
 // shrink bookkeeping shared by the eight scans of DIP.cpp:617-940
+#ifndef AFE_SHRINK_QUAL
+#define AFE_SHRINK_QUAL            /* tools/planner_inline_probe.sh builds one variant with `volatile` here */
+#endif
 struct Shrink {
-  int right, left, top, bottom;
+  AFE_SHRINK_QUAL int right, left, top, bottom;
 };
 
 // NOTE on `noinline` below (build_mask, first_blocking_ring, side_scan, corner_scan, inflate_pyramid): with these
@@ -383,6 +386,15 @@ struct Shrink {
 // chunk at once.
 // (the result is the same in every lane; readfirstlane tells the compiler so, which moves whatever is
 // derived from it -- edges, loop bounds, addresses -- into scalar registers and the scalar ALU)
+// A value that is the same in every lane of the wave by construction, said so to the compiler (it lands in a scalar
+// register and every decision made from it is a scalar branch).  The out-of-line helpers below take such values as
+// arguments -- which arrive in vector registers, "divergent" as far as the compiler can know; decisions made from them
+// inside loops whose other state is scalar were what the round-2 / round-3 `noinline` mystery came down to.
+#ifndef AFE_PLANNER_DIVERGENT_ARGS
+#define PL_UNIFORM(x) ((x) = __builtin_amdgcn_readfirstlane(x))
+#else
+#define PL_UNIFORM(x) ((void)0)
+#endif
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o < v ? o : v; }
@@ -431,6 +443,8 @@ __device__ __forceinline__ unsigned range_bits8(const uint4 q, unsigned lo1, uns
 template <bool WANT_MIN>
 __device__ AFE_NI_MASK int build_mask(const uint16_t *__restrict__ img, int W, int H, int lane, uint64_t *mask, int WW, uint16_t lo,
                           uint16_t hi) {
+  PL_UNIFORM(W); PL_UNIFORM(H); PL_UNIFORM(WW);
+  { int l = lo, h = hi; PL_UNIFORM(l); PL_UNIFORM(h); lo = (uint16_t)l; hi = (uint16_t)h; }
   int lane_min = 65535;
   // The bit image is written by one set of lanes and read by others.  The block is a single wave,
   // so these barriers cost nothing, but they are what orders the LDS traffic: readers of the
@@ -556,6 +570,7 @@ __device__ __forceinline__ bool mask_bit(const uint64_t *mask, int WW, int x, in
 // before it are clear and can be taken in one step.  Returns that ring index (>= 1) or INT_MAX.
 __device__ AFE_NI_RING int first_blocking_ring(const uint64_t *mask, int WW, int lane, int xlo, int xhi, int ylo, int yhi, int L,
                                    int R, int T, int B) {
+  PL_UNIFORM(WW); PL_UNIFORM(xlo); PL_UNIFORM(xhi); PL_UNIFORM(ylo); PL_UNIFORM(yhi); PL_UNIFORM(L); PL_UNIFORM(R); PL_UNIFORM(T); PL_UNIFORM(B);
   const int wa = xlo >> 6, nw = (xhi >> 6) - wa + 1, total = nw * (yhi - ylo + 1);
   const unsigned magic = div_magic(nw);
   int best = 0x7fffffff;
@@ -610,6 +625,8 @@ template <int SIDE>
 __device__ AFE_NI_SIDE bool side_scan(const uint16_t *__restrict__ src, int sx, int sy, const uint64_t *mask, int WW, int lane,
                           int total, int inner, int xa, int ya, int dxo, int dyo, int dxi, int dyi, int num, int buf,
                           int x0, int y0, int dmin, Shrink &s) {
+  PL_UNIFORM(sx); PL_UNIFORM(sy); PL_UNIFORM(WW); PL_UNIFORM(total); PL_UNIFORM(inner); PL_UNIFORM(xa); PL_UNIFORM(ya);
+  PL_UNIFORM(dxo); PL_UNIFORM(dyo); PL_UNIFORM(dxi); PL_UNIFORM(dyi); PL_UNIFORM(num); PL_UNIFORM(buf); PL_UNIFORM(x0); PL_UNIFORM(y0); PL_UNIFORM(dmin);
   const unsigned magic = div_magic(inner);
   for (int base0 = 0; base0 < total; base0 += 64 * kScanBatch) {
     {  // lines run outward from the rectangle: once even the nearest marked depth cannot reach the
@@ -726,6 +743,8 @@ __device__ AFE_NI_CORNER bool corner_scan(const uint16_t *__restrict__ img, int 
                             int inner, int xa, int ya, int num, int buf, int x0, int y0, int dmin, Shrink &s) {
   constexpr bool RIGHT = (CORNER == CORNER_TR || CORNER == CORNER_BR);
   constexpr bool TOP = (CORNER == CORNER_TR || CORNER == CORNER_TL);
+  PL_UNIFORM(W); PL_UNIFORM(WW); PL_UNIFORM(rows); PL_UNIFORM(inner); PL_UNIFORM(xa); PL_UNIFORM(ya); PL_UNIFORM(num); PL_UNIFORM(buf);
+  PL_UNIFORM(x0); PL_UNIFORM(y0); PL_UNIFORM(dmin);
   {  // within a corner scan the right edge only moves left (the left edge only right), so pixels
      // farther out than ceil(num / dmin) from where it stands now can never act: narrow the rows
     const int reach = (num + dmin - 1) / dmin;
@@ -805,6 +824,21 @@ __device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uin
                                 double minimumDepth, PlannerPyramid &out) {
 #pragma clang fp contract(off)
   PL_COUNT(22, 1);
+#ifndef AFE_PLANNER_DIVERGENT_ARGS
+  // Every lane of the wave holds the same seed pixel and depth, but as arguments of an out-of-line function they arrive
+  // in vector registers and the compiler has to assume they differ: every decision made from them (the scans' "would this
+  // cut the seed pixel off" tests, their `return false`) is then a DIVERGENT exit from loops whose other state -- the
+  // edges, the ballot masks -- it keeps in scalar registers.  Saying that they are uniform makes those exits scalar
+  // branches.  (Round 4: this is what the failing build of round 2 / 3 depended on -- tools/planner_opt_bisect.sh,
+  // DESIGN.md planner section.)
+  x0 = __builtin_amdgcn_readfirstlane(x0);
+  y0 = __builtin_amdgcn_readfirstlane(y0);
+  {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(minimumDepth);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    minimumDepth = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  }
+#endif
   const int W = c.width, H = c.height, buf = c.pixel_buffer;
   const int edgeOff = (int)(c.focal_length * c.true_vehicle_radius / c.min_checking_dist);
   if (x0 <= edgeOff + buf + 1 || x0 > W - edgeOff - buf - 1 || y0 <= edgeOff + buf + 1 || y0 > H - edgeOff - buf - 1)
