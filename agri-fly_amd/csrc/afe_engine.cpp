@@ -1410,7 +1410,8 @@ extern "C" int afe_steps_completed(afe_engine *e, uint64_t *steps) {
     if (e->p_resume < e->p_next && (rc = persist_launch(e))) return rc;
   }
   if (e->p_running) {
-    const uint64_t seen = std::max<uint64_t>(p_status(e)[1], e->p_resume);
+    // (the pump's sweep over the workers' marks, or the workers' own answer to a sync request -- whichever is further)
+    const uint64_t seen = std::max<uint64_t>(std::max<uint64_t>(p_status(e)[1], p_status(e)[AFE_PERSIST_SYNC_WORD]), e->p_resume);
     pending = e->p_next - std::min<uint64_t>(seen, e->p_next);
   }
   *steps = e->steps_issued - pending;
