@@ -904,6 +904,9 @@ def main():
         ex.close()
 
     out = None
+    if rank != 0:             # (rank 0 still takes the roofline's measurements on its engine, then lets it go as well)
+        e.close()
+        e = None
     if rank == 0:
         bytes_step, tick_frac = mean_bytes_per_step(e, afa, args.steps)
         # device time per step over the timed cadence: HIP events on the engine's stream around K steps, repeated
@@ -924,10 +927,14 @@ def main():
             t_launch = median([kernel_time_events(e, long_steps) for _ in range(3)])
             e.set_step_mode(mode)
         traffic, traffic_src, rocprof_us = committed_traffic(n_local)
+        # the headline's engine is done.  (It goes before the rows of smaller shards are measured: a rank of an 8-GPU run
+        # holds its own shard and nothing else, and a second large engine that has had a resident grid costs a small
+        # engine's synchronised blocks ~0.5 us per step while it exists -- measured, tools/sync_cost_probe.py; cause open.)
+        e.close()
+        e = None
         # what the box streams in this launch shape, in this run (measured figure next to the nominal peak)
         probe = None
         if not args.headline_only:
-            e.sync()
             us164 = afa.stream_probe(n_local, 24, 17, 200, local_rank)
             us132 = afa.stream_probe(n_local, 20, 13, 200, local_rank)
             probe = {"GBs_164B": n_local * 164 / us164 / 1e3, "GBs_132B": n_local * 132 / us132 / 1e3,
@@ -1124,7 +1131,8 @@ def main():
             sys.stderr.write("bench.py rank %d: shared_world failed: %s\n" % (rank, sw["error"]))
         if rank == 0:
             out["shared_world"] = sw
-    e.close()
+    if e is not None:
+        e.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
