@@ -125,6 +125,11 @@ def timed_blocks(e, steps, per_launch, sync, barrier, reduce_max, min_total_s=0.
     settled = 0.0
     while settled < settle_s:
         settled += max(reduce_max(time_steps(e, steps, per_launch, sync, barrier)), 1e-6)
+    # ... and the timed blocks are not served by the FIRST resident grid of an engine: that one is 1-5 % slower for as long
+    # as it lives (20 % for the very first of a process; every later grid of the same engine is not: tools/sync_cost_probe.py,
+    # DESIGN.md section 6 -- cause open).  Any getter ends it; here afe_grid_time does.
+    if settle_s > 0 and hasattr(e, "grid_time"):
+        e.grid_time()
     blocks, total = [], 0.0
     while len(blocks) < min_blocks or (total < min_total_s and len(blocks) < max_blocks):
         t_own = time_steps(e, steps, per_launch, sync, barrier)
