@@ -54,7 +54,7 @@ def one(seed):
     b, _ = make(n, hv, int(rng.choice(modes[:3])), logic, seed)
     issued, blob, blob_a = 0, None, None
     for op in range(200):
-        what = rng.choice(["step", "step", "step", "burst", "pause", "get", "get1", "cmd", "noise", "gust", "mode", "completed", "save", "load"])
+        what = rng.choice(["step", "step", "step", "burst", "pause", "get", "get1", "cmd", "noise", "gust", "mode", "completed", "save", "load", "sync", "sync", "devsync"])
         if os.environ.get("SOAK_TRACE"): print("  seed %d op %d: %s" % (seed, op, what), file=sys.stderr, flush=True)
         if what == "step":
             dt, k = int(rng.choice([1000, 1000, 500, 2000])), int(rng.integers(1, 40))
@@ -91,6 +91,11 @@ def one(seed):
             m = int(rng.choice(modes))
             if os.environ.get("SOAK_VERBOSE"): print("  seed %d op %d: mode %d" % (seed, op, m), file=sys.stderr, flush=True)
             b.set_step_mode(m)
+        elif what == "sync":             # round 4: waits for the steps, a resident grid stays; the completion word is true afterwards
+            b.sync(); a.sync()
+            assert b.steps_completed == issued == a.steps_completed, (seed, op, "sync")
+        elif what == "devsync":          # a device-wide synchronise issued outside the engine: neither waits for the grid nor ends it
+            torch.cuda.synchronize()
         elif what == "completed":
             assert b.steps_completed <= issued == a.steps_completed
         elif what == "save":
