@@ -134,6 +134,7 @@ struct afe_engine {
   bool view_exported = false;       // afe_get_device_view has handed the slabs to somebody: afe_sync must leave them readable
   uint64_t p_grid_ns = 0, p_grid_steps = 0;          // device time and steps of the grids collected so far (afe_grid_time)
   uint64_t p_launch_start = 0;                       // the step the grid now resident started from
+  uint64_t p_quiesced = 0;                           // every step below this index is known to be done (the last successful wait)
 
   std::string err;
 };
@@ -788,6 +789,7 @@ int quiesce(afe_engine *e) {
         return fail(e, AFE_ERR_HIP, "persistent step kernel makes no progress");
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    e->p_quiesced = e->p_next;
   }
   if (!e->p_running && e->stream_pending) {
     AFE_HIP(e, hipStreamSynchronize(e->stream));
@@ -1426,7 +1428,7 @@ extern "C" int afe_steps_completed(afe_engine *e, uint64_t *steps) {
   }
   if (e->p_running) {
     // (the pump's sweep over the workers' marks, or the workers' own answer to a sync request -- whichever is further)
-    const uint64_t seen = std::max<uint64_t>(std::max<uint64_t>(p_status(e)[1], p_status(e)[AFE_PERSIST_SYNC_WORD]), e->p_resume);
+    const uint64_t seen = std::max<uint64_t>(std::max<uint64_t>(std::max<uint64_t>(p_status(e)[1], p_status(e)[AFE_PERSIST_SYNC_WORD]), e->p_resume), e->p_quiesced);
     pending = e->p_next - std::min<uint64_t>(seen, e->p_next);
   }
   *steps = e->steps_issued - pending;
