@@ -605,16 +605,17 @@ bool aql_launch(afe_engine *e, const afe::AqlKernel &k, const StepView<R> &v, co
   // the queue is not ordered behind the HIP stream: whatever the stream still holds (setters, a memset) finishes first
   if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
   e->stream_pending = false;
-  // A grid that does not fill the device must be SPREAD over it: the dispatcher hands workgroups to whichever compute
-  // units have room at that instant, and a resident grid keeps the places it was given -- measured, 2 049 workgroups:
-  // 2.97 to 3.56 us per step from one dispatch to the next (the worst right behind the uploads of a new engine).  The
-  // kernel uses no LDS, so asking for a slice of it per workgroup costs nothing and caps how many a compute unit can
-  // take: 160 KB / (the even share + 1).
+  // AFE_PERSIST_SPREAD=1 (measurement aid, off by default): a grid that does not fill the device can be SPREAD over it by
+  // asking for an unused LDS slice per workgroup, which caps how many a compute unit takes (160 KB / (the even share +
+  // slack)).  Measured at 131 072 / 262 144 vehicles: later grids of an engine 2.97 against 3.00 us per step with one
+  // workgroup of slack, nothing with two -- and with NONE the grid does not fit (4 097 workgroups at 17 per compute unit:
+  // stalls, 3 ms per step until the safety net has shrunk it).  Not worth a cliff: off.
   afe::AqlKernel kd = k;
   {
     const int wgs = 1 + a.n_workers, cus = e->p_cus > 0 ? e->p_cus : 256;
-    const int share = (wgs + cus - 1) / cus + 1;
-    static const bool spread = [] { const char *s = std::getenv("AFE_PERSIST_SPREAD"); return !(s && s[0] == '0'); }();
+    static const int slack = [] { const char *s = std::getenv("AFE_PERSIST_SPREAD_SLACK"); return s && *s ? std::atoi(s) : 2; }();
+    const int share = (wgs + cus - 1) / cus + (slack < 1 ? 1 : slack);
+    static const bool spread = [] { const char *s = std::getenv("AFE_PERSIST_SPREAD"); return s && s[0] == '1'; }();
     if (spread && kd.group_bytes == 0 && share <= 20) {
       uint32_t lds = (uint32_t)((160 * 1024) / share) & ~255u;
       kd.group_bytes = lds > 65536u ? 65536u : lds;
