@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -235,7 +236,8 @@ __global__ void __launch_bounds__(256) world_scatter_kernel(const float *__restr
 // and the host is told to sort again (host_flag, pinned memory).
 __global__ void __launch_bounds__(256) world_regather_kernel(const float *__restrict__ xyz, int64_t n, const uint32_t *__restrict__ cell,
                                                              const uint32_t *__restrict__ slot, const float *__restrict__ ref, int64_t ref_stride,
-                                                             uint4 *__restrict__ sorted, float *__restrict__ partial, uint32_t *__restrict__ left_count) {
+                                                             uint4 *__restrict__ sorted, float *partial, uint32_t *__restrict__ left_count,
+                                                             uint32_t *words, uint32_t *host_flag) {
 #pragma clang fp contract(off)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i == 0) { left_count[0] = 0; left_count[1] = 0; }   // this query's leftover counter
@@ -254,28 +256,35 @@ __global__ void __launch_bounds__(256) world_regather_kernel(const float *__rest
     const uint32_t c = cell[i];
     if (c != AFE_WORLD_DROPPED) sorted[slot[i]] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), (uint32_t)i);
   }
-  // one partial maximum per workgroup, reduced by world_moved_kernel (thousands of waves taking an atomic maximum on one
-  // word serialise at the memory side: measured, that alone made the kept order slower than the sort)
+  // one partial maximum per workgroup (thousands of waves taking an atomic maximum on one word serialise at the memory
+  // side: measured, that alone made the kept order slower than the sort); the workgroup that finishes LAST -- a ticket --
+  // reduces the partials, so the bound is in words[0] when the launch ends and no second launch is needed
   __shared__ float wave_max[4];
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) moved = fmaxf(moved, __shfl_xor(moved, s));
-  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = moved;
-  __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
-}
-__global__ void __launch_bounds__(256) world_moved_kernel(const float *__restrict__ partial, int64_t n_partial, uint32_t *__restrict__ words,
-                                                          uint32_t *host_flag) {
-  __shared__ float wave_max[4];
-  float moved = 0.0f;
-  for (int64_t k = threadIdx.x; k < n_partial; k += 256) moved = fmaxf(moved, partial[k]);
+  __shared__ bool last_block;
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) moved = fmaxf(moved, __shfl_xor(moved, s));
   if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = moved;
   __syncthreads();
   if (threadIdx.x == 0) {
-    moved = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
-    words[0] = __float_as_uint(moved);
-    if (moved > 3.0e38f) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&partial[blockIdx.x], fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last_block = atomicAdd(&words[1], 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last_block) return;
+  __threadfence();
+  float all = 0.0f;
+  for (unsigned k = threadIdx.x; k < gridDim.x; k += 256) all = fmaxf(all, __hip_atomic_load(&partial[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) all = fmaxf(all, __shfl_xor(all, s));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = all;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    all = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+    words[0] = __float_as_uint(all);
+    words[1] = 0;                                    // the ticket counter for the next regather
+    if (all > 3.0e38f) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -375,11 +384,11 @@ __device__ __forceinline__ void finish_query(bool done, int64_t local, float bes
 // r*h away, so once the best squared distance is below ((r - 0.05) h)^2 (the margin covers the fp32
 // cell assignment) no unvisited cell can improve it.  Queries still unresolved after AFE_WORLD_MAX_RING
 // rings (isolated vehicles) go to a leftover list that a brute-force kernel finishes.
-__global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restrict__ sorted, int64_t n_all, const uint32_t *__restrict__ starts,
-                                                          GridDesc g, int64_t first_global, int64_t n_self, float *__restrict__ dist2_out,
-                                                          int32_t *__restrict__ index_out, uint32_t *__restrict__ leftover_count,
-                                                          int32_t *__restrict__ leftover, uint64_t *__restrict__ leftover_keys,
-                                                          const uint32_t *__restrict__ words) {
+__device__ __forceinline__ void query_one(const uint4 *__restrict__ sorted, int64_t n_all, const uint32_t *__restrict__ starts,
+                                          const GridDesc &g, int64_t first_global, int64_t n_self, float *__restrict__ dist2_out,
+                                          int32_t *__restrict__ index_out, uint32_t *__restrict__ leftover_count,
+                                          int32_t *__restrict__ leftover, uint64_t *__restrict__ leftover_keys,
+                                          const uint32_t *__restrict__ words) {
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= n_all || s >= (int64_t)starts[g.n_cells + 1]) return;   // the end sentinel: how many points were sorted
   const uint4 qb = sorted[s];
@@ -397,6 +406,60 @@ __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restric
   const float clear = clearance(g, q.x, q.y, q.z) - moved;   // a dropped vehicle may have come that much closer
   if (clear > 0.0f) done = ring_search(sorted, starts, g, q.x, q.y, q.z, me, cx, cy, cz, clear, moved, 1, best, best_j);
   finish_query(done, local, best, best_j, dist2_out, index_out, leftover_count, leftover, leftover_keys);
+}
+
+// The workgroup that finishes LAST (a ticket) closes the query: it tells the host how many queries the rings left over
+// (pinned memory: the host reads it when it prepares the NEXT query, without waiting) and -- tail_brute -- answers them
+// itself by the brute-force definition, one after the other, all 256 threads on each.  That is the common case: nothing
+// is left over (every bench world), or a handful of isolated vehicles; the two brute-force launches behind every query
+// (9 us of a 60-100 us query) are then not launched at all.  A world that does leave queries over is noticed at the next
+// call and gets the launches back for its next 64 queries (world_nearest).
+__global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restrict__ sorted, int64_t n_all, const uint32_t *__restrict__ starts,
+                                                          GridDesc g, int64_t first_global, int64_t n_self, float *__restrict__ dist2_out,
+                                                          int32_t *__restrict__ index_out, uint32_t *leftover_count,
+                                                          int32_t *leftover, uint64_t *__restrict__ leftover_keys,
+                                                          uint32_t *words, const float *__restrict__ all_xyz, int tail_brute, uint32_t *host_left) {
+  query_one(sorted, n_all, starts, g, first_global, n_self, dist2_out, index_out, leftover_count, leftover, leftover_keys, words);
+  __shared__ bool last_block;
+  __shared__ unsigned long long wave_key[4];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last_block = atomicAdd(&words[2], 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last_block) return;
+  __threadfence();
+  const uint32_t n_left = __hip_atomic_load(leftover_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    words[2] = 0;                                    // the ticket counter for the next query
+    __hip_atomic_store(host_left, n_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (!tail_brute) return;
+  for (uint32_t k = 0; k < n_left; k++) {
+    const int64_t local = __hip_atomic_load(&leftover[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int me = (int)(first_global + local);
+    const float x = all_xyz[me], y = all_xyz[n_all + me], z = all_xyz[2 * n_all + me];
+    float best = 3.4e38f;
+    int best_j = -1;
+    if (finite3(x, y, z))
+      for (int64_t j = threadIdx.x; j < n_all; j += 256)
+        consider(dist2(all_xyz[j], all_xyz[n_all + j], all_xyz[2 * n_all + j], x, y, z), (int)j, me, best, best_j);
+    unsigned long long key = best_j >= 0 ? ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_j : AFE_WORLD_KEY_NONE;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      const unsigned long long o = __shfl_xor(key, sft);
+      key = o < key ? o : key;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wave_key[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int wv = 1; wv < 4; wv++) key = wave_key[wv] < key ? wave_key[wv] : key;
+      dist2_out[local] = __uint_as_float((uint32_t)(key >> 32));
+      index_out[local] = (int32_t)(uint32_t)key;     // 0xffffffff = -1: nobody
+    }
+  }
 }
 
 // Brute force for listed queries.  The work is cut into (query, chunk of the ensemble) items that the whole launch
@@ -509,7 +572,9 @@ struct afe_world {
   bool sort_valid = false;
   float *ref = nullptr;         // [3][cap_points]: positions at the last sort, original order
   uint32_t *words = nullptr;    // device: [0] bound on the movement since the sort (float bits)
-  uint32_t *host_flag = nullptr;   // pinned: a kernel asks for a new sort
+  uint32_t *host_flag = nullptr;   // pinned: [0] a kernel asks for a new sort, [1] queries the last finished query's rings left over
+  int brute_countdown = 0;         // queries that still get the two brute-force launches (a recent query left something over)
+  bool always_brute_launches = std::getenv("AFE_WORLD_BRUTE_LAUNCHES") != nullptr;   // measurement aid: round 3's launch sequence
   uint32_t last_leftover = 0;
   std::string err;
 };
@@ -627,7 +692,7 @@ int ensure_capacity(afe_world *w, int64_t n_all, int64_t n_cells_total) {
   }
   if (!w->lohi) W_HIP(w, hipMalloc((void **)&w->lohi, 8 * sizeof(int)));
   if (!w->words) { W_HIP(w, hipMalloc((void **)&w->words, 4 * sizeof(uint32_t))); W_HIP(w, hipMemset(w->words, 0, 4 * sizeof(uint32_t))); }
-  if (!w->host_flag) { W_HIP(w, hipHostMalloc((void **)&w->host_flag, 64, hipHostMallocCoherent | hipHostMallocMapped)); *w->host_flag = 0; }
+  if (!w->host_flag) { W_HIP(w, hipHostMalloc((void **)&w->host_flag, 64, hipHostMallocCoherent | hipHostMallocMapped)); w->host_flag[0] = 0; w->host_flag[1] = 0; }
   if (!w->bounds_part) W_HIP(w, hipMalloc((void **)&w->bounds_part, AFE_WORLD_BOUNDS_BLOCKS * sizeof(BoundsPartial)));
   return AFE_OK;
 }
@@ -724,8 +789,7 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
     // (the partial maxima live in the leftover-key scratch: the brute force behind the query is the next to touch it)
     float *partial = (float *)w->leftover_keys;
     hipLaunchKernelGGL(world_regather_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, w->cell, w->slot, w->ref, w->cap_points, w->sorted, partial,
-                       (uint32_t *)(w->lohi + 6));
-    hipLaunchKernelGGL(world_moved_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)pb, w->words, w->host_flag);
+                       (uint32_t *)(w->lohi + 6), w->words, w->host_flag);
   } else {
     // 2. counting sort by cell
     W_HIP(w, hipMemsetAsync(w->counts, 0, (size_t)m * 4, st));
@@ -740,11 +804,21 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   }
   // 3. queries in cell order; isolated vehicles finish in the brute-force kernel
   uint32_t *left_count = (uint32_t *)(w->lohi + 6);
+  // What the rings leave over is finished by the brute force: inside the query launch by its last workgroup (the common
+  // case: nothing or next to nothing left over), or -- when an earlier query of this world reported leftovers (pinned
+  // word, read without waiting: it is the count of the last query that has FINISHED) -- by the two launches that share
+  // the work over the whole device, for the next 64 queries.
+  volatile uint32_t *host_left = w->host_flag + 1;
+  if (*host_left > 0) w->brute_countdown = 64;
+  const bool launches = w->brute_countdown > 0 || w->always_brute_launches;
+  if (w->brute_countdown > 0) w->brute_countdown--;
   hipLaunchKernelGGL(world_query_kernel, dim3(pb), dim3(256), 0, st, w->sorted, n_all, w->counts, g, first_global, n_self, dist2_out,
-                     index_out, left_count, w->leftover, w->leftover_keys, w->words);
-  hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(1024), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global,
-                     (unsigned long long *)w->leftover_keys);
-  hipLaunchKernelGGL(world_brute_finish_kernel, dim3(64), dim3(256), 0, st, w->leftover, left_count, w->leftover_keys, dist2_out, index_out);
+                     index_out, left_count, w->leftover, w->leftover_keys, w->words, all_xyz, launches ? 0 : 1, w->host_flag + 1);
+  if (launches) {
+    hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(1024), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global,
+                       (unsigned long long *)w->leftover_keys);
+    hipLaunchKernelGGL(world_brute_finish_kernel, dim3(64), dim3(256), 0, st, w->leftover, left_count, w->leftover_keys, dist2_out, index_out);
+  }
   W_HIP(w, hipGetLastError());
   return AFE_OK;
 }

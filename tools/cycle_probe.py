@@ -9,6 +9,7 @@ afa = importlib.import_module("agri-fly_amd")
 import bench
 n = 1 << 20
 e = bench.build_shard(afa, n, 0, n, 0)
+e.set_step_mode(afa.AFE_STEP_AUTO)      # ten steps per call: the engine fuses them
 comm = afa.Comm(afa.Comm.unique_id(), 0, 1, device=0)
 e.set_neighbour_grid_refresh(16); e.set_neighbour_sort_reuse(8)
 xyz = torch.empty((3, n), dtype=torch.float32, device="cuda")
