@@ -227,6 +227,23 @@ __global__ void __launch_bounds__(256) world_scatter_kernel(const float *__restr
   sorted[at] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), (uint32_t)i);
 }
 
+// "Which workgroup of this launch finishes last?" -- thread 0 of every workgroup takes a ticket when its workgroup's
+// stores are acknowledged; exactly one call per launch returns true.  Two levels (64 shard counters, a line each, then one
+// top counter): thousands of tickets on ONE word would queue up at the memory side (~12 ns each).  No cache write-back is
+// involved (an agent-scope fence per workgroup costs microseconds and made the fused launches slower than the separate
+// ones they replaced: measured): what the last workgroup reads of the others' work was stored with agent-scope atomics.
+#define AFE_WORLD_TICKET_WORDS (16 * 65)
+__device__ __forceinline__ bool last_workgroup(uint32_t *tickets) {
+  const unsigned nb = gridDim.x, shard = blockIdx.x & 63u;
+  const unsigned in_shard = (nb - shard + 63u) / 64u, shards = nb < 64u ? nb : 64u;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (__hip_atomic_fetch_add(&tickets[16 * shard], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != in_shard) return false;
+  __hip_atomic_store(&tickets[16 * shard], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // for the next launch
+  if (__hip_atomic_fetch_add(&tickets[16 * 64], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != shards) return false;
+  __hip_atomic_store(&tickets[16 * 64], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
 // A query that KEEPS the cell order of an earlier one (afe_set_neighbour_sort_reuse): every point's current position
 // goes to the place the sort gave it, and words[0] becomes an upper bound of how far any point -- sorted or dropped --
 // has moved since the sort (float bits; non-negative floats order like their bit patterns).  The query -- which looks
@@ -237,7 +254,7 @@ __global__ void __launch_bounds__(256) world_scatter_kernel(const float *__restr
 __global__ void __launch_bounds__(256) world_regather_kernel(const float *__restrict__ xyz, int64_t n, const uint32_t *__restrict__ cell,
                                                              const uint32_t *__restrict__ slot, const float *__restrict__ ref, int64_t ref_stride,
                                                              uint4 *__restrict__ sorted, float *partial, uint32_t *__restrict__ left_count,
-                                                             uint32_t *words, uint32_t *host_flag) {
+                                                             uint32_t *words, uint32_t *host_flag, uint32_t *tickets) {
 #pragma clang fp contract(off)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i == 0) { left_count[0] = 0; left_count[1] = 0; }   // this query's leftover counter
@@ -267,12 +284,10 @@ __global__ void __launch_bounds__(256) world_regather_kernel(const float *__rest
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_store(&partial[blockIdx.x], fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    last_block = atomicAdd(&words[1], 1u) == gridDim.x - 1;
+    last_block = last_workgroup(tickets);
   }
   __syncthreads();
   if (!last_block) return;
-  __threadfence();
   float all = 0.0f;
   for (unsigned k = threadIdx.x; k < gridDim.x; k += 256) all = fmaxf(all, __hip_atomic_load(&partial[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
@@ -283,7 +298,6 @@ __global__ void __launch_bounds__(256) world_regather_kernel(const float *__rest
   if (threadIdx.x == 0) {
     all = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
     words[0] = __float_as_uint(all);
-    words[1] = 0;                                    // the ticket counter for the next regather
     if (all > 3.0e38f) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -373,7 +387,7 @@ __device__ __forceinline__ void finish_query(bool done, int64_t local, float bes
   if (done) { dist2_out[local] = best; index_out[local] = best_j; }
   else {
     const uint32_t k = atomicAdd(leftover_count, 1u);
-    leftover[k] = (int32_t)local;
+    __hip_atomic_store(&leftover[k], (int32_t)local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by the launch's last workgroup)
     leftover_keys[k] = AFE_WORLD_KEY_NONE;
   }
 }
@@ -418,23 +432,18 @@ __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restric
                                                           GridDesc g, int64_t first_global, int64_t n_self, float *__restrict__ dist2_out,
                                                           int32_t *__restrict__ index_out, uint32_t *leftover_count,
                                                           int32_t *leftover, uint64_t *__restrict__ leftover_keys,
-                                                          uint32_t *words, const float *__restrict__ all_xyz, int tail_brute, uint32_t *host_left) {
+                                                          uint32_t *words, const float *__restrict__ all_xyz, int tail_brute, uint32_t *host_left,
+                                                          uint32_t *tickets) {
   query_one(sorted, n_all, starts, g, first_global, n_self, dist2_out, index_out, leftover_count, leftover, leftover_keys, words);
   __shared__ bool last_block;
   __shared__ unsigned long long wave_key[4];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    last_block = atomicAdd(&words[2], 1u) == gridDim.x - 1;
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's entry of the leftover list is acknowledged ...
+  __syncthreads();                                   // ... and so is everybody's of this workgroup
+  if (threadIdx.x == 0) last_block = last_workgroup(tickets + AFE_WORLD_TICKET_WORDS);
   __syncthreads();
   if (!last_block) return;
-  __threadfence();
   const uint32_t n_left = __hip_atomic_load(leftover_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (threadIdx.x == 0) {
-    words[2] = 0;                                    // the ticket counter for the next query
-    __hip_atomic_store(host_left, n_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (threadIdx.x == 0) __hip_atomic_store(host_left, n_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (!tail_brute) return;
   for (uint32_t k = 0; k < n_left; k++) {
     const int64_t local = __hip_atomic_load(&leftover[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -572,6 +581,7 @@ struct afe_world {
   bool sort_valid = false;
   float *ref = nullptr;         // [3][cap_points]: positions at the last sort, original order
   uint32_t *words = nullptr;    // device: [0] bound on the movement since the sort (float bits)
+  uint32_t *tickets = nullptr;  // device: last_workgroup counters of the regather launch, then of the query launch
   uint32_t *host_flag = nullptr;   // pinned: [0] a kernel asks for a new sort, [1] queries the last finished query's rings left over
   int brute_countdown = 0;         // queries that still get the two brute-force launches (a recent query left something over)
   bool always_brute_launches = std::getenv("AFE_WORLD_BRUTE_LAUNCHES") != nullptr;   // measurement aid: round 3's launch sequence
@@ -692,6 +702,7 @@ int ensure_capacity(afe_world *w, int64_t n_all, int64_t n_cells_total) {
   }
   if (!w->lohi) W_HIP(w, hipMalloc((void **)&w->lohi, 8 * sizeof(int)));
   if (!w->words) { W_HIP(w, hipMalloc((void **)&w->words, 4 * sizeof(uint32_t))); W_HIP(w, hipMemset(w->words, 0, 4 * sizeof(uint32_t))); }
+  if (!w->tickets) { W_HIP(w, hipMalloc((void **)&w->tickets, 2 * AFE_WORLD_TICKET_WORDS * sizeof(uint32_t))); W_HIP(w, hipMemset(w->tickets, 0, 2 * AFE_WORLD_TICKET_WORDS * sizeof(uint32_t))); }
   if (!w->host_flag) { W_HIP(w, hipHostMalloc((void **)&w->host_flag, 64, hipHostMallocCoherent | hipHostMallocMapped)); w->host_flag[0] = 0; w->host_flag[1] = 0; }
   if (!w->bounds_part) W_HIP(w, hipMalloc((void **)&w->bounds_part, AFE_WORLD_BOUNDS_BLOCKS * sizeof(BoundsPartial)));
   return AFE_OK;
@@ -722,6 +733,7 @@ void afe::world_destroy(afe_world *w) {
   if (w->bounds_part) (void)hipFree(w->bounds_part);
   if (w->self_scratch) (void)hipFree(w->self_scratch);
   if (w->words) (void)hipFree(w->words);
+  if (w->tickets) (void)hipFree(w->tickets);
   if (w->host_flag) (void)hipHostFree(w->host_flag);
   delete w;
 }
@@ -789,7 +801,7 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
     // (the partial maxima live in the leftover-key scratch: the brute force behind the query is the next to touch it)
     float *partial = (float *)w->leftover_keys;
     hipLaunchKernelGGL(world_regather_kernel, dim3(pb), dim3(256), 0, st, all_xyz, n_all, w->cell, w->slot, w->ref, w->cap_points, w->sorted, partial,
-                       (uint32_t *)(w->lohi + 6), w->words, w->host_flag);
+                       (uint32_t *)(w->lohi + 6), w->words, w->host_flag, w->tickets);
   } else {
     // 2. counting sort by cell
     W_HIP(w, hipMemsetAsync(w->counts, 0, (size_t)m * 4, st));
@@ -813,7 +825,7 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   const bool launches = w->brute_countdown > 0 || w->always_brute_launches;
   if (w->brute_countdown > 0) w->brute_countdown--;
   hipLaunchKernelGGL(world_query_kernel, dim3(pb), dim3(256), 0, st, w->sorted, n_all, w->counts, g, first_global, n_self, dist2_out,
-                     index_out, left_count, w->leftover, w->leftover_keys, w->words, all_xyz, launches ? 0 : 1, w->host_flag + 1);
+                     index_out, left_count, w->leftover, w->leftover_keys, w->words, all_xyz, launches ? 0 : 1, w->host_flag + 1, w->tickets);
   if (launches) {
     hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(1024), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global,
                        (unsigned long long *)w->leftover_keys);
