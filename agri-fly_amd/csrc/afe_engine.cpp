@@ -1472,6 +1472,12 @@ extern "C" int afe_set_cache_policy(afe_engine *e, int policy) {
   return AFE_OK;
 }
 
+extern "C" int afe_cache_policy_in_use(const afe_engine *e, int *policy) {
+  if (!e || !policy) return AFE_ERR_INVALID_ARG;
+  *policy = resolve_cache_policy(e);
+  return AFE_OK;
+}
+
 extern "C" int afe_set_max_fused_steps(afe_engine *e, int k) {
   if (!e || k < 1 || k > 64) return fail(e, AFE_ERR_INVALID_ARG, "max fused steps must be in 1..64");
   e->max_fused = k;

@@ -47,7 +47,7 @@ ABI_FUNCTIONS = [
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
     "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running", "afe_stream_probe",
     "afe_set_noise_seed", "afe_set_gust_process", "afe_get_external_force", "afe_nearest_neighbour_async", "afe_query_sync",
-    "afe_gather_exchange", "afe_set_cache_policy", "afe_grid_time",
+    "afe_gather_exchange", "afe_set_cache_policy", "afe_grid_time", "afe_cache_policy_in_use",
 ]
 
 
@@ -340,6 +340,7 @@ def library():
         "afe_group_create": [C.POINTER(vp), i64, ci, vp, ci],
         "afe_group_peer_access": [vp, C.POINTER(ci)],
         "afe_set_cache_policy": [eng, ci],
+        "afe_cache_policy_in_use": [eng, C.POINTER(ci)],
         "afe_grid_time": [eng, C.POINTER(u64), C.POINTER(u64)],
         "afe_group_destroy": [vp],
         "afe_group_size": [vp, C.POINTER(ci), C.POINTER(i64)],
@@ -892,6 +893,12 @@ class Ensemble:
     def set_cache_policy(self, policy):
         """-1 automatic, 0 default, 1 inputs / outputs nt, 2 everything nt, 3 everything nt + one range per XCD"""
         self._ck(self._L.afe_set_cache_policy(self._h, int(policy)))
+
+    @property
+    def cache_policy_in_use(self):
+        p = C.c_int(0)
+        self._ck(self._L.afe_cache_policy_in_use(self._h, C.byref(p)))
+        return p.value
 
     def algorithmic_bytes_per_step(self, imu_tick):
         b = C.c_double(0)

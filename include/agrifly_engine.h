@@ -545,6 +545,9 @@ int afe_grid_time(afe_engine *e, uint64_t *device_ns, uint64_t *steps);
  * outputs (IMU samples) are streamed past it; not even the state: everything is streamed, one contiguous range per XCD.
  * 0 / 1 / 2 / 3 force one of these.  Replaces nothing in the reference (a CPU's caches decide for themselves). */
 int afe_set_cache_policy(afe_engine *e, int policy);
+/* the policy (0..3) the next one-step launch of this engine would carry: the forced one, or what the automatic rule
+ * resolves to for the engine's size and configuration (diagnostic; tests use it) */
+int afe_cache_policy_in_use(const afe_engine *e, int *policy);
 
 /* How many sub-steps afe_step may fuse into one kernel launch (1..64, default
  * 64).  1 = one launch per step (state goes through HBM every step: the

@@ -52,3 +52,26 @@ def test_policy_argument_is_validated():
         for bad in (-2, 4):
             with pytest.raises(afa.AfeError):
                 e.set_cache_policy(bad)
+
+
+@pytest.mark.parametrize("log2n,expect", [(22, 1), (23, 3)])
+def test_automatic_policy_at_the_sizes_it_is_for_gives_the_default_bits(log2n, expect):
+    """2^22 vehicles (the state fits the Infinity Cache: inputs and outputs nt) and 2^23 (nothing fits: everything nt, one
+    range per XCD) on the bench's own workload, two streams: twenty steps under the automatic policy against policy 0,
+    every bit of the state and the IMU samples"""
+    import bench
+    n = 1 << log2n
+    out = []
+    for policy in (0, -1):
+        e = bench.build_shard(afa, n, 0, n, 0)
+        e.set_cache_policy(policy)
+        assert e.cache_policy_in_use == (0 if policy == 0 else expect)
+        for _ in range(20):
+            e.step(1000, 1)
+        st = e.get_state(dtype=np.float32)
+        g, a = e.get_imu()
+        out.append(dict(st, gyro=g, acc=a))
+        e.close()
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k], equal_nan=True), k
+    assert out[0]["pos"].shape[1] == n and np.isfinite(out[0]["vel"]).all()
