@@ -14,6 +14,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -29,7 +30,7 @@ namespace {
   X(hsa_system_get_major_extension_table) X(hsa_system_get_info) X(hsa_executable_get_symbol_by_name)                  \
   X(hsa_executable_symbol_get_info) X(hsa_amd_agent_iterate_memory_pools) X(hsa_amd_memory_pool_get_info)              \
   X(hsa_amd_memory_pool_allocate) X(hsa_amd_memory_pool_free) X(hsa_amd_agents_allow_access)                           \
-  X(hsa_amd_queue_cu_set_mask) X(hsa_amd_profiling_set_profiler_enabled) X(hsa_amd_profiling_get_dispatch_time)
+  X(hsa_amd_queue_cu_set_mask) X(hsa_amd_queue_cu_get_mask) X(hsa_amd_profiling_set_profiler_enabled) X(hsa_amd_profiling_get_dispatch_time)
 
 struct Api {
 #define X(f) decltype(&::f) f = nullptr;
@@ -294,6 +295,46 @@ bool aql_set_cu_mask(AqlQueue *q, const uint32_t *mask, uint32_t bits) {
   Api &a = api();
   if (!q || !a.ok || !q->queue) return false;
   return a.hsa_amd_queue_cu_set_mask(q->queue, bits, mask) == HSA_STATUS_SUCCESS;
+}
+
+bool aql_reserve_cus(AqlQueue *q, int per_xcc, int *cus_left, std::string *why) {
+  Api &a = api();
+  if (!q || !a.ok || !q->queue || per_xcc < 0) { if (why) *why = "aql_reserve_cus: bad arguments"; return false; }
+  uint32_t cus = 0, xcc = 1;
+  if (a.hsa_agent_get_info(q->gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_COMPUTE_UNIT_COUNT, &cus) != HSA_STATUS_SUCCESS || cus == 0) { if (why) *why = "compute-unit count unknown"; return false; }
+  if (a.hsa_agent_get_info(q->gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_NUM_XCC, &xcc) != HSA_STATUS_SUCCESS || xcc == 0) xcc = 1;
+  if (per_xcc == 0) {
+    if (cus_left) *cus_left = (int)cus;
+    return a.hsa_amd_queue_cu_set_mask(q->queue, 0, nullptr) == HSA_STATUS_SUCCESS;
+  }
+  // Slot i of the mask is compute unit i / n_xcc of XCC i % n_xcc, and inside an XCC consecutive units go round the shader
+  // engines.  The dispatcher keeps the shader engines of an XCC symmetric: with ONE unit of one engine masked off every
+  // engine of that XCC works with one unit less (measured: 248 and 240 set bits both left 224 units' worth of workgroups
+  // resident).  So the reservation comes in rows of one unit per shader engine: per_xcc is rounded up to a multiple of the
+  // engines per XCC (4 here: a row is 32 of 256 units), and the count handed back is what really remains.
+  uint32_t n_se = 0;
+  if (a.hsa_agent_get_info(q->gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_NUM_SHADER_ENGINES, &n_se) != HSA_STATUS_SUCCESS || n_se == 0) n_se = 4 * xcc;
+  const uint32_t se_per_xcc = n_se >= xcc && n_se % xcc == 0 ? n_se / xcc : 4;
+  const uint32_t rows = ((uint32_t)per_xcc + se_per_xcc - 1) / se_per_xcc;
+  constexpr uint32_t kWords = 32;                      // 1 024 slots
+  uint32_t mask[kWords] = {0};
+  hsa_status_t st = a.hsa_amd_queue_cu_set_mask(q->queue, 0, nullptr);       // (back to everything first)
+  st = a.hsa_amd_queue_cu_get_mask(q->queue, kWords * 32, mask);
+  if (st != HSA_STATUS_SUCCESS) { if (why) *why = hsa_err(a, st, "hsa_amd_queue_cu_get_mask"); return false; }
+  uint32_t active = 0;
+  int top = -1;
+  for (uint32_t i = 0; i < kWords * 32; i++) if (mask[i / 32] >> (i % 32) & 1u) { active++; top = (int)i; }
+  uint32_t off = rows * se_per_xcc * xcc;
+  if (active == 0 || off >= active) { if (why) *why = "cannot reserve that many compute units (" + std::to_string(active) + " in the queue's mask)"; return false; }
+  const uint32_t left = active - off;
+  for (int i = top; i >= 0 && off > 0; i--) if (mask[i / 32] >> (i % 32) & 1u) { mask[i / 32] &= ~(1u << (i % 32)); off--; }
+  const uint32_t words = (uint32_t)top / 32 + 1;
+  st = a.hsa_amd_queue_cu_set_mask(q->queue, words * 32, mask);
+  if (st != HSA_STATUS_SUCCESS && st != (hsa_status_t)HSA_STATUS_CU_MASK_REDUCED) { if (why) *why = hsa_err(a, st, "hsa_amd_queue_cu_set_mask"); return false; }
+  if (cus_left) *cus_left = (int)left;
+  static const bool debug = std::getenv("AFE_PERSIST_DEBUG") != nullptr;
+  if (debug) std::fprintf(stderr, "agrifly_engine: compute-unit mask: %u slots active of %d, %d per XCC x %u XCCs reserved, %d usable\n", active, top + 1, per_xcc, xcc, cus_left ? *cus_left : -1);
+  return true;
 }
 
 }  // namespace afe

@@ -38,5 +38,8 @@ int aql_wait(AqlQueue *q, uint64_t timeout_us, std::string *why);
 uint64_t aql_last_duration_ns(const AqlQueue *q);
 // restrict the queue to the compute units whose bit is set (bits = number of valid bits, a multiple of 32)
 bool aql_set_cu_mask(AqlQueue *q, const uint32_t *mask, uint32_t bits);
+// keep `per_xcc` compute units of every XCC out of this queue's reach (0: all of them back); *cus_left = what remains.
+// (mask bit i is compute unit i / n_xcc of XCC i % n_xcc: the last per_xcc x n_xcc bits are cleared)
+bool aql_reserve_cus(AqlQueue *q, int per_xcc, int *cus_left, std::string *why);
 
 }  // namespace afe

@@ -114,6 +114,8 @@ struct afe_engine {
   unsigned long long *p_dev = nullptr;       // device memory: ring[AFE_PERSIST_DEV_RING] + done[p_workers]
   int p_workers = 0;
   int p_cus = 0;
+  int p_reserve = 0, p_reserve_applied = -1;   // compute units per XCD kept out of the resident grid's reach (afe_set_reserved_compute_units)
+  int p_cus_usable = 0;                        // what that leaves (0: all)
   int p_shrink_num = 16;    // sixteenths of the computed capacity still trusted (two stalled grids in a row take one off)
   int p_stall_streak = 0;
   int p_capacity = 0;       // resident one-wave workgroups per CU of the current configuration's kernel (p_capacity_key)
@@ -130,6 +132,7 @@ struct afe_engine {
   afe::AqlQueue *aql = nullptr;
   bool aql_tried = false;
   bool p_on_aql = false;            // the grid now resident was dispatched there
+  bool p_on_aql_next = false;       // the grid about to be sized will be (the reservation applies only there)
   std::map<unsigned, afe::AqlKernel> aql_kernels;    // by configuration key (persist_size_grid's) | precision << 8
   bool view_exported = false;       // afe_get_device_view has handed the slabs to somebody: afe_sync must leave them readable
   uint64_t p_grid_ns = 0, p_grid_steps = 0;          // device time and steps of the grids collected so far (afe_grid_time)
@@ -518,7 +521,8 @@ void persist_size_grid(afe_engine *e) {
   }
   const int per_cu = e->p_capacity;
   const int64_t chunks = (e->n + 63) / 64;
-  int64_t cap = (int64_t)e->p_cus * per_cu - 1;     // the pump takes one slot
+  const int cus = e->p_on_aql_next && e->p_cus_usable > 0 ? e->p_cus_usable : e->p_cus;
+  int64_t cap = (int64_t)cus * per_cu - 1;          // the pump takes one slot
   cap = cap * e->p_shrink_num / 16;
   if (cap < 1) cap = 1;
   // Every resident slot gets a wave, even when the chunks do not divide evenly (2^20 vehicles: 16 384 chunks over 6 143
@@ -635,6 +639,16 @@ int persist_launch(afe_engine *e) {
   volatile unsigned long long *st = p_status(e);
   st[0] = 0; st[1] = e->p_resume; st[2] = 0; st[7] = 0;
   st[AFE_PERSIST_SYNC_WORD] = 0; st[AFE_PERSIST_SYNCREQ_WORD] = 0;
+  const afe::AqlKernel *ak = aql_kernel_for(e);      // nullptr: launch on the HIP stream
+  e->p_on_aql_next = ak != nullptr;
+  if (ak && e->p_reserve != e->p_reserve_applied) {
+    // compute units kept free for everybody else's kernels (collectives, the host's own work) while the grid is resident
+    std::string why;
+    int left = 0;
+    if (afe::aql_reserve_cus(e->aql, e->p_reserve, &left, &why)) { e->p_cus_usable = e->p_reserve ? left : 0; }
+    else { std::fprintf(stderr, "agrifly_engine: compute units not reserved (%s)\n", why.c_str()); e->p_cus_usable = 0; }
+    e->p_reserve_applied = e->p_reserve;
+  }
   persist_size_grid(e);
   for (int w = 0; w < AFE_PERSIST_HOST_MARKS; w++) st[8 + w] = w < e->p_workers ? e->p_resume : ~0ull;
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -667,7 +681,6 @@ int persist_launch(afe_engine *e) {
   const LaunchFlags &f = e->p_flags;
   const DevLogic *ulogic = e->logic_on ? &e->logic_table[0] : nullptr;
   static const DevLogic no_logic = {};
-  const afe::AqlKernel *ak = aql_kernel_for(e);      // nullptr: launch on the HIP stream
   int lrc = 0;
   bool on_aql = false;
   if (e->precision == AFE_F64) {
@@ -982,6 +995,7 @@ static int create_engine(afe_engine **out, int64_t n_vehicles, int precision, in
   if (launch_seed_rng(e->rng, e->n, e->first_global, e->seed_policy, main_stream(e)) != 0)
     return bail("seed kernel launch (is the gfx950 code object present?)", hipGetLastError());
   if ((err = hipStreamSynchronize(main_stream(e))) != hipSuccess) return bail("seed kernel", err);
+  if (const char *rs = std::getenv("AFE_PERSIST_RESERVE_CUS")) { const int k = std::atoi(rs); if (k >= 0 && k <= 8) e->p_reserve = k; }
   if (const char *fm = std::getenv("AFE_FORCE_STEP_MODE")) {   // test hook: every engine of this process steps by the resident grid where it can (1 persistent, 3 resident state)
     const int m = std::atoi(fm);
     if (m >= AFE_STEP_LAUNCH && m <= AFE_STEP_RESIDENT) e->step_mode = m;
@@ -1469,6 +1483,15 @@ extern "C" int afe_set_split_stepping(afe_engine *e, int parts) {
 extern "C" int afe_set_cache_policy(afe_engine *e, int policy) {
   if (!e || policy < -1 || policy > 3) return fail(e, AFE_ERR_INVALID_ARG, "cache policy: -1 (automatic), 0 (default), 1 (inputs and outputs nt), 2 (everything nt) or 3 (everything nt, one range per XCD)");
   e->cache_policy = policy;
+  return AFE_OK;
+}
+
+extern "C" int afe_set_reserved_compute_units(afe_engine *e, int per_xcd) {
+  if (!e || per_xcd < 0 || per_xcd > 8) return fail(e, AFE_ERR_INVALID_ARG, "reserved compute units per XCD: 0 .. 8");
+  AFE_HIP(e, hipSetDevice(e->device));
+  const int rc = persist_park(e);
+  if (rc) return rc;
+  e->p_reserve = per_xcd;
   return AFE_OK;
 }
 

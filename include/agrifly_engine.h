@@ -538,6 +538,17 @@ int afe_persistent_running(const afe_engine *e, int *running);
  * measured in the run.  Ends the grid now resident (it is counted).  Both 0 when the grids ran on the HIP stream
  * (AFE_PERSIST_AQL=0, a caller's stream): use afe_event_record there.  Replaces nothing in the reference. */
 int afe_grid_time(afe_engine *e, uint64_t *device_ns, uint64_t *steps);
+/* Keep compute units out of the resident grid's reach (its queue's compute-unit mask; 0, the default: none).  A resident
+ * grid of a large ensemble otherwise holds every wave slot of the device, and any other kernel of the process -- an RCCL
+ * collective between two blocks of steps, the host's own work -- waits until it has idled out (200 us) or been parked.
+ * With a reservation such kernels start at once beside it and the grid stays resident across them (measured, one-rank
+ * RCCL all-reduce beside a fed 2^20-vehicle grid: 0.36 -> 0.05 ms).  The hardware keeps the shader engines of an XCD
+ * symmetric, so the reservation comes in rows of one unit per shader engine: per_xcd is rounded up to a multiple of 4,
+ * i.e. 32 of 256 units at least -- and a grid on 224 units steps 4 % slower at 2^20 vehicles, 25 % at 131 072
+ * (tools/reserve_probe.py).  A trade for hosts that interleave collectives or their own kernels with every few steps; not
+ * used by bench.py.  Ends the grid now resident; applies from the next one.  No effect on grids launched on a HIP stream.
+ * Replaces nothing in the reference (one thread, one loop). */
+int afe_set_reserved_compute_units(afe_engine *e, int per_xcd);
 
 /* Cache-policy hints of the one-step launches' slab accesses (`nt` bits on the buffer instructions; never a different
  * result bit).  -1 automatic (default): by what the 256 MiB Infinity Cache can keep from one step to the next --

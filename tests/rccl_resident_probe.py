@@ -44,7 +44,18 @@ def main():
             dist.all_reduce(x, op=dist.ReduceOp.MAX)          # torch's stream, RCCL's kernel: beside / after the grid
             torch.cuda.synchronize()
             rec["all_reduce_ms"] = (time.perf_counter() - t0) * 1e3
+            rec["resident_after_collective"] = bool(e.persistent_running)     # (with compute units reserved the grid never left)
             rec["all_reduce_ok"] = bool((x == 3.0).all().item())
+            # the same with the grid kept fed, as between two blocks of a run whose host does not pause
+            ts = []
+            for _ in range(10):
+                e.step(1000, 1)
+                t0 = time.perf_counter()
+                dist.all_reduce(x, op=dist.ReduceOp.MAX)
+                x.cpu()                                       # waits for the collective alone (torch's stream), not for the device
+                ts.append((time.perf_counter() - t0) * 1e3)
+            rec["all_reduce_ms_grid_fed"] = float(np.median(ts))
+            rec["resident_after_fed_collectives"] = bool(e.persistent_running)
             for _ in range(5):
                 e.step(1000, 1)                               # a grid is resident again
             rec["resident_before_gather"] = bool(e.persistent_running)
@@ -57,7 +68,7 @@ def main():
             for _ in range(20):
                 e.step(1000, 1)
         else:
-            for _ in range(25):
+            for _ in range(35):           # (25 + the ten steps of the fed-grid collectives)
                 e.step(1000, 1)
         e.sync()
         st = e.get_state()
