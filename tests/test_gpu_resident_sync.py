@@ -148,16 +148,16 @@ def test_reserved_compute_units_let_other_kernels_run_beside_the_grid():
     b, _ = make(n, afa.AFE_F32, False)
     with a, b:
         x = torch.ones(1 << 20, device="cuda")
-        med = {}
+        med, steps = {}, 0
         for reserve in (0, 1):
             a.set_reserved_compute_units(reserve)
-            a.step(1000, 30); b.step(1000, 30)
+            a.step(1000, 30); steps += 30
             a.sync()
             assert a.persistent_running
             torch.cuda.synchronize()
             ts = []
             for _ in range(20):
-                a.step(1000, 1); b.step(1000, 1)              # the grid has work while the other kernels want to start
+                a.step(1000, 1); steps += 1                   # the grid has work while the other kernels want to start
                 t0 = time.perf_counter()
                 y = float((x * 2).sum().item())               # torch's stream: two small kernels and a read-back
                 ts.append(time.perf_counter() - t0)
@@ -166,5 +166,7 @@ def test_reserved_compute_units_let_other_kernels_run_beside_the_grid():
         assert med[0] > 200e-6, "without a reservation the kernels should have waited for the grid's idle patience: %.0f us" % (med[0] * 1e6)
         assert med[1] < 0.6 * med[0], "reserved compute units did not let the kernels in: %.0f against %.0f us" % (med[1] * 1e6, med[0] * 1e6)
         a.set_reserved_compute_units(0)                       # parks; the next grid has the whole device again
-        a.step(1000, 10); b.step(1000, 10)
+        a.step(1000, 10); steps += 10
+        a.sync()
+        b.step(1000, steps)                                   # (the launched engine afterwards: its kernels want the whole device too)
         assert_same(a, b, "with and without reserved compute units")
