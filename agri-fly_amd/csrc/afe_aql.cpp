@@ -147,7 +147,8 @@ struct AqlQueue {
   hsa_queue_t *queue = nullptr;
   hsa_signal_t done{};
   bool have_signal = false;
-  void *kernarg = nullptr;          // two slots of KERNARG_SLOT bytes, used in turn
+  void *kernarg = nullptr;          // host kernarg pool (kept for devices without the device-side copy): two slots of KERNARG_SLOT bytes
+  void *kernarg_dev = nullptr;      // the same two slots in DEVICE memory: what the packets point at (see aql_dispatch)
   unsigned slot = 0;
   bool in_flight = false;
   bool initialised = false;         // hsa_init taken (to be given back)
@@ -195,6 +196,12 @@ AqlQueue *aql_open(int hip_device, std::string *why) {
   if (st != HSA_STATUS_SUCCESS) { q->kernarg = nullptr; return bail(hsa_err(a, st, "hsa_amd_memory_pool_allocate (kernarg)")); }
   st = a.hsa_amd_agents_allow_access(1, &q->gpu, nullptr, q->kernarg);
   if (st != HSA_STATUS_SUCCESS) return bail(hsa_err(a, st, "hsa_amd_agents_allow_access (kernarg)"));
+  // The arguments of a resident grid are not read once: 186 dwords do not all stay in scalar registers, and what the
+  // scalar cache drops is fetched again from the kernel-argument segment inside the step loop.  In host memory that is a
+  // PCIe round trip per miss -- measured: grids dispatched with host-side arguments step 2.5 % slower than the same kernel
+  // launched by HIP (which keeps arguments in device memory), 11 % in an engine's first 100 ms.  So: device memory.
+  static const bool host_kernarg = std::getenv("AFE_AQL_HOST_KERNARG") != nullptr;      // measurement aid
+  if (!host_kernarg && hipMalloc(&q->kernarg_dev, 2 * KERNARG_SLOT) != hipSuccess) { (void)hipGetLastError(); q->kernarg_dev = nullptr; }
   return q;
 }
 
@@ -206,6 +213,7 @@ void aql_close(AqlQueue *q) {
     if (q->queue) (void)a.hsa_queue_destroy(q->queue);
     if (q->have_signal) (void)a.hsa_signal_destroy(q->done);
     if (q->kernarg) (void)a.hsa_amd_memory_pool_free(q->kernarg);
+    if (q->kernarg_dev) (void)hipFree(q->kernarg_dev);
     if (q->initialised) (void)a.hsa_shut_down();
   }
   delete q;
@@ -245,6 +253,11 @@ bool aql_dispatch(AqlQueue *q, const AqlKernel &k, const void *kernarg, size_t b
   q->slot ^= 1u;
   char *ka = static_cast<char *>(q->kernarg) + q->slot * KERNARG_SLOT;
   std::memcpy(ka, kernarg, bytes);
+  if (q->kernarg_dev) {
+    char *kd = static_cast<char *>(q->kernarg_dev) + q->slot * KERNARG_SLOT;
+    if (hipMemcpy(kd, kernarg, bytes, hipMemcpyHostToDevice) == hipSuccess) ka = kd;      // (synchronous: in memory before the doorbell rings)
+    else (void)hipGetLastError();
+  }
   const uint64_t idx = a.hsa_queue_load_write_index_relaxed(q->queue);
   if (idx - a.hsa_queue_load_read_index_scacquire(q->queue) >= q->queue->size) { if (why) *why = "AQL queue full"; return false; }
   hsa_kernel_dispatch_packet_t *p = static_cast<hsa_kernel_dispatch_packet_t *>(q->queue->base_address) + (idx & (q->queue->size - 1));

@@ -812,6 +812,11 @@ int quiesce(afe_engine *e) {
   return AFE_OK;
 }
 
+long persist_refresh_steps() {
+  static const long refresh = [] { const char *s = std::getenv("AFE_PERSIST_REFRESH_STEPS"); return s && *s ? std::atol(s) : 512L; }();
+  return refresh;
+}
+
 // The pump parks itself after 200 us without news.  If it decides to while entries are being written, they would wait
 // for a grid nobody starts before the next engine call -- a host that synchronises outside the engine
 // (hipDeviceSynchronize) would see state short of the steps it asked for.  The pump announces where it means to park
@@ -865,6 +870,13 @@ int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   if (e->p_running && (e->p_dt_us != dt_us || f.ext_force != e->p_flags.ext_force || f.noise != e->p_flags.noise || f.logic != e->p_flags.logic || f.counter_noise != e->p_flags.counter_noise))
     if ((rc = persist_park(e))) return rc;
   volatile unsigned long long *st = p_status(e);
+  // A resident grid slows down as it ages: measured at 2^20 / 2^19 / 131 072 vehicles, grids retired after 512 steps
+  // step 2.7 / 3 / 6 % faster than grids that live on (19.58 -> 19.05, 10.6 -> 10.3, 2.35 -> 2.21 us per step; the same
+  // with a fresh grid per block: tools/sync_cost_probe.py).  Why is open (the waves' drift apart is
+  // the suspect; re-aligning them at a sync marker does not help, a fresh dispatch does).  So a grid that has served
+  // persist_refresh_steps() steps is retired here -- the host waits for what it has authorised, ~20 us of dispatch follow --
+  // and at the next afe_sync (afe_sync below).  AFE_PERSIST_REFRESH_STEPS=0: never.
+  if (e->p_running && persist_refresh_steps() > 0 && (long)(e->p_next - e->p_launch_start) >= persist_refresh_steps() && (rc = persist_park(e))) return rc;
   if (e->p_running && st[0] != 0) {       // it parked itself (idle): collect it, a new grid starts below
     if ((rc = persist_collect(e))) return rc;
   }
@@ -1524,7 +1536,8 @@ extern "C" int afe_steps_until_tick(const afe_engine *e, uint64_t dt_us, int *n_
 extern "C" int afe_sync(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
-  if (e->p_running && e->p_on_aql && !e->view_exported) {
+  if (e->p_running && e->p_on_aql && !e->view_exported &&
+      !(persist_refresh_steps() > 0 && (long)(e->p_next - e->p_launch_start) >= persist_refresh_steps())) {     // (an aged grid is retired: persist_step)
     // Every authorised step has run and its stores are acknowledged; the grid STAYS (it lives on the engine's own queue,
     // which no HIP synchronisation waits for) and takes the next afe_step without a launch.  Whoever reads the state does
     // so through an entry point of the engine, which ends the grid first (kernel end = the caches written back).  Once
