@@ -29,7 +29,7 @@ namespace {
   X(hsa_queue_load_read_index_scacquire) X(hsa_queue_load_write_index_relaxed) X(hsa_queue_store_write_index_screlease) \
   X(hsa_system_get_major_extension_table) X(hsa_system_get_info) X(hsa_executable_get_symbol_by_name)                  \
   X(hsa_executable_symbol_get_info) X(hsa_amd_agent_iterate_memory_pools) X(hsa_amd_memory_pool_get_info)              \
-  X(hsa_amd_memory_pool_allocate) X(hsa_amd_memory_pool_free) X(hsa_amd_agents_allow_access)                           \
+  X(hsa_amd_memory_pool_allocate) X(hsa_amd_memory_pool_free) X(hsa_amd_agents_allow_access) X(hsa_amd_agent_memory_pool_get_info)                           \
   X(hsa_amd_queue_cu_set_mask) X(hsa_amd_queue_cu_get_mask) X(hsa_amd_profiling_set_profiler_enabled) X(hsa_amd_profiling_get_dispatch_time)
 
 struct Api {
@@ -117,6 +117,30 @@ hsa_status_t pool_cb(hsa_amd_memory_pool_t pool, void *data) {
   return HSA_STATUS_SUCCESS;
 }
 
+struct FindDevPool {
+  const Api *a;
+  hsa_agent_t cpu;
+  hsa_amd_memory_pool_t pool{};
+  bool found = false;
+};
+
+// a pool of the GPU's own memory that is fine-grained and that the host may be given access to (large-BAR systems)
+hsa_status_t dev_pool_cb(hsa_amd_memory_pool_t pool, void *data) {
+  FindDevPool *f = static_cast<FindDevPool *>(data);
+  hsa_amd_segment_t seg;
+  uint32_t flags = 0;
+  bool alloc = false;
+  if (f->a->hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+  (void)f->a->hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+  (void)f->a->hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+  if (!alloc || !(flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_FINE_GRAINED)) return HSA_STATUS_SUCCESS;
+  hsa_amd_memory_pool_access_t acc = HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED;
+  if (f->a->hsa_amd_agent_memory_pool_get_info(f->cpu, pool, HSA_AMD_AGENT_MEMORY_POOL_INFO_ACCESS, &acc) != HSA_STATUS_SUCCESS ||
+      acc == HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED) return HSA_STATUS_SUCCESS;
+  f->pool = pool; f->found = true;
+  return HSA_STATUS_INFO_BREAK;
+}
+
 struct FindSymbol {
   const Api *a;
   hsa_agent_t agent;
@@ -149,6 +173,7 @@ struct AqlQueue {
   bool have_signal = false;
   void *kernarg = nullptr;          // host kernarg pool (kept for devices without the device-side copy): two slots of KERNARG_SLOT bytes
   void *kernarg_dev = nullptr;      // the same two slots in DEVICE memory: what the packets point at (see aql_dispatch)
+  bool kernarg_dev_mapped = false;  // ... which the host writes directly (fine-grained device memory through the BAR); else by hipMemcpy
   unsigned slot = 0;
   bool in_flight = false;
   bool initialised = false;         // hsa_init taken (to be given back)
@@ -201,7 +226,22 @@ AqlQueue *aql_open(int hip_device, std::string *why) {
   // PCIe round trip per miss -- measured: grids dispatched with host-side arguments step 2.5 % slower than the same kernel
   // launched by HIP (which keeps arguments in device memory), 11 % in an engine's first 100 ms.  So: device memory.
   static const bool host_kernarg = std::getenv("AFE_AQL_HOST_KERNARG") != nullptr;      // measurement aid
-  if (!host_kernarg && hipMalloc(&q->kernarg_dev, 2 * KERNARG_SLOT) != hipSuccess) { (void)hipGetLastError(); q->kernarg_dev = nullptr; }
+  static const bool no_bar = std::getenv("AFE_AQL_NO_BAR_KERNARG") != nullptr;          // measurement aid
+  if (!host_kernarg && !no_bar) {
+    // ... written by the host itself where the device's memory is host-visible (fine-grained pool, large BAR): a copy call
+    // costs the host 12 us before every dispatch, stores through the BAR one
+    FindDevPool fd{};
+    fd.a = &a; fd.cpu = q->cpu;
+    (void)a.hsa_amd_agent_iterate_memory_pools(q->gpu, dev_pool_cb, &fd);
+    void *p = nullptr;
+    if (fd.found && a.hsa_amd_memory_pool_allocate(fd.pool, 2 * KERNARG_SLOT, 0, &p) == HSA_STATUS_SUCCESS) {
+      hsa_agent_t both[2] = {q->cpu, q->gpu};
+      if (a.hsa_amd_agents_allow_access(2, both, nullptr, p) == HSA_STATUS_SUCCESS) { q->kernarg_dev = p; q->kernarg_dev_mapped = true; }
+      else (void)a.hsa_amd_memory_pool_free(p);
+    }
+  }
+  if (!host_kernarg && !q->kernarg_dev && hipMalloc(&q->kernarg_dev, 2 * KERNARG_SLOT) != hipSuccess) { (void)hipGetLastError(); q->kernarg_dev = nullptr; }
+  if (std::getenv("AFE_PERSIST_DEBUG")) std::fprintf(stderr, "agrifly_engine: AQL queue: kernel arguments in %s\n", !q->kernarg_dev ? "host memory" : q->kernarg_dev_mapped ? "device memory written through the BAR" : "device memory written by hipMemcpy");
   return q;
 }
 
@@ -213,7 +253,8 @@ void aql_close(AqlQueue *q) {
     if (q->queue) (void)a.hsa_queue_destroy(q->queue);
     if (q->have_signal) (void)a.hsa_signal_destroy(q->done);
     if (q->kernarg) (void)a.hsa_amd_memory_pool_free(q->kernarg);
-    if (q->kernarg_dev) (void)hipFree(q->kernarg_dev);
+    if (q->kernarg_dev && q->kernarg_dev_mapped) (void)a.hsa_amd_memory_pool_free(q->kernarg_dev);
+    else if (q->kernarg_dev) (void)hipFree(q->kernarg_dev);
     if (q->initialised) (void)a.hsa_shut_down();
   }
   delete q;
@@ -255,7 +296,12 @@ bool aql_dispatch(AqlQueue *q, const AqlKernel &k, const void *kernarg, size_t b
   std::memcpy(ka, kernarg, bytes);
   if (q->kernarg_dev) {
     char *kd = static_cast<char *>(q->kernarg_dev) + q->slot * KERNARG_SLOT;
-    if (hipMemcpy(kd, kernarg, bytes, hipMemcpyHostToDevice) == hipSuccess) ka = kd;      // (synchronous: in memory before the doorbell rings)
+    if (q->kernarg_dev_mapped) {
+      std::memcpy(kd, kernarg, bytes);
+      __atomic_thread_fence(__ATOMIC_SEQ_CST);                                           // (write-combined stores out before the doorbell's)
+      volatile char probe = *static_cast<volatile char *>(static_cast<void *>(kd + bytes - 1)); (void)probe;   // a read behind the writes: they have landed
+      ka = kd;
+    } else if (hipMemcpy(kd, kernarg, bytes, hipMemcpyHostToDevice) == hipSuccess) ka = kd;      // (synchronous: in memory before the doorbell rings)
     else (void)hipGetLastError();
   }
   const uint64_t idx = a.hsa_queue_load_write_index_relaxed(q->queue);

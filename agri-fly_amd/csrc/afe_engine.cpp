@@ -567,6 +567,50 @@ bool persist_eligible(const afe_engine *e) {
   return e->kernel_bytes < 0xffff0000ull && logic_arena_bytes(e) < 0xffff0000ull;
 }
 
+// The first user-mode queue on which a process dispatches a KERNEL is slower than every later one, for as long as it
+// lives: measured, an engine whose queue was that one stepped 2^20 vehicles in 19.9-20.1 us where every later engine of the
+// process -- and the same engine after giving that queue up for a new one -- took 19.2-19.4 (queues created but not used
+// before it, or used for a barrier packet only, change nothing; the HIP runtime's own queues do not show it).  Cause
+// unknown (firmware scheduling state is the guess).  So the process's first dispatch goes to a throwaway queue: the
+// resident kernel with no workers and a park entry already waiting -- one wave that zeroes a few counters and leaves.
+void aql_prime_process(afe_engine *e) {
+  static bool primed = false;
+  if (primed || std::getenv("AFE_AQL_NO_PRIME")) return;
+  primed = true;
+  std::string why;
+  afe::AqlQueue *q = afe::aql_open(e->device, &why);
+  if (!q) return;
+  afe::AqlKernel k;
+  LaunchFlags f;
+  f.ext_force = false; f.ext_torque = false; f.noise = false; f.logic = false;
+  unsigned long long *host = nullptr, *host_dev = nullptr, *dev = nullptr;
+  const size_t hwords = 64 + AFE_PERSIST_STATUS_WORDS, dwords = 8 + 64 + 32 + AFE_PERSIST_SYNC_AREA_WORDS;
+  if (afe::aql_find_kernel(q, persistent_kernel_fn_f32(f), &k, &why) &&
+      hipHostMalloc((void **)&host, hwords * 8, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
+      hipHostGetDevicePointer((void **)&host_dev, host, 0) == hipSuccess && hipMalloc((void **)&dev, dwords * 8) == hipSuccess &&
+      hipMemset(dev, 0, dwords * 8) == hipSuccess) {
+    std::memset(host, 0, hwords * 8);
+    host[0] = (1ull << 2) | AFE_PERSIST_PARK;            // "park before step 0": the pump's first look ends the launch
+    PersistArgs a = {};
+    a.host_ring = host_dev; a.host_status = host_dev + 64; a.dev_ring = dev + 8; a.done = dev + 8 + 64;
+    a.start = 0; a.host_mask = 63; a.dev_mask = 63; a.n_workers = 0; a.n_chunks = 0;
+    a.idle_ticks = 1000; a.give_up_ticks = 100000; a.epoch = 1;
+    StepView<float> v = {};
+    DevParams<float> P = {};
+    DevLogic G = {};
+    alignas(16) char buf[2048];
+    size_t o = 0;
+    auto put = [&](const void *p, size_t bytes, size_t align) { o = (o + align - 1) / align * align; std::memcpy(buf + o, p, bytes); o += bytes; };
+    std::memset(buf, 0, sizeof(buf));
+    put(&v, sizeof(v), alignof(StepView<float>)); put(&P, sizeof(P), alignof(DevParams<float>)); put(&G, sizeof(G), alignof(DevLogic)); put(&a, sizeof(a), alignof(PersistArgs));
+    if (afe::aql_dispatch(q, k, buf, o, 1, 64, &why)) (void)afe::aql_wait(q, 2000000ull, &why);
+  }
+  (void)hipGetLastError();
+  afe::aql_close(q);
+  if (dev) (void)hipFree(dev);
+  if (host) (void)hipHostFree(host);
+}
+
 // The engine's own AQL queue and the descriptor of the kernel of the current configuration, or nullptr: this grid goes to
 // the HIP stream (AFE_PERSIST_AQL=0; a caller's stream; the runtime out of reach -- said once on stderr).
 const afe::AqlKernel *aql_kernel_for(afe_engine *e) {
@@ -575,6 +619,7 @@ const afe::AqlKernel *aql_kernel_for(afe_engine *e) {
   if (!e->aql_tried) {
     e->aql_tried = true;
     std::string why;
+    aql_prime_process(e);
     e->aql = afe::aql_open(e->device, &why);
     if (!e->aql) std::fprintf(stderr, "agrifly_engine: no AQL queue for the resident grid (%s); it is launched on the HIP stream and parked at every synchronisation\n", why.c_str());
   }
@@ -590,6 +635,7 @@ const afe::AqlKernel *aql_kernel_for(afe_engine *e) {
       std::fprintf(stderr, "agrifly_engine: resident grid stays on the HIP stream (%s)\n", why.c_str());
       k = afe::AqlKernel();       // object 0: remembered as not available
     }
+    if (std::getenv("AFE_PERSIST_DEBUG")) std::fprintf(stderr, "agrifly_engine: kernel descriptor at %#llx (kernarg %u B, scratch %u B) for configuration %#x\n", (unsigned long long)k.object, k.kernarg_bytes, k.private_bytes, key);
     it = e->aql_kernels.emplace(key, k).first;
   }
   return it->second.object ? &it->second : nullptr;
@@ -607,8 +653,11 @@ bool aql_launch(afe_engine *e, const afe::AqlKernel &k, const StepView<R> &v, co
   put(&G, sizeof(G), alignof(DevLogic));
   put(&a, sizeof(a), alignof(PersistArgs));
   // the queue is not ordered behind the HIP stream: whatever the stream still holds (setters, a memset) finishes first
+  static const bool timing = std::getenv("AFE_AQL_TIMING") != nullptr;
+  const auto tt0 = std::chrono::steady_clock::now();
   if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
   e->stream_pending = false;
+  const auto tt1 = std::chrono::steady_clock::now();
   // AFE_PERSIST_SPREAD=1 (measurement aid, off by default): a grid that does not fill the device can be SPREAD over it by
   // asking for an unused LDS slice per workgroup, which caps how many a compute unit takes (160 KB / (the even share +
   // slack)).  Measured at 131 072 / 262 144 vehicles: later grids of an engine 2.97 against 3.00 us per step with one
@@ -631,6 +680,12 @@ bool aql_launch(afe_engine *e, const afe::AqlKernel &k, const StepView<R> &v, co
     if (!said) std::fprintf(stderr, "agrifly_engine: AQL dispatch of the resident grid refused (%s); using the HIP stream\n", why.c_str());
     said = true;
     return false;
+  }
+  if (timing) {
+    const auto tt2 = std::chrono::steady_clock::now();
+    static double a1 = 0, a2 = 0; static int nn = 0;
+    a1 += std::chrono::duration<double, std::micro>(tt1 - tt0).count(); a2 += std::chrono::duration<double, std::micro>(tt2 - tt1).count();
+    if (++nn % 200 == 0) { std::fprintf(stderr, "aql launch: stream sync %.1f us, pack + kernarg copy + dispatch %.1f us (mean of 200)\n", a1 / 200, a2 / 200); a1 = a2 = 0; }
   }
   return true;
 }
@@ -713,7 +768,14 @@ int persist_collect(afe_engine *e) {
   const bool was_aql = e->p_on_aql;
   if (e->p_on_aql) {
     std::string why;
+    static const bool timing = std::getenv("AFE_AQL_TIMING") != nullptr;
+    const auto tw0 = std::chrono::steady_clock::now();
     const int w = afe::aql_wait(e->aql, 120000000ull, &why);     // (the grid's own patience ends long before: 50 ms without progress)
+    if (timing) {
+      static double aw = 0; static int nw = 0;
+      aw += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count();
+      if (++nw % 200 == 0) { std::fprintf(stderr, "aql collect: waited %.1f us for the grid to leave (mean of 200)\n", aw / 200); aw = 0; }
+    }
     if (w != 0) {
       e->p_running = false; e->p_on_aql = false; e->p_failed = true;
       return fail(e, AFE_ERR_HIP, "persistent step kernel on the engine's AQL queue: " + (w > 0 ? std::string("still running after 120 s") : why));
