@@ -162,7 +162,7 @@ def kernel_time_events(e, launches):
     e.destroy_event(ev0)
     e.destroy_event(ev1)
     grid_s, grid_steps = e.grid_time()
-    if grid_steps == launches and grid_s > 0:
+    if grid_steps == launches and 0.5 * ms * 1e-3 <= grid_s <= 1.5 * ms * 1e-3:     # (nonsense under a profiler that owns the timestamps)
         return grid_s / launches
     return ms * 1e-3 / launches
 
@@ -898,7 +898,10 @@ def main():
         xg_s, xg_steps = ex.grid_time()
         xbytes, _ = mean_bytes_per_step(ex, afa, args.steps)
         tx = median(xblocks) / args.steps
-        tx_kernel = (xg_s / xg_steps if xg_steps > 0 and xg_s > 0 else event_blocks(ex, args.steps)[0]) if rank == 0 else None
+        tx_grid = xg_s / xg_steps if xg_steps > 0 and xg_s > 0 else None
+        if tx_grid is not None and not (0.5 * tx <= tx_grid <= 1.5 * tx):
+            tx_grid = None
+        tx_kernel = (tx_grid if tx_grid is not None else event_blocks(ex, args.steps)[0]) if rank == 0 else None
         exact = {"value": n_global / tx, "unit": "vehicle-steps/s", "ms_per_step": tx * 1e3, "steps": args.steps, "repeats": len(xblocks),
                  "algorithmic_bytes_per_vehicle_step": xbytes, "kernel_us": None if tx_kernel is None else tx_kernel * 1e6,
                  "frac": None if tx_kernel is None else n_local * xbytes / tx_kernel / 1e9 / HBM_PEAK_GBS,
@@ -919,7 +922,12 @@ def main():
         # launch mode: HIP events around the K launches of a block.  Resident grid: one grid serves all the blocks of the
         # timed region -- its device time / the steps it served; the one-block-per-dispatch figure (a grid started and
         # parked around every block, as round 3 had to) stays in the record as kernel_us_dispatch_per_block
-        t_kernel = grid_s / grid_steps if grid_steps > 0 and grid_s > 0 else t_block
+        # (under rocprofv3 the runtime's dispatch timestamps are the profiler's, not ours: what comes back is nonsense --
+        # a figure far from the wall time per step is dropped for the event-style one)
+        t_grid = grid_s / grid_steps if grid_steps > 0 and grid_s > 0 else None
+        if t_grid is not None and not (0.5 * elapsed / args.steps <= t_grid <= 1.5 * elapsed / args.steps):
+            t_grid, grid_steps = None, 0
+        t_kernel = t_grid if t_grid is not None else t_block
         achieved = n_local * bytes_step / t_kernel / 1e9
         # the same over a long run: a resident grid's launch and exit (and a stream's first launches) amortised away
         long_steps = max(args.steps, 2000)

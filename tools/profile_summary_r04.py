@@ -60,6 +60,8 @@ def gridlog(name):
 
 def paired(dirname, logname):
     d, g = dispatches(dirname), gridlog(logname)
+    if len(d) == len(g) + 1:
+        d = d[1:]         # the process's first dispatch is the primer on its throwaway queue (one wave, no steps, not in the engine's log)
     if not d or len(d) != len(g):
         return None, len(d), len(g)
     return [(dur, steps) for (_, dur), (_, _, steps, _) in zip(d, g)], len(d), len(g)
@@ -93,7 +95,7 @@ for name, src, log, block in (("blocks_of_20_steps", "prof_k20_%s" % tag, "gridl
         summary[name] = {"error": "%d dispatches in the trace, %d grids in the engine's log" % (nd, ng)}
         continue
     served = [(dur, s) for dur, s in p if s > 0]
-    long_ = [(dur, s) for dur, s in served if s > 4 * block]            # the grid that lived through the timed blocks (settle + blocks)
+    long_ = [(dur, s) for dur, s in served if s > 4 * block or (s >= 256 and s != block)]   # the grids that lived through the timed blocks (a grid is retired after 512 steps)
     one_block = [dur / s for dur, s in served if s == block]            # grids parked after exactly one block (the event-style measurement)
     tot_ns, tot_steps = sum(d for d, _ in served), sum(s for _, s in served)
     rec = {"dispatches": nd, "steps_served": tot_steps, "device_ms": tot_ns / 1e6, "us_per_step_all_dispatches": tot_ns / tot_steps / 1e3}
@@ -113,6 +115,8 @@ for name, src, log, block in (("blocks_of_20_steps", "prof_k20_%s" % tag, "gridl
 steps_of = {}
 for cname, src, log in (("FETCH_SIZE", "pmc_fetch_%s" % tag, "gridlog_fetch_%s.csv" % tag), ("WRITE_SIZE", "pmc_write_%s" % tag, "gridlog_write_%s.csv" % tag)):
     c, g = counter_per_dispatch(src).get(cname), gridlog(log)
+    if c and len(c) == len(g) + 1:
+        c = c[1:]         # the primer
     if c and len(c) == len(g):
         tot, st = sum(v for v, (_, _, s, _) in zip(c, g) if s > 0), sum(s for (_, _, s, _) in g if s > 0)
         steps_of[cname] = (tot, st)
@@ -134,6 +138,8 @@ if len(steps_of) == 2:
                    "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summed over the resident grid's dispatches / steps served, separate passes, "
                              "FETCH_SIZE x2 gfx950 correction)" % tag}, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 sq, g = counter_per_dispatch("pmc_sq_%s" % tag), gridlog("gridlog_sq_%s.csv" % tag)
+if sq.get("SQ_WAVES") and len(sq["SQ_WAVES"]) == len(g) + 1:
+    sq = {k: v[1:] for k, v in sq.items()}     # the primer
 if sq.get("SQ_WAVES") and len(sq["SQ_WAVES"]) == len(g):
     st = sum(s for (_, _, s, _) in g if s > 0)
     rec = {c: sum(v) for c, v in sorted(sq.items())}
