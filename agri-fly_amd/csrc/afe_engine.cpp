@@ -574,9 +574,10 @@ bool persist_eligible(const afe_engine *e) {
 // unknown (firmware scheduling state is the guess).  So the process's first dispatch goes to a throwaway queue: the
 // resident kernel with no workers and a park entry already waiting -- one wave that zeroes a few counters and leaves.
 void aql_prime_process(afe_engine *e) {
-  static bool primed = false;
-  if (primed || std::getenv("AFE_AQL_NO_PRIME")) return;
-  primed = true;
+  static unsigned long long primed = 0;          // one bit per device (the observation is per device: its first dispatching queue)
+  const unsigned long long bit = 1ull << (e->device & 63);
+  if ((primed & bit) || std::getenv("AFE_AQL_NO_PRIME")) return;
+  primed |= bit;
   std::string why;
   afe::AqlQueue *q = afe::aql_open(e->device, &why);
   if (!q) return;
