@@ -47,7 +47,7 @@ ABI_FUNCTIONS = [
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
     "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running", "afe_stream_probe",
     "afe_set_noise_seed", "afe_set_gust_process", "afe_get_external_force", "afe_nearest_neighbour_async", "afe_query_sync",
-    "afe_gather_exchange", "afe_set_cache_policy", "afe_grid_time", "afe_cache_policy_in_use", "afe_set_reserved_compute_units",
+    "afe_gather_exchange", "afe_set_cache_policy", "afe_grid_time", "afe_cache_policy_in_use", "afe_set_reserved_compute_units", "afe_set_resident_queue",
 ]
 
 
@@ -342,6 +342,7 @@ def library():
         "afe_set_cache_policy": [eng, ci],
         "afe_cache_policy_in_use": [eng, C.POINTER(ci)],
         "afe_set_reserved_compute_units": [eng, ci],
+        "afe_set_resident_queue": [eng, ci],
         "afe_grid_time": [eng, C.POINTER(u64), C.POINTER(u64)],
         "afe_group_destroy": [vp],
         "afe_group_size": [vp, C.POINTER(ci), C.POINTER(i64)],
@@ -894,6 +895,10 @@ class Ensemble:
     def set_cache_policy(self, policy):
         """-1 automatic, 0 default, 1 inputs / outputs nt, 2 everything nt, 3 everything nt + one range per XCD"""
         self._ck(self._L.afe_set_cache_policy(self._h, int(policy)))
+
+    def set_resident_queue(self, mode):
+        """-1 automatic (own queue up to 262 144 vehicles), 0 the HIP stream, 1 the engine's own queue"""
+        self._ck(self._L.afe_set_resident_queue(self._h, int(mode)))
 
     def set_reserved_compute_units(self, per_xcd):
         """compute units per XCD kept free of the resident grid (other kernels run beside it); 0: none"""

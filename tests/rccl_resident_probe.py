@@ -34,6 +34,7 @@ def main():
     def fly(interleave):
         e = bench.build_shard(afa, n, 0, n, 0)
         e.set_step_mode(afa.AFE_STEP_PERSISTENT)
+        e.set_resident_queue(1)                  # the grid that survives afe_sync: the case this probe is about
         rec = {}
         for _ in range(25):
             e.step(1000, 1)

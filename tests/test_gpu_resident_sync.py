@@ -147,6 +147,7 @@ def test_reserved_compute_units_let_other_kernels_run_beside_the_grid():
     a, _ = make(n, afa.AFE_F32, True)
     b, _ = make(n, afa.AFE_F32, False)
     with a, b:
+        a.set_resident_queue(1)                               # (automatic would put a grid of this size on the HIP stream)
         x = torch.ones(1 << 20, device="cuda")
         med, steps = {}, 0
         for reserve in (0, 1):
