@@ -1794,6 +1794,15 @@ extern "C" int afe_event_destroy(void *event) {
 extern "C" int afe_event_record(afe_engine *e, void *event) {
   if (!e || !event) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
+  if (e->p_running && !e->p_on_aql && !e->split_dirty) {
+    // A resident grid on the engine's stream: the event goes onto the stream BEHIND it and the grid is told to leave after
+    // the last authorised step -- the event's time is then the moment the grid left the device, not the moment the host had
+    // noticed (which is what recording after the park gave: ~10 us later, 0.5 us per step of a 20-step block).
+    __atomic_store_n(&e->p_host[e->p_next & (AFE_PERSIST_HOST_RING - 1)], ((e->p_next + 1) << 2) | AFE_PERSIST_PARK, __ATOMIC_RELEASE);
+    AFE_HIP(e, hipEventRecord((hipEvent_t)event, e->stream));
+    e->stream_pending = true;
+    return persist_park(e);
+  }
   AFE_HIP(e, hipEventRecord((hipEvent_t)event, main_stream(e)));
   return AFE_OK;
 }

@@ -66,7 +66,9 @@ for src, dst in (("prof_%s" % tag, "%s_kernel_stats.csv" % tag), ("prof_k20_%s" 
     if d and src == "prof_" + tag:
         shutil.copy(d, os.path.join(prof, dst.replace("kernel_stats", "domain_stats")))
 
-for name, src, steps in (("blocks_of_2000_steps", "prof_%s" % tag, 2000), ("blocks_of_20_steps", "prof_k20_%s" % tag, 20)):
+# (round 4: a grid is retired after 512 steps, so a 2000-step block is launches of 512, 512, 512 and 464 steps: the median launch serves 512)
+LONG_STEPS = int(sys.argv[5]) if len(sys.argv) > 5 else 2000
+for name, src, steps in (("blocks_of_2000_steps", "prof_%s" % tag, LONG_STEPS), ("blocks_of_20_steps", "prof_k20_%s" % tag, 20)):
     d = launches(src)
     if not d:
         continue
