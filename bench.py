@@ -528,6 +528,8 @@ def shared_world(afa, n_local, rank, world, local_rank, dist, torch, sync, barri
     req = rng.integers(0, n_all, 1024).astype(np.int32)
     res = rng.integers(0, n_all, 1024).astype(np.int32)
 
+    one_device = os.environ.get("AFE_BENCH_ONE_DEVICE") == "1"      # (gloo instead of RCCL: the collective's tensor lives on the host)
+
     def reduce_max(x):
         if dist is None:
             return x

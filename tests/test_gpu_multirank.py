@@ -75,3 +75,18 @@ def test_rccl_collectives_beside_a_full_size_resident_grid():
     assert d["resident_before_collective"] and d["resident_before_gather"]
     assert d["all_reduce_ok"] and d["gathered_equals_state"] and d["bits_identical"]
     assert d["all_reduce_ms"] < 5.0 and d["gather_ms"] < 5.0, d
+
+
+def test_bench_under_torchrun_with_one_rccl_rank_runs_the_shared_world_part():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 ...`: a real RCCL process group (one rank), the
+    timing collectives and the shared-world exchange (all-gather + consumers) all through it -- exit status 0, one line,
+    no error recorded in the shared-world part (round 4 found a NameError there that only a launcher-started run could hit)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--no-sweep", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert "error" not in d["shared_world"], d["shared_world"]
+    assert d["shared_world"]["rccl_ranks"] == 1
