@@ -1794,7 +1794,7 @@ extern "C" int afe_event_destroy(void *event) {
 extern "C" int afe_event_record(afe_engine *e, void *event) {
   if (!e || !event) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
-  if (e->p_running && !e->p_on_aql && !e->split_dirty) {
+  if (e->p_running && !e->p_on_aql && !e->split_dirty && p_status(e)[0] == 0) {     // (a grid that has already left by itself takes the ordinary way)
     // A resident grid on the engine's stream: the event goes onto the stream BEHIND it and the grid is told to leave after
     // the last authorised step -- the event's time is then the moment the grid left the device, not the moment the host had
     // noticed (which is what recording after the park gave: ~10 us later, 0.5 us per step of a 20-step block).
