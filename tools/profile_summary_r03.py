@@ -27,6 +27,7 @@ BYTES_MEAN = float(sys.argv[4]) if len(sys.argv) > 4 else 144.0      # algorithm
 
 def one(pattern):
     g = glob.glob(os.path.join(out, pattern), recursive=True)
+    g.sort(key=os.path.getsize, reverse=True)      # (a pass that starts child processes leaves one set of files per process: the bench's own is the largest)
     return g[0] if g else None
 
 

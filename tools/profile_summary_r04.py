@@ -31,6 +31,7 @@ KERNEL = "afe_step_persistent_kernel"
 
 def one(pattern):
     g = glob.glob(os.path.join(out, pattern), recursive=True)
+    g.sort(key=os.path.getsize, reverse=True)      # (a pass that starts child processes leaves one set of files per process: the bench's own is the largest)
     return g[0] if g else None
 
 
