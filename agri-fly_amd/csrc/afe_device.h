@@ -139,10 +139,16 @@ struct PersistArgs {
 #define AFE_PERSIST_SYNC_SHARDS 64
 #define AFE_PERSIST_SYNC_AREA_WORDS (16 * (AFE_PERSIST_SYNC_SHARDS + 3))   /* a pad line, 64 shard lines, the top line, slack */
 #define AFE_PERSIST_HOST_IO 0x10000u   /* PersistArgs::epoch */
+#define AFE_PERSIST_PRIO 0x20000u      /* PersistArgs::epoch: workers set their issue priority by the steps they have left (afe_kernels.hip) */
 #define AFE_PERSIST_HOST_MARKS 64      /* host-visible arenas: grids of up to this many workers also write their marks to host_status[8 + w] */
 #define AFE_PERSIST_SYNC_WORD (8 + AFE_PERSIST_HOST_MARKS)      /* host_status: the step count the last sync request was answered for */
 #define AFE_PERSIST_SYNCREQ_WORD (9 + AFE_PERSIST_HOST_MARKS)   /* host_status: the host's sync request (a step count) */
+#ifdef AFE_SYNC_TRACE   /* development aid: where a sync request spends its time (device stamps, 10 ns units) */
+#define AFE_PERSIST_TRACE_BASE (16 + AFE_PERSIST_HOST_MARKS)
+#define AFE_PERSIST_STATUS_WORDS (16 + AFE_PERSIST_HOST_MARKS + 4 + 4 * 8192)
+#else
 #define AFE_PERSIST_STATUS_WORDS (16 + AFE_PERSIST_HOST_MARKS)
+#endif
 #define AFE_PERSIST_TICK 1ull
 #define AFE_PERSIST_PARK 2ull
 #define AFE_PERSIST_HOST_RING 4096

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "afe_aql.h"
@@ -138,6 +139,7 @@ struct afe_engine {
   bool view_exported = false;       // afe_get_device_view has handed the slabs to somebody: afe_sync must leave them readable
   uint64_t p_grid_ns = 0, p_grid_steps = 0;          // device time and steps of the grids collected so far (afe_grid_time)
   uint64_t p_launch_start = 0;                       // the step the grid now resident started from
+  bool p_prio = false;                               // the grid now resident balances its workers by issue priority (persist_launch)
   uint64_t p_quiesced = 0;                           // every step below this index is known to be done (the last successful wait)
 
   std::string err;
@@ -618,14 +620,15 @@ void aql_prime_process(afe_engine *e) {
 const afe::AqlKernel *aql_kernel_for(afe_engine *e) {
   // Where the resident grid lives.  On the engine's own queue it survives afe_sync (and no HIP synchronisation waits for
   // it), which is worth a launch and a park per synchronised block; but a dispatch there costs the host 14 us against 3
-  // of a HIP launch, a grid that lives on slows with age, and the pauses between blocks are inside it.  Measured, 20-step
-  // blocks / 2 000-step blocks, us per step, own queue against HIP stream: 131 072 vehicles 3.02 / 2.22 against 3.33 / 2.15;
-  // 262 144: 4.76 / 3.62 against 4.79 / 3.52; 524 288: 11.55 / 10.42 against 11.22 / 10.18; 2^20: 20.20 / 18.89 against
-  // 20.12 / 18.85.  Automatic: the own queue up to 262 144 vehicles, the HIP stream beyond.
+  // of a HIP launch, workers that are done poll where on the HIP stream they would have left, and the pauses between
+  // blocks are inside it.  Measured, 20-step blocks (afe_sync alone on both sides) / 2 000-step blocks, us per step, own
+  // queue against HIP stream: 131 072 vehicles 2.70 / 2.20 against 3.22 / 2.19; 262 144: 4.15 / 3.54 against 4.70 / 3.61;
+  // 524 288: 10.56 / 10.11 against 11.14 / 10.08; 2^20: 20.43 / 19.24 against 20.13 / 19.32.
+  // Automatic: the own queue up to 524 288 vehicles, the HIP stream beyond.
   // afe_set_resident_queue / AFE_PERSIST_AQL = 0 | 1 force one.
   static const int env_mode = [] { const char *s = std::getenv("AFE_PERSIST_AQL"); return !s || !*s ? -1 : (s[0] == '0' ? 0 : 1); }();
   const int mode = e->aql_mode >= 0 ? e->aql_mode : env_mode;
-  if (mode == 0 || (mode < 0 && e->n > 262144) || e->stream != e->own_stream) return nullptr;
+  if (mode == 0 || (mode < 0 && e->n > 524288) || e->stream != e->own_stream) return nullptr;
   if (!e->aql_tried) {
     e->aql_tried = true;
     std::string why;
@@ -728,7 +731,17 @@ int persist_launch(afe_engine *e) {
   a.n_chunks = (int)((e->n + 63) / 64);
   a.idle_ticks = 20000;         // 200 us
   a.give_up_ticks = 5000000;    // 50 ms without any progress while steps are waiting
-  a.epoch = (++e->p_epoch & 0xffffu) | (e->host_arena ? AFE_PERSIST_HOST_IO : 0u);
+  // Issue priority by steps in hand (afe_kernels.hip, persist_set_priority): where workers share a SIMD and the step is
+  // bound by instruction issue and latency, not by HBM.  Measured (tools/sync_cost_probe.py / refresh_probe.py, 20-step /
+  // 2 000-step blocks, us per step without -> with): 131 072 vehicles 2.88 -> 2.70 / 2.36 -> 2.20, 262 144 4.96 -> 4.19 /
+  // 4.21 -> 3.58, 393 216 6.9 -> 6.7 / 6.4 -> 5.95, 524 288 11.4 -> 11.3 / 10.7 -> 10.1; one worker per SIMD (65 536) 2.13 ->
+  // 2.18: nothing to arbitrate; 2^20 (2.7 chunks per worker, HBM-bound) 20.3 -> 20.5 / no change: waves in step with each
+  // other load together and compute together.  AFE_PERSIST_PRIO=0|1 forces it (measurement aid).
+  static const int prio_env = [] { const char *s = std::getenv("AFE_PERSIST_PRIO"); return s && *s ? std::atoi(s) : -1; }();
+  const int64_t chunks_now = (e->n + 63) / 64;
+  const bool prio = prio_env >= 0 ? prio_env != 0 : (e->p_workers > 4 * e->p_cus && chunks_now <= 2 * (int64_t)e->p_workers);
+  e->p_prio = prio;
+  a.epoch = (++e->p_epoch & 0xffffu) | (e->host_arena ? AFE_PERSIST_HOST_IO : 0u) | (prio ? AFE_PERSIST_PRIO : 0u);
   // The books at step p_resume, where this grid starts (the host's own clock, tick count and gust epoch are already
   // those of step p_next, the end of everything authorised): its start time is linear in the step index since
   // p_seg_start; the ticks before it are the engine's count less the tick flags of the entries still ahead of it;
@@ -873,8 +886,83 @@ int quiesce(afe_engine *e) {
       }
       if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
         return fail(e, AFE_ERR_HIP, "persistent step kernel makes no progress");
+      static const long nap = [] { const char *s = std::getenv("AFE_QUIESCE_NAP_US"); return s && *s ? std::atol(s) : 0L; }();
+      if (nap > 0) std::this_thread::sleep_for(std::chrono::microseconds(nap));
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+#ifdef AFE_SYNC_TRACE
+    {
+      static int calls = 0;
+      if (e->p_running && (++calls % 64) == 0) {
+        const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        const long long tm = (long long)st[AFE_PERSIST_TRACE_BASE + 1], tr = (long long)st[AFE_PERSIST_TRACE_BASE];
+        std::vector<long long> out, ans;
+        for (int w = 0; w < e->p_workers && w < 8192; w++) { out.push_back((long long)st[AFE_PERSIST_TRACE_BASE + 4 + w] - tm); ans.push_back((long long)st[AFE_PERSIST_TRACE_BASE + 4 + 8192 + w] - tm); }
+        std::sort(out.begin(), out.end()); std::sort(ans.begin(), ans.end());
+        const size_t k = out.size();
+        std::fprintf(stderr, "sync trace: host waited %.1f us; pump saw the request %.2f us before the marker; workers ran out of steps at %.2f / %.2f / %.2f / %.2f / %.2f us "
+                             "(min / 10 %% / median / 90 %% / max) and answered at %.2f / %.2f / %.2f us (min / median / max) after the marker\n",
+                     host_us, (tm - tr) / 100.0, out[0] / 100.0, out[k / 10] / 100.0, out[k / 2] / 100.0, out[k * 9 / 10] / 100.0, out[k - 1] / 100.0,
+                     ans[0] / 100.0, ans[k / 2] / 100.0, ans[k - 1] / 100.0);
+        {
+          const long long tn = (long long)st[AFE_PERSIST_TRACE_BASE + 2];
+          std::vector<long long> stt;
+          for (int w = 0; w < e->p_workers && w < 8192; w++) stt.push_back((long long)st[AFE_PERSIST_TRACE_BASE + 4 + 3 * 8192 + w] - tn);
+          std::sort(stt.begin(), stt.end());
+          { const unsigned long long h = st[AFE_PERSIST_TRACE_BASE - 2];
+            std::fprintf(stderr, "   pump on xcc/se/cu/simd %llu/%llu/%llu/%llu\n", (h >> 32) & 15, (h >> 13) & 7, (h >> 8) & 15, (h >> 4) & 3); }
+          std::fprintf(stderr, "   pump: %.1f us of the following inside the scalar probes\n", st[AFE_PERSIST_TRACE_BASE - 1] / 100.0);
+          std::fprintf(stderr, "   pump: %llu iterations in the %.1f us between two markers = %.2f us each\n", (unsigned long long)(st[AFE_PERSIST_TRACE_BASE + 3] >> 32),
+                       (st[AFE_PERSIST_TRACE_BASE + 3] & 0xffffffffull) / 100.0, (st[AFE_PERSIST_TRACE_BASE + 3] & 0xffffffffull) / 100.0 / std::max<double>(1.0, (double)(st[AFE_PERSIST_TRACE_BASE + 3] >> 32)));
+          std::fprintf(stderr, "   from the pump's first sight of the block: workers started at %.2f / %.2f / %.2f / %.2f us (min / median / 90 %% / max); request seen at %.2f, marker at %.2f, "
+                               "workers out at %.2f / %.2f / %.2f (median / 90 %% / max), last answer at %.2f us\n",
+                       stt[0] / 100.0, stt[k / 2] / 100.0, stt[k * 9 / 10] / 100.0, stt[k - 1] / 100.0, (tr - tn) / 100.0, (tm - tn) / 100.0,
+                       (out[k / 2] + tm - tn) / 100.0, (out[k * 9 / 10] + tm - tn) / 100.0, (out[k - 1] + tm - tn) / 100.0, (ans[k - 1] + tm - tn) / 100.0);
+        }
+        // finish time against how many of the grid's waves share the wave's SIMD (HW_ID: simd 5:4, cu 11:8, sh 12, se 15:13; XCC_ID 3:0)
+        std::map<unsigned long long, std::vector<long long>> by_simd, by_cu;
+        for (int w = 0; w < e->p_workers && w < 8192; w++) {
+          const unsigned long long h = st[AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + w];
+          const unsigned long long cu = ((h >> 8) & 0xff) | ((h >> 32) & 0xf) << 8;
+          const long long t = (long long)st[AFE_PERSIST_TRACE_BASE + 4 + w] - tm;
+          by_cu[cu].push_back(t); by_simd[cu << 2 | ((h >> 4) & 3)].push_back(t);
+        }
+        std::map<size_t, std::pair<int, double>> per_share, per_cu_share;
+        for (auto &kv : by_simd) for (long long t : kv.second) { auto &r = per_share[kv.second.size()]; r.first++; r.second += t / 100.0; }
+        for (auto &kv : by_cu) for (long long t : kv.second) { auto &r = per_cu_share[kv.second.size()]; r.first++; r.second += t / 100.0; }
+        {
+          double xs[16] = {0}, ses[8] = {0}, bs[16] = {0}; int xn[16] = {0}, sen[8] = {0}, bn[16] = {0};
+          for (int w = 0; w < e->p_workers && w < 8192; w++) {
+            const unsigned long long h = st[AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + w];
+            const double t = ((long long)st[AFE_PERSIST_TRACE_BASE + 4 + w] - tm) / 100.0;
+            xs[(h >> 32) & 15] += t; xn[(h >> 32) & 15]++; ses[(h >> 13) & 7] += t; sen[(h >> 13) & 7]++;
+            const int b = (int)((long long)w * 16 / e->p_workers); bs[b] += t; bn[b]++;
+          }
+          std::fprintf(stderr, "   by XCC:"); for (int i = 0; i < 16; i++) if (xn[i]) std::fprintf(stderr, " %d: %.0f (%d)", i, xs[i] / xn[i], xn[i]);
+          std::fprintf(stderr, "\n   by SE:"); for (int i = 0; i < 8; i++) if (sen[i]) std::fprintf(stderr, " %d: %.0f (%d)", i, ses[i] / sen[i], sen[i]);
+          std::fprintf(stderr, "\n   by sixteenth of the worker index:"); for (int i = 0; i < 16; i++) if (bn[i]) std::fprintf(stderr, " %.0f", bs[i] / bn[i]);
+          std::fprintf(stderr, "\n   slowest 16 workers (index, xcc, se, cu, simd):");
+          std::vector<std::pair<long long, int>> tw;
+          for (int w = 0; w < e->p_workers && w < 8192; w++) tw.push_back({(long long)st[AFE_PERSIST_TRACE_BASE + 4 + w] - tm, w});
+          std::sort(tw.begin(), tw.end());
+          for (size_t i = tw.size() - 64; i < tw.size(); i++) { const unsigned long long h = st[AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + tw[i].second];
+            std::fprintf(stderr, " %d:%llu/%llu/%llu/%llu=%.0f", tw[i].second, (h >> 32) & 15, (h >> 13) & 7, (h >> 8) & 15, (h >> 4) & 3, tw[i].first / 100.0); }
+          { int late[16] = {0}; const long long med = tw[tw.size() * 3 / 4].first;
+            for (auto &x : tw) if (x.first > med + 1500) late[(st[AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + x.second] >> 32) & 15]++;
+            std::fprintf(stderr, "\n   more than 15 us behind the third quartile, by XCC:"); for (int i = 0; i < 8; i++) std::fprintf(stderr, " %d", late[i]); }
+          std::fprintf(stderr, "\n   fastest 16:");
+          for (size_t i = 0; i < 16; i++) { const unsigned long long h = st[AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + tw[i].second];
+            std::fprintf(stderr, " %d:%llu/%llu/%llu/%llu", tw[i].second, (h >> 32) & 15, (h >> 13) & 7, (h >> 8) & 15, (h >> 4) & 3); }
+          std::fprintf(stderr, "\n");
+        }
+        std::fprintf(stderr, "   %zu SIMDs, %zu CUs in use; by waves on the SIMD:", by_simd.size(), by_cu.size());
+        for (auto &kv : per_share) std::fprintf(stderr, "  %zu: %d waves, mean %.1f us;", kv.first, kv.second.first, kv.second.second / kv.second.first);
+        std::fprintf(stderr, "\n   by waves on the CU:");
+        for (auto &kv : per_cu_share) std::fprintf(stderr, "  %zu: %d waves, mean %.1f us;", kv.first, kv.second.first, kv.second.second / kv.second.first);
+        std::fprintf(stderr, "\n");
+      }
+    }
+#endif
     e->p_quiesced = e->p_next;
   }
   if (!e->p_running && e->stream_pending) {
@@ -942,13 +1030,16 @@ int persist_step(afe_engine *e, uint64_t dt_us, int n_steps) {
   if (e->p_running && (e->p_dt_us != dt_us || f.ext_force != e->p_flags.ext_force || f.noise != e->p_flags.noise || f.logic != e->p_flags.logic || f.counter_noise != e->p_flags.counter_noise))
     if ((rc = persist_park(e))) return rc;
   volatile unsigned long long *st = p_status(e);
-  // A resident grid slows down as it ages: measured at 2^20 / 2^19 / 131 072 vehicles, grids retired after 512 steps
-  // step 2.7 / 3 / 6 % faster than grids that live on (19.58 -> 19.05, 10.6 -> 10.3, 2.35 -> 2.21 us per step; the same
-  // with a fresh grid per block: tools/sync_cost_probe.py).  Why is open (the waves' drift apart is
-  // the suspect; re-aligning them at a sync marker does not help, a fresh dispatch does).  So a grid that has served
-  // persist_refresh_steps() steps is retired here -- the host waits for what it has authorised, ~20 us of dispatch follow --
-  // and at the next afe_sync (afe_sync below).  AFE_PERSIST_REFRESH_STEPS=0: never.
-  if (e->p_running && persist_refresh_steps() > 0 && (long)(e->p_next - e->p_launch_start) >= persist_refresh_steps() && (rc = persist_park(e))) return rc;
+  // A grid whose workers do NOT finish a block together steps faster when it is retired now and then: 2^20 vehicles on
+  // the own queue, 2 000-step blocks, 19.6 -> 19.2 us per step with grids retired after 512 steps (tools/refresh_probe.py).
+  // Not age (round 4's first reading; tools/ageing_probe.py shows a grid's windows getting no slower): the workers that
+  // finish their share early -- those with two chunks where others have three -- LEAVE at a park entry and stop competing,
+  // while in a grid that stays they poll the ring until the slowest is done.  Where issue priority keeps the workers
+  // together (persist_launch) there is nobody to send home and a grid lives on (131 072 / 262 144 vehicles, retired against
+  // not: 2.20 / 3.54 against 2.19 / 3.51).  Otherwise a grid that has served persist_refresh_steps() steps is retired here
+  // -- the host waits for what it has authorised, ~20 us of dispatch follow -- and at the next afe_sync (afe_sync below).
+  // AFE_PERSIST_REFRESH_STEPS=0: never.
+  if (e->p_running && !e->p_prio && persist_refresh_steps() > 0 && (long)(e->p_next - e->p_launch_start) >= persist_refresh_steps() && (rc = persist_park(e))) return rc;
   if (e->p_running && st[0] != 0) {       // it parked itself (idle): collect it, a new grid starts below
     if ((rc = persist_collect(e))) return rc;
   }
@@ -1618,7 +1709,7 @@ extern "C" int afe_sync(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
   if (e->p_running && e->p_on_aql && !e->view_exported &&
-      !(persist_refresh_steps() > 0 && (long)(e->p_next - e->p_launch_start) >= persist_refresh_steps())) {     // (an aged grid is retired: persist_step)
+      !(!e->p_prio && persist_refresh_steps() > 0 && (long)(e->p_next - e->p_launch_start) >= persist_refresh_steps())) {     // (an aged grid is retired: persist_step)
     // Every authorised step has run and its stores are acknowledged; the grid STAYS (it lives on the engine's own queue,
     // which no HIP synchronisation waits for) and takes the next afe_step without a launch.  Whoever reads the state does
     // so through an entry point of the engine, which ends the grid first (kernel end = the caches written back).  Once

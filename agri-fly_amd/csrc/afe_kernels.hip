@@ -976,6 +976,28 @@ __device__ __forceinline__ u64_t ld_agent(const u64_t *p) { return __hip_atomic_
 __device__ __forceinline__ void st_agent(u64_t *p, u64_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64_t ld_system(const u64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_system(u64_t *p, u64_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Two words of host memory through the SCALAR memory path (the scalar cache is dropped first: what the host wrote since
+// the last look must come from memory).  Why not a vector load: a CU returns vector-memory data in order, so every load of
+// every wave on the pump's CU queues behind the pump's ~1.5 us read across PCIe -- the eight workers that share the CU
+// lose 0.25 us per step, and a synchronised block ends when ITS slowest worker does (tools/ageing_probe.py with
+// -DAFE_SYNC_TRACE: four workers of 2 048, all on the pump's CU, finished 65 us behind everybody else in a block of 256
+// steps).  Scalar loads return out of order and go round that queue.
+typedef unsigned int afe_u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ u64_t afe_uniform64(unsigned long long a) {
+  return ((u64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+}
+// eight consecutive words at p0 (no wrap inside) and one at p1; glc: past the scalar cache, from memory
+__device__ __forceinline__ void sld_system_8_1(const u64_t *p0, const u64_t *p1, u64_t (&x)[8], u64_t &y) {
+  afe_u32x16 v;
+  const u64_t u0 = afe_uniform64((unsigned long long)p0), u1 = afe_uniform64((unsigned long long)p1);
+  asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx2 %1, %3, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v), "=&s"(y) : "s"(u0), "s"(u1) : "memory");
+#pragma unroll
+  for (int i = 0; i < 8; i++) x[i] = ((u64_t)v[2 * i + 1] << 32) | v[2 * i];
+}
+__device__ __forceinline__ void sld_system2(const u64_t *p0, const u64_t *p1, u64_t &x0, u64_t &x1) {
+  const u64_t u0 = afe_uniform64((unsigned long long)p0), u1 = afe_uniform64((unsigned long long)p1);
+  asm volatile("s_load_dwordx2 %0, %2, 0x0 glc\n\ts_load_dwordx2 %1, %3, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(x0), "=&s"(x1) : "s"(u0), "s"(u1) : "memory");
+}
 __device__ __forceinline__ u64_t ticks100() { return __builtin_amdgcn_s_memrealtime(); }   // 100 MHz, constant
 __device__ __forceinline__ int ones_from_bit0(u64_t m) { return m == ~0ull ? 64 : (int)__builtin_ctzll(~m); }
 // ring entry: bits 0-1 flags, 2-47 step index + 1, 48-63 the launch that published it (device ring only: a park entry
@@ -1013,28 +1035,69 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
   if (lane == 0) st_agent(persist_sync_counters(a) + 16 * AFE_PERSIST_SYNC_SHARDS, 0);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   u64_t req_marked = 0;
+#ifdef AFE_SYNC_TRACE
+  u64_t req_seen = 0;
+  bool had_news = false;
+  u64_t trace_iters = 0, trace_t0 = ticks100(), trace_probe = 0;
+  if (lane == 0) st_system(a.host_status + AFE_PERSIST_TRACE_BASE - 2, (u64_t)__builtin_amdgcn_s_getreg(63492) | ((u64_t)__builtin_amdgcn_s_getreg(63508) << 32));
+#endif
   u64_t acc = ~0ull;                    // this lane's minimum over the part of done[] swept so far in the current cycle
   int sw = 0;                           // where the next partial sweep starts
+  u64_t d[8];                           // a slice of done[] (and the help word) on its way: asked for at the end of one iteration,
+  u64_t help_in = 0, help_seen = 0;     //   looked at two iterations later, when it has long arrived -- nobody waits for it
+  int slice_age = -1;                   // iterations since the slice was asked for (-1: none under way)
+#pragma unroll
+  for (int j = 0; j < 8; j++) d[j] = ~0ull;
   for (;;) {
-    // (1) the host's next entries and a slice of the workers' progress, both in flight together: the host read takes
-    // ~1.5 us, and an iteration must not take much longer than that (a park entry waits for one iteration).  512 workers
-    // per iteration; a cycle over a full grid of 6 143 takes 12 iterations, so `m` and the host's completion word are at
-    // most ~30 us old -- `m` errs low, which only makes the ring's window and the patience below conservative.
+    // (1) The host's next entries and the sync request: ONE trip across PCIe per iteration (~1.1 us), through the scalar
+    // path (sld_system_8_1 says why).  A host a few entries ahead is served from those eight words; the vector read of up
+    // to 64 entries only when all eight are waiting (the host is far ahead: a second trip costs nobody anything).
+    // The workers' progress comes in slices of 512 marks that are never waited for (above): a cycle over a full grid of
+    // 6 143 takes 36 iterations, so `m` and the host's completion word are up to ~50 us old (every iteration when the
+    // ring's window is nearly used up) -- `m` errs low, which only makes the window and the patience below conservative.
     const u64_t idx = p + (u64_t)lane;
-    const u64_t h = ld_system(a.host_ring + (idx & a.host_mask));
-    const u64_t req = ld_system(a.host_status + AFE_PERSIST_SYNCREQ_WORD);     // (in flight with the ring read: no iteration gets longer)
-    u64_t d[8];
+#ifdef AFE_SYNC_TRACE
+    trace_iters++;
+    const u64_t trace_ta = ticks100();
+#endif
+    u64_t e8[8], req;
+    const u64_t slot = p & a.host_mask;
+    if (slot + 8 <= a.host_mask + 1) sld_system_8_1(a.host_ring + slot, a.host_status + AFE_PERSIST_SYNCREQ_WORD, e8, req);
+    else {                                         // (the eight would wrap: the next one alone)
+      sld_system2(a.host_ring + slot, a.host_status + AFE_PERSIST_SYNCREQ_WORD, e8[0], req);
 #pragma unroll
-    for (int j = 0; j < 8; j++) { const int w = sw + lane + 64 * j; d[j] = w < a.n_workers ? ld_agent(a.done + w) : ~0ull; }
+      for (int i = 1; i < 8; i++) e8[i] = 0;
+    }
+    const bool news = entry_index(e8[0]) == p + 1;
+#ifdef AFE_SYNC_TRACE
+    trace_probe += ticks100() - trace_ta;
+    if (news && !had_news && lane == 0) st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 2, ticks100());
+    had_news = news;
+#endif
+    bool all8 = true;
 #pragma unroll
-    for (int j = 0; j < 8; j++) acc = d[j] < acc ? d[j] : acc;
-    sw += 512;
-    if (sw >= a.n_workers) {
-      u64_t r = acc;
+    for (int i = 0; i < 8; i++) all8 = all8 && entry_index(e8[i]) == p + 1 + (u64_t)i;
+    const bool fetch = all8 && p + 64 < m + (u64_t)a.dev_mask + 1;
+    u64_t h = 0;
+    if (fetch) h = ld_system(a.host_ring + (idx & a.host_mask));
+    else {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { const u64_t other = __shfl_xor(r, o, 64); r = other < r ? other : r; }
-      m = r; acc = ~0ull; sw = 0;
-      if (lane == 0) st_system(a.host_status + 1, m);
+      for (int i = 0; i < 8; i++) h = lane == i ? e8[i] : h;
+    }
+    const bool tight = p + 192 >= m + (u64_t)a.dev_mask + 1;       // the window is nearly used up: a fresh `m` every iteration
+    if (slice_age >= (tight ? 0 : 2)) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc = d[j] < acc ? d[j] : acc;
+      help_seen = help_in;
+      slice_age = -1;
+      sw += 512;
+      if (sw >= a.n_workers) {
+        u64_t r = acc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const u64_t other = __shfl_xor(r, o, 64); r = other < r ? other : r; }
+        m = r; acc = ~0ull; sw = 0;
+        if (lane == 0) st_system(a.host_status + 1, m);
+      }
     }
     // (2) up to 64 new entries, in order, never more than a device ring (less one sweep) ahead of the slowest worker
     const bool ready = entry_index(h) == idx + 1;
@@ -1050,19 +1113,26 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
     // index and BOTH flags, which no step and no park ever carries.  A worker that finds it under its own count answers
     // once (persistent kernel below); the next real entry for that slot simply overwrites it.  (Slot p is free: as for a
     // park entry.)
+#ifdef AFE_SYNC_TRACE
+    if (req != req_marked && req != req_seen) { req_seen = req; if (lane == 0) st_system(a.host_status + AFE_PERSIST_TRACE_BASE, ticks100()); }
+#endif
     if (req != req_marked && req == p) {
       if (lane == 0) st_agent(a.dev_ring + (p & a.dev_mask), entry_stamp(((p + 1) << 2) | AFE_PERSIST_PARK | AFE_PERSIST_TICK, a.epoch));
       req_marked = req;
+#ifdef AFE_SYNC_TRACE
+      if (lane == 0) { st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 1, ticks100()); st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 3, (trace_iters << 32) | (ticks100() - trace_t0)); st_system(a.host_status + AFE_PERSIST_TRACE_BASE - 1, trace_probe); }
+      trace_iters = 0; trace_t0 = ticks100(); trace_probe = 0;
+#endif
     }
     const u64_t now = ticks100();
-    const bool fed = (__ballot(ready) & 1ull) != 0;       // the host is ahead of us (there may just be no room yet)
+    const bool fed = news;                                 // the host is ahead of us (there may just be no room yet)
     if (fed || m < p) t_fed = now;                         // patience runs only while the workers have nothing left to do:
                                                            // the completion word stays true to the end, and a grid with work never leaves
     if (cnt > 0 || !fed || m != m_seen) t_moving = now;    // not stuck: entries moved, or there were none to move, or the slowest worker advanced
     m_seen = m;
     // (3) nobody feeds us: park at p.  Slot p is free: p < min_done + ring by (2).
     const bool idle = now - t_fed > (u64_t)a.idle_ticks;
-    const bool gave_up = now - t_moving > (u64_t)a.give_up_ticks || ld_agent(help) != 0;   // entries waiting and the workers never made room, or a worker starved
+    const bool gave_up = now - t_moving > (u64_t)a.give_up_ticks || help_seen != 0;       // entries waiting and the workers never made room, or a worker starved
     if (idle && !gave_up) {
       // Leaving because the host is quiet must not race with a host that speaks at this very moment (an entry written
       // between our last look at slot p and the status word below would wait for a grid nobody starts): say where we
@@ -1083,6 +1153,12 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
       if (gave_up) err = 1;
       break;
     }
+    if (slice_age < 0) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { const int w = sw + lane + 64 * j; d[j] = w < a.n_workers ? ld_agent(a.done + w) : ~0ull; }
+      help_in = ld_agent(help);
+      slice_age = 0;
+    } else slice_age++;
   }
   if (err) {
     // what the pump saw when it gave up, for the host's message: the slowest worker, how many stand with it, where the
@@ -1113,6 +1189,20 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
     if (err) st_system(a.host_status + 2, err);
     st_system(a.host_status + 0, park_pos + 1);
   }
+}
+
+// Issue priority by the steps a worker still has in hand.  The waves of a SIMD are served oldest first, so of two (four,
+// six) workers that share one the first-dispatched runs ahead at the latency-bound pace of a wave alone (1.6 us per step
+// at 131 072 vehicles) and the last-dispatched gets what is left -- and then finishes the block alone, at that same
+// latency-bound pace, with the SIMD three quarters idle (tools/ageing_probe.py with -DAFE_SYNC_TRACE: the halves of a
+// 2 048-worker grid ran out of a 256-step block at 284 and 429 us).  Whoever has more steps left goes first instead:
+// the laggard catches up while the SIMD is still shared, and the block ends when the SIMD's work does.  Level 0 stays
+// with the pump (the oldest wave of its SIMD; it needs few slots and must not take them from a worker).
+__device__ __forceinline__ void persist_set_priority(const PersistArgs &a, int steps_left) {
+  if (!(a.epoch & AFE_PERSIST_PRIO)) return;
+  if (steps_left >= 8) __builtin_amdgcn_s_setprio(3);
+  else if (steps_left >= 4) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(1);
 }
 
 // host-visible arenas: system-scope fences around a step's slab accesses.  (Measured: the cheaper pair -- invalidate the
@@ -1148,6 +1238,13 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
     const bool marker = ready && (e & 3ull) == 3ull;                        // the pump's sync marker: not a step, not a park
     const int cnt = ones_from_bit0(__ballot(ready && !marker));
     if (cnt == 0) {
+#ifdef AFE_SYNC_TRACE
+      if (idle_polls == 0 && lane == 0 && w < 8192) {
+        st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 4 + w, ticks100());
+        st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + w, (u64_t)__builtin_amdgcn_s_getreg(63492) | ((u64_t)__builtin_amdgcn_s_getreg(63508) << 32));
+      }
+      if (!sync_answered && (__ballot(marker) & 1ull) && lane == 0 && w < 8192) st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 4 + 8192 + w, ticks100());
+#endif
       if (!sync_answered && (__ballot(marker) & 1ull)) {
         // the host waits for everything before this slot and this wave has done it: say so once.  The stores of the last
         // step are acknowledged first.  Arrivals never interleave between two requests (the host waits for each), so a
@@ -1190,6 +1287,9 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
       for (int b = 1; b < (1 << ex); b++) __builtin_amdgcn_s_sleep(2);
       continue;
     }
+#ifdef AFE_SYNC_TRACE
+    if (idle_polls > 0 && lane == 0 && w < 8192) st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 4 + 3 * 8192 + w, ticks100());
+#endif
     idle_polls = 0; sync_answered = false;
     // host-visible arena (afe_create_host_visible): what the host wrote before it authorised these steps is read from
     // host memory, not from a cache line of an earlier step
@@ -1221,6 +1321,7 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
         t_us += (u64_t)run * a.dt_us;
       }
       if (run > 0) {
+        persist_set_priority(a, run);
         const u64_t batch_ticks = ticks & (run == 64 ? ~0ull : ((1ull << run) - 1));
         for (int c = w; c < a.n_chunks; c += a.n_workers) {
           const int64_t i = (int64_t)c * 64 + lane;
@@ -1239,6 +1340,7 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
       continue;
     }
     for (int k = 0; k < run; k++) {
+      persist_set_priority(a, run - k);
       const u64_t tick = (ticks >> k) & 1ull;                              // wave-uniform (scalar)
       if (a.gust_period_us) {
         while (t_us >= gust_next_us) { gust_epoch++; gust_next_us += a.gust_period_us; }

@@ -96,7 +96,7 @@ for name, src, log, block in (("blocks_of_20_steps", "prof_k20_%s" % tag, "gridl
         summary[name] = {"error": "%d dispatches in the trace, %d grids in the engine's log" % (nd, ng)}
         continue
     served = [(dur, s) for dur, s in p if s > 0]
-    # the grids that lived through the timed blocks (a grid is retired after 512 steps): in dispatch order they come before the
+    # the grids that lived through the timed blocks (where workers are not kept together by issue priority a grid is retired after 512 steps): in dispatch order they come before the
     # first grid that served exactly one block (bench.py's event-style measurement follows its timed region)
     first_one = next((i for i, (_, s) in enumerate(served) if s == block), len(served))
     long_ = [(dur, s) for dur, s in served[:first_one] if s >= 256 or s > 4 * block]
@@ -107,7 +107,7 @@ for name, src, log, block in (("blocks_of_20_steps", "prof_k20_%s" % tag, "gridl
         dur, s = sum(d for d, _ in long_), sum(st for _, st in long_)
         rec["resident_through_the_timed_blocks"] = {"dispatches": len(long_), "steps": s, "device_ms": dur / 1e6, "us_per_step": dur / s / 1e3,
                                                     "algorithmic_GBs": N * BYTES_MEAN / (dur / s), "frac_of_8TBs": N * BYTES_MEAN / (dur / s) / 8000.0,
-                                                    "note": "the grids that lived through several blocks (a grid is retired after 512 steps), each from its first wave to its park; "
+                                                    "note": "the grids that lived through several blocks (2^20 vehicles: a grid is retired after 512 steps), each from its first wave to its park; "
                                                             "the host's pauses between blocks (barrier + synchronise + the clock) are inside"}
     if one_block:
         t = median(one_block)
