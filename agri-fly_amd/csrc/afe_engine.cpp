@@ -733,7 +733,7 @@ int persist_launch(afe_engine *e) {
   a.give_up_ticks = 5000000;    // 50 ms without any progress while steps are waiting
   // Issue priority by steps in hand (afe_kernels.hip, persist_set_priority): where workers share a SIMD and the step is
   // bound by instruction issue and latency, not by HBM.  Measured (tools/sync_cost_probe.py / refresh_probe.py, 20-step /
-  // 2 000-step blocks, us per step without -> with): 131 072 vehicles 2.88 -> 2.70 / 2.36 -> 2.20, 262 144 4.96 -> 4.19 /
+  // 2 000-step blocks, us per step without -> with, fixed bands of 8 / 4 steps): 131 072 vehicles 2.88 -> 2.70 / 2.36 -> 2.20, 262 144 4.96 -> 4.19 /
   // 4.21 -> 3.58, 393 216 6.9 -> 6.7 / 6.4 -> 5.95, 524 288 11.4 -> 11.3 / 10.7 -> 10.1; one worker per SIMD (65 536) 2.13 ->
   // 2.18: nothing to arbitrate; 2^20 (2.7 chunks per worker, HBM-bound) 20.3 -> 20.5 / no change: waves in step with each
   // other load together and compute together.  AFE_PERSIST_PRIO=0|1 forces it (measurement aid).
