@@ -314,6 +314,14 @@ __device__ __forceinline__ void six_normals(uint32_t &s, float d[6]) {
 //   r = sqrt(-2 ln u_r);  z_a = r cos(2 pi u_a);  z_b = r sin(2 pi u_a)
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  // The key is wave-uniform and the same for every step: left alone, the compiler forms the twenty round keys once,
+  // outside the step loop, carries them in scalar registers it does not have, and brings each back with a v_readlane
+  // where a scalar add would have made it (22 of the 55 lane reads of a step).  Opaque here: the adds stay here
+  // (131 072 vehicles 2.13 -> 2.01 us per step, 4 096 vehicles 1.66 -> 1.58).
+  asm volatile("" : "+s"(k0), "+s"(k1));
+  // (the products as ONE v_mad_u64_u32 each instead of v_mul_hi_u32 + v_mul_lo_u32 -- 10.5 against 2 x 7.75 cycles of issue,
+  // tools/mul_rate_probe.hip -- measured in the kernel: nothing at 131 072 vehicles, 4 % slower at 4 096, where one wave
+  // has a SIMD to itself and the chain of ten rounds waits for the longer instruction.  Not used.)
 #pragma unroll
   for (int r = 0; r < 10; r++) {
     const uint32_t h0 = __umulhi(M0, c[0]), l0 = M0 * c[0], h1 = __umulhi(M1, c[2]), l1 = M1 * c[2];
@@ -1235,6 +1243,8 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
   u64_t gust_in_slab = a.gust_epoch_applied, gust_epoch = a.gust_epoch0;
   u64_t gust_next_us = (a.gust_epoch0 + 1) * a.gust_period_us, t_us = a.t0_us;
   bool sync_answered = false;                        // this wave has answered the sync marker standing at its count
+  // fewer chunks than the most loaded worker by a quarter or more: time to spare in every step
+  const bool spare = 4 * ((a.n_chunks - w + a.n_workers - 1) / a.n_workers) <= 3 * ((a.n_chunks + a.n_workers - 1) / a.n_workers);
   for (;;) {
     const u64_t idx = s + (u64_t)lane;
     const u64_t e = ld_agent(a.dev_ring + (idx & a.dev_mask));
@@ -1286,7 +1296,10 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevL
       // (the first ~30 us of a wait stop at ~0.5 us between polls: a host that synchronises after every block of steps
       // comes back within microseconds, and the first step of its next block should not wait 2 us for each wave to look)
       if (idle_polls < 64 && !(a.epoch & AFE_PERSIST_HOST_IO)) idle_polls++;   // (a host-visible arena means few waves and a host waiting on every step: they keep polling)
-      const int ex = idle_polls < 3 ? idle_polls : (idle_polls < 64 ? 3 : 5);
+      // (a worker with fewer chunks than the others -- two where most have three at 2^20 vehicles -- runs out of every block
+      // early and has a third of every step to spare: it looks every ~8 us from its fourth poll on.  Its polls were what a
+      // grid that stays paid for not sending it home: 2^20 vehicles on the own queue, 64-step windows, 19.5 -> 19.1 us per step)
+      const int ex = idle_polls < 3 ? idle_polls : (spare ? 7 : (idle_polls < 64 ? 3 : 5));
       __builtin_amdgcn_s_sleep(2);
       for (int b = 1; b < (1 << ex); b++) __builtin_amdgcn_s_sleep(2);
       continue;
