@@ -624,11 +624,14 @@ const afe::AqlKernel *aql_kernel_for(afe_engine *e) {
   // blocks are inside it.  Measured, 20-step blocks (afe_sync alone on both sides) / 2 000-step blocks, us per step, own
   // queue against HIP stream: 131 072 vehicles 2.70 / 2.20 against 3.22 / 2.19; 262 144: 4.15 / 3.54 against 4.70 / 3.61;
   // 524 288: 10.56 / 10.11 against 11.14 / 10.08; 2^20: 20.43 / 19.24 against 20.13 / 19.32.
-  // Automatic: the own queue up to 524 288 vehicles, the HIP stream beyond.
-  // afe_set_resident_queue / AFE_PERSIST_AQL = 0 | 1 force one.
+  // Automatic: the own queue up to 262 144 vehicles, the HIP stream beyond -- not 524 288, where the own queue is 5 % ahead in
+  // 20-step blocks: from ~400 000 vehicles on a grid holds every wave slot of the device, and a grid that afe_sync leaves
+  // resident makes whatever else the process launches next (an RCCL collective between two blocks, a torch kernel) wait
+  // for its 200 us of idle patience; at 262 144 it holds 16 of a compute unit's 24 and others run beside it.
+  // afe_set_resident_queue / AFE_PERSIST_AQL = 0 | 1 force one (with afe_set_reserved_compute_units where others must run).
   static const int env_mode = [] { const char *s = std::getenv("AFE_PERSIST_AQL"); return !s || !*s ? -1 : (s[0] == '0' ? 0 : 1); }();
   const int mode = e->aql_mode >= 0 ? e->aql_mode : env_mode;
-  if (mode == 0 || (mode < 0 && e->n > 524288) || e->stream != e->own_stream) return nullptr;
+  if (mode == 0 || (mode < 0 && e->n > 262144) || e->stream != e->own_stream) return nullptr;
   if (!e->aql_tried) {
     e->aql_tried = true;
     std::string why;

@@ -897,7 +897,7 @@ class Ensemble:
         self._ck(self._L.afe_set_cache_policy(self._h, int(policy)))
 
     def set_resident_queue(self, mode):
-        """-1 automatic (own queue up to 524 288 vehicles), 0 the HIP stream, 1 the engine's own queue"""
+        """-1 automatic (own queue up to 262 144 vehicles), 0 the HIP stream, 1 the engine's own queue"""
         self._ck(self._L.afe_set_resident_queue(self._h, int(mode)))
 
     def set_reserved_compute_units(self, per_xcd):

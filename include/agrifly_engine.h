@@ -541,7 +541,8 @@ int afe_grid_time(afe_engine *e, uint64_t *device_ns, uint64_t *steps);
 /* Where the resident grid is dispatched: 1 = a user-mode queue of the engine's own (the grid survives afe_sync, no HIP
  * synchronisation of the process waits for it; a dispatch costs the host 14 us), 0 = the engine's HIP stream (every
  * afe_sync ends the grid, a launch costs 3 us, workers that are done leave), -1 = automatic (default): the own queue up to
- * 524 288 vehicles, the HIP stream beyond -- whichever was faster in blocks of 20 and of 2 000 steps.
+ * 262 144 vehicles, where it is faster and the grid leaves a third of the wave slots to others; the HIP stream beyond
+ * (at 524 288 the own queue is 5 % faster in 20-step blocks but the grid fills the device: DESIGN.md section 6).
  * Same bits either way.  Ends the grid now resident.  Replaces nothing in the reference. */
 int afe_set_resident_queue(afe_engine *e, int mode);
 /* Keep compute units out of the resident grid's reach (its queue's compute-unit mask; 0, the default: none).  A resident
