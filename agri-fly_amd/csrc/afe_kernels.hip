@@ -1227,12 +1227,33 @@ __device__ __forceinline__ void persist_set_priority(const PersistArgs &a, int s
 // of 6 143).  The resident-state ones without logic are held to five waves (96 registers; 101-104 on their own, a few
 // dwords of scratch instead): measured 3.1 -> 2.7 us per step at 262 144 vehicles, 11.0 -> 10.7 at 2^20
 template <typename R, bool LOGIC, bool RESIDENT>
-constexpr int persistent_min_waves() { return sizeof(R) != 4 ? 1 : (!RESIDENT ? 6 : (LOGIC ? 1 : 5)); }
+constexpr int persistent_min_waves() { return sizeof(R) != 4 ? 1 : (!RESIDENT ? 6 : (LOGIC ? 3 : 5)); }
+// (resident state + logic, constants from LDS: 136-140 registers on their own, three waves; left alone the noise-free
+// instantiations take 214 and two.  Held to four waves: the same within the noise at every size.)
 template <typename R, bool FEXT, int NOISE, bool LOGIC, bool RESIDENT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(persistent_min_waves<R, LOGIC, RESIDENT>())))
-afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P, const DevLogic G, const PersistArgs a) {
+afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P_arg, const DevLogic G_arg, const PersistArgs a) {
   if (blockIdx.x == 0) { persist_pump(a); return; }
   const int lane = (int)threadIdx.x;
+  // The per-type constants of the kernels that carry the on-device logic AND keep the state in registers from step to
+  // step come from LDS, not from scalar registers: DevParams + DevLogic are 84 dwords beside ~100 of views and loop state
+  // for 102 scalar registers, and the step body brought 154 of them back with a v_readlane each (14 % of its vector
+  // instructions, 80 wait states behind them).  A broadcast ds_read costs no vector issue slot.  Closed loop, us per step
+  // (tools/small_n_probe.py, AFE_STEP_AUTO): 131 072 vehicles 2.54 -> 2.36, 262 144 5.54 -> 5.0, 2^20 20.3 -> 19.6, 4 096
+  // unchanged.  Not for the other instantiations: held to 80 / 96 vector registers for residency they would spill the
+  // temporaries to scratch (measured: the per-step logic kernel 3.14 -> 3.57 at 131 072).
+  constexpr bool lds_params = LOGIC && RESIDENT;
+  __shared__ DevParams<R> P_lds;
+  __shared__ DevLogic G_lds;
+  if (lds_params) {
+    const uint32_t *ps = reinterpret_cast<const uint32_t *>(&P_arg), *gs = reinterpret_cast<const uint32_t *>(&G_arg);
+    uint32_t *pd = reinterpret_cast<uint32_t *>(&P_lds), *gd = reinterpret_cast<uint32_t *>(&G_lds);
+    for (int k = lane; k < (int)(sizeof(DevParams<R>) / 4); k += 64) pd[k] = ps[k];
+    if (LOGIC) for (int k = lane; k < (int)(sizeof(DevLogic) / 4); k += 64) gd[k] = gs[k];
+    __syncthreads();
+  }
+  const DevParams<R> &P = lds_params ? P_lds : P_arg;
+  const DevLogic &G = lds_params ? G_lds : G_arg;
   const int w = (int)blockIdx.x - 1;
   u64_t s = a.start;
   u64_t t_wait = ticks100();

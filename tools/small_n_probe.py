@@ -1,5 +1,5 @@
 """small ensembles (BASELINE config 2 and below): microseconds per step by stepping mode, open loop and with the on-device
-rates logic, one afe_step call per step, 400-step bracketed blocks.   python tools/small_n_probe.py"""
+rates logic, one afe_step call per step, 400-step bracketed blocks.   python tools/small_n_probe.py [vehicles ...]"""
 import importlib, os, sys, time
 import numpy as np
 import torch
@@ -8,7 +8,7 @@ afa = importlib.import_module("agri-fly_amd")
 import bench
 sync = torch.cuda.synchronize
 modes = (("launch", afa.AFE_STEP_LAUNCH), ("persistent", afa.AFE_STEP_PERSISTENT), ("resident", afa.AFE_STEP_RESIDENT), ("auto", afa.AFE_STEP_AUTO))
-for n in (1024, 4096, 16384, 65536, 131072):
+for n in ([int(a) for a in sys.argv[1:]] or (1024, 4096, 16384, 65536, 131072)):
     for closed in (False, True):
         row = []
         for name, mode in modes:
