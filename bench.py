@@ -1094,7 +1094,7 @@ def main():
                                        "note": "one GPU's shard of the 1M-vehicle ensemble on 8 GPUs, measured on this one GPU; shards do not communicate while stepping "
                                                "(no data-path collective), so 8 ranks deliver 8x this rate up to barrier skew -- a projection until the driver's --gpus 8 run.  "
                                                "frac is algorithmic bytes / time / 8 TB/s and can exceed 1 here: the shard's 19 MB live in the XCDs' L2s, HBM sees about one byte per "
-                                               "vehicle-step (profiles/r03c_ns_summary.json)"}
+                                               "vehicle-step (profiles/r04e_ns_summary.json: 1.5 B)"}
             # config 2 closed on the GPU: on-device onboard rates logic, hover command
             closed = []
             for n in (4096, 131072, 1 << 20):
