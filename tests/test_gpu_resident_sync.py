@@ -50,6 +50,35 @@ def test_sync_leaves_the_grid_resident_and_blocks_of_steps_are_the_launched_bits
         assert_same(a, b, "double sync")
 
 
+@pytest.mark.parametrize("n, logic, resident, own_queue", [
+    (200000, False, False, -1),    # 3 125 workers, three or four on a SIMD: issue priority by steps in hand, own queue by size
+    (200000, True, True, -1),      # ... the resident-state kernel with the logic: per-type constants from LDS
+    (400000, False, False, 1),     # 6 250 chunks on 6 143 workers: some have two, most one (they poll every 8 us), priority on
+    (1 << 20, False, False, 1),    # 2.7 chunks per worker: priority off, grids retired after 512 steps
+])
+def test_irregular_blocks_on_grids_of_every_regime_are_the_launched_bits(n, logic, resident, own_queue):
+    """The second half of round 4 changed how a resident grid schedules itself, never what it computes: the pump reads the
+    host's ring through the scalar path (eight entries at a time, 64 when the host is far ahead), workers take issue
+    priority by the steps they have in hand, workers with chunks to spare poll rarely, the logic's constants come from
+    LDS.  Blocks of every length from one step to more than a ring read, posted step by step and in bursts."""
+    a, _ = make(n, afa.AFE_F32, True, logic=logic, resident=resident, seed=11)
+    b, _ = make(n, afa.AFE_F32, False, logic=logic, seed=11)
+    with a, b:
+        a.set_resident_queue(own_queue)
+        total = 0
+        for block, k in enumerate((1, 2, 3, 5, 8, 13, 21, 70, 9, 1, 150, 4)):
+            if block % 3 == 2:
+                a.step(1000, k)                       # one call: the host is k entries ahead at once
+            else:
+                for _ in range(k):
+                    a.step(1000, 1)
+            b.step(1000, k)
+            total += k
+            a.sync()
+            assert a.steps_completed == total
+        assert_same(a, b, "%d vehicles, logic %s, resident state %s, queue %d" % (n, logic, resident, own_queue))
+
+
 def test_a_device_wide_synchronise_neither_waits_for_the_grid_nor_ends_it():
     import torch
     n = 1 << 18
