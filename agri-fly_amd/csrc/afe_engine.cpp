@@ -11,7 +11,6 @@
 #include <cstring>
 #include <map>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "afe_aql.h"
@@ -860,40 +859,12 @@ int persist_park(afe_engine *e) {
   }
 }
 
-// Host-visible arenas: every authorised step has run and nothing is queued -- but a resident grid STAYS (its workers
-// read and write the slabs only between seeing a ring entry and publishing their completion mark, and the pump's
-// completion word is written after the marks it summarises: once it stands at p_next the slabs are the host's).
-int quiesce(afe_engine *e) {
-  join_streams(e);
-  if (e->p_running) {
-    volatile unsigned long long *st = p_status(e);
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0;; spins++) {
-      if (st[0] != 0) {                          // it has parked (idle host, or a stall): collect, finish what is left
-        int rc = persist_collect(e);
-        if (rc) return rc;
-        if (e->p_resume > e->p_next) { e->p_failed = true; return fail(e, AFE_ERR_HIP, "persistent step kernel ran past the authorised steps"); }
-        if (e->p_resume == e->p_next) break;
-        if ((rc = persist_launch(e))) return rc;
-        continue;
-      }
-      if (st[1] >= e->p_next) break;
-      // ask the workers themselves (afe_device.h, sync marker): the pump's sweep over thousands of marks is tens of
-      // microseconds old, a worker answers the moment its own count stands at the request
-      if (st[AFE_PERSIST_SYNCREQ_WORD] != e->p_next) __atomic_store_n(&e->p_host[AFE_PERSIST_HOST_RING + AFE_PERSIST_SYNCREQ_WORD], (unsigned long long)e->p_next, __ATOMIC_RELEASE);
-      if (st[AFE_PERSIST_SYNC_WORD] >= e->p_next) break;
-      if (e->host_arena && e->p_workers <= AFE_PERSIST_HOST_MARKS) {   // small grids write their marks here themselves: no wait for the pump's sweep
-        unsigned long long low = ~0ull;
-        for (int w = 0; w < e->p_workers; w++) { const unsigned long long d = st[8 + w]; low = d < low ? d : low; }
-        if (low >= e->p_next) break;
-      }
-      if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
-        return fail(e, AFE_ERR_HIP, "persistent step kernel makes no progress");
-      static const long nap = [] { const char *s = std::getenv("AFE_QUIESCE_NAP_US"); return s && *s ? std::atol(s) : 0L; }();
-      if (nap > 0) std::this_thread::sleep_for(std::chrono::microseconds(nap));
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
 #ifdef AFE_SYNC_TRACE
+// Development aid (make EXTRA=-DAFE_SYNC_TRACE; tools/ageing_probe.py): the pump and every worker stamp the device's 100 MHz
+// clock into the status block (afe_kernels.hip) -- when the pump first saw a block, saw the sync request, placed the marker;
+// when each worker started, ran out of steps, answered; where it sat (HW_ID / XCC_ID).  Every 64th afe_sync that waited
+// prints the timeline of the block it ended.
+static void sync_trace_report(afe_engine *e, volatile unsigned long long *st, std::chrono::steady_clock::time_point t0) {
     {
       static int calls = 0;
       if (e->p_running && (++calls % 64) == 0) {
@@ -965,6 +936,42 @@ int quiesce(afe_engine *e) {
         std::fprintf(stderr, "\n");
       }
     }
+}
+#endif
+
+// Host-visible arenas: every authorised step has run and nothing is queued -- but a resident grid STAYS (its workers
+// read and write the slabs only between seeing a ring entry and publishing their completion mark, and the pump's
+// completion word is written after the marks it summarises: once it stands at p_next the slabs are the host's).
+int quiesce(afe_engine *e) {
+  join_streams(e);
+  if (e->p_running) {
+    volatile unsigned long long *st = p_status(e);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+      if (st[0] != 0) {                          // it has parked (idle host, or a stall): collect, finish what is left
+        int rc = persist_collect(e);
+        if (rc) return rc;
+        if (e->p_resume > e->p_next) { e->p_failed = true; return fail(e, AFE_ERR_HIP, "persistent step kernel ran past the authorised steps"); }
+        if (e->p_resume == e->p_next) break;
+        if ((rc = persist_launch(e))) return rc;
+        continue;
+      }
+      if (st[1] >= e->p_next) break;
+      // ask the workers themselves (afe_device.h, sync marker): the pump's sweep over thousands of marks is tens of
+      // microseconds old, a worker answers the moment its own count stands at the request
+      if (st[AFE_PERSIST_SYNCREQ_WORD] != e->p_next) __atomic_store_n(&e->p_host[AFE_PERSIST_HOST_RING + AFE_PERSIST_SYNCREQ_WORD], (unsigned long long)e->p_next, __ATOMIC_RELEASE);
+      if (st[AFE_PERSIST_SYNC_WORD] >= e->p_next) break;
+      if (e->host_arena && e->p_workers <= AFE_PERSIST_HOST_MARKS) {   // small grids write their marks here themselves: no wait for the pump's sweep
+        unsigned long long low = ~0ull;
+        for (int w = 0; w < e->p_workers; w++) { const unsigned long long d = st[8 + w]; low = d < low ? d : low; }
+        if (low >= e->p_next) break;
+      }
+      if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+        return fail(e, AFE_ERR_HIP, "persistent step kernel makes no progress");
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+#ifdef AFE_SYNC_TRACE
+    sync_trace_report(e, st, t0);
 #endif
     e->p_quiesced = e->p_next;
   }
