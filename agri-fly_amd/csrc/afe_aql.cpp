@@ -3,6 +3,7 @@
 // loaded into the process (never a second copy), its entry points are taken with dlsym, the kernel's descriptor is
 // found in the executable HIP loaded.
 #include "afe_aql.h"
+#include "afe_host.h"   // afe_dev_env
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -30,7 +31,7 @@ namespace {
   X(hsa_system_get_major_extension_table) X(hsa_system_get_info) X(hsa_executable_get_symbol_by_name)                  \
   X(hsa_executable_symbol_get_info) X(hsa_amd_agent_iterate_memory_pools) X(hsa_amd_memory_pool_get_info)              \
   X(hsa_amd_memory_pool_allocate) X(hsa_amd_memory_pool_free) X(hsa_amd_agents_allow_access) X(hsa_amd_agent_memory_pool_get_info)                           \
-  X(hsa_amd_queue_cu_set_mask) X(hsa_amd_queue_cu_get_mask) X(hsa_amd_profiling_set_profiler_enabled) X(hsa_amd_profiling_get_dispatch_time)
+  X(hsa_amd_profiling_set_profiler_enabled) X(hsa_amd_profiling_get_dispatch_time)
 
 struct Api {
 #define X(f) decltype(&::f) f = nullptr;
@@ -74,13 +75,21 @@ std::string hsa_err(const Api &a, hsa_status_t st, const char *what) {
   return std::string(what) + ": " + (s ? s : "unknown HSA status");
 }
 
+// Which HSA agent is HIP device `hip_device`?  HIP numbers the devices it was allowed to see (HIP_VISIBLE_DEVICES,
+// ROCR_VISIBLE_DEVICES re-order and filter), HSA enumerates agents: the index proves nothing.  Two identities HIP reports
+// for its device are the agent's own: the PCI address (domain : bus : device) and the 16-character unique id (HIP copies
+// it from HSA_AMD_AGENT_INFO_UUID's "GPU-xxxxxxxxxxxxxxxx").  An agent must match the PCI address; where several do
+// (never seen) or none does (a hypervisor that renumbers the bus for one of the two views), the unique id decides.  Only
+// when both fail and the process sees exactly one GPU agent is that one taken -- and AFE_PERSIST_DEBUG says which rule
+// chose (tests/test_gpu_resident_sync.py holds the first rule on the boxes the suite runs on).
 struct FindAgent {
   const Api *a;
   uint32_t domain, bus, dev;
-  hsa_agent_t gpu{}, cpu{};
-  bool have_gpu = false, have_cpu = false;
-  int n_gpus = 0;
-  hsa_agent_t only_gpu{};
+  char uuid[17];
+  hsa_agent_t by_pci{}, by_uuid{}, cpu{}, only_gpu{};
+  int n_pci = 0, n_uuid = 0, n_gpus = 0;
+  bool have_cpu = false;
+  std::string seen;      // what the GPU agents looked like (for the failure message)
 };
 
 hsa_status_t agent_cb(hsa_agent_t agent, void *data) {
@@ -92,9 +101,15 @@ hsa_status_t agent_cb(hsa_agent_t agent, void *data) {
     f->n_gpus++;
     f->only_gpu = agent;
     uint32_t bdf = 0, domain = 0;
+    char uuid[64] = {0};
     (void)f->a->hsa_agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
     (void)f->a->hsa_agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
-    if (!f->have_gpu && ((bdf >> 8) & 0xffu) == f->bus && ((bdf >> 3) & 0x1fu) == f->dev && domain == f->domain) { f->gpu = agent; f->have_gpu = true; }
+    (void)f->a->hsa_agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_UUID, uuid);
+    if (((bdf >> 8) & 0xffu) == f->bus && ((bdf >> 3) & 0x1fu) == f->dev && domain == f->domain) { if (f->n_pci++ == 0) f->by_pci = agent; }
+    if (f->uuid[0] && std::strncmp(uuid, "GPU-", 4) == 0 && std::strncmp(uuid + 4, f->uuid, 16) == 0) { if (f->n_uuid++ == 0) f->by_uuid = agent; }
+    char line[128];
+    std::snprintf(line, sizeof(line), " [%04x:%02x:%02x %s]", domain, (bdf >> 8) & 0xffu, (bdf >> 3) & 0x1fu, uuid);
+    f->seen += line;
   }
   return HSA_STATUS_SUCCESS;
 }
@@ -201,11 +216,24 @@ AqlQueue *aql_open(int hip_device, std::string *why) {
   auto bail = [&](const std::string &msg) -> AqlQueue * { if (why) *why = msg; aql_close(q); return nullptr; };
   FindAgent fa{};
   fa.a = &a; fa.domain = (uint32_t)prop.pciDomainID; fa.bus = (uint32_t)prop.pciBusID; fa.dev = (uint32_t)prop.pciDeviceID;
+  std::memcpy(fa.uuid, prop.uuid.bytes, 16);
+  fa.uuid[16] = 0;
+  for (int i = 0; i < 16; i++) if (fa.uuid[i] < 0x20 || fa.uuid[i] > 0x7e) { fa.uuid[0] = 0; break; }     // (not the printable id: no such rule)
   st = a.hsa_iterate_agents(agent_cb, &fa);
   if (st != HSA_STATUS_SUCCESS && st != HSA_STATUS_INFO_BREAK) return bail(hsa_err(a, st, "hsa_iterate_agents"));
-  if (!fa.have_gpu && fa.n_gpus == 1) { fa.gpu = fa.only_gpu; fa.have_gpu = true; }     // one GPU: no doubt which
-  if (!fa.have_gpu || !fa.have_cpu) return bail("no HSA agent matches the HIP device's PCI address");
-  q->gpu = fa.gpu; q->cpu = fa.cpu;
+  const char *rule = nullptr;
+  if (fa.n_pci == 1) { q->gpu = fa.by_pci; rule = "PCI address"; }
+  else if (fa.n_uuid == 1) { q->gpu = fa.by_uuid; rule = "unique id"; }
+  else if (fa.n_gpus == 1) { q->gpu = fa.only_gpu; rule = "being the only GPU agent"; }
+  if (!rule || !fa.have_cpu) {
+    char want[96];
+    std::snprintf(want, sizeof(want), "%04x:%02x:%02x %s", fa.domain, fa.bus, fa.dev, fa.uuid);
+    return bail(std::string("no HSA agent matches HIP device ") + std::to_string(hip_device) + " (" + want + "); GPU agents:" + fa.seen);
+  }
+  q->cpu = fa.cpu;
+  if (std::getenv("AFE_PERSIST_DEBUG"))
+    std::fprintf(stderr, "agrifly_engine: AQL queue: HIP device %d (%04x:%02x:%02x %s) is the HSA agent chosen by %s; %d GPU agent(s):%s\n", hip_device, fa.domain, fa.bus,
+                 fa.dev, fa.uuid, rule, fa.n_gpus, fa.seen.c_str());
   (void)a.hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &q->ticks_per_s);
   st = a.hsa_queue_create(q->gpu, 64, HSA_QUEUE_TYPE_SINGLE, queue_error_cb, q, UINT32_MAX, UINT32_MAX, &q->queue);
   if (st != HSA_STATUS_SUCCESS) { q->queue = nullptr; return bail(hsa_err(a, st, "hsa_queue_create")); }
@@ -225,8 +253,8 @@ AqlQueue *aql_open(int hip_device, std::string *why) {
   // scalar cache drops is fetched again from the kernel-argument segment inside the step loop.  In host memory that is a
   // PCIe round trip per miss -- measured: grids dispatched with host-side arguments step 2.5 % slower than the same kernel
   // launched by HIP (which keeps arguments in device memory), 11 % in an engine's first 100 ms.  So: device memory.
-  static const bool host_kernarg = std::getenv("AFE_AQL_HOST_KERNARG") != nullptr;      // measurement aid
-  static const bool no_bar = std::getenv("AFE_AQL_NO_BAR_KERNARG") != nullptr;          // measurement aid
+  static const bool host_kernarg = afe_dev_env("AFE_AQL_HOST_KERNARG") != nullptr;      // measurement aid
+  static const bool no_bar = afe_dev_env("AFE_AQL_NO_BAR_KERNARG") != nullptr;          // measurement aid
   if (!host_kernarg && !no_bar) {
     // ... written by the host itself where the device's memory is host-visible (fine-grained pool, large BAR): a copy call
     // costs the host 12 us before every dispatch, stores through the BAR one
@@ -245,11 +273,20 @@ AqlQueue *aql_open(int hip_device, std::string *why) {
   return q;
 }
 
-void aql_close(AqlQueue *q) {
-  if (!q) return;
+bool aql_close(AqlQueue *q) {
+  if (!q) return true;
   Api &a = api();
   if (a.ok) {
-    if (q->in_flight) { std::string w; (void)aql_wait(q, 30000000ull, &w); }
+    if (q->in_flight) {
+      std::string w;
+      if (aql_wait(q, 30000000ull, &w) != 0) {
+        // The grid did not leave (or the queue broke under it): it may still be writing.  Nothing it can reach is freed --
+        // the queue, its signal and the argument slots are LEAKED, and the caller (afe_destroy) leaks the rings and the
+        // arena for the same reason (aql_close returns false).
+        std::fprintf(stderr, "agrifly_engine: the resident grid did not leave its queue within 30 s (%s); its queue and buffers are leaked rather than freed under it\n", w.c_str());
+        return false;
+      }
+    }
     if (q->queue) (void)a.hsa_queue_destroy(q->queue);
     if (q->have_signal) (void)a.hsa_signal_destroy(q->done);
     if (q->kernarg) (void)a.hsa_amd_memory_pool_free(q->kernarg);
@@ -258,6 +295,7 @@ void aql_close(AqlQueue *q) {
     if (q->initialised) (void)a.hsa_shut_down();
   }
   delete q;
+  return true;
 }
 
 bool aql_find_kernel(AqlQueue *q, const void *fn, AqlKernel *out, std::string *why) {
@@ -348,52 +386,6 @@ int aql_wait(AqlQueue *q, uint64_t timeout_us, std::string *why) {
     q->last_ns = (uint64_t)((double)(t.end - t.start) * 1e9 / (double)q->ticks_per_s);
   else q->last_ns = 0;
   return 0;
-}
-
-bool aql_set_cu_mask(AqlQueue *q, const uint32_t *mask, uint32_t bits) {
-  Api &a = api();
-  if (!q || !a.ok || !q->queue) return false;
-  return a.hsa_amd_queue_cu_set_mask(q->queue, bits, mask) == HSA_STATUS_SUCCESS;
-}
-
-bool aql_reserve_cus(AqlQueue *q, int per_xcc, int *cus_left, std::string *why) {
-  Api &a = api();
-  if (!q || !a.ok || !q->queue || per_xcc < 0) { if (why) *why = "aql_reserve_cus: bad arguments"; return false; }
-  uint32_t cus = 0, xcc = 1;
-  if (a.hsa_agent_get_info(q->gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_COMPUTE_UNIT_COUNT, &cus) != HSA_STATUS_SUCCESS || cus == 0) { if (why) *why = "compute-unit count unknown"; return false; }
-  if (a.hsa_agent_get_info(q->gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_NUM_XCC, &xcc) != HSA_STATUS_SUCCESS || xcc == 0) xcc = 1;
-  if (per_xcc == 0) {
-    if (cus_left) *cus_left = (int)cus;
-    return a.hsa_amd_queue_cu_set_mask(q->queue, 0, nullptr) == HSA_STATUS_SUCCESS;
-  }
-  // Slot i of the mask is compute unit i / n_xcc of XCC i % n_xcc, and inside an XCC consecutive units go round the shader
-  // engines.  The dispatcher keeps the shader engines of an XCC symmetric: with ONE unit of one engine masked off every
-  // engine of that XCC works with one unit less (measured: 248 and 240 set bits both left 224 units' worth of workgroups
-  // resident).  So the reservation comes in rows of one unit per shader engine: per_xcc is rounded up to a multiple of the
-  // engines per XCC (4 here: a row is 32 of 256 units), and the count handed back is what really remains.
-  uint32_t n_se = 0;
-  if (a.hsa_agent_get_info(q->gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_NUM_SHADER_ENGINES, &n_se) != HSA_STATUS_SUCCESS || n_se == 0) n_se = 4 * xcc;
-  const uint32_t se_per_xcc = n_se >= xcc && n_se % xcc == 0 ? n_se / xcc : 4;
-  const uint32_t rows = ((uint32_t)per_xcc + se_per_xcc - 1) / se_per_xcc;
-  constexpr uint32_t kWords = 32;                      // 1 024 slots
-  uint32_t mask[kWords] = {0};
-  hsa_status_t st = a.hsa_amd_queue_cu_set_mask(q->queue, 0, nullptr);       // (back to everything first)
-  st = a.hsa_amd_queue_cu_get_mask(q->queue, kWords * 32, mask);
-  if (st != HSA_STATUS_SUCCESS) { if (why) *why = hsa_err(a, st, "hsa_amd_queue_cu_get_mask"); return false; }
-  uint32_t active = 0;
-  int top = -1;
-  for (uint32_t i = 0; i < kWords * 32; i++) if (mask[i / 32] >> (i % 32) & 1u) { active++; top = (int)i; }
-  uint32_t off = rows * se_per_xcc * xcc;
-  if (active == 0 || off >= active) { if (why) *why = "cannot reserve that many compute units (" + std::to_string(active) + " in the queue's mask)"; return false; }
-  const uint32_t left = active - off;
-  for (int i = top; i >= 0 && off > 0; i--) if (mask[i / 32] >> (i % 32) & 1u) { mask[i / 32] &= ~(1u << (i % 32)); off--; }
-  const uint32_t words = (uint32_t)top / 32 + 1;
-  st = a.hsa_amd_queue_cu_set_mask(q->queue, words * 32, mask);
-  if (st != HSA_STATUS_SUCCESS && st != (hsa_status_t)HSA_STATUS_CU_MASK_REDUCED) { if (why) *why = hsa_err(a, st, "hsa_amd_queue_cu_set_mask"); return false; }
-  if (cus_left) *cus_left = (int)left;
-  static const bool debug = std::getenv("AFE_PERSIST_DEBUG") != nullptr;
-  if (debug) std::fprintf(stderr, "agrifly_engine: compute-unit mask: %u slots active of %d, %d per XCC x %u XCCs reserved, %d usable\n", active, top + 1, per_xcc, xcc, cus_left ? *cus_left : -1);
-  return true;
 }
 
 }  // namespace afe

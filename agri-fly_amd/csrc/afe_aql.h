@@ -25,7 +25,9 @@ struct AqlQueue;   // opaque
 
 // nullptr when the runtime cannot be reached (why says so); the caller then stays with HIP launches
 AqlQueue *aql_open(int hip_device, std::string *why);
-void aql_close(AqlQueue *q);
+// false: a dispatch was still in flight after 30 s (or the queue had failed under it) -- NOTHING was freed, and the caller
+// must not free what that dispatch can reach either
+bool aql_close(AqlQueue *q);
 // the kernel behind a HIP __global__ function's host address, as loaded by HIP on this queue's device
 bool aql_find_kernel(AqlQueue *q, const void *hip_host_function, AqlKernel *out, std::string *why);
 // one dispatch of `workgroups` x `workgroup_size` work-items; kernarg is copied (bytes must equal k.kernarg_bytes).
@@ -36,10 +38,4 @@ bool aql_in_flight(const AqlQueue *q);
 int aql_wait(AqlQueue *q, uint64_t timeout_us, std::string *why);
 // device time of the last completed dispatch in nanoseconds (0 when unknown)
 uint64_t aql_last_duration_ns(const AqlQueue *q);
-// restrict the queue to the compute units whose bit is set (bits = number of valid bits, a multiple of 32)
-bool aql_set_cu_mask(AqlQueue *q, const uint32_t *mask, uint32_t bits);
-// keep `per_xcc` compute units of every XCC out of this queue's reach (0: all of them back); *cus_left = what remains.
-// (mask bit i is compute unit i / n_xcc of XCC i % n_xcc: the last per_xcc x n_xcc bits are cleared)
-bool aql_reserve_cus(AqlQueue *q, int per_xcc, int *cus_left, std::string *why);
-
 }  // namespace afe

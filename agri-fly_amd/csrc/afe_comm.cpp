@@ -235,6 +235,7 @@ struct afe_group {
   std::vector<hipEvent_t> pulled;     // per shard: it has pulled every block it needs
   int64_t n_total = 0;
   bool peer_ok = true;                // every pair of distinct devices reads the other's memory directly
+  bool staged = false;                // the gather copies row by row with hipMemcpyPeerAsync (no peer access, or asked for)
   std::string err;
 };
 
@@ -267,16 +268,18 @@ extern "C" int afe_group_create(afe_group **out, int64_t n_vehicles, int precisi
     g->pulled.push_back(ev2);
     first += cnt;
   }
-  // Every device reads every other one's memory directly where it can (xGMI): afe_group_gather_positions issues
-  // device-to-device copies between the shards' scratch buffers.  A pair without peer access (IOMMU, a VM, a restricted
-  // container) is still served -- the runtime stages such copies through the host -- only slower: say so once, with the
-  // pair, remember it (afe_group_peer_access) and go on.  A copy that really fails is reported by the gather itself.
-  const bool assume_none = std::getenv("AFE_GROUP_ASSUME_NO_PEER") != nullptr;    // test hook: as if no pair had peer access
+  // Every device reads every other one's memory directly where it can (xGMI): afe_group_gather_positions then issues one
+  // strided device-to-device copy per pair of shards.  A group with a pair that lacks peer access (IOMMU, a VM, a
+  // restricted container) is still served, by the STAGED path: one hipMemcpyPeerAsync per row of a block, which the
+  // runtime carries through host memory where the devices cannot reach each other -- slower; said once, with the pair,
+  // and remembered (afe_group_peer_access).  afe_group_set_staged_copies selects that path by hand.  Not verified on a
+  // machine whose devices really lack peer access (none available): the staged path is exercised on peers and on logical
+  // shards of one device (tests/test_gpu_sharedworld.py).
   for (int a = 0; a < n_devices; a++)
     for (int b = 0; b < n_devices; b++) {
-      if (devices[a] == devices[b] && !assume_none) continue;
+      if (devices[a] == devices[b]) continue;
       int can = 0;
-      hipError_t perr = assume_none ? hipSuccess : hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
+      hipError_t perr = hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
       if (perr == hipSuccess && can) {
         (void)hipSetDevice(devices[a]);
         perr = hipDeviceEnablePeerAccess(devices[b], 0);
@@ -288,11 +291,19 @@ extern "C" int afe_group_create(afe_group **out, int64_t n_vehicles, int precisi
       if (perr != hipSuccess) {
         if (g->peer_ok)
           std::fprintf(stderr, "agrifly_engine: afe_group_create: device %d cannot access device %d's memory directly (%s); the group's position "
-                               "gather falls back to copies staged by the runtime\n", devices[a], devices[b], hipGetErrorString(perr));
+                               "gather uses staged copies (hipMemcpyPeerAsync)\n", devices[a], devices[b], hipGetErrorString(perr));
         g->peer_ok = false;
       }
     }
+  g->staged = !g->peer_ok;
   *out = g;
+  return AFE_OK;
+}
+
+extern "C" int afe_group_set_staged_copies(afe_group *g, int staged) {
+  if (!g) return AFE_ERR_INVALID_ARG;
+  if (!staged && !g->peer_ok) { g->err = "a pair of the group's devices lacks peer access: the direct copies are not available"; return AFE_ERR_INVALID_ARG; }
+  g->staged = staged != 0;
   return AFE_OK;
 }
 
@@ -380,9 +391,18 @@ extern "C" int afe_group_gather_positions(afe_group *g, float **dev_xyz_all_out)
     for (size_t off = 0; off < G; off++) {
       const size_t s = (d + off) % G;   // start with the own block, then walk the ring so the links load evenly
       if (s != d && hipStreamWaitEvent(streams[d], g->packed[s], 0) != hipSuccess) { g->err = "hipStreamWaitEvent (packed) failed"; return AFE_ERR_HIP; }
-      const hipError_t err = hipMemcpy2DAsync(g->all_xyz[d] + g->first[s], (size_t)g->n_total * 4, scratch[s], (size_t)g->count[s] * 4,
-                                              (size_t)g->count[s] * 4, 3, hipMemcpyDeviceToDevice, streams[d]);
-      if (err != hipSuccess) { g->err = std::string("peer copy: ") + hipGetErrorString(err); return AFE_ERR_HIP; }
+      hipError_t err = hipSuccess;
+      if (g->staged && s != d) {
+        // no direct access between the two devices (or the host asked): the runtime's peer copy, which stages through
+        // host memory where it has to; contiguous rows, so one call per component
+        for (int c = 0; c < 3 && err == hipSuccess; c++)
+          err = hipMemcpyPeerAsync(g->all_xyz[d] + (size_t)c * g->n_total + g->first[s], g->devices[d], scratch[s] + (size_t)c * g->count[s], g->devices[s],
+                                   (size_t)g->count[s] * 4, streams[d]);
+      } else {
+        err = hipMemcpy2DAsync(g->all_xyz[d] + g->first[s], (size_t)g->n_total * 4, scratch[s], (size_t)g->count[s] * 4,
+                               (size_t)g->count[s] * 4, 3, hipMemcpyDeviceToDevice, streams[d]);
+      }
+      if (err != hipSuccess) { g->err = std::string(g->staged && s != d ? "staged peer copy: " : "peer copy: ") + hipGetErrorString(err); return AFE_ERR_HIP; }
     }
     if (dev_xyz_all_out) dev_xyz_all_out[d] = g->all_xyz[d];
   }

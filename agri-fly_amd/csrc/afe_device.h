@@ -1,5 +1,6 @@
 // afe_device.h -- structures shared by the host engine and the HIP kernels.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace afe {
@@ -130,6 +131,20 @@ struct PersistArgs {
   unsigned long long gust_period_us, gust_seed, gust_n_global, gust_epoch0, gust_epoch_applied, t0_us, dt_us;
   double gust_sigma_max;
 };
+// The kernel-argument segment of afe_step_persistent_kernel(StepView<R>, DevParams<R>, DevLogic, PersistArgs) as the
+// host packs it for a dispatch on the engine's own queue (afe_engine.cpp aql_launch): the same four objects in the same
+// order, each at its natural alignment -- the rule the compiler lays the segment out by.  The segment ends with its last
+// argument (no tail padding), hence persist_kernarg_bytes.
+template <typename R>
+struct PersistKernarg {
+  StepView<R> v;
+  DevParams<R> P;
+  DevLogic G;
+  PersistArgs a;
+};
+template <typename R>
+constexpr size_t persist_kernarg_bytes() { return offsetof(PersistKernarg<R>, a) + sizeof(PersistArgs); }
+
 // "tell me when step S - 1 is done" without ending the grid (afe_sync on a grid that stays resident): the host writes S
 // into host_status[AFE_PERSIST_SYNCREQ_WORD]; once everything before S is republished the pump puts a MARKER into slot S of
 // the device ring (the index of an entry for step S, both flags set: neither a step nor a park); a worker that finds the
@@ -143,12 +158,7 @@ struct PersistArgs {
 #define AFE_PERSIST_HOST_MARKS 64      /* host-visible arenas: grids of up to this many workers also write their marks to host_status[8 + w] */
 #define AFE_PERSIST_SYNC_WORD (8 + AFE_PERSIST_HOST_MARKS)      /* host_status: the step count the last sync request was answered for */
 #define AFE_PERSIST_SYNCREQ_WORD (9 + AFE_PERSIST_HOST_MARKS)   /* host_status: the host's sync request (a step count) */
-#ifdef AFE_SYNC_TRACE   /* development aid: where a sync request spends its time (device stamps, 10 ns units) */
-#define AFE_PERSIST_TRACE_BASE (16 + AFE_PERSIST_HOST_MARKS)
-#define AFE_PERSIST_STATUS_WORDS (16 + AFE_PERSIST_HOST_MARKS + 4 + 4 * 8192)
-#else
 #define AFE_PERSIST_STATUS_WORDS (16 + AFE_PERSIST_HOST_MARKS)
-#endif
 #define AFE_PERSIST_TICK 1ull
 #define AFE_PERSIST_PARK 2ull
 #define AFE_PERSIST_HOST_RING 4096

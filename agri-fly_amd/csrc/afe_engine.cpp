@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -114,8 +116,6 @@ struct afe_engine {
   unsigned long long *p_dev = nullptr;       // device memory: ring[AFE_PERSIST_DEV_RING] + done[p_workers]
   int p_workers = 0;
   int p_cus = 0;
-  int p_reserve = 0, p_reserve_applied = -1;   // compute units per XCD kept out of the resident grid's reach (afe_set_reserved_compute_units)
-  int p_cus_usable = 0;                        // what that leaves (0: all)
   int p_shrink_num = 16;    // sixteenths of the computed capacity still trusted (two stalled grids in a row take one off)
   int p_stall_streak = 0;
   int p_capacity = 0;       // resident one-wave workgroups per CU of the current configuration's kernel (p_capacity_key)
@@ -133,13 +133,13 @@ struct afe_engine {
   bool aql_tried = false;
   int aql_mode = -1;                // afe_set_resident_queue: -1 automatic (by size), 0 the HIP stream, 1 the engine's own queue
   bool p_on_aql = false;            // the grid now resident was dispatched there
-  bool p_on_aql_next = false;       // the grid about to be sized will be (the reservation applies only there)
   std::map<unsigned, afe::AqlKernel> aql_kernels;    // by configuration key (persist_size_grid's) | precision << 8
   bool view_exported = false;       // afe_get_device_view has handed the slabs to somebody: afe_sync must leave them readable
   uint64_t p_grid_ns = 0, p_grid_steps = 0;          // device time and steps of the grids collected so far (afe_grid_time)
   uint64_t p_launch_start = 0;                       // the step the grid now resident started from
   bool p_prio = false;                               // the grid now resident balances its workers by issue priority (persist_launch)
   uint64_t p_quiesced = 0;                           // every step below this index is known to be done (the last successful wait)
+  uint64_t p_sync_posted = 0;                        // 1 + the step count of the sync request posted to the grid now resident (0: none)
 
   std::string err;
 };
@@ -516,14 +516,14 @@ void persist_size_grid(afe_engine *e) {
   if (e->p_capacity_key != key) {
     int cap = e->precision == AFE_F64 ? persistent_capacity_f64(e->p_flags) : persistent_capacity_f32(e->p_flags);
     if (cap < 1) cap = 1;
-    if (const char *s = std::getenv("AFE_PERSIST_WAVES_PER_CU")) { const int k = std::atoi(s); if (k >= 1 && k <= 32) cap = k; }
+    if (const char *s = afe_dev_env("AFE_PERSIST_WAVES_PER_CU")) { const int k = std::atoi(s); if (k >= 1 && k <= 32) cap = k; }
     e->p_capacity = cap;
     e->p_capacity_key = key;
-    e->p_balanced = std::getenv("AFE_PERSIST_BALANCED") != nullptr;
+    e->p_balanced = afe_dev_env("AFE_PERSIST_BALANCED") != nullptr;
   }
   const int per_cu = e->p_capacity;
   const int64_t chunks = (e->n + 63) / 64;
-  const int cus = e->p_on_aql_next && e->p_cus_usable > 0 ? e->p_cus_usable : e->p_cus;
+  const int cus = e->p_cus;
   int64_t cap = (int64_t)cus * per_cu - 1;          // the pump takes one slot
   cap = cap * e->p_shrink_num / 16;
   if (cap < 1) cap = 1;
@@ -576,10 +576,14 @@ bool persist_eligible(const afe_engine *e) {
 // unknown (firmware scheduling state is the guess).  So the process's first dispatch goes to a throwaway queue: the
 // resident kernel with no workers and a park entry already waiting -- one wave that zeroes a few counters and leaves.
 void aql_prime_process(afe_engine *e) {
-  static unsigned long long primed = 0;          // one bit per device (the observation is per device: its first dispatching queue)
-  const unsigned long long bit = 1ull << (e->device & 63);
-  if ((primed & bit) || std::getenv("AFE_AQL_NO_PRIME")) return;
-  primed |= bit;
+  // once per device (the observation is per device: its first dispatching queue).  Engines may be created from several
+  // host threads (one engine per thread): the lock is held across the priming dispatch, so no second engine's grid can
+  // become the device's first dispatch while the throwaway one is still on its way.
+  static std::mutex lock;
+  static std::set<int> primed;
+  std::lock_guard<std::mutex> guard(lock);
+  if (primed.count(e->device) || afe_dev_env("AFE_AQL_NO_PRIME")) return;
+  primed.insert(e->device);
   std::string why;
   afe::AqlQueue *q = afe::aql_open(e->device, &why);
   if (!q) return;
@@ -601,15 +605,16 @@ void aql_prime_process(afe_engine *e) {
     StepView<float> v = {};
     DevParams<float> P = {};
     DevLogic G = {};
-    alignas(16) char buf[2048];
-    size_t o = 0;
-    auto put = [&](const void *p, size_t bytes, size_t align) { o = (o + align - 1) / align * align; std::memcpy(buf + o, p, bytes); o += bytes; };
+    alignas(16) char buf[sizeof(PersistKernarg<float>)];
     std::memset(buf, 0, sizeof(buf));
-    put(&v, sizeof(v), alignof(StepView<float>)); put(&P, sizeof(P), alignof(DevParams<float>)); put(&G, sizeof(G), alignof(DevLogic)); put(&a, sizeof(a), alignof(PersistArgs));
-    if (afe::aql_dispatch(q, k, buf, o, 1, 64, &why)) (void)afe::aql_wait(q, 2000000ull, &why);
+    std::memcpy(buf + offsetof(PersistKernarg<float>, v), &v, sizeof(v));
+    std::memcpy(buf + offsetof(PersistKernarg<float>, P), &P, sizeof(P));
+    std::memcpy(buf + offsetof(PersistKernarg<float>, G), &G, sizeof(G));
+    std::memcpy(buf + offsetof(PersistKernarg<float>, a), &a, sizeof(a));
+    if (afe::aql_dispatch(q, k, buf, persist_kernarg_bytes<float>(), 1, 64, &why)) (void)afe::aql_wait(q, 2000000ull, &why);
   }
   (void)hipGetLastError();
-  afe::aql_close(q);
+  if (!afe::aql_close(q)) return;     // (the throwaway dispatch never left: its two buffers stay, see aql_close)
   if (dev) (void)hipFree(dev);
   if (host) (void)hipHostFree(host);
 }
@@ -627,7 +632,7 @@ const afe::AqlKernel *aql_kernel_for(afe_engine *e) {
   // 20-step blocks: from ~400 000 vehicles on a grid holds every wave slot of the device, and a grid that afe_sync leaves
   // resident makes whatever else the process launches next (an RCCL collective between two blocks, a torch kernel) wait
   // for its 200 us of idle patience; at 262 144 it holds 16 of a compute unit's 24 and others run beside it.
-  // afe_set_resident_queue / AFE_PERSIST_AQL = 0 | 1 force one (with afe_set_reserved_compute_units where others must run).
+  // afe_set_resident_queue / AFE_PERSIST_AQL = 0 | 1 force one.
   static const int env_mode = [] { const char *s = std::getenv("AFE_PERSIST_AQL"); return !s || !*s ? -1 : (s[0] == '0' ? 0 : 1); }();
   const int mode = e->aql_mode >= 0 ? e->aql_mode : env_mode;
   if (mode == 0 || (mode < 0 && e->n > 262144) || e->stream != e->own_stream) return nullptr;
@@ -656,51 +661,28 @@ const afe::AqlKernel *aql_kernel_for(afe_engine *e) {
   return it->second.object ? &it->second : nullptr;
 }
 
-// kernel-argument segment as the code object lays it out: the four by-value arguments, each at its own alignment
+// The kernel-argument segment of a resident grid: PersistKernarg<R> (afe_device.h) IS the layout -- the four by-value
+// arguments in order, each at its natural alignment, which is the rule the code object's own argument offsets follow
+// (tests/test_kernel_resources.py compares every argument's offset and size in the code object's metadata with
+// afe_persistent_kernarg_layout(); aql_dispatch compares the total).
 template <typename R>
-bool aql_launch(afe_engine *e, const afe::AqlKernel &k, const StepView<R> &v, const DevParams<R> &P, const DevLogic &G, const PersistArgs &a) {
-  alignas(16) char buf[2048];
-  size_t o = 0;
-  auto put = [&](const void *p, size_t bytes, size_t align) { o = (o + align - 1) / align * align; std::memcpy(buf + o, p, bytes); o += bytes; };
-  std::memset(buf, 0, sizeof(buf));
-  put(&v, sizeof(v), alignof(StepView<R>));
-  put(&P, sizeof(P), alignof(DevParams<R>));
-  put(&G, sizeof(G), alignof(DevLogic));
-  put(&a, sizeof(a), alignof(PersistArgs));
+bool aql_launch(afe_engine *e, const afe::AqlKernel &k, const StepView<R> &v, const DevParams<R> &P, const DevLogic &G, const PersistArgs &a, int *stream_error) {
+  alignas(16) char buf[sizeof(PersistKernarg<R>)];
+  std::memset(buf, 0, sizeof(buf));                    // (padding between the arguments is zero, not stack)
+  std::memcpy(buf + offsetof(PersistKernarg<R>, v), &v, sizeof(v));
+  std::memcpy(buf + offsetof(PersistKernarg<R>, P), &P, sizeof(P));
+  std::memcpy(buf + offsetof(PersistKernarg<R>, G), &G, sizeof(G));
+  std::memcpy(buf + offsetof(PersistKernarg<R>, a), &a, sizeof(a));
   // the queue is not ordered behind the HIP stream: whatever the stream still holds (setters, a memset) finishes first
-  static const bool timing = std::getenv("AFE_AQL_TIMING") != nullptr;
-  const auto tt0 = std::chrono::steady_clock::now();
-  if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+  const hipError_t serr = hipStreamSynchronize(e->stream);
+  if (serr != hipSuccess) { *stream_error = (int)serr; return false; }     // (a broken stream is an error, not a reason to launch on it)
   e->stream_pending = false;
-  const auto tt1 = std::chrono::steady_clock::now();
-  // AFE_PERSIST_SPREAD=1 (measurement aid, off by default): a grid that does not fill the device can be SPREAD over it by
-  // asking for an unused LDS slice per workgroup, which caps how many a compute unit takes (160 KB / (the even share +
-  // slack)).  Measured at 131 072 / 262 144 vehicles: later grids of an engine 2.97 against 3.00 us per step with one
-  // workgroup of slack, nothing with two -- and with NONE the grid does not fit (4 097 workgroups at 17 per compute unit:
-  // stalls, 3 ms per step until the safety net has shrunk it).  Not worth a cliff: off.
-  afe::AqlKernel kd = k;
-  {
-    const int wgs = 1 + a.n_workers, cus = e->p_cus > 0 ? e->p_cus : 256;
-    static const int slack = [] { const char *s = std::getenv("AFE_PERSIST_SPREAD_SLACK"); return s && *s ? std::atoi(s) : 2; }();
-    const int share = (wgs + cus - 1) / cus + (slack < 1 ? 1 : slack);
-    static const bool spread = [] { const char *s = std::getenv("AFE_PERSIST_SPREAD"); return s && s[0] == '1'; }();
-    if (spread && kd.group_bytes == 0 && share <= 20) {
-      uint32_t lds = (uint32_t)((160 * 1024) / share) & ~255u;
-      kd.group_bytes = lds > 65536u ? 65536u : lds;
-    }
-  }
   std::string why;
-  if (!afe::aql_dispatch(e->aql, kd, buf, o, (uint32_t)(1 + a.n_workers), 64, &why)) {
+  if (!afe::aql_dispatch(e->aql, k, buf, persist_kernarg_bytes<R>(), (uint32_t)(1 + a.n_workers), 64, &why)) {
     static bool said = false;
     if (!said) std::fprintf(stderr, "agrifly_engine: AQL dispatch of the resident grid refused (%s); using the HIP stream\n", why.c_str());
     said = true;
     return false;
-  }
-  if (timing) {
-    const auto tt2 = std::chrono::steady_clock::now();
-    static double a1 = 0, a2 = 0; static int nn = 0;
-    a1 += std::chrono::duration<double, std::micro>(tt1 - tt0).count(); a2 += std::chrono::duration<double, std::micro>(tt2 - tt1).count();
-    if (++nn % 200 == 0) { std::fprintf(stderr, "aql launch: stream sync %.1f us, pack + kernarg copy + dispatch %.1f us (mean of 200)\n", a1 / 200, a2 / 200); a1 = a2 = 0; }
   }
   return true;
 }
@@ -709,16 +691,8 @@ int persist_launch(afe_engine *e) {
   volatile unsigned long long *st = p_status(e);
   st[0] = 0; st[1] = e->p_resume; st[2] = 0; st[7] = 0;
   st[AFE_PERSIST_SYNC_WORD] = 0; st[AFE_PERSIST_SYNCREQ_WORD] = 0;
+  e->p_sync_posted = 0;
   const afe::AqlKernel *ak = aql_kernel_for(e);      // nullptr: launch on the HIP stream
-  e->p_on_aql_next = ak != nullptr;
-  if (ak && e->p_reserve != e->p_reserve_applied) {
-    // compute units kept free for everybody else's kernels (collectives, the host's own work) while the grid is resident
-    std::string why;
-    int left = 0;
-    if (afe::aql_reserve_cus(e->aql, e->p_reserve, &left, &why)) { e->p_cus_usable = e->p_reserve ? left : 0; }
-    else { std::fprintf(stderr, "agrifly_engine: compute units not reserved (%s)\n", why.c_str()); e->p_cus_usable = 0; }
-    e->p_reserve_applied = e->p_reserve;
-  }
   persist_size_grid(e);
   for (int w = 0; w < AFE_PERSIST_HOST_MARKS; w++) st[8 + w] = w < e->p_workers ? e->p_resume : ~0ull;
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -739,7 +713,7 @@ int persist_launch(afe_engine *e) {
   // 4.21 -> 3.58, 393 216 6.9 -> 6.7 / 6.4 -> 5.95, 524 288 11.4 -> 11.3 / 10.7 -> 10.1; one worker per SIMD (65 536) 2.13 ->
   // 2.18: nothing to arbitrate; 2^20 (2.7 chunks per worker, HBM-bound) 20.3 -> 20.5 / no change: waves in step with each
   // other load together and compute together.  AFE_PERSIST_PRIO=0|1 forces it (measurement aid).
-  static const int prio_env = [] { const char *s = std::getenv("AFE_PERSIST_PRIO"); return s && *s ? std::atoi(s) : -1; }();
+  static const int prio_env = [] { const char *s = afe_dev_env("AFE_PERSIST_PRIO"); return s && *s ? std::atoi(s) : -1; }();
   const int64_t chunks_now = (e->n + 63) / 64;
   const bool prio = prio_env >= 0 ? prio_env != 0 : (e->p_workers > 4 * e->p_cus && chunks_now <= 2 * (int64_t)e->p_workers);
   e->p_prio = prio;
@@ -761,21 +735,22 @@ int persist_launch(afe_engine *e) {
   const LaunchFlags &f = e->p_flags;
   const DevLogic *ulogic = e->logic_on ? &e->logic_table[0] : nullptr;
   static const DevLogic no_logic = {};
-  int lrc = 0;
+  int lrc = 0, stream_error = 0;
   bool on_aql = false;
   if (e->precision == AFE_F64) {
     StepView<double> v;
     fill_view(e, v);
     v.dt = dt; v.inv_dt = 1.0 / dt; v.n_steps = 1; v.tick_mask = 0; v.tick_base = ticks0;
-    if (ak) on_aql = aql_launch(e, *ak, v, e->table_f64[0], ulogic ? *ulogic : no_logic, a);
-    if (!on_aql) lrc = launch_persistent_f64(v, f, e->table_f64[0], ulogic, a, e->stream);
+    if (ak) on_aql = aql_launch(e, *ak, v, e->table_f64[0], ulogic ? *ulogic : no_logic, a, &stream_error);
+    if (!on_aql && !stream_error) lrc = launch_persistent_f64(v, f, e->table_f64[0], ulogic, a, e->stream);
   } else {
     StepView<float> v;
     fill_view(e, v);
     v.dt = (float)dt; v.inv_dt = (float)(1.0 / dt); v.n_steps = 1; v.tick_mask = 0; v.tick_base = ticks0;
-    if (ak) on_aql = aql_launch(e, *ak, v, e->table_f32[0], ulogic ? *ulogic : no_logic, a);
-    if (!on_aql) lrc = launch_persistent_f32(v, f, e->table_f32[0], ulogic, a, e->stream);
+    if (ak) on_aql = aql_launch(e, *ak, v, e->table_f32[0], ulogic ? *ulogic : no_logic, a, &stream_error);
+    if (!on_aql && !stream_error) lrc = launch_persistent_f32(v, f, e->table_f32[0], ulogic, a, e->stream);
   }
+  if (stream_error) return fail(e, AFE_ERR_HIP, std::string("engine stream ahead of the resident grid's dispatch: ") + hipGetErrorString((hipError_t)stream_error));
   if (lrc != 0) return fail(e, AFE_ERR_HIP, std::string("persistent step kernel launch: ") + hipGetErrorString((hipError_t)lrc));
   e->p_on_aql = on_aql;
   e->p_launch_start = e->p_resume;
@@ -793,14 +768,7 @@ int persist_collect(afe_engine *e) {
   const bool was_aql = e->p_on_aql;
   if (e->p_on_aql) {
     std::string why;
-    static const bool timing = std::getenv("AFE_AQL_TIMING") != nullptr;
-    const auto tw0 = std::chrono::steady_clock::now();
     const int w = afe::aql_wait(e->aql, 120000000ull, &why);     // (the grid's own patience ends long before: 50 ms without progress)
-    if (timing) {
-      static double aw = 0; static int nw = 0;
-      aw += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count();
-      if (++nw % 200 == 0) { std::fprintf(stderr, "aql collect: waited %.1f us for the grid to leave (mean of 200)\n", aw / 200); aw = 0; }
-    }
     if (w != 0) {
       e->p_running = false; e->p_on_aql = false; e->p_failed = true;
       return fail(e, AFE_ERR_HIP, "persistent step kernel on the engine's AQL queue: " + (w > 0 ? std::string("still running after 120 s") : why));
@@ -809,7 +777,7 @@ int persist_collect(afe_engine *e) {
     e->p_on_aql = false;
     // AFE_GRID_LOG=<file> (profiling aid, tools/profile_r04.sh): one line per grid that has left the device -- the steps it
     // served and its device time -- in dispatch order, to be laid beside rocprofv3's kernel trace of the same run
-    static FILE *const grid_log = [] { const char *p = std::getenv("AFE_GRID_LOG"); return p && *p ? std::fopen(p, "a") : (FILE *)nullptr; }();
+    static FILE *const grid_log = [] { const char *p = afe_dev_env("AFE_GRID_LOG"); return p && *p ? std::fopen(p, "a") : (FILE *)nullptr; }();
     if (grid_log) {
       volatile unsigned long long *stl = p_status(e);
       std::fprintf(grid_log, "%lld,%d,%llu,%llu\n", (long long)e->n, e->p_workers, (unsigned long long)(stl[0] ? stl[0] - 1 - e->p_launch_start : 0),
@@ -859,85 +827,6 @@ int persist_park(afe_engine *e) {
   }
 }
 
-#ifdef AFE_SYNC_TRACE
-// Development aid (make EXTRA=-DAFE_SYNC_TRACE; tools/ageing_probe.py): the pump and every worker stamp the device's 100 MHz
-// clock into the status block (afe_kernels.hip) -- when the pump first saw a block, saw the sync request, placed the marker;
-// when each worker started, ran out of steps, answered; where it sat (HW_ID / XCC_ID).  Every 64th afe_sync that waited
-// prints the timeline of the block it ended.
-static void sync_trace_report(afe_engine *e, volatile unsigned long long *st, std::chrono::steady_clock::time_point t0) {
-    {
-      static int calls = 0;
-      if (e->p_running && (++calls % 64) == 0) {
-        const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        const long long tm = (long long)st[AFE_PERSIST_TRACE_BASE + 1], tr = (long long)st[AFE_PERSIST_TRACE_BASE];
-        std::vector<long long> out, ans;
-        for (int w = 0; w < e->p_workers && w < 8192; w++) { out.push_back((long long)st[AFE_PERSIST_TRACE_BASE + 4 + w] - tm); ans.push_back((long long)st[AFE_PERSIST_TRACE_BASE + 4 + 8192 + w] - tm); }
-        std::sort(out.begin(), out.end()); std::sort(ans.begin(), ans.end());
-        const size_t k = out.size();
-        std::fprintf(stderr, "sync trace: host waited %.1f us; pump saw the request %.2f us before the marker; workers ran out of steps at %.2f / %.2f / %.2f / %.2f / %.2f us "
-                             "(min / 10 %% / median / 90 %% / max) and answered at %.2f / %.2f / %.2f us (min / median / max) after the marker\n",
-                     host_us, (tm - tr) / 100.0, out[0] / 100.0, out[k / 10] / 100.0, out[k / 2] / 100.0, out[k * 9 / 10] / 100.0, out[k - 1] / 100.0,
-                     ans[0] / 100.0, ans[k / 2] / 100.0, ans[k - 1] / 100.0);
-        {
-          const long long tn = (long long)st[AFE_PERSIST_TRACE_BASE + 2];
-          std::vector<long long> stt;
-          for (int w = 0; w < e->p_workers && w < 8192; w++) stt.push_back((long long)st[AFE_PERSIST_TRACE_BASE + 4 + 3 * 8192 + w] - tn);
-          std::sort(stt.begin(), stt.end());
-          { const unsigned long long h = st[AFE_PERSIST_TRACE_BASE - 2];
-            std::fprintf(stderr, "   pump on xcc/se/cu/simd %llu/%llu/%llu/%llu\n", (h >> 32) & 15, (h >> 13) & 7, (h >> 8) & 15, (h >> 4) & 3); }
-          std::fprintf(stderr, "   pump: %.1f us of the following inside the scalar probes\n", st[AFE_PERSIST_TRACE_BASE - 1] / 100.0);
-          std::fprintf(stderr, "   pump: %llu iterations in the %.1f us between two markers = %.2f us each\n", (unsigned long long)(st[AFE_PERSIST_TRACE_BASE + 3] >> 32),
-                       (st[AFE_PERSIST_TRACE_BASE + 3] & 0xffffffffull) / 100.0, (st[AFE_PERSIST_TRACE_BASE + 3] & 0xffffffffull) / 100.0 / std::max<double>(1.0, (double)(st[AFE_PERSIST_TRACE_BASE + 3] >> 32)));
-          std::fprintf(stderr, "   from the pump's first sight of the block: workers started at %.2f / %.2f / %.2f / %.2f us (min / median / 90 %% / max); request seen at %.2f, marker at %.2f, "
-                               "workers out at %.2f / %.2f / %.2f (median / 90 %% / max), last answer at %.2f us\n",
-                       stt[0] / 100.0, stt[k / 2] / 100.0, stt[k * 9 / 10] / 100.0, stt[k - 1] / 100.0, (tr - tn) / 100.0, (tm - tn) / 100.0,
-                       (out[k / 2] + tm - tn) / 100.0, (out[k * 9 / 10] + tm - tn) / 100.0, (out[k - 1] + tm - tn) / 100.0, (ans[k - 1] + tm - tn) / 100.0);
-        }
-        // finish time against how many of the grid's waves share the wave's SIMD (HW_ID: simd 5:4, cu 11:8, sh 12, se 15:13; XCC_ID 3:0)
-        std::map<unsigned long long, std::vector<long long>> by_simd, by_cu;
-        for (int w = 0; w < e->p_workers && w < 8192; w++) {
-          const unsigned long long h = st[AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + w];
-          const unsigned long long cu = ((h >> 8) & 0xff) | ((h >> 32) & 0xf) << 8;
-          const long long t = (long long)st[AFE_PERSIST_TRACE_BASE + 4 + w] - tm;
-          by_cu[cu].push_back(t); by_simd[cu << 2 | ((h >> 4) & 3)].push_back(t);
-        }
-        std::map<size_t, std::pair<int, double>> per_share, per_cu_share;
-        for (auto &kv : by_simd) for (long long t : kv.second) { auto &r = per_share[kv.second.size()]; r.first++; r.second += t / 100.0; }
-        for (auto &kv : by_cu) for (long long t : kv.second) { auto &r = per_cu_share[kv.second.size()]; r.first++; r.second += t / 100.0; }
-        {
-          double xs[16] = {0}, ses[8] = {0}, bs[16] = {0}; int xn[16] = {0}, sen[8] = {0}, bn[16] = {0};
-          for (int w = 0; w < e->p_workers && w < 8192; w++) {
-            const unsigned long long h = st[AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + w];
-            const double t = ((long long)st[AFE_PERSIST_TRACE_BASE + 4 + w] - tm) / 100.0;
-            xs[(h >> 32) & 15] += t; xn[(h >> 32) & 15]++; ses[(h >> 13) & 7] += t; sen[(h >> 13) & 7]++;
-            const int b = (int)((long long)w * 16 / e->p_workers); bs[b] += t; bn[b]++;
-          }
-          std::fprintf(stderr, "   by XCC:"); for (int i = 0; i < 16; i++) if (xn[i]) std::fprintf(stderr, " %d: %.0f (%d)", i, xs[i] / xn[i], xn[i]);
-          std::fprintf(stderr, "\n   by SE:"); for (int i = 0; i < 8; i++) if (sen[i]) std::fprintf(stderr, " %d: %.0f (%d)", i, ses[i] / sen[i], sen[i]);
-          std::fprintf(stderr, "\n   by sixteenth of the worker index:"); for (int i = 0; i < 16; i++) if (bn[i]) std::fprintf(stderr, " %.0f", bs[i] / bn[i]);
-          std::fprintf(stderr, "\n   slowest 16 workers (index, xcc, se, cu, simd):");
-          std::vector<std::pair<long long, int>> tw;
-          for (int w = 0; w < e->p_workers && w < 8192; w++) tw.push_back({(long long)st[AFE_PERSIST_TRACE_BASE + 4 + w] - tm, w});
-          std::sort(tw.begin(), tw.end());
-          for (size_t i = tw.size() - 64; i < tw.size(); i++) { const unsigned long long h = st[AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + tw[i].second];
-            std::fprintf(stderr, " %d:%llu/%llu/%llu/%llu=%.0f", tw[i].second, (h >> 32) & 15, (h >> 13) & 7, (h >> 8) & 15, (h >> 4) & 3, tw[i].first / 100.0); }
-          { int late[16] = {0}; const long long med = tw[tw.size() * 3 / 4].first;
-            for (auto &x : tw) if (x.first > med + 1500) late[(st[AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + x.second] >> 32) & 15]++;
-            std::fprintf(stderr, "\n   more than 15 us behind the third quartile, by XCC:"); for (int i = 0; i < 8; i++) std::fprintf(stderr, " %d", late[i]); }
-          std::fprintf(stderr, "\n   fastest 16:");
-          for (size_t i = 0; i < 16; i++) { const unsigned long long h = st[AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + tw[i].second];
-            std::fprintf(stderr, " %d:%llu/%llu/%llu/%llu", tw[i].second, (h >> 32) & 15, (h >> 13) & 7, (h >> 8) & 15, (h >> 4) & 3); }
-          std::fprintf(stderr, "\n");
-        }
-        std::fprintf(stderr, "   %zu SIMDs, %zu CUs in use; by waves on the SIMD:", by_simd.size(), by_cu.size());
-        for (auto &kv : per_share) std::fprintf(stderr, "  %zu: %d waves, mean %.1f us;", kv.first, kv.second.first, kv.second.second / kv.second.first);
-        std::fprintf(stderr, "\n   by waves on the CU:");
-        for (auto &kv : per_cu_share) std::fprintf(stderr, "  %zu: %d waves, mean %.1f us;", kv.first, kv.second.first, kv.second.second / kv.second.first);
-        std::fprintf(stderr, "\n");
-      }
-    }
-}
-#endif
 
 // Host-visible arenas: every authorised step has run and nothing is queued -- but a resident grid STAYS (its workers
 // read and write the slabs only between seeing a ring entry and publishing their completion mark, and the pump's
@@ -956,23 +845,30 @@ int quiesce(afe_engine *e) {
         if ((rc = persist_launch(e))) return rc;
         continue;
       }
-      if (st[1] >= e->p_next) break;
-      // ask the workers themselves (afe_device.h, sync marker): the pump's sweep over thousands of marks is tens of
-      // microseconds old, a worker answers the moment its own count stands at the request
-      if (st[AFE_PERSIST_SYNCREQ_WORD] != e->p_next) __atomic_store_n(&e->p_host[AFE_PERSIST_HOST_RING + AFE_PERSIST_SYNCREQ_WORD], (unsigned long long)e->p_next, __ATOMIC_RELEASE);
-      if (st[AFE_PERSIST_SYNC_WORD] >= e->p_next) break;
-      if (e->host_arena && e->p_workers <= AFE_PERSIST_HOST_MARKS) {   // small grids write their marks here themselves: no wait for the pump's sweep
-        unsigned long long low = ~0ull;
-        for (int w = 0; w < e->p_workers; w++) { const unsigned long long d = st[8 + w]; low = d < low ? d : low; }
-        if (low >= e->p_next) break;
+      if (e->p_sync_posted == e->p_next + 1) {
+        // A request for this count has been posted: from here on the ONLY way out is the workers' own answer (or the
+        // grid's park, above).  The arrival counters of a launch are never reset -- a shard is complete at every multiple
+        // of its size -- so a request that is left while only part of the workers have answered its marker (through the
+        // pump's older word, say, with the slot then overwritten by the next real entry) would leave them misaligned for
+        // the life of the grid, and a later request would be "answered" while workers are still stepping.
+        if (st[AFE_PERSIST_SYNC_WORD] >= e->p_next) break;
+      } else {
+        if (st[1] >= e->p_next) break;             // the pump's sweep already says so: nothing posted, nothing to answer
+        if (e->host_arena && e->p_workers <= AFE_PERSIST_HOST_MARKS) {   // small grids write their marks here themselves: no request, no wait for the pump's sweep
+          unsigned long long low = ~0ull;
+          for (int w = 0; w < e->p_workers; w++) { const unsigned long long d = st[8 + w]; low = d < low ? d : low; }
+          if (low >= e->p_next) break;
+        } else {
+          // ask the workers themselves (afe_device.h, sync marker): the pump's sweep over thousands of marks is tens of
+          // microseconds old, a worker answers the moment its own count stands at the request
+          __atomic_store_n(&e->p_host[AFE_PERSIST_HOST_RING + AFE_PERSIST_SYNCREQ_WORD], (unsigned long long)e->p_next, __ATOMIC_RELEASE);
+          e->p_sync_posted = e->p_next + 1;
+        }
       }
       if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
         return fail(e, AFE_ERR_HIP, "persistent step kernel makes no progress");
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-#ifdef AFE_SYNC_TRACE
-    sync_trace_report(e, st, t0);
-#endif
     e->p_quiesced = e->p_next;
   }
   if (!e->p_running && e->stream_pending) {
@@ -983,7 +879,7 @@ int quiesce(afe_engine *e) {
 }
 
 long persist_refresh_steps() {
-  static const long refresh = [] { const char *s = std::getenv("AFE_PERSIST_REFRESH_STEPS"); return s && *s ? std::atol(s) : 512L; }();
+  static const long refresh = [] { const char *s = afe_dev_env("AFE_PERSIST_REFRESH_STEPS"); return s && *s ? std::atol(s) : 512L; }();
   return refresh;
 }
 
@@ -1180,7 +1076,6 @@ static int create_engine(afe_engine **out, int64_t n_vehicles, int precision, in
   if (launch_seed_rng(e->rng, e->n, e->first_global, e->seed_policy, main_stream(e)) != 0)
     return bail("seed kernel launch (is the gfx950 code object present?)", hipGetLastError());
   if ((err = hipStreamSynchronize(main_stream(e))) != hipSuccess) return bail("seed kernel", err);
-  if (const char *rs = std::getenv("AFE_PERSIST_RESERVE_CUS")) { const int k = std::atoi(rs); if (k >= 0 && k <= 8) e->p_reserve = k; }
   if (const char *fm = std::getenv("AFE_FORCE_STEP_MODE")) {   // test hook: every engine of this process steps by the resident grid where it can (1 persistent, 3 resident state)
     const int m = std::atoi(fm);
     if (m >= AFE_STEP_LAUNCH && m <= AFE_STEP_RESIDENT) e->step_mode = m;
@@ -1207,7 +1102,16 @@ extern "C" int afe_destroy(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   (void)hipSetDevice(e->device);
   if (e->p_running) (void)persist_park(e);
-  if (e->aql) { afe::aql_close(e->aql); e->aql = nullptr; }     // (waits for a grid that did not take the park: nothing is freed under it)
+  if (e->aql) {
+    const bool left = afe::aql_close(e->aql);     // waits (30 s) for a grid that did not take the park
+    e->aql = nullptr;
+    if (!left) {
+      // the grid is still on the device and may write the rings and the slabs: they are leaked, not freed under it
+      // (the engine object too: its status block is what the message of the next call would read)
+      std::fprintf(stderr, "agrifly_engine: afe_destroy: a resident grid is still running; the engine's device memory is leaked\n");
+      return AFE_ERR_HIP;
+    }
+  }
   if (e->p_dev) (void)hipFree(e->p_dev);
   if (e->p_host) (void)hipHostFree(e->p_host);
   if (e->side_stream) (void)hipStreamSynchronize(e->side_stream);
@@ -1677,15 +1581,6 @@ extern "C" int afe_set_resident_queue(afe_engine *e, int mode) {
   const int rc = persist_park(e);
   if (rc) return rc;
   e->aql_mode = mode;
-  return AFE_OK;
-}
-
-extern "C" int afe_set_reserved_compute_units(afe_engine *e, int per_xcd) {
-  if (!e || per_xcd < 0 || per_xcd > 8) return fail(e, AFE_ERR_INVALID_ARG, "reserved compute units per XCD: 0 .. 8");
-  AFE_HIP(e, hipSetDevice(e->device));
-  const int rc = persist_park(e);
-  if (rc) return rc;
-  e->p_reserve = per_xcd;
   return AFE_OK;
 }
 

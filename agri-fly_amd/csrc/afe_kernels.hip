@@ -1043,12 +1043,6 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
   if (lane == 0) st_agent(persist_sync_counters(a) + 16 * AFE_PERSIST_SYNC_SHARDS, 0);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   u64_t req_marked = 0;
-#ifdef AFE_SYNC_TRACE
-  u64_t req_seen = 0;
-  bool had_news = false;
-  u64_t trace_iters = 0, trace_t0 = ticks100(), trace_probe = 0;
-  if (lane == 0) st_system(a.host_status + AFE_PERSIST_TRACE_BASE - 2, (u64_t)__builtin_amdgcn_s_getreg(63492) | ((u64_t)__builtin_amdgcn_s_getreg(63508) << 32));
-#endif
   u64_t acc = ~0ull;                    // this lane's minimum over the part of done[] swept so far in the current cycle
   int sw = 0;                           // where the next partial sweep starts
   u64_t d[8];                           // a slice of done[] (and the help word) on its way: asked for at the end of one iteration,
@@ -1064,10 +1058,6 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
     // 6 143 takes 36 iterations, so `m` and the host's completion word are up to ~50 us old (every iteration when the
     // ring's window is nearly used up) -- `m` errs low, which only makes the window and the patience below conservative.
     const u64_t idx = p + (u64_t)lane;
-#ifdef AFE_SYNC_TRACE
-    trace_iters++;
-    const u64_t trace_ta = ticks100();
-#endif
     u64_t e8[8], req;
     const u64_t slot = p & a.host_mask;
     if (slot + 8 <= a.host_mask + 1) sld_system_8_1(a.host_ring + slot, a.host_status + AFE_PERSIST_SYNCREQ_WORD, e8, req);
@@ -1077,11 +1067,6 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
       for (int i = 1; i < 8; i++) e8[i] = 0;
     }
     const bool news = entry_index(e8[0]) == p + 1;
-#ifdef AFE_SYNC_TRACE
-    trace_probe += ticks100() - trace_ta;
-    if (news && !had_news && lane == 0) st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 2, ticks100());
-    had_news = news;
-#endif
     bool all8 = true;
 #pragma unroll
     for (int i = 0; i < 8; i++) all8 = all8 && entry_index(e8[i]) == p + 1 + (u64_t)i;
@@ -1121,16 +1106,9 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
     // index and BOTH flags, which no step and no park ever carries.  A worker that finds it under its own count answers
     // once (persistent kernel below); the next real entry for that slot simply overwrites it.  (Slot p is free: as for a
     // park entry.)
-#ifdef AFE_SYNC_TRACE
-    if (req != req_marked && req != req_seen) { req_seen = req; if (lane == 0) st_system(a.host_status + AFE_PERSIST_TRACE_BASE, ticks100()); }
-#endif
     if (req != req_marked && req == p) {
       if (lane == 0) st_agent(a.dev_ring + (p & a.dev_mask), entry_stamp(((p + 1) << 2) | AFE_PERSIST_PARK | AFE_PERSIST_TICK, a.epoch));
       req_marked = req;
-#ifdef AFE_SYNC_TRACE
-      if (lane == 0) { st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 1, ticks100()); st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 3, (trace_iters << 32) | (ticks100() - trace_t0)); st_system(a.host_status + AFE_PERSIST_TRACE_BASE - 1, trace_probe); }
-      trace_iters = 0; trace_t0 = ticks100(); trace_probe = 0;
-#endif
     }
     const u64_t now = ticks100();
     const bool fed = news;                                 // the host is ahead of us (there may just be no room yet)
@@ -1273,13 +1251,6 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P_arg, const 
     const bool marker = ready && (e & 3ull) == 3ull;                        // the pump's sync marker: not a step, not a park
     const int cnt = ones_from_bit0(__ballot(ready && !marker));
     if (cnt == 0) {
-#ifdef AFE_SYNC_TRACE
-      if (idle_polls == 0 && lane == 0 && w < 8192) {
-        st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 4 + w, ticks100());
-        st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 4 + 2 * 8192 + w, (u64_t)__builtin_amdgcn_s_getreg(63492) | ((u64_t)__builtin_amdgcn_s_getreg(63508) << 32));
-      }
-      if (!sync_answered && (__ballot(marker) & 1ull) && lane == 0 && w < 8192) st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 4 + 8192 + w, ticks100());
-#endif
       if (!sync_answered && (__ballot(marker) & 1ull)) {
         // the host waits for everything before this slot and this wave has done it: say so once.  The stores of the last
         // step are acknowledged first.  Arrivals never interleave between two requests (the host waits for each), so a
@@ -1325,9 +1296,6 @@ afe_step_persistent_kernel(const StepView<R> v, const DevParams<R> P_arg, const 
       for (int b = 1; b < (1 << ex); b++) __builtin_amdgcn_s_sleep(2);
       continue;
     }
-#ifdef AFE_SYNC_TRACE
-    if (idle_polls > 0 && lane == 0 && w < 8192) st_system(a.host_status + AFE_PERSIST_TRACE_BASE + 4 + 3 * 8192 + w, ticks100());
-#endif
     idle_polls = 0; sync_answered = false;
     // host-visible arena (afe_create_host_visible): what the host wrote before it authorised these steps is read from
     // host memory, not from a cache line of an earlier step

@@ -281,6 +281,33 @@ extern "C" int afe_plan_ticks(double logic_period_s, uint64_t *elapsed_us, uint6
 
 extern "C" int afe_abi_version(void) { return AFE_ABI_VERSION; }
 
+extern "C" int afe_has_dev_hooks(void) {
+#ifdef AFE_DEV_HOOKS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+namespace {
+template <typename R>
+void kernarg_layout(int32_t offsets[4], int32_t sizes[4], int32_t *segment_bytes) {
+  using K = afe::PersistKernarg<R>;
+  offsets[0] = (int32_t)offsetof(K, v); sizes[0] = (int32_t)sizeof(afe::StepView<R>);
+  offsets[1] = (int32_t)offsetof(K, P); sizes[1] = (int32_t)sizeof(afe::DevParams<R>);
+  offsets[2] = (int32_t)offsetof(K, G); sizes[2] = (int32_t)sizeof(afe::DevLogic);
+  offsets[3] = (int32_t)offsetof(K, a); sizes[3] = (int32_t)sizeof(afe::PersistArgs);
+  *segment_bytes = (int32_t)afe::persist_kernarg_bytes<R>();
+}
+}  // namespace
+
+extern "C" int afe_persistent_kernarg_layout(int precision, int32_t offsets[4], int32_t sizes[4], int32_t *segment_bytes) {
+  if (!offsets || !sizes || !segment_bytes || (precision != AFE_F32 && precision != AFE_F64)) return AFE_ERR_INVALID_ARG;
+  if (precision == AFE_F64) kernarg_layout<double>(offsets, sizes, segment_bytes);
+  else kernarg_layout<float>(offsets, sizes, segment_bytes);
+  return AFE_OK;
+}
+
 extern "C" const char *afe_status_string(int status) {
   switch (status) {
     case AFE_OK: return "ok";

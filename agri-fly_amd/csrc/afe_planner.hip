@@ -24,6 +24,7 @@
 #include <stdio.h>
 
 #include "afe_planner.h"
+#include "afe_host.h"   // afe_dev_env
 
 namespace afe {
 namespace {
@@ -1470,14 +1471,14 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   PlannerBatch bb = b;
   bb.ordered = 0;
   int64_t rounds_from = INT64_MAX;
-  if (const char *env = std::getenv("AFE_PLANNER_ROUNDS_FROM")) rounds_from = std::strtoll(env, nullptr, 10);
+  if (const char *env = afe_dev_env("AFE_PLANNER_ROUNDS_FROM")) rounds_from = std::strtoll(env, nullptr, 10);
   // Longest first: a short sizing round (every planner works for at most `sizing` microseconds; most finish), then ONE
   // finishing round that starts the interrupted planners in the order of the work they may still have -- the launch
   // then ends when the work runs out, not when a long planner that happened to start late does.
   int64_t lpt_from = 16384;           // beyond four times what the chip holds at once (4 096 waves); measured: profiles/r03_planner_lpt.txt
   unsigned sizing_us = 400;
-  if (const char *env = std::getenv("AFE_PLANNER_LPT_FROM")) lpt_from = std::strtoll(env, nullptr, 10);
-  if (const char *env = std::getenv("AFE_PLANNER_SIZING_US")) sizing_us = (unsigned)std::strtoul(env, nullptr, 10);
+  if (const char *env = afe_dev_env("AFE_PLANNER_LPT_FROM")) lpt_from = std::strtoll(env, nullptr, 10);
+  if (const char *env = afe_dev_env("AFE_PLANNER_SIZING_US")) sizing_us = (unsigned)std::strtoul(env, nullptr, 10);
   if (b.resume && b.bin_count && b.n > lpt_from && b.n <= rounds_from) {
     (void)hipMemsetAsync(b.bin_count, 0, PlannerBatch::kBins * sizeof(int32_t), (hipStream_t)stream);
     bb.round = 0; bb.budget_ticks = sizing_us * 100u;
@@ -1491,7 +1492,7 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
     bb.bin_count = nullptr;
     unsigned budgets_us[16] = {1000, 2000, 4000, 8000, 16000, 32000};
     int n_rounds = 6;
-    if (const char *env = std::getenv("AFE_PLANNER_ROUNDS_US")) {     // measurement aid: "500,1000,..." (a last unlimited round is always added)
+    if (const char *env = afe_dev_env("AFE_PLANNER_ROUNDS_US")) {     // measurement aid: "500,1000,..." (a last unlimited round is always added)
       n_rounds = 0;
       for (const char *q = env; *q && n_rounds < 16;) {
         budgets_us[n_rounds++] = (unsigned)std::strtoul(q, nullptr, 10);

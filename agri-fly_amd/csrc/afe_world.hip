@@ -423,16 +423,17 @@ __device__ __forceinline__ void query_one(const uint4 *__restrict__ sorted, int6
 }
 
 // The workgroup that finishes LAST (a ticket) closes the query: it tells the host how many queries the rings left over
-// (pinned memory: the host reads it when it prepares the NEXT query, without waiting) and -- tail_brute -- answers them
-// itself by the brute-force definition, one after the other, all 256 threads on each.  That is the common case: nothing
-// is left over (every bench world), or a handful of isolated vehicles; the two brute-force launches behind every query
-// (9 us of a 60-100 us query) are then not launched at all.  A world that does leave queries over is noticed at the next
-// call and gets the launches back for its next 64 queries (world_nearest).
+// (pinned memory, informational) and answers up to AFE_WORLD_TAIL_MAX of them itself by the brute-force definition, one
+// after the other, all 256 threads on each -- the common case: nothing is left over (every bench world) or a handful of
+// isolated vehicles.  More than that is NOT one compute unit's work (n_left x n_all distance evaluations: 10^4 leftovers
+// among 10^6 points would hold the stream for 0.4 s): the count goes to `big_count`, and the launch that follows every
+// query (world_brute_chunks_kernel: 1 024 workgroups that leave at once when the word is zero) shares it over the device.
+#define AFE_WORLD_TAIL_MAX 32u
 __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restrict__ sorted, int64_t n_all, const uint32_t *__restrict__ starts,
                                                           GridDesc g, int64_t first_global, int64_t n_self, float *__restrict__ dist2_out,
                                                           int32_t *__restrict__ index_out, uint32_t *leftover_count,
                                                           int32_t *leftover, uint64_t *__restrict__ leftover_keys,
-                                                          uint32_t *words, const float *__restrict__ all_xyz, int tail_brute, uint32_t *host_left,
+                                                          uint32_t *words, const float *__restrict__ all_xyz, uint32_t *big_count, uint32_t *host_left,
                                                           uint32_t *tickets) {
   query_one(sorted, n_all, starts, g, first_global, n_self, dist2_out, index_out, leftover_count, leftover, leftover_keys, words);
   __shared__ bool last_block;
@@ -443,8 +444,11 @@ __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restric
   __syncthreads();
   if (!last_block) return;
   const uint32_t n_left = __hip_atomic_load(leftover_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (threadIdx.x == 0) __hip_atomic_store(host_left, n_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (!tail_brute) return;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(host_left, n_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(big_count, n_left > AFE_WORLD_TAIL_MAX ? n_left : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (n_left > AFE_WORLD_TAIL_MAX) return;
   for (uint32_t k = 0; k < n_left; k++) {
     const int64_t local = __hip_atomic_load(&leftover[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int me = (int)(first_global + local);
@@ -481,12 +485,18 @@ __global__ void __launch_bounds__(256) world_brute_init_kernel(uint64_t *__restr
   for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < *n_queries; k += gridDim.x * 256) keys[k] = AFE_WORLD_KEY_NONE;
 }
 
+// (`tickets` != nullptr: the launch's last workgroup also writes the answers out -- world_brute_finish_kernel's loop --
+// so that the launch behind every grid query is ONE; it leaves at once, before any ticket, when there is nothing listed)
 __global__ void __launch_bounds__(256) world_brute_chunks_kernel(const float *__restrict__ all_xyz, int64_t n_all, const int32_t *__restrict__ queries,
                                                                  const uint32_t *__restrict__ n_queries, int64_t first_global,
-                                                                 unsigned long long *__restrict__ keys) {
+                                                                 unsigned long long *__restrict__ keys, uint32_t *tickets,
+                                                                 float *__restrict__ dist2_out, int32_t *__restrict__ index_out) {
   __shared__ unsigned long long wave_key[4];
+  __shared__ bool last_block;
+  const uint32_t nq = *n_queries;
+  if (nq == 0) return;
   const int64_t n_chunks = (n_all + AFE_WORLD_BRUTE_CHUNK - 1) / AFE_WORLD_BRUTE_CHUNK;
-  const int64_t items = (int64_t)*n_queries * n_chunks;
+  const int64_t items = (int64_t)nq * n_chunks;
   for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
     const int64_t qi = item / n_chunks, chunk = item - qi * n_chunks;
     const int me = (int)(first_global + queries[qi]);
@@ -511,6 +521,17 @@ __global__ void __launch_bounds__(256) world_brute_chunks_kernel(const float *__
       for (int w = 1; w < 4; w++) key = wave_key[w] < key ? wave_key[w] : key;
       if (key != AFE_WORLD_KEY_NONE) atomicMin(&keys[qi], key);
     }
+  }
+  if (!tickets) return;
+  __syncthreads();
+  if (threadIdx.x == 0) last_block = last_workgroup(tickets);      // (its atomic minima are acknowledged: s_waitcnt inside)
+  __syncthreads();
+  if (!last_block) return;
+  for (uint32_t k = threadIdx.x; k < nq; k += 256) {
+    const int64_t local = queries[k];
+    const unsigned long long key = __hip_atomic_load(&keys[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    dist2_out[local] = __uint_as_float((uint32_t)(key >> 32));
+    index_out[local] = (int32_t)(uint32_t)key;   // 0xffffffff = -1: nobody
   }
 }
 
@@ -564,7 +585,7 @@ struct afe_world {
   uint4 *sorted = nullptr;
   int32_t *leftover = nullptr;
   uint64_t *leftover_keys = nullptr;   // per listed query: packed (distance, index) minimum of the brute force
-  int *lohi = nullptr;         // 6 ints + leftover counter
+  int *lohi = nullptr;         // 6 ints + leftover counter [6], the explicit brute force's count [7], the query's count for the launch behind it [8]
   BoundsPartial *bounds_part = nullptr;   // one record per workgroup of the bounds kernel
   int64_t cap_self = 0;
   float *self_scratch = nullptr;
@@ -581,11 +602,8 @@ struct afe_world {
   bool sort_valid = false;
   float *ref = nullptr;         // [3][cap_points]: positions at the last sort, original order
   uint32_t *words = nullptr;    // device: [0] bound on the movement since the sort (float bits)
-  uint32_t *tickets = nullptr;  // device: last_workgroup counters of the regather launch, then of the query launch
-  uint32_t *host_flag = nullptr;   // pinned: [0] a kernel asks for a new sort, [1] queries the last finished query's rings left over
-  int brute_countdown = 0;         // queries that still get the two brute-force launches (a recent query left something over)
-  bool always_brute_launches = std::getenv("AFE_WORLD_BRUTE_LAUNCHES") != nullptr;   // measurement aid: round 3's launch sequence
-  uint32_t last_leftover = 0;
+  uint32_t *tickets = nullptr;  // device: last_workgroup counters of the regather launch, of the query launch, of the brute-force launch behind it
+  uint32_t *host_flag = nullptr;   // pinned: [0] a kernel asks for a new sort, [1] queries the last finished query's rings left over (informational)
   std::string err;
 };
 
@@ -700,9 +718,9 @@ int ensure_capacity(afe_world *w, int64_t n_all, int64_t n_cells_total) {
     W_HIP(w, hipMalloc((void **)&w->block_sums, (size_t)((cap + 1023) / 1024 + 1) * 4));
     w->cap_cells = cap;
   }
-  if (!w->lohi) W_HIP(w, hipMalloc((void **)&w->lohi, 8 * sizeof(int)));
+  if (!w->lohi) W_HIP(w, hipMalloc((void **)&w->lohi, 16 * sizeof(int)));
   if (!w->words) { W_HIP(w, hipMalloc((void **)&w->words, 4 * sizeof(uint32_t))); W_HIP(w, hipMemset(w->words, 0, 4 * sizeof(uint32_t))); }
-  if (!w->tickets) { W_HIP(w, hipMalloc((void **)&w->tickets, 2 * AFE_WORLD_TICKET_WORDS * sizeof(uint32_t))); W_HIP(w, hipMemset(w->tickets, 0, 2 * AFE_WORLD_TICKET_WORDS * sizeof(uint32_t))); }
+  if (!w->tickets) { W_HIP(w, hipMalloc((void **)&w->tickets, 3 * AFE_WORLD_TICKET_WORDS * sizeof(uint32_t))); W_HIP(w, hipMemset(w->tickets, 0, 3 * AFE_WORLD_TICKET_WORDS * sizeof(uint32_t))); }
   if (!w->host_flag) { W_HIP(w, hipHostMalloc((void **)&w->host_flag, 64, hipHostMallocCoherent | hipHostMallocMapped)); w->host_flag[0] = 0; w->host_flag[1] = 0; }
   if (!w->bounds_part) W_HIP(w, hipMalloc((void **)&w->bounds_part, AFE_WORLD_BOUNDS_BLOCKS * sizeof(BoundsPartial)));
   return AFE_OK;
@@ -816,21 +834,16 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   }
   // 3. queries in cell order; isolated vehicles finish in the brute-force kernel
   uint32_t *left_count = (uint32_t *)(w->lohi + 6);
-  // What the rings leave over is finished by the brute force: inside the query launch by its last workgroup (the common
-  // case: nothing or next to nothing left over), or -- when an earlier query of this world reported leftovers (pinned
-  // word, read without waiting: it is the count of the last query that has FINISHED) -- by the two launches that share
-  // the work over the whole device, for the next 64 queries.
-  volatile uint32_t *host_left = w->host_flag + 1;
-  if (*host_left > 0) w->brute_countdown = 64;
-  const bool launches = w->brute_countdown > 0 || w->always_brute_launches;
-  if (w->brute_countdown > 0) w->brute_countdown--;
+  // What the rings leave over is finished by the brute force: up to AFE_WORLD_TAIL_MAX queries inside the query launch by
+  // its last workgroup (the common case: nothing or next to nothing left over), more than that by the launch behind it,
+  // which shares (query, chunk of the ensemble) items over the whole device and leaves at once when its count is zero.
+  // No host-side guess is involved: a world that suddenly leaves 10^5 queries over (a fleet scattered beyond the grid's
+  // rings) is answered in milliseconds by that launch, not in seconds by one compute unit.
+  uint32_t *big_count = (uint32_t *)(w->lohi + 8);
   hipLaunchKernelGGL(world_query_kernel, dim3(pb), dim3(256), 0, st, w->sorted, n_all, w->counts, g, first_global, n_self, dist2_out,
-                     index_out, left_count, w->leftover, w->leftover_keys, w->words, all_xyz, launches ? 0 : 1, w->host_flag + 1, w->tickets);
-  if (launches) {
-    hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(1024), dim3(256), 0, st, all_xyz, n_all, w->leftover, left_count, first_global,
-                       (unsigned long long *)w->leftover_keys);
-    hipLaunchKernelGGL(world_brute_finish_kernel, dim3(64), dim3(256), 0, st, w->leftover, left_count, w->leftover_keys, dist2_out, index_out);
-  }
+                     index_out, left_count, w->leftover, w->leftover_keys, w->words, all_xyz, big_count, w->host_flag + 1, w->tickets);
+  hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(1024), dim3(256), 0, st, all_xyz, n_all, w->leftover, big_count, first_global,
+                     (unsigned long long *)w->leftover_keys, w->tickets + 2 * AFE_WORLD_TICKET_WORDS, dist2_out, index_out);
   W_HIP(w, hipGetLastError());
   return AFE_OK;
 }
@@ -878,7 +891,7 @@ int afe::world_nearest_bruteforce(afe_world *w, void *hip_stream, const float *a
   W_HIP(w, hipStreamSynchronize(st));   // nq lives on this stack frame
   hipLaunchKernelGGL(world_brute_init_kernel, dim3(64), dim3(256), 0, st, w->leftover_keys, cnt);
   hipLaunchKernelGGL(world_brute_chunks_kernel, dim3(2048), dim3(256), 0, st, all_xyz, n_all, dev_queries, cnt, first_global,
-                     (unsigned long long *)w->leftover_keys);
+                     (unsigned long long *)w->leftover_keys, (uint32_t *)nullptr, (float *)nullptr, (int32_t *)nullptr);
   hipLaunchKernelGGL(world_brute_finish_kernel, dim3(64), dim3(256), 0, st, dev_queries, cnt, w->leftover_keys, dist2_out, index_out);
   W_HIP(w, hipGetLastError());
   return AFE_OK;

@@ -47,7 +47,8 @@ ABI_FUNCTIONS = [
     "afe_uwb_create", "afe_uwb_destroy", "afe_uwb_set_noise", "afe_uwb_draw", "afe_uwb_range",
     "afe_set_step_mode", "afe_steps_completed", "afe_persistent_running", "afe_stream_probe",
     "afe_set_noise_seed", "afe_set_gust_process", "afe_get_external_force", "afe_nearest_neighbour_async", "afe_query_sync",
-    "afe_gather_exchange", "afe_set_cache_policy", "afe_grid_time", "afe_cache_policy_in_use", "afe_set_reserved_compute_units", "afe_set_resident_queue",
+    "afe_gather_exchange", "afe_set_cache_policy", "afe_grid_time", "afe_cache_policy_in_use", "afe_set_resident_queue",
+    "afe_has_dev_hooks", "afe_persistent_kernarg_layout", "afe_group_set_staged_copies",
 ]
 
 
@@ -341,7 +342,9 @@ def library():
         "afe_group_peer_access": [vp, C.POINTER(ci)],
         "afe_set_cache_policy": [eng, ci],
         "afe_cache_policy_in_use": [eng, C.POINTER(ci)],
-        "afe_set_reserved_compute_units": [eng, ci],
+        "afe_has_dev_hooks": [],
+        "afe_persistent_kernarg_layout": [ci, vp, vp, vp],
+        "afe_group_set_staged_copies": [vp, ci],
         "afe_set_resident_queue": [eng, ci],
         "afe_grid_time": [eng, C.POINTER(u64), C.POINTER(u64)],
         "afe_group_destroy": [vp],
@@ -900,10 +903,6 @@ class Ensemble:
         """-1 automatic (own queue up to 262 144 vehicles), 0 the HIP stream, 1 the engine's own queue"""
         self._ck(self._L.afe_set_resident_queue(self._h, int(mode)))
 
-    def set_reserved_compute_units(self, per_xcd):
-        """compute units per XCD kept free of the resident grid (other kernels run beside it); 0: none"""
-        self._ck(self._L.afe_set_reserved_compute_units(self._h, int(per_xcd)))
-
     @property
     def cache_policy_in_use(self):
         p = C.c_int(0)
@@ -1079,6 +1078,10 @@ class Group:
         ok = C.c_int(0)
         self._ck(self._L.afe_group_peer_access(self._h, C.byref(ok)))
         return bool(ok.value)
+
+    def set_staged_copies(self, staged):
+        """the gather's staged path (hipMemcpyPeerAsync row by row) even between peers; False: direct copies again"""
+        self._ck(self._L.afe_group_set_staged_copies(self._h, 1 if staged else 0))
 
     def step(self, dt_us, n_steps=1):
         self._ck(self._L.afe_group_step(self._h, int(dt_us), int(n_steps)))

@@ -413,41 +413,91 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
                     "bit-identical to the CPU checkers in tests/test_gpu_render.py / test_gpu_planner.py"}
 
 
-def cpu_baseline(afa, budget_vehicle_steps=24_000_000):
-    """the oracle (double, scalar C, 1 thread) on a bounded sample of the same
-    workload; test infrastructure used here only as the reported baseline.  Both legs together stay below ~10 s (the
-    driver's run is mostly this otherwise): ~6 s on one thread, ~3 s on all host cores"""
-    from oracle import oracle_py
-    n, steps = 16384, max(10, budget_vehicle_steps // 16384)
-    p = afa.params_from_type(5)
-    data = afa.scenarios.hover_ensemble(n, p)
-    b = oracle_py.Batch(n, [oracle_py.params_from_type(5)])
-    b.pos[:], b.vel[:], b.att[:], b.ang_vel[:] = data.pos, data.vel, data.att, data.ang_vel
-    b.motor_speed[:], b.motor_cmd[:] = data.motor_speed, data.motor_cmd
+def host_cores():
+    """(threads this process may run on, cgroup CPU quota in cores or None, CPU model): os.cpu_count() is the HOST's count --
+    a container is often given a slice of it (round 4: 256 reported, 8 usable)"""
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = os.cpu_count() or 1
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),):
+        try:
+            quota = parse(open(path).read())
+        except (OSError, ValueError, IndexError):
+            pass
+    if quota is None:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return affinity, quota, model
 
-    def run(k, t0_us, tick_base):
+
+def cpu_baseline(afa, budget_vehicle_steps=20_000_000):
+    """the oracle (double, scalar C) on a bounded sample of the same workload; test infrastructure used here only as the
+    reported baseline.  Three legs, ~10 s together: one thread under the headline's noise policy (counter-based: Philox +
+    Box-Muller, no libstdc++ draw), one thread on the reference's own libstdc++ streams (reference_noise_streams'
+    policy), and every core this process may use (OpenMP over vehicles, >= 64 vehicles per thread, vehicles outer /
+    steps inner: no shared data)."""
+    from oracle import oracle_py
+    p = afa.params_from_type(5)
+
+    def batch(n):
+        data = afa.scenarios.hover_ensemble(n, p)
+        b = oracle_py.Batch(n, [oracle_py.params_from_type(5)])
+        b.pos[:], b.vel[:], b.att[:], b.ang_vel[:] = data.pos, data.vel, data.att, data.ang_vel
+        b.motor_speed[:], b.motor_cmd[:] = data.motor_speed, data.motor_cmd
+        b.rng[:] = 1 + np.arange(n, dtype=np.uint32)          # AFE_SEED_DECORRELATED: seed = 1 + global index
+        return b
+
+    def run(b, k, t0_us, tick_base, counter):
         ticks, _ = afa.plan_ticks(LOGIC_PERIOD, 0, DT_US, k)
         t0 = time.perf_counter()
-        oracle_py.step_counter(b, DT_US, k, ticks, counter_noise=True, seed=NOISE_SEED, first_global=0, tick_base=tick_base,
+        oracle_py.step_counter(b, DT_US, k, ticks, counter_noise=counter, seed=NOISE_SEED, first_global=0, tick_base=tick_base,
                                gust_seed=GUST_SEED, gust_period_us=GUST_PERIOD_US, t0_us=t0_us, n_global=1 << 20, sigma_max=GUST_SIGMA_MAX)
-        return time.perf_counter() - t0, int(ticks.sum())
+        return time.perf_counter() - t0
 
-    run(10, 0, 0)  # warm
-    dt, nt = run(steps, 10 * DT_US, 5)
+    n = 16384
+    steps = max(10, budget_vehicle_steps // n)
+    b = batch(n)
+    run(b, 10, 0, 0, True)  # warm
+    dt = run(b, steps, 10 * DT_US, 5, True)
+    affinity, quota, model = host_cores()
     out = {"value": n * steps / dt, "unit": "vehicle-steps/s", "cores": 1, "kind": "port",
            "sample": "%d vehicles x %d steps of the same workload (gust process, IMU + counter-based noise every 2nd step), "
                      "oracle/agrifly_oracle.c + agrifly_oracle_counter.c double precision, gcc -O2, 1 thread, %.1f s" % (n, steps, dt),
-           "host_cpus": os.cpu_count()}
-    # the same port spread over every host core (OpenMP over vehicles), SURVEY 8d CPU-baseline (ii)
-    threads = os.cpu_count() or 1
+           "cpu_model": model, "host_cpus": os.cpu_count(), "affinity_cpus": affinity, "cgroup_quota_cpus": quota}
+    # the reference's own noise machinery (per-vehicle minstd_rand0 + polar method), one thread
+    bx = batch(n)
+    steps_x = max(10, steps // 2)
+    run(bx, 10, 0, 0, False)
+    dtx = run(bx, steps_x, 10 * DT_US, 5, False)
+    out["reference_noise_streams"] = {"value": n * steps_x / dtx, "unit": "vehicle-steps/s", "cores": 1,
+                                      "sample": "%d vehicles x %d steps, libstdc++-exact streams (seed 1 + index), 1 thread, %.1f s" % (n, steps_x, dtx)}
+    # the same port on every core this process may use, SURVEY 8d CPU-baseline (ii)
+    threads = max(1, min(affinity, int(np.ceil(quota)) if quota else affinity))
     if threads > 1:
+        n_mt = max(n, 64 * threads)
+        bm = batch(n_mt)
         oracle_py.lib().ora_set_batch_threads(threads)
-        run(10, 0, 0)
-        steps_mt = max(10, steps * min(threads, 32) // 8)
-        dt_mt, _ = run(steps_mt, 0, 0)
+        run(bm, 10, 0, 0, True)
+        steps_mt = int(min(20000, max(100, 3.0 * out["value"] * threads / n_mt)))     # ~3 s if it scales
+        dt_mt = run(bm, steps_mt, 10 * DT_US, 5, True)
         oracle_py.lib().ora_set_batch_threads(1)
-        out["all_cores"] = {"value": n * steps_mt / dt_mt, "unit": "vehicle-steps/s", "cores": threads,
-                            "sample": "%d vehicles x %d steps, %d OpenMP threads, %.1f s" % (n, steps_mt, threads, dt_mt)}
+        v = n_mt * steps_mt / dt_mt
+        out["all_cores"] = {"value": v, "unit": "vehicle-steps/s", "cores": threads, "speedup_over_one_thread": v / out["value"],
+                            "sample": "%d vehicles x %d steps, %d OpenMP threads (%d vehicles each), %.1f s" % (n_mt, steps_mt, threads, n_mt // threads, dt_mt)}
     return out
 
 
@@ -710,7 +760,10 @@ def compact_line(full):
         c = _pick(cb, ("value", "unit", "cores", "kind"))
         c["sample"] = str(cb.get("sample", ""))[:200]
         if cb.get("all_cores"):
-            c["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+            c["all_cores"] = _pick(cb["all_cores"], ("value", "cores", "speedup_over_one_thread"))
+        if cb.get("reference_noise_streams"):
+            c["reference_noise_streams"] = _pick(cb["reference_noise_streams"], ("value", "cores"))
+        c["cpu_model"] = str(cb.get("cpu_model", ""))[:60]
         line["cpu_baseline"] = c
     st = full.get("config4_as_stated")
     if st:

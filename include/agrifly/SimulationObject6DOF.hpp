@@ -16,6 +16,12 @@
 #pragma once
 
 #ifdef AGRIFLY_USE_REFERENCE_TYPES
+// (the tree's header names std::shared_ptr without including <memory> -- its own includers happen to have done so,
+// Quadcopter_T.hpp:4; found by tests/test_dropin_reference_headers.py, which compiles this branch against the tree)
+#include <stdint.h>
+
+#include <memory>
+
 #include "Components/Simulation/SimulationObject6DOF.hpp"
 #else
 #include <stdint.h>

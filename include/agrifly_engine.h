@@ -35,7 +35,10 @@ extern "C" {
 /* 2: afe_device_view starts with `struct_bytes` (set by the caller; the engine never writes past it) and carries
  *    pos_anchor_xy -- AFE_F32 engines keep x and y in `pos` RELATIVE to the last set point (round 3 changed the meaning of
  *    view.pos without changing this number: a host built against version 1 must be rebuilt, afe_abi_version() tells). */
-#define AFE_ABI_VERSION 2
+/* 3: afe_set_reserved_compute_units is gone (no consumer; a reservation cost the grid 4-25 %); added
+ *    afe_has_dev_hooks and afe_persistent_kernarg_layout.  Nothing else moved: a version-2 host that never called the
+ *    removed function runs unchanged after a rebuild. */
+#define AFE_ABI_VERSION 3
 
 typedef struct afe_engine afe_engine; /* opaque */
 
@@ -131,6 +134,15 @@ int afe_destroy(afe_engine *e);
 const char *afe_last_error(const afe_engine *e);
 const char *afe_status_string(int status);
 int afe_abi_version(void);
+/* 1 when the loaded library was built with -DAFE_DEV_HOOKS (the kernel lab's measurement variables of tools/ are
+ * read), 0 for the release build, which reads exactly six environment variables:
+ * AFE_PERSIST_AQL, AFE_FORCE_STEP_MODE, AFE_FORCE_SPLIT, AFE_FORCE_HOST_ARENA, AFE_CACHE_POLICY, AFE_PERSIST_DEBUG. */
+int afe_has_dev_hooks(void);
+/* Build self-check (no GPU needed): byte offset and size of each of the four by-value arguments of the resident step
+ * kernel -- StepView, DevParams, DevLogic, PersistArgs -- as the HOST packs them for a dispatch on the engine's own
+ * queue (precision AFE_F32 / AFE_F64), and the size of the whole segment.  tests/test_kernel_resources.py holds them
+ * against the argument table of every instantiation in the gfx950 code object inside the library. */
+int afe_persistent_kernarg_layout(int precision, int32_t offsets[4], int32_t sizes[4], int32_t *segment_bytes);
 
 /* Use a caller-owned HIP stream (hipStream_t) for all engine work, e.g.
  * torch's current stream.  NULL restores the engine's own stream. */
@@ -545,17 +557,6 @@ int afe_grid_time(afe_engine *e, uint64_t *device_ns, uint64_t *steps);
  * (at 524 288 the own queue is 5 % faster in 20-step blocks but the grid fills the device: DESIGN.md section 6).
  * Same bits either way.  Ends the grid now resident.  Replaces nothing in the reference. */
 int afe_set_resident_queue(afe_engine *e, int mode);
-/* Keep compute units out of the resident grid's reach (its queue's compute-unit mask; 0, the default: none).  A resident
- * grid of a large ensemble otherwise holds every wave slot of the device, and any other kernel of the process -- an RCCL
- * collective between two blocks of steps, the host's own work -- waits until it has idled out (200 us) or been parked.
- * With a reservation such kernels start at once beside it and the grid stays resident across them (measured, one-rank
- * RCCL all-reduce beside a fed 2^20-vehicle grid: 0.36 -> 0.05 ms).  The hardware keeps the shader engines of an XCD
- * symmetric, so the reservation comes in rows of one unit per shader engine: per_xcd is rounded up to a multiple of 4,
- * i.e. 32 of 256 units at least -- and a grid on 224 units steps 4 % slower at 2^20 vehicles, 25 % at 131 072
- * (tools/reserve_probe.py).  A trade for hosts that interleave collectives or their own kernels with every few steps; not
- * used by bench.py.  Ends the grid now resident; applies from the next one.  No effect on grids launched on a HIP stream.
- * Replaces nothing in the reference (one thread, one loop). */
-int afe_set_reserved_compute_units(afe_engine *e, int per_xcd);
 
 /* Cache-policy hints of the one-step launches' slab accesses (`nt` bits on the buffer instructions; never a different
  * result bit).  -1 automatic (default): by what the 256 MiB Infinity Cache can keep from one step to the next --
@@ -735,10 +736,15 @@ int afe_group_sync(afe_group *g);
 int afe_group_gather_positions(afe_group *g, float **dev_xyz_all_out);
 const char *afe_group_last_error(const afe_group *g);
 /* *all_pairs = 1 if every pair of the group's devices has direct peer access; 0 if some pair has none
- * (IOMMU, VMs, restricted containers): such a group still works -- the runtime stages those copies through
- * the host -- afe_group_create says so once on stderr and the gather is slower.  (The reference's analogue is
- * one address space for all vehicles: nothing to ask.) */
+ * (IOMMU, VMs, restricted containers): such a group still works -- its gather then copies row by row with
+ * hipMemcpyPeerAsync, which the runtime stages through host memory where it must -- afe_group_create says so once on
+ * stderr and the gather is slower.  UNVERIFIED on a machine whose devices really lack peer access (none was available):
+ * the staged path itself runs in the test suite, between peers and between logical shards of one device.  (The
+ * reference's analogue is one address space for all vehicles: nothing to ask.) */
 int afe_group_peer_access(const afe_group *g, int *all_pairs);
+/* staged != 0: the gather uses the staged path (above) even between peers -- for a host that knows its direct copies
+ * misbehave; 0: back to direct copies (refused with AFE_ERR_INVALID_ARG when a pair has no peer access). */
+int afe_group_set_staged_copies(afe_group *g, int staged);
 
 /* ---- shared-world consumers of the gathered buffer -----------------------
  * Nearest neighbour (collision / separation monitoring): for each local vehicle

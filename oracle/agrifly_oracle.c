@@ -385,6 +385,17 @@ void ora_quad_step(const ora_params *p, ora_state *s, const float motor_cmd[4],
                    const double ext_force[3], const double ext_torque[3],
                    double dt, int logic_tick, float gyro[3], float acc_meas[3],
                    double acc_world[3]) {
+  ora_quad_step_normals(p, s, motor_cmd, ext_force, ext_torque, dt, logic_tick, NULL, gyro, acc_meas, acc_world);
+}
+
+/* The same step with the six N(0,1) values of a logic tick supplied by the caller in DRAW order (normals6[0] is what the
+ * reference's first draw would be: it lands on gyro z, :167-169) -- for noise policies that are not the libstdc++ stream
+ * (agrifly_oracle_counter.c); s->rng is then neither read nor advanced.  normals6 == NULL: drawn from s->rng, i.e.
+ * ora_quad_step. */
+void ora_quad_step_normals(const ora_params *p, ora_state *s, const float motor_cmd[4],
+                           const double ext_force[3], const double ext_torque[3],
+                           double dt, int logic_tick, const double *normals6, float gyro[3], float acc_meas[3],
+                           double acc_world[3]) {
   static const double zero3[3] = {0, 0, 0};
   if (!ext_force) ext_force = zero3;
   if (!ext_torque) ext_torque = zero3;
@@ -457,9 +468,13 @@ void ora_quad_step(const ora_params *p, ora_state *s, const float motor_cmd[4],
     /* g++ evaluates the three ctor arguments right to left:
      * z <- 1st draw, y <- 2nd, x <- 3rd; six draws = three polar pairs. */
     double n[6];
-    ora_normal_pair(&s->rng, &n[0], &n[1]);
-    ora_normal_pair(&s->rng, &n[2], &n[3]);
-    ora_normal_pair(&s->rng, &n[4], &n[5]);
+    if (normals6) {
+      for (int k = 0; k < 6; k++) n[k] = normals6[k];
+    } else {
+      ora_normal_pair(&s->rng, &n[0], &n[1]);
+      ora_normal_pair(&s->rng, &n[2], &n[3]);
+      ora_normal_pair(&s->rng, &n[4], &n[5]);
+    }
 
     float w_f[3] = {(float)s->ang_vel[0], (float)s->ang_vel[1], (float)s->ang_vel[2]}; /* :165 */
     float g[3];

@@ -97,6 +97,11 @@ void ora_quad_step(const ora_params *p, ora_state *s, const float motor_cmd[4],
                    const double ext_force[3], const double ext_torque[3],
                    double dt, int logic_tick, float gyro[3], float acc[3],
                    double acc_world[3]);
+/* the same step with the tick's six N(0,1) values supplied in draw order (NULL: drawn from s->rng = ora_quad_step) */
+void ora_quad_step_normals(const ora_params *p, ora_state *s, const float motor_cmd[4],
+                           const double ext_force[3], const double ext_torque[3],
+                           double dt, int logic_tick, const double *normals6, float gyro[3], float acc_meas[3],
+                           double acc_world[3]);
 
 /* Motor::Run (Motor.cpp:39-84) for one motor; returns new speed, writes
  * thrust[3], torque[3], ang_mom[3] (body frame) and instantaneous power. */

@@ -57,9 +57,11 @@ void ora_gust_force(uint64_t seed, uint64_t index, uint64_t n_global, uint64_t e
   for (int k = 0; k < 3; k++) force[k] = sigma * z[k];
 }
 
-/* ora_quad_step draws its six normals from s->rng in g++'s argument order (z <- 1st ...).  To feed it other normals
- * without touching that function the step is run noise-free (sigma = 0 in a copy of the record) and the noise is
- * added afterwards exactly where ora_quad_step adds it: a float product added to the float sample. */
+/* Under the counter policy the six normals of a tick come from Philox and go into the step in the reference's DRAW
+ * order (ora_quad_step_normals): gyro x y z = z0 z1 z2 are draws 3 2 1, accelerometer x y z = z3 z4 z5 draws 6 5 4.  The
+ * libstdc++ stream is neither drawn from nor advanced (round-4 review: the earlier version ran the step with sigma = 0,
+ * which still drew and discarded six libstdc++ normals per tick -- the most expensive item of a CPU step -- and made
+ * the CPU baseline of this policy slower than the algorithm it stands for). */
 void ora_step_batch_counter(int64_t n, int n_steps, const ora_params *table, const uint8_t *types, double *pos, double *vel,
                             double *att, double *ang_vel, double *motor_speed, uint32_t *rng, const float *motor_cmd,
                             double *ext_force, const double *ext_torque, uint64_t dt_us, const uint8_t *tick_per_step,
@@ -69,9 +71,7 @@ void ora_step_batch_counter(int64_t n, int n_steps, const ora_params *table, con
   const int threads = ora_get_batch_threads();
 #pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
   for (int64_t i = 0; i < n; i++) {
-    ora_params p = table[types ? types[i] : 0];
-    const float sg = (float)p.sigma_gyro, sa = (float)p.sigma_acc;
-    if (use_counter_noise) { p.sigma_gyro = 0; p.sigma_acc = 0; }
+    const ora_params p = table[types ? types[i] : 0];
     ora_state s;
     for (int k = 0; k < 3; k++) { s.pos[k] = pos[k * n + i]; s.vel[k] = vel[k * n + i]; s.ang_vel[k] = ang_vel[k * n + i]; }
     for (int k = 0; k < 4; k++) { s.att[k] = att[k * n + i]; s.motor_speed[k] = motor_speed[k * n + i]; }
@@ -80,20 +80,23 @@ void ora_step_batch_counter(int64_t n, int n_steps, const ora_params *table, con
     double fe[3] = {0, 0, 0}, te[3] = {0, 0, 0};
     if (ext_force && !gust_period_us) for (int k = 0; k < 3; k++) fe[k] = ext_force[k * n + i];
     if (ext_torque) for (int k = 0; k < 3; k++) te[k] = ext_torque[k * n + i];
-    uint64_t ticks = tick_base;
+    uint64_t ticks = tick_base, gust_epoch = ~(uint64_t)0;
     for (int st = 0; st < n_steps; st++) {
-      if (gust_period_us) ora_gust_force(gust_seed, first_global + (uint64_t)i, n_global, (t0_us + (uint64_t)st * dt_us) / gust_period_us, sigma_max, fe);
+      if (gust_period_us) {          /* piecewise constant: evaluated when a step starts in a new epoch, like the engine does */
+        const uint64_t epoch = (t0_us + (uint64_t)st * dt_us) / gust_period_us;
+        if (epoch != gust_epoch) { ora_gust_force(gust_seed, first_global + (uint64_t)i, n_global, epoch, sigma_max, fe); gust_epoch = epoch; }
+      }
       const int tick = tick_per_step ? tick_per_step[st] : 0;
       float g[3], a[3];
-      uint32_t keep = s.rng;
-      ora_quad_step(&p, &s, cmd, fe, te, dt, tick, g, a, 0);
+      if (tick && use_counter_noise) {
+        double z[6];
+        ora_imu_normals(seed, first_global + (uint64_t)i, ticks, z);
+        const double draws[6] = {z[2], z[1], z[0], z[5], z[4], z[3]};
+        ora_quad_step_normals(&p, &s, cmd, fe, te, dt, tick, draws, g, a, 0);
+      } else {
+        ora_quad_step(&p, &s, cmd, fe, te, dt, tick, g, a, 0);
+      }
       if (tick) {
-        if (use_counter_noise) {
-          s.rng = keep;                     /* the libstdc++ stream is not used under this policy: it does not advance */
-          double z[6];
-          ora_imu_normals(seed, first_global + (uint64_t)i, ticks, z);
-          for (int k = 0; k < 3; k++) { g[k] = g[k] + sg * (float)z[k]; a[k] = a[k] + sa * (float)z[3 + k]; }
-        }
         ticks++;
         for (int k = 0; k < 3; k++) { if (gyro) gyro[k * n + i] = g[k]; if (acc) acc[k * n + i] = a[k]; }
       }

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(afa):
     lib = C.CDLL(afa.library_path())
     for name in _header_functions():
         assert hasattr(lib, name), "missing export: " + name
-    assert afa.library().afe_abi_version() == 2
+    assert afa.library().afe_abi_version() == 3
 
 
 def test_library_carries_gfx950_code_object(afa):
@@ -41,7 +41,7 @@ def test_library_carries_gfx950_code_object(afa):
 
 def test_header_compiles_as_c_and_cxx(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "agrifly_engine.h"\nint main(void){afe_vehicle_params p; (void)p; return AFE_ABI_VERSION==2?0:1;}\n')
+    src.write_text('#include "agrifly_engine.h"\nint main(void){afe_vehicle_params p; (void)p; return AFE_ABI_VERSION==3?0:1;}\n')
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, "-c", str(src), "-o", str(tmp_path / "t.o")])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "t2.o")])

@@ -59,6 +59,41 @@ def test_planner_matches_oracle_varied_states_and_images(ora):
     assert max(r[0].n_pyramids for r in refs) >= 3
 
 
+def test_a_big_batch_starts_its_longest_planners_first_and_plans_the_same():
+    """The release library's own use of the interruptible search: from 16 385 planners up a batch runs a 0.4 ms sizing
+    round and then ONE finishing round that starts the interrupted planners longest first (launch_rappids).  20 000
+    planners on cluttered orchard views in one call, against the same planners in two calls of 10 000 (below the
+    threshold: one uninterrupted launch each) -- plans, every candidate's flags and all counters identical."""
+    rng = np.random.default_rng(23)
+    n, m, n_img = 20000, 192, 24
+    scene = afa.Scene(afa.scenarios.orchard_mesh(rows=8, cols=8, seed=3))
+    cam = afa.camera_default(320, 240)
+    pos = np.stack([rng.uniform(-3, 25, n_img), rng.uniform(-3, 30, n_img), rng.uniform(0.8, 2.5, n_img)])
+    yaw = rng.uniform(-np.pi, np.pi, n_img)
+    att = np.stack([np.cos(yaw / 2), 0 * yaw, 0 * yaw, np.sin(yaw / 2)])
+    images, _ = scene.render(cam, pos, att, afa.camera_default_mount())
+    images = np.asarray(images).reshape(n_img, 240, 320)
+    cfg = afa.planner_default_config(320, 240, 10.0 / 256.0, 160.0, 0.116, 0.174, 0.5)
+    cfg.max_pyramids = 64
+    idx = rng.integers(0, n_img, n).astype(np.int32)
+    vel0 = np.stack([rng.normal(0, 0.4, n), rng.normal(0, 0.2, n), rng.uniform(0, 2.0, n)])
+    acc0 = rng.normal(0, 0.3, (3, n))
+    grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n))
+    samples = afa.planner_samples(0, 320, 240, m)
+    out, flags, _ = afa.rappids_plan(cfg, images, vel0, acc0, grav, samples, image_index=idx, want_flags=True)
+    whole = np.frombuffer(bytes(out), np.uint8)
+    parts, part_flags = [], []
+    for a, b in ((0, n // 2), (n // 2, n)):
+        o, f, _ = afa.rappids_plan(cfg, images, vel0[:, a:b], acc0[:, a:b], grav[:, a:b], samples, image_index=idx[a:b], want_flags=True)
+        parts.append(np.frombuffer(bytes(o), np.uint8))
+        part_flags.append(f)
+    assert np.mean([o.n_pyramids for o in out]) > 3                 # cluttered enough to make the planners work (and differ in length)
+    assert np.array_equal(whole, np.concatenate(parts))
+    assert np.array_equal(flags, np.concatenate(part_flags, axis=0 if flags.shape[0] == n else 1))
+
+
+@pytest.mark.skipif(not afa.library().afe_has_dev_hooks(), reason="AFE_PLANNER_* are measurement variables of the -DAFE_DEV_HOOKS build; the release "
+                    "library's longest-first scheduling is covered at its natural size by the test above")
 def test_search_in_budgeted_rounds_is_the_uninterrupted_search():
     """The search is interruptible (launch_rappids: a planner works for a budget, writes down the sequential loop's
     variables and leaves its slot; a later launch picks it up).  Big batches use it to start their longest planners

@@ -167,36 +167,89 @@ print(json.dumps({"stayed": stayed, "digest": hashlib.sha256(b"".join(np.asconti
     assert out["0"]["digest"] == out["1"]["digest"]
 
 
-def test_reserved_compute_units_let_other_kernels_run_beside_the_grid():
-    """afe_set_reserved_compute_units: the grid's queue is masked off a row of compute units (one per shader engine and XCD);
-    another stream's kernels then run beside a grid that is kept fed instead of waiting for it to idle out (200 us), and
-    the bits are the launches' either way"""
-    import torch
-    n = 1 << 20
-    a, _ = make(n, afa.AFE_F32, True)
-    b, _ = make(n, afa.AFE_F32, False)
+def test_the_own_queue_finds_its_agent_by_identity_not_by_being_alone():
+    """Round-4 review, multi-GPU-only code: which HSA agent is HIP device d?  On a one-GPU box the old code could fall back
+    to "the only GPU agent" and nobody would have noticed a PCI match that never worked -- on the 8-GPU node there is no
+    such fallback and the grid would silently stay on the HIP stream.  AFE_PERSIST_DEBUG says which rule chose the agent:
+    it must be the PCI address (or the unique id), the grid of a north-star shard (131 072 vehicles) must live on the own
+    queue, survive afe_sync, and step the launched bits."""
+    code = r'''
+import importlib, json, sys, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+afa = importlib.import_module("agri-fly_amd")
+from tests.test_gpu_persistent import make, everything
+res = {}
+for name, persistent in (("grid", True), ("launches", False)):
+    e, _ = make(131072, afa.AFE_F32, persistent, seed=5)
+    stayed = 0
+    for block in range(5):
+        for _ in range(9):
+            e.step(1000, 1)
+        e.sync()
+        stayed += int(e.persistent_running)
+    x = everything(e)
+    res[name] = {"stayed": stayed, "digest": hashlib.sha256(b"".join(np.ascontiguousarray(x[k]).tobytes() for k in sorted(x))).hexdigest()}
+    e.close()
+print(json.dumps(res))
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AFE_PERSIST_DEBUG="1"), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    chosen = [l for l in r.stderr.splitlines() if "is the HSA agent chosen by" in l]
+    assert chosen, r.stderr[-2000:]
+    assert all(("chosen by PCI address" in l) or ("chosen by unique id" in l) for l in chosen), chosen
+    assert out["grid"]["stayed"] >= 4, out                     # on the own queue: afe_sync left it resident
+    assert out["grid"]["digest"] == out["launches"]["digest"]
+
+
+@pytest.mark.parametrize("n, host_visible, own_queue", [
+    (16384, True, -1),       # 256 workers on a host-visible arena: more than the 64 host marks -> the sync request's path; the host reads the slabs in place
+    (1 << 20, False, 1),     # forced own queue: 6 143 workers, a third of them with chunks to spare (they poll every ~8 us)
+    (200000, False, -1),
+])
+def test_sync_after_sync_with_pauses_around_the_grids_patience_never_returns_early(n, host_visible, own_queue):
+    """Round-4 advisor: the workers' arrival counters of a sync request are never reset within a launch, so a request the
+    host LEFT while only part of the workers had answered (through the pump's older completion word) misaligned them for
+    the life of the grid, and a later afe_sync could return while workers were still stepping.  quiesce now leaves a
+    posted request only through the workers' own answer.  Random pauses between afe_sync and the next afe_step -- below,
+    at and above the grid's 200 us of idle patience, so that grids also park themselves in between -- random block
+    lengths; after EVERY afe_sync the completed count is exact, and on the host-visible arena (where the host reads the
+    slabs in place, without ending the grid) the state is the launched engine's, bit for bit."""
+    rng = np.random.default_rng(n)
+    d = random_ensemble(n, seed=21, with_wrench=True, type_ids=(5,)).data
+
+    def engine(persistent):
+        e = afa.Ensemble(n, precision=afa.AFE_F32, host_visible=host_visible)
+        e.set_type_table([afa.params_from_type(d.type_ids[0])])
+        e.set_logic_period(1 / 500)
+        e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+        e.set_state(d.pos, d.vel, d.att, d.ang_vel, d.motor_speed)
+        e.set_motor_cmds(d.motor_cmd)
+        e.set_external_force(d.ext_force)
+        e.set_split_stepping(1)
+        e.set_step_mode(afa.AFE_STEP_PERSISTENT if persistent else afa.AFE_STEP_LAUNCH)
+        return e
+
+    a, b = engine(True), engine(False)
     with a, b:
-        a.set_resident_queue(1)                               # (automatic would put a grid of this size on the HIP stream)
-        x = torch.ones(1 << 20, device="cuda")
-        med, steps = {}, 0
-        for reserve in (0, 1):
-            a.set_reserved_compute_units(reserve)
-            a.step(1000, 30); steps += 30
+        if own_queue >= 0:
+            a.set_resident_queue(own_queue)
+        total = 0
+        for block in range(60 if n <= 200000 else 30):
+            k = int(rng.integers(1, 12))
+            for _ in range(k):
+                a.step(1000, 1)
+            b.step(1000, k)
+            total += k
             a.sync()
-            assert a.persistent_running
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(20):
-                a.step(1000, 1); steps += 1                   # the grid has work while the other kernels want to start
-                t0 = time.perf_counter()
-                y = float((x * 2).sum().item())               # torch's stream: two small kernels and a read-back
-                ts.append(time.perf_counter() - t0)
-                assert y == 2.0 * (1 << 20)
-            med[reserve] = float(np.median(ts))
-        assert med[0] > 200e-6, "without a reservation the kernels should have waited for the grid's idle patience: %.0f us" % (med[0] * 1e6)
-        assert med[1] < 0.6 * med[0], "reserved compute units did not let the kernels in: %.0f against %.0f us" % (med[1] * 1e6, med[0] * 1e6)
-        a.set_reserved_compute_units(0)                       # parks; the next grid has the whole device again
-        a.step(1000, 10); steps += 10
-        a.sync()
-        b.step(1000, steps)                                   # (the launched engine afterwards: its kernels want the whole device too)
-        assert_same(a, b, "with and without reserved compute units")
+            assert a.steps_completed == total
+            if host_visible:
+                sa, sb = a.get_state(), b.get_state()
+                for key in sa:
+                    assert np.array_equal(sa[key], sb[key], equal_nan=True), (block, key)
+            pause = float(rng.choice([0.0, 20e-6, 150e-6, 220e-6, 400e-6]))
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < pause:
+                pass
+        assert_same(a, b, "%d vehicles, %d steps in random blocks with pauses" % (n, total))

@@ -59,3 +59,50 @@ def test_fp32_one_step_grid_kernels_keep_six_waves_per_simd(tmp_path):
         assert m["private_segment_fixed_size"] == 0, (name, m)   # and nothing spilled to scratch to get there
     headline = [m for n, m in grid.items() if "IfLb1ELi2ELb0ELb0E" in n]      # FEXT, counter noise, no logic, one step
     assert len(headline) == 1 and headline[0]["vgpr_count"] <= 80
+
+
+def kernel_arguments(tmp_path):
+    """{kernel name: ([(offset, size, value_kind), ...], kernarg_segment_size)} of every kernel in the gfx950 code objects"""
+    kernels = {}
+    for k, blob in enumerate(gfx950_code_objects(LIB)):
+        f = tmp_path / ("args%d.elf" % k)
+        f.write_bytes(blob)
+        notes = subprocess.run([READELF, "--notes", str(f)], capture_output=True, text=True).stdout
+        for block in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block)
+            seg = re.search(r"\.kernarg_segment_size:\s+(\d+)", block)
+            if not name or not seg:
+                continue
+            args_text = block.split(".args:")[1].split(".group_segment_fixed_size")[0] if ".args:" in block else ""
+            args = []
+            for item in args_text.split("- .")[1:]:
+                fields = dict(re.findall(r"\.?(offset|size|value_kind):\s+(\S+)", item))
+                args.append((int(fields["offset"]), int(fields["size"]), fields["value_kind"]))
+            kernels[name.group(1)] = (args, int(seg.group(1)))
+    return kernels
+
+
+@pytest.mark.skipif(not os.path.exists(LIB) or not os.path.exists(READELF), reason="needs the built library and llvm-readelf")
+def test_host_kernarg_layout_is_the_code_objects_argument_table(tmp_path):
+    """Round-4 review: the resident grid's dispatch on the engine's own AQL queue packs the kernel-argument segment by
+    hand and checked the TOTAL size only.  The host now packs through one struct (afe_device.h PersistKernarg) and says
+    where it puts each argument (afe_persistent_kernarg_layout); here every one of the 48 instantiations' argument tables
+    in the code object -- offset, size, by-value kind of each of the four arguments, and the segment size, hidden
+    arguments included if the compiler ever adds any -- must be exactly that."""
+    import ctypes as C
+    import importlib
+    afa = importlib.import_module("agri-fly_amd")
+    L = afa.library()
+    kernels = kernel_arguments(tmp_path)
+    seen = 0
+    for precision, tag in ((afa.AFE_F32, "If"), (afa.AFE_F64, "Id")):
+        off, size, seg = (C.c_int32 * 4)(), (C.c_int32 * 4)(), C.c_int32(0)
+        assert L.afe_persistent_kernarg_layout(precision, off, size, C.byref(seg)) == 0
+        host = [(off[k], size[k], "by_value") for k in range(4)]
+        grid = {n: v for n, v in kernels.items() if "afe_step_persistent_kernel" + tag in n}
+        assert len(grid) == 24, sorted(grid)
+        for name, (args, segment) in grid.items():
+            assert args == host, (name, args, host)
+            assert segment == seg.value, (name, segment, seg.value)       # the segment ends with its last argument: no hidden arguments
+            seen += 1
+    assert seen == 48
