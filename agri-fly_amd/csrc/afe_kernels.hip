@@ -758,8 +758,13 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
       // torque = aero*axis + p x (0,0,thrust) - ang_acc*J*axis   :71-79
       const R tz_m = lagged ? (aero * spin) - rotor_tz : aero * spin;
       Fz = Fz + thrust;                                      // Quadcopter_T.cpp:102
-      Tx = fm(P.mpy[m], thrust, Tx);                         // Vec3.hpp:106-109
-      Ty = fm(-P.mpx[m], thrust, Ty);                        // z*rx - x*rz, rx = 0
+      // p x (0, 0, thrust), Vec3.hpp:106-109, with ROUNDED products added one after the other like the reference's
+      // (no fused multiply-add here, on purpose): four equal thrusts on arms of equal length then cancel to an exact
+      // zero, as they do in the reference -- a hovering vehicle's body rates stay exactly zero.  The FMA chain that stood
+      // here left the chain's rounding residue (~1 ulp of arm x thrust) as a torque: 3e-7 rad/s of drift per 0.1 s on the
+      // bench's hovering ensemble where the reference has none (round-5 ledger, full-size tests).
+      Tx = Tx + P.mpy[m] * thrust;
+      Ty = Ty - P.mpx[m] * thrust;                           // z*rx - x*rz, rx = 0
       Tz = Tz + tz_m;
     }
 
@@ -988,7 +993,7 @@ __device__ __forceinline__ void st_system(u64_t *p, u64_t x) { __hip_atomic_stor
 // the last look must come from memory).  Why not a vector load: a CU returns vector-memory data in order, so every load of
 // every wave on the pump's CU queues behind the pump's ~1.5 us read across PCIe -- the eight workers that share the CU
 // lose 0.25 us per step, and a synchronised block ends when ITS slowest worker does (tools/ageing_probe.py with
-// -DAFE_SYNC_TRACE: four workers of 2 048, all on the pump's CU, finished 65 us behind everybody else in a block of 256
+// the round-4 trace build (commit 75db42d, -DAFE_SYNC_TRACE): four workers of 2 048, all on the pump's CU, finished 65 us behind everybody else in a block of 256
 // steps).  Scalar loads return out of order and go round that queue.
 typedef unsigned int afe_u32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ u64_t afe_uniform64(unsigned long long a) {
@@ -1180,7 +1185,7 @@ __device__ __forceinline__ void persist_pump(const PersistArgs &a) {
 // Issue priority by the steps a worker still has in hand.  The waves of a SIMD are served oldest first, so of two (four,
 // six) workers that share one the first-dispatched runs ahead at the latency-bound pace of a wave alone (1.6 us per step
 // at 131 072 vehicles) and the last-dispatched gets what is left -- and then finishes the block alone, at that same
-// latency-bound pace, with the SIMD three quarters idle (tools/ageing_probe.py with -DAFE_SYNC_TRACE: the halves of a
+// latency-bound pace, with the SIMD three quarters idle (round-4 trace build: the halves of a
 // 2 048-worker grid ran out of a 256-step block at 284 and 429 us).  Whoever has more steps left goes first instead:
 // the laggard catches up while the SIMD is still shared, and the block ends when the SIMD's work does.  Level 0 stays
 // with the pump (the oldest wave of its SIMD; it needs few slots and must not take them from a worker).

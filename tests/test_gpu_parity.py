@@ -15,7 +15,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.scenarios import FLOORS, afa, random_ensemble, record_parity, rel_err
+from tests.scenarios import FLOORS, afa, random_ensemble, record_parity, rel_err, rel_err_vec
 
 pytestmark = pytest.mark.gpu
 
@@ -272,6 +272,24 @@ def test_motor_lag_types():
             st = e.get_state()
             gyro, acc = e.get_imu()
         _cmp_state(st, b, tol, "motor lag / J_m / CoM / inertia / IMU mount", imu=(gyro, acc))
+        if precision == afa.AFE_F32:
+            # Round-4 review: 9.2e-6 of 1e-5 here.  It is the fp32 STORAGE of a lagged rotor's speed and nothing else:
+            # the double checker with only motor_speed narrowed to float after every step lands on the same figures
+            # (tests/test_oracle_physics.py::test_fp32_storage_of_a_lagged_rotor_speed_bounds_the_rates: ang_vel 4.7e-6,
+            # gyro 9.0e-6 on this very ensemble) -- the engine's arithmetic adds at most a third on top.
+            twin = oracle_py.Batch(n, olist, ens.data.types)
+            twin.pos[:], twin.vel[:], twin.att[:], twin.ang_vel[:] = d.pos, d.vel, d.att, d.ang_vel
+            twin.motor_speed[:], twin.motor_cmd[:] = d.motor_speed.astype(np.float32), d.motor_cmd
+            twin.ext_force[:], twin.ext_torque[:] = d.ext_force, d.ext_torque
+            for s_ in range(20):
+                twin.step(1e-3, 1, ticks=ticks[s_:s_ + 1])
+                twin.motor_speed[:] = twin.motor_speed.astype(np.float32)
+            storage = {k: rel_err_vec(getattr(twin, k), getattr(b, k), FLOORS[k]) for k in ("ang_vel", "gyro")}
+            engine = {"ang_vel": rel_err_vec(st["ang_vel"], b.ang_vel, FLOORS["ang_vel"]), "gyro": rel_err_vec(gyro, b.gyro, FLOORS["gyro"])}
+            from tests.scenarios import MEASUREMENTS
+            MEASUREMENTS["lagged_rotor_fp32_storage_bound"] = {"double_checker_with_float_rotor_speed": storage, "fp32_engine": engine}
+            for k in storage:
+                assert engine[k] <= 2.0 * storage[k] + 1e-6, (k, engine[k], storage[k])
 
 
 def test_oracle_regression_fixture_on_gpu(golden_dir):
@@ -321,14 +339,19 @@ def test_full_size_properties_1m_vehicles():
     b = TestEnsemble(sub).to_oracle_batch()
     b.rng[:] = 1 + idx
     b.step(1e-3, 100, ticks=_ticks(afa, 1 / 500, 1000, 100))
-    # A hovering ensemble: velocities and body rates are ZERO by construction (up to the gust, which starts at
-    # sigma = 0) -- the velocity is the integral of thrust/m - g, two ~9.81 m/s^2 terms, over 0.1 s, the rate the
-    # integral of four cancelling motor torques.  Their errors (1e-6 m/s, 2e-7 rad/s) are judged against those
-    # integrated magnitudes: floor 0.1 instead of the general 0.01 (the gyro sample is that rate plus noise).
+    # A hovering ensemble.  Body rates: four equal thrusts on equal arms cancel to an EXACT zero torque in the reference
+    # (rounded products summed one after the other, Vec3.hpp:106-109 / Quadcopter_T.cpp:103) and, since round 5, in the
+    # engine (afe_kernels.hip: no fused multiply-add in that sum) -- every one of the 2^20 vehicles keeps ang_vel == 0
+    # bit for bit, and rates and gyro are judged at the general floor (round 4 needed 0.1: an FMA chain's residue drifted
+    # 3e-7 rad/s).  Velocity stays at floor 0.1: a hovering vehicle's v_z is the integral of thrust/m - g, two 9.81 m/s^2
+    # terms, and fp32 k_f and 1/m carry 6e-8 each -- 1.5e-6 m/s^2 of bias, 1.6e-7 m/s after 0.1 s, which is 1.6e-5 of a
+    # 0.01 floor on the vehicles whose gust is ~0 (the ledger's at_floor column keeps that figure) and 2e-6 of the
+    # g t = 1 m/s the two integrals have.
+    assert np.abs(st["ang_vel"]).max() == 0.0 and np.abs(b.ang_vel).max() == 0.0
     for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, gyro=b.gyro).items():
         got = gyro if k == "gyro" else st[k]
         assert record_parity("2^20 vehicles x 100 steps, 512-vehicle subsample", afa.AFE_F32, k, got[:, idx], ref,
-                             floor=0.1 if k in ("vel", "ang_vel", "gyro") else None) <= F32_TOL, k
+                             floor=0.1 if k == "vel" else None) <= F32_TOL, k
     # noise statistics over the decorrelated ensemble
     assert abs(float(gyro[2].std()) - 0.1) < 2e-3
 
@@ -366,8 +389,10 @@ def test_full_size_on_the_bench_workload_itself():
             getattr(b, f)[:, k:k + 1] = getattr(one, f)
     for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, gyro=b.gyro, acc=b.acc).items():
         got = dict(st, gyro=gyro, acc=acc)[k]
+        # (floors: as in the test above -- rates and gyro at the general floor, exact-zero torque; v_z of a hovering vehicle at 0.1)
         assert record_parity("bench workload: 2^20 vehicles on the 4 km lattice x 150 steps, 512-vehicle subsample", afa.AFE_F32, k, got[:, idx], ref,
-                             floor=0.1 if k in ("vel", "ang_vel", "gyro") else None) <= F32_TOL, k
+                             floor=0.1 if k == "vel" else None) <= F32_TOL, k
+    assert np.abs(st["ang_vel"]).max() == 0.0           # open loop, force-only gusts: no vehicle of the 2^20 ever turns, as in the reference
     assert np.abs(force[:, idx] - b.ext_force).max() <= 1e-6 * 0.5
     # what fp32 positions cost out there, in metres: the displacement over the 150 steps against the checker's
     moved_e, moved_o = st["pos"][:, idx] - p0[:, idx], b.pos - p0[:, idx]
