@@ -775,9 +775,10 @@ int persist_collect(afe_engine *e) {
     }
     e->p_grid_ns += afe::aql_last_duration_ns(e->aql);
     e->p_on_aql = false;
-    // AFE_GRID_LOG=<file> (profiling aid, tools/profile_r04.sh): one line per grid that has left the device -- the steps it
-    // served and its device time -- in dispatch order, to be laid beside rocprofv3's kernel trace of the same run
-    static FILE *const grid_log = [] { const char *p = afe_dev_env("AFE_GRID_LOG"); return p && *p ? std::fopen(p, "a") : (FILE *)nullptr; }();
+    // AFE_GRID_LOG=<file> (one of the release library's six variables; tools/profile_r05.sh): one line per grid that has
+    // left the engine's own queue -- the steps it served and its device time -- in dispatch order, to be laid beside
+    // rocprofv3's kernel trace of the same run (a grid there serves however many blocks were authorised while it lived)
+    static FILE *const grid_log = [] { const char *p = std::getenv("AFE_GRID_LOG"); return p && *p ? std::fopen(p, "a") : (FILE *)nullptr; }();
     if (grid_log) {
       volatile unsigned long long *stl = p_status(e);
       std::fprintf(grid_log, "%lld,%d,%llu,%llu\n", (long long)e->n, e->p_workers, (unsigned long long)(stl[0] ? stl[0] - 1 - e->p_launch_start : 0),
@@ -915,7 +916,7 @@ int persist_settle(afe_engine *e) {
 // profiles/r04_cache_policy.txt): 2^21 vehicles 42.3 / 46.1 / 53.6 / 54.7; 3 x 2^20 74.8 / 66.6 / 82.2 / 89.7; 2^22
 // 115.8 / 91.3 / 108.4 / 106.4; 6 x 2^20 173.7 / 158.0 / 165.0 / 177.1; 2^23 231.7 / 225.9 / 219.6 / 214.8.
 int resolve_cache_policy(const afe_engine *e) {
-  static const int forced = [] { const char *s = std::getenv("AFE_CACHE_POLICY"); return s && *s ? std::atoi(s) : -1; }();
+  static const int forced = [] { const char *s = afe_dev_env("AFE_CACHE_POLICY"); return s && *s ? std::atoi(s) : -1; }();
   const int asked = forced >= 0 && forced <= 3 ? forced : e->cache_policy;
   if (asked >= 0) return asked;
   if (e->host_arena) return 0;        // host memory: the policy bits mean nothing the bus honours

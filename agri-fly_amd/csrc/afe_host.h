@@ -12,7 +12,7 @@
 namespace afe {
 
 // Environment hooks.  The RELEASE library reads six variables, all documented in INTEGRATION.md section 3:
-//   AFE_PERSIST_AQL, AFE_FORCE_STEP_MODE, AFE_FORCE_SPLIT, AFE_FORCE_HOST_ARENA, AFE_CACHE_POLICY, AFE_PERSIST_DEBUG
+//   AFE_PERSIST_AQL, AFE_FORCE_STEP_MODE, AFE_FORCE_SPLIT, AFE_FORCE_HOST_ARENA, AFE_PERSIST_DEBUG, AFE_GRID_LOG
 // (plain std::getenv at their call sites).  Every other variable is a measurement aid of the kernel lab (tools/) and is
 // read only by a library built with -DAFE_DEV_HOOKS (make EXTRA=-DAFE_DEV_HOOKS); afe_has_dev_hooks() says which one
 // is loaded.  In the release build this folds to nullptr and the code behind each hook is dead.

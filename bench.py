@@ -14,10 +14,12 @@ until 50 ms have been timed; the line carries the median block.  Workload: the
 config-4 shape of BASELINE.json -- a hovering MINIQUAD ensemble with a
 per-vehicle wind-gust force from the on-device gust process (the
 SetExternalForce port), IMU synthesis at the 500 Hz onboard-logic cadence with
-Gaussian noise from the counter-based generator (AFE_SEED_COUNTER; the same
-workload on the reference's own std::minstd_rand0 / std::normal_distribution
-streams is measured with the same protocol and printed beside it as
-`reference_noise_streams`) -- 1,048,576 vehicles PER GPU (weak scaling; inputs
+Gaussian noise from the reference's own machinery -- one std::minstd_rand0 +
+std::normal_distribution stream per vehicle, words bit-exact (AFE_SEED_DECORRELATED:
+a reference vehicle seeded 1 + index draws the same numbers); the same workload on
+the engine's counter-based generator (AFE_SEED_COUNTER: no per-vehicle word, no
+rejection loop) is measured with the same protocol and printed beside it as
+`counter_noise_policy` -- 1,048,576 vehicles PER GPU (weak scaling; inputs
 resident in HBM before the timed region).  For N > 1 there is one rank process per GPU: either the caller
 starts them (python -m torch.distributed.run ... bench.py --gpus N: RANK /
 WORLD_SIZE are in the environment) or `python bench.py --gpus N` starts them
@@ -30,7 +32,9 @@ separately in `shared_world`.
 
 Prints ONE JSON line on rank 0 (see the repo task contract), kept below 6 kB
 (compact_line; tests/test_bench_line.py holds the bound), including
-  roofline     -- algorithmic HBM bytes / measured kernel time vs 8 TB/s
+  roofline     -- algorithmic bytes / measured kernel time vs 8 TB/s, WHERE the working set lives (the 2^20 headline: the
+                  256 MiB Infinity Cache; `traffic` is fabric-side bytes there), and `hbm_streaming`: the same kernels at
+                  2^23 vehicles, where nothing survives a step on-die -- the path's true HBM row
   cpu_baseline -- the CPU oracle (port of the reference's algorithm) timed on
                   one host core over a bounded sample (rank 0, N = 1 only)
 Everything else that is measured (size sweep, perception rows, disturbance
@@ -57,13 +61,22 @@ LOGIC_PERIOD = 1.0 / 500.0
 
 
 GUST_SEED, NOISE_SEED, GUST_SIGMA_MAX, GUST_PERIOD_US = 4, 5, 0.5, 100000
+INFINITY_CACHE_BYTES = 256 << 20      # MI355X_MICROARCH.md: 256 MiB die-level L3
+L2_BYTES = 32 << 20                   # 8 XCDs x 4 MiB
+L2_PEAK_GBS = 34500.0                 # MI355X_MICROARCH.md: aggregate L2 bandwidth
+# The headline's IMU noise: True = the reference's own per-vehicle libstdc++ streams (what a reference vehicle seeded
+# 1 + index reproduces word for word), False = the counter-based generator (faster: the `counter_noise_policy` row).
+HEADLINE_EXACT_STREAMS = True
 
 
-def build_shard(afa, n_local, first_global, n_global, device, fext=True, precision=None, exact_stream=False):
+def build_shard(afa, n_local, first_global, n_global, device, fext=True, precision=None, exact_stream=None):
     """config 4: hovering CF_MINIQUAD ensemble in one shared world (4 m lattice by GLOBAL index), per-vehicle wind gusts
     from the on-device gust process (sigma swept 0 .. 0.5 N over the global index, resampled every 100 ms), IMU synthesis
     with Gaussian noise at the 500 Hz logic gate -- from the counter-based generator (AFE_SEED_COUNTER), or with
-    exact_stream=True from per-vehicle libstdc++ minstd_rand0 / normal_distribution streams (AFE_SEED_DECORRELATED)"""
+    exact_stream=True from per-vehicle libstdc++ minstd_rand0 / normal_distribution streams (AFE_SEED_DECORRELATED);
+    None: the headline's policy (HEADLINE_EXACT_STREAMS)"""
+    if exact_stream is None:
+        exact_stream = HEADLINE_EXACT_STREAMS
     p = afa.params_from_type(5)  # QC_TYPE_CF_MINIQUAD: vehicle id 1 of every shipped main
     data = afa.scenarios.hover_ensemble(n_local, p)
     idx = np.arange(first_global, first_global + n_local)
@@ -144,6 +157,68 @@ def timed_blocks(e, steps, per_launch, sync, barrier, reduce_max, min_total_s=0.
 def median(xs):
     xs = sorted(xs)
     return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
+def residency(footprint_bytes):
+    """where a step's working set lives between two steps: the XCDs' L2s, the Infinity Cache, or nowhere on-die (HBM)"""
+    if footprint_bytes <= L2_BYTES:
+        return "l2"
+    if footprint_bytes <= INFINITY_CACHE_BYTES * 0.94:      # (the guide: a table stays resident while table + stream fit in about 256 MiB)
+        return "infinity_cache"
+    return "hbm"
+
+
+SIMDS = 1024      # 256 CUs x 4 SIMDs
+
+
+def bound_fields(n, bytes_per_vehicle_step, seconds_per_step, ns_profile=None):
+    """The honest ceiling of a row (round-4 review).  Rows whose working set fits the XCDs' L2s are not bound by any memory
+    roofline: they get no HBM fraction but the L2-side rate of the algorithmic bytes against the L2 peak, and a bound by how
+    many worker waves share a SIMD: from ~1.5 up the step is bound by vector-instruction ISSUE (131 072 vehicles: two waves
+    per SIMD whose vector pipes are busy 77 % of the time -- the committed SQ counters of that very grid, attached to that
+    row), below by the LATENCY of one wave's dependent chain (4 096 vehicles: one wave on 64 of 1 024 SIMDs).  Rows beyond
+    the L2s get the fraction of the 8 TB/s HBM peak and where the working set really lives (infinity_cache: the bytes are
+    served on-die; hbm: they cross the memory interface).  Residency goes by the DISTINCT bytes a step touches (the state is
+    read and written in place: counted once; an IMU sample and an engine word exist once though a tick comes every 2nd step)."""
+    distinct = n * max(1.0, bytes_per_vehicle_step - 40.0)
+    where = residency(distinct)
+    rate = n * bytes_per_vehicle_step / seconds_per_step / 1e9
+    if where == "l2":
+        waves_per_simd = ((n + 63) // 64) / float(SIMDS)
+        out = {"bound": "valu_issue" if waves_per_simd >= 1.5 else "latency", "resident_in": "l2", "l2_GBs": rate, "l2_frac": rate / L2_PEAK_GBS}
+        if ns_profile and n == 131072:
+            out.update({"valu_busy_frac": ns_profile.get("simd_valu_busy_frac"), "valu_active_frac_per_wave": ns_profile.get("valu_active_frac"),
+                        "valu_instructions_per_wave_step": ns_profile.get("valu_instructions_per_wave_step"), "counters_from": ns_profile.get("counters_from")})
+        return out
+    return {"bound": "hbm", "resident_in": where, "frac": rate / HBM_PEAK_GBS}
+
+
+def committed_ns_profile(exact_stream=None):
+    """SQ counters of the north-star shard's resident grid under the given noise policy, from the newest committed summary"""
+    import glob
+    want = "reference_streams" if (HEADLINE_EXACT_STREAMS if exact_stream is None else exact_stream) else "counter"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ns_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("valu_active_frac_of_wave_cycles") and d.get("noise_policy", "counter") == want:
+                return {"valu_active_frac": d["valu_active_frac_of_wave_cycles"], "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"),
+                        "simd_valu_busy_frac": d.get("simd_valu_busy_frac"),
+                        "valu_instructions_per_wave_step": d.get("valu_instructions_per_wave_and_step"), "counters_from": os.path.relpath(f, ROOT)}
+        except (OSError, ValueError):
+            pass
+    return None
+
+
+def committed_json(pattern, pick):
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            r = pick(json.load(open(f)))
+            if r is not None:
+                return r, os.path.relpath(f, ROOT)
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
+    return None, None
 
 
 def kernel_time_events(e, launches):
@@ -258,14 +333,16 @@ def companion_rows(afa, n_local, device, sync, barrier, split=False):
     return rows
 
 
-def committed_traffic(n_local):
-    """PMC-derived HBM bytes per step (= per launch on one stream, two launches when the shard steps as two halves) of this exact workload, from the rocprofv3
-    summary committed under profiles/ (counters cannot be read inside the run)"""
+def committed_traffic(n_local, exact_stream):
+    """PMC-derived bytes per step through the L2s' fabric side (FETCH_SIZE / WRITE_SIZE: Infinity-Cache hits are counted, so
+    for a working set that fits the Infinity Cache this is L2 <-> Infinity Cache traffic, not HBM traffic) of this exact
+    workload, from the rocprofv3 summary committed under profiles/ (counters cannot be read inside the run)"""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(path))
         w = t["workload"]
-        if w["vehicles_per_gpu"] == n_local and w["dt_us"] == DT_US and w["fext"] and w["noise"]:
+        policy = w.get("noise_policy", "counter")
+        if w["vehicles_per_gpu"] == n_local and w["dt_us"] == DT_US and w["fext"] and w["noise"] and policy == ("reference_streams" if exact_stream else "counter"):
             return t.get("traffic_bytes_per_step", t["traffic_bytes_per_launch"]), t["source"], t.get("rocprof_kernel_us_per_step")
     except (OSError, KeyError, ValueError):
         pass
@@ -380,8 +457,14 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
     ray_flops = 9 * 2 + 6 + 4          # direction = R (u, v, 1), final floor(z / scale)
     fp64_flops = st["tri_fp64_tests_per_ray"] * mt_flops + rays * ray_flops
     node_bytes = st["nodes_per_wave"] * 64.0 + st["tri_box_tests_per_wave"] * 96.0   # scalar loads, served by L2
+    rpmc, rsrc = committed_json("r*_render_pmc.json", lambda d: d if d.get("valu_issue_fraction_of_busy_cycles") else None)
+    ppmc, psrc = committed_json("r*_planner_pmc.json", lambda d: d if d.get("valu_issue_fraction_of_busy_cycles") else None)
+    rpmc, ppmc = rpmc or {}, ppmc or {}
     render_roofline = {
-        "bound": "vector-instruction issue (SQ_ACTIVE_INST_VALU x 4 / SIMD = 93 % of busy cycles, scalar unit 65 %: profiles/r03_render_pmc.json; 768 vector instructions and 14.9 node visits per wave of 64 rays), not HBM and not fp64 throughput",
+        "bound": "vector-instruction issue (a vector instruction issues in most of the SIMDs' busy cycles: the committed SQ counters below), not HBM and not fp64 throughput",
+        "valu_issue_fraction_of_busy_cycles": rpmc.get("valu_issue_fraction_of_busy_cycles"),
+        "valu_instructions_per_ray": (rpmc.get("per_ray") or {}).get("valu_instructions", (rpmc.get("per_wave") or {}).get("valu_instructions", 0) / 64.0 or None),
+        "counters_from": rsrc,
         "per_ray": {"triangle_box_tests": st["tri_box_tests_per_ray"] / rays, "fp64_triangle_tests": st["tri_fp64_tests_per_ray"] / rays},
         "per_wave_of_64_rays": {"nodes_visited": st["nodes_per_wave"] / waves, "triangle_box_tests": st["tri_box_tests_per_wave"] / waves,
                                 "fp64_triangle_tests_executed": st["tri_fp64_tests_per_wave"] / waves},
@@ -395,8 +478,11 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
     # rectangle; plus the candidate kernel's and the transpose's passes over the inputs
     plan_bytes = float(plans["n_pyramids"].sum()) * 2.0 * px_bytes + n_views * 2.0 * px_bytes + n_planners * n_candidates * 9.0
     planner_roofline = {
-        "bound": "the longest planner of the launch (one wave per planner, a sequential search: profiles/r02d_planner_pmc.json -- the shader "
-                 "engines are busy 57 % of the launch, the vector pipe issues in 64 % of their busy cycles), not HBM",
+        "bound": "latency of a sequential search (one wave per planner; longest-first scheduling keeps the shader engines busy to the end of the launch: "
+                 "the committed SQ counters below), not HBM",
+        "valu_issue_fraction_of_busy_cycles": ppmc.get("valu_issue_fraction_of_busy_cycles"),
+        "valu_instructions_per_plan": (ppmc.get("per_plan") or {}).get("valu_instructions"),
+        "counters_from": psrc,
         "pyramids_per_plan": float(plans["n_pyramids"].mean()), "collision_checks_per_plan": float(plans["n_collision_checks"].mean()),
         "algorithmic_bytes": plan_bytes, "achieved_GBs": plan_bytes / (ms_plan * 1e-3) / 1e9,
         "hbm_frac": plan_bytes / (ms_plan * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -693,9 +779,10 @@ def shard_row(afa, n, device, sync, barrier, reduce_max, block_steps, mode=None,
     blocks = timed_blocks(e, block_steps, 1, sync, barrier, reduce_max, min_total_s=min_total_s)
     t = median(blocks) / block_steps
     bytes_step, _ = mean_bytes_per_step(e, afa, block_steps)
-    row = {"vehicles": n, "us_per_step": t * 1e6, "vsteps_per_s": n / t, "frac": n * bytes_step / t / 1e9 / HBM_PEAK_GBS,
+    row = {"vehicles": n, "us_per_step": t * 1e6, "vsteps_per_s": n / t, "algorithmic_GBs": n * bytes_step / t / 1e9,
            "stepping": "persistent" if uses_persistent(afa, mode, n) else ("split launches" if n >= (1 << 19) and parts != 1 else "launches"),
            "block_steps": block_steps, "repeats": len(blocks)}
+    row.update(bound_fields(n, bytes_step, t, committed_ns_profile()))
     return e, row
 
 
@@ -736,24 +823,30 @@ def compact_line(full):
                       "dt_us": cfg.get("dt_us"), "steps_per_call": cfg.get("steps_per_call"), "stepping": cfg.get("stepping"),
                       "noise": cfg.get("noise"), "parallelism": cfg.get("parallelism_short", cfg.get("parallelism"))}
     line.update(_pick(full, ("repeats", "ms_per_step_min", "ms_per_step_max")) or {})
-    r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel_us", "kernel_us_min", "kernel_us_max",
-                     "kernel_us_rocprof", "kernel_us_dispatch_per_block", "algorithmic_bytes_per_vehicle_step")) or {}
+    r = _pick(roof, ("bound", "resident_in", "working_set_bytes", "infinity_cache_bytes", "achieved", "peak", "unit", "frac", "traffic", "traffic_is",
+                     "traffic_source", "kernel_us", "kernel_us_min", "kernel_us_max",
+                     "kernel_us_rocprof", "algorithmic_bytes_per_vehicle_step")) or {}
+    r.setdefault("traffic", None)          # (the contract's key: a number from the committed PMC summary, or null)
     kr = roof.get("kernel_us_rocprof")
     if isinstance(kr, dict):      # the committed trace holds one figure per block length: the line carries this run's
         nums = {k: v for k, v in kr.items() if isinstance(v, (int, float))}
         r["kernel_us_rocprof"] = nums.get("blocks_of_%s_steps" % full.get("steps"), next(iter(nums.values()), None))
     r["kernel"] = (roof.get("kernel_short") or roof.get("kernel") or "")[:120]
     if roof.get("traffic_source"):
-        r["traffic_source"] = str(roof["traffic_source"])[:100]
+        r["traffic_source"] = str(roof["traffic_source"])[:60]
     pm = roof.get("peak_measured")
     if pm:
         r["peak_measured"] = [pm.get("GBs_164B"), pm.get("GBs_132B")]
+        r["ratio_to_stream_probe"] = roof.get("frac_of_measured")
     if roof.get("steady_state"):
-        r["steady_state"] = _pick(roof["steady_state"], ("steps", "kernel_us", "frac"))
+        r["steady_state"] = _pick(roof["steady_state"], ("steps", "kernel_us", "achieved_GBs", "ratio_to_stream_probe"))
     if roof.get("launch_mode"):
-        r["launch_mode"] = _pick(roof["launch_mode"], ("kernel_us", "frac"))
+        r["launch_mode"] = _pick(roof["launch_mode"], ("kernel_us", "achieved_GBs", "ratio_to_stream_probe"))
     if roof.get("beyond_cache"):
-        r["beyond_cache"] = _pick(roof["beyond_cache"], ("vehicles", "us_per_step", "frac", "frac_of_6290", "stepping"))
+        r["beyond_cache"] = _pick(roof["beyond_cache"], ("vehicles", "us_per_step", "frac", "resident_in", "stepping"))
+    if roof.get("hbm_streaming"):
+        r["hbm_streaming"] = _pick(roof["hbm_streaming"], ("vehicles", "us_per_step", "achieved", "frac", "frac_of_6290", "probe_GBs", "ratio_to_stream_probe", "pmc_over_algorithmic",
+                                                           "pmc_from", "stepping", "error"))
     line["roofline"] = r
     cb = full.get("cpu_baseline")
     if cb:
@@ -767,26 +860,37 @@ def compact_line(full):
         line["cpu_baseline"] = c
     st = full.get("config4_as_stated")
     if st:
-        c4 = _pick(st, ("scaling", "vehicles_total", "vehicles_per_gpu", "n_gpus", "value", "unit", "ms_per_step", "frac_per_gpu", "stepping"))
+        c4 = _pick(st, ("scaling", "vehicles_total", "vehicles_per_gpu", "n_gpus", "value", "unit", "ms_per_step", "stepping", "bound", "resident_in", "frac", "l2_GBs", "l2_frac", "valu_busy_frac"))
         if st.get("steady_state"):
-            c4["steady_state"] = _pick(st["steady_state"], ("steps", "ms_per_step", "value", "frac_per_gpu"))
+            c4["steady_state"] = _pick(st["steady_state"], ("steps", "ms_per_step", "value"))
         line["config4_as_stated"] = c4
     ns = full.get("north_star_shard")
     if ns:
-        line["north_star_shard"] = _pick(ns, ("vehicles_per_gpu", "us_per_step", "us_per_step_k_blocks", "vsteps_per_s_per_gpu", "frac", "launch_mode_frac"))
-    rn = full.get("reference_noise_streams")
+        line["north_star_shard"] = _pick(ns, ("vehicles_per_gpu", "us_per_step", "us_per_step_k_blocks", "vsteps_per_s_per_gpu", "bound", "resident_in", "l2_GBs", "l2_frac",
+                                              "valu_busy_frac", "valu_active_frac_per_wave", "valu_instructions_per_wave_step", "counters_from", "launch_mode_us_per_step"))
+    rn = full.get("counter_noise_policy")
     if rn:
-        line["reference_noise_streams"] = _pick(rn, ("value", "unit", "ms_per_step", "algorithmic_bytes_per_vehicle_step", "kernel_us", "frac", "stepping", "seed_policy"))
+        line["counter_noise_policy"] = _pick(rn, ("value", "unit", "ms_per_step", "algorithmic_bytes_per_vehicle_step", "kernel_us", "achieved_GBs", "ratio_to_stream_probe", "resident_in", "stepping", "seed_policy"))
+    sc = full.get("scaling_check")
+    if sc:
+        line["scaling_check"] = sc
     comp = full.get("companions")
     if comp:
         line["companions"] = {k: v.get("value") for k, v in comp.items() if isinstance(v, dict) and "value" in v}
     cl = full.get("closed_loop_on_device")
     if cl:
-        line["closed_loop_on_device"] = [_pick(c, ("vehicles", "us_per_step", "us_per_step_auto", "vsteps_per_s", "frac")) for c in cl]
+        line["closed_loop_on_device"] = [_pick(c, ("vehicles", "us_per_step", "us_per_step_auto", "vsteps_per_s", "bound", "resident_in", "frac", "l2_GBs")) for c in cl]       # (no instruction count is committed for the logic kernels: bound says latency for the L2-resident rows)
     pr = full.get("perception_rows")
     if pr and "depth_camera" in pr:
-        line["perception"] = {"depth_ms_per_%d_views" % pr["depth_camera"]["views"]: pr["depth_camera"]["kernel_ms"],
-                              "plan_ms_65536_planners": pr["rappids_planner"]["config3_size"]["kernel_ms"],
+        dc, rp = pr["depth_camera"], pr["rappids_planner"]
+        line["perception"] = {"depth_camera": {"views": dc["views"], "ms": dc["kernel_ms"], "rays_per_s": dc["rays_per_s"], "bound": "valu issue",
+                                               "valu_issue_frac": dc["roofline"].get("valu_issue_fraction_of_busy_cycles"),
+                                               "valu_instructions_per_ray": dc["roofline"].get("valu_instructions_per_ray"),
+                                               "counters_from": dc["roofline"].get("counters_from")},
+                              "planner": {"planners": rp["config3_size"]["planners"], "ms": rp["config3_size"]["kernel_ms"], "plans_per_s": rp["config3_size"]["plans_per_s"],
+                                          "bound": "latency (one wave per sequential search)", "valu_issue_frac": rp["roofline"].get("valu_issue_fraction_of_busy_cycles"),
+                                          "valu_instructions_per_plan": rp["roofline"].get("valu_instructions_per_plan"),
+                                          "counters_from": rp["roofline"].get("counters_from")},
                               "frame_ms_4096_vehicles": pr["closed_perception_loop_frame"]["frame_ms"]}
     sw = full.get("shared_world")
     if sw:
@@ -801,7 +905,7 @@ def compact_line(full):
         line["config1_host_in_loop"] = _pick(c1, ("us_per_step", "realtime_factor", "error"))
     line["detail"] = full.get("detail", DETAIL_FILE)
     line = _r(line)
-    for victim in ("config1_host_in_loop", "perception", "closed_loop_on_device", "shared_world", "companions", "reference_noise_streams",
+    for victim in ("config1_host_in_loop", "perception", "closed_loop_on_device", "shared_world", "companions", "counter_noise_policy",
                    "north_star_shard", "config4_as_stated"):
         if len(json.dumps(line)) <= LINE_LIMIT:
             break
@@ -850,11 +954,16 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed cadence (for rocprofv3 passes: no comparisons, no per-kernel breakdown, no sweep)")
     ap.add_argument("--step-mode", choices=("auto", "launch", "persistent"), default="auto")
+    ap.add_argument("--noise", choices=("reference", "counter"), default=None,
+                    help="the headline's IMU noise: the reference's per-vehicle libstdc++ streams (default) or the counter-based generator")
     ap.add_argument("--watchdog", type=int, default=240, help="seconds the shared-world part may take before the line is printed without it")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args)     # before torch / the engine are imported: this process stays off the GPUs
+    global HEADLINE_EXACT_STREAMS
+    if args.noise is not None:
+        HEADLINE_EXACT_STREAMS = args.noise == "reference"
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -884,6 +993,14 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
+        # Before anything is timed: the process group IS N ranks over RCCL, one per GPU (round-4 review: RCCL had only ever
+        # run with one rank; a group that came up smaller, or on another backend, must not produce a line that looks like N GPUs)
+        if not one_device:
+            ones = torch.ones(1, device="cuda")
+            dist.all_reduce(ones)
+            if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl" or int(ones.item()) != args.gpus:
+                raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s) on backend %s (all-reduce of ones: %g)"
+                                 % (args.gpus, dist.get_world_size(), dist.get_backend(), ones.item()))
 
     def barrier():
         if dist is not None:
@@ -936,16 +1053,16 @@ def main():
                   "scaling": "strong", "vehicles_total": n_strong * world, "vehicles_per_gpu": n_strong, "n_gpus": world,
                   "stepping": "persistent" if uses_persistent(afa, mode, n_strong) else "launches",
                   "value": n_strong * world / ts, "unit": "vehicle-steps/s", "ms_per_step": ts * 1e3, "steps": args.steps, "repeats": len(sblocks),
-                  "frac_per_gpu": n_strong * sbytes / ts / 1e9 / HBM_PEAK_GBS,
-                  "steady_state": {"steps": long_steps, "ms_per_step": tl * 1e3, "value": n_strong * world / tl,
-                                   "frac_per_gpu": n_strong * sbytes / tl / 1e9 / HBM_PEAK_GBS}}
+                  "steady_state": {"steps": long_steps, "ms_per_step": tl * 1e3, "value": n_strong * world / tl}}
+        strong.update(bound_fields(n_strong, sbytes, ts, committed_ns_profile()))     # per GPU: what bounds one rank's shard
         es.close()
 
-    # ---- the same workload on the reference's own noise machinery (per-vehicle std::minstd_rand0 + std::normal_distribution
-    # streams, bit-exact words and polar-method decisions: Quadcopter_T.cpp:165-180), the headline's protocol ----
-    exact = None
+    # ---- the same workload under the OTHER noise policy, the headline's protocol: the counter-based generator when the
+    # headline runs on the reference's streams (per-vehicle std::minstd_rand0 + std::normal_distribution, bit-exact words and
+    # polar-method decisions: Quadcopter_T.cpp:165-180), and the other way round with --noise counter ----
+    other = None
     if not args.headline_only:
-        ex = build_shard(afa, n_local, rank * n_local, n_global, local_rank, exact_stream=True)
+        ex = build_shard(afa, n_local, rank * n_local, n_global, local_rank, exact_stream=not HEADLINE_EXACT_STREAMS)
         ex.set_step_mode(mode)
         time_steps(ex, max(args.warmup, 50), 1, sync, barrier)
         ex.grid_time()
@@ -957,13 +1074,16 @@ def main():
         if tx_grid is not None and not (0.5 * tx <= tx_grid <= 1.5 * tx):
             tx_grid = None
         tx_kernel = (tx_grid if tx_grid is not None else event_blocks(ex, args.steps)[0]) if rank == 0 else None
-        exact = {"value": n_global / tx, "unit": "vehicle-steps/s", "ms_per_step": tx * 1e3, "steps": args.steps, "repeats": len(xblocks),
+        other = {"value": n_global / tx, "unit": "vehicle-steps/s", "ms_per_step": tx * 1e3, "steps": args.steps, "repeats": len(xblocks),
                  "algorithmic_bytes_per_vehicle_step": xbytes, "kernel_us": None if tx_kernel is None else tx_kernel * 1e6,
                  "frac": None if tx_kernel is None else n_local * xbytes / tx_kernel / 1e9 / HBM_PEAK_GBS,
-                 "frac_wall": n_local * xbytes / tx / 1e9 / HBM_PEAK_GBS,
-                 "stepping": "persistent" if uses_persistent(afa, mode, n_local) else "launches", "seed_policy": "AFE_SEED_DECORRELATED",
-                 "note": "IMU noise from per-vehicle libstdc++-exact streams (seed 1 + global index) instead of the counter-based generator; same "
-                         "timing protocol as the headline (median of bracketed K-step blocks), frac from HIP events like roofline.frac"}
+                 "frac_wall": n_local * xbytes / tx / 1e9 / HBM_PEAK_GBS, "resident_in": residency(n_local * xbytes),
+                 "stepping": "persistent" if uses_persistent(afa, mode, n_local) else "launches",
+                 "seed_policy": "AFE_SEED_COUNTER" if HEADLINE_EXACT_STREAMS else "AFE_SEED_DECORRELATED",
+                 "note": ("IMU noise from the counter-based generator (Philox4x32-10 + Box-Muller per vehicle and tick: no per-vehicle word, no rejection loop; "
+                          "a stream no reference run produces)" if HEADLINE_EXACT_STREAMS else
+                          "IMU noise from per-vehicle libstdc++-exact streams (seed 1 + global index)") +
+                         "; same timing protocol as the headline (median of bracketed K-step blocks), frac from device time like roofline.frac"}
         ex.close()
 
     out = None
@@ -994,7 +1114,8 @@ def main():
             time_steps(e, 100, 1, sync, lambda: None)
             t_launch = median([kernel_time_events(e, long_steps) for _ in range(3)])
             e.set_step_mode(mode)
-        traffic, traffic_src, rocprof_us = committed_traffic(n_local)
+        traffic, traffic_src, rocprof_us = committed_traffic(n_local, HEADLINE_EXACT_STREAMS)
+        e_footprint = 52.0 + 16.0 + 12.0 + 24.0 + (4.0 if HEADLINE_EXACT_STREAMS else 0.0)      # distinct bytes a step touches per fp32 vehicle of this workload
         # the headline's engine is done.  (It goes before the rows of smaller shards are measured: a rank of an 8-GPU run
         # holds its own shard and nothing else, and a second large engine that has had a resident grid costs a small
         # engine's synchronised blocks ~0.5 us per step while it exists -- measured, tools/sync_cost_probe.py; cause open.)
@@ -1030,11 +1151,15 @@ def main():
                 "workload_short": "BASELINE config 4 per GPU: %d hovering CF_MINIQUAD vehicles, per-vehicle wind gusts (on-device gust process, sigma 0..0.5 N, "
                                   "100 ms epochs), IMU synthesis + Gaussian noise at the 500 Hz logic gate, one afe_step call per 1 ms step, state "
                                   "through memory every step (no temporal fusion)" % n_local,
-                "noise": "AFE_SEED_COUNTER (Philox4x32-10 + Box-Muller); the reference's libstdc++ streams: reference_noise_streams",
+                "noise": ("AFE_SEED_DECORRELATED: the reference's per-vehicle std::minstd_rand0 + std::normal_distribution streams, words bit-exact; the "
+                          "counter-based generator: counter_noise_policy" if HEADLINE_EXACT_STREAMS else
+                          "AFE_SEED_COUNTER (Philox4x32-10 + Box-Muller); the reference's libstdc++ streams: reference_noise_streams"),
                 "parallelism_short": "contiguous shards, %d rank(s), no data-path collective" % world,
                 "workload": "config 4: hovering CF_MINIQUAD ensemble, per-vehicle wind gusts from the on-device gust process (sigma swept 0..0.5 N over "
-                            "the global index, piecewise constant, resampled every 100 ms; afe_set_gust_process), IMU synthesis with Gaussian noise from the "
-                            "counter-based generator (AFE_SEED_COUNTER: Philox4x32-10 + Box-Muller per vehicle and tick) at the 500 Hz logic gate, "
+                            "the global index, piecewise constant, resampled every 100 ms; afe_set_gust_process), IMU synthesis with Gaussian noise from " +
+                            ("the reference's own machinery (one std::minstd_rand0 + std::normal_distribution stream per vehicle, seed 1 + global index: AFE_SEED_DECORRELATED)"
+                             if HEADLINE_EXACT_STREAMS else "the counter-based generator (AFE_SEED_COUNTER: Philox4x32-10 + Box-Muller per vehicle and tick)") +
+                            " at the 500 Hz logic gate, "
                             "one afe_step call per 1 ms step, state through HBM every step (no temporal fusion); " +
                             ("stepping by one resident grid (afe_set_step_mode: every wave advances its vehicles through each authorised step, "
                              "no kernel boundary between steps)" if persistent else
@@ -1050,6 +1175,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
+                # where the headline's working set lives between two steps: every distinct byte a step touches (state 52 B, commands
+                # 16, force 12, IMU sample 24, engine word 4 per vehicle) against the 256 MiB Infinity Cache.  Inside it, `frac` is
+                # algorithmic bytes / time against the HBM peak with the Infinity Cache serving the bytes ("fits the 256 MB
+                # Infinity Cache ... the reported fraction uses algorithmic bytes / time") -- the row that streams from HBM is hbm_streaming
+                "resident_in": residency(n_local * e_footprint),
+                "working_set_bytes": n_local * e_footprint,
+                "infinity_cache_bytes": INFINITY_CACHE_BYTES,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -1057,10 +1189,11 @@ def main():
                 "peak_measured": probe,
                 "frac_of_measured": None if probe is None else achieved / probe["GBs_164B"],
                 "traffic": traffic,
+                "traffic_is": "L2-fabric bytes per step (FETCH_SIZE / WRITE_SIZE count Infinity-Cache hits): L2 <-> Infinity Cache traffic here, not HBM bytes",
                 "traffic_source": traffic_src,
-                "kernel_short": "afe_step_persistent_kernel<float,FEXT,NOISE=counter>" if persistent else "afe_step_kernel<float,FEXT,NOISE 0/1,SINGLE>",
-                "kernel": ("afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=2 (counter), LOGIC=0>: one launch serves every step between two "
-                           "synchronisations; its rocprofv3 duration / the steps it served = kernel_us_rocprof, the HIP events around a block = kernel_us" if persistent else
+                "kernel_short": ("afe_step_persistent_kernel<float,FEXT,NOISE=%s>" % ("libstdc++ streams" if HEADLINE_EXACT_STREAMS else "counter")) if persistent else "afe_step_kernel<float,FEXT,NOISE 0/1,SINGLE>",
+                "kernel": (("afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=%s, LOGIC=0>: one launch serves every step between two " % ("1 (libstdc++ streams)" if HEADLINE_EXACT_STREAMS else "2 (counter)")) +
+                           "synchronisations; its rocprofv3 duration / the steps it served = kernel_us_rocprof, the HIP events around a block = kernel_us") if persistent else (
                            "afe::afe_step_kernel<float, FEXT=1, TEXT=0, NOISE, LOGIC=0, SINGLE=1>, 64-lane workgroups -- the timed region "
                            "alternates NOISE=0 (no logic tick) and NOISE=1 (tick: IMU + six Gaussian draws) launches"),
                 "kernel_us": t_kernel * 1e6,
@@ -1084,14 +1217,36 @@ def main():
                     "note": "the same engine with afe_set_step_mode(AFE_STEP_LAUNCH): one kernel launch per step" +
                             (" and half of the shard (two streams)" if n_local >= (1 << 19) else "")},
                 "per_kernel": None if args.headline_only else per_kernel_breakdown(afa, n_local, local_rank),
-                "note": "achieved = algorithmic bytes per step / HIP-event time per step over the timed cadence (kernel_us: events on the "
-                        "engine's stream around %d steps, median of kernel_repeats).  In-place state (%.0f MB per step) fits the 256 MiB "
-                        "Infinity Cache; beyond_cache holds the same measurement at 2^22 vehicles.  traffic = HBM bytes per step from the "
-                        "committed rocprofv3 PMC summary" % (args.steps, n_local * bytes_step / 1e6),
+                "note": "achieved = algorithmic bytes per step / device time per step over the timed cadence (kernel_us).  The distinct bytes of a step "
+                        "(%.0f MB) fit the 256 MiB Infinity Cache: resident_in says so, and traffic is fabric-side bytes, not HBM bytes.  beyond_cache: 2^22 "
+                        "vehicles (the state alone still fits: cache-policy hints keep it on-die); hbm_streaming: 2^23 vehicles, nothing survives a step on-die -- "
+                        "the row whose fraction is a fraction of HBM bandwidth" % (n_local * e_footprint / 1e6),
             },
             "config4_as_stated": strong,
-            "reference_noise_streams": exact,
+            "counter_noise_policy" if HEADLINE_EXACT_STREAMS else "reference_noise_streams": other,
         }
+        if world > 1:
+            exp, exp_src = committed_json("expected_rates.json", lambda d: d)
+            if exp:
+                sc = {"from": exp_src, "what": "per-GPU rate of this run against what ONE GPU measured on the same shard with the same arguments (independent shards: ratio 1 = linear scaling)"}
+                w = (exp.get("weak_per_gpu") or {}).get(str(n_local))
+                if w:
+                    sc["weak"] = {"vehicles_per_gpu": n_local, "expected_per_gpu": w["vsteps_per_s"], "measured_per_gpu": value / world, "ratio": value / world / w["vsteps_per_s"]}
+                st_ = (exp.get("strong_shard") or {}).get(str(n_strong))
+                if st_ and strong:
+                    sc["strong"] = {"vehicles_per_gpu": n_strong, "expected_per_gpu": st_["vsteps_per_s"], "measured_per_gpu": strong["value"] / world,
+                                    "ratio": strong["value"] / world / st_["vsteps_per_s"]}
+                out["scaling_check"] = sc
+        # rows whose bytes are served by the Infinity Cache: their ceiling is what a pure streaming kernel of the step kernel's
+        # shape reaches at the same size and residency in this run (afe_stream_probe), not the HBM peak -- frac_of_probe
+        if probe is not None:
+            pg = probe["GBs_164B"]
+            for row in (out["roofline"]["steady_state"], out["roofline"]["launch_mode"], other):
+                if row and row.get("achieved_GBs"):
+                    row["ratio_to_stream_probe"] = row["achieved_GBs"] / pg
+                elif row and row.get("frac") is not None:
+                    row["achieved_GBs"] = row["frac"] * HBM_PEAK_GBS
+                    row["ratio_to_stream_probe"] = row["achieved_GBs"] / pg
         if world == 1 and not args.no_sweep and not args.headline_only:
             # beyond the Infinity Cache: 2^22 vehicles (620 MB per step)
             nb = 4 << 20
@@ -1099,11 +1254,34 @@ def main():
             eb.sync()
             usb = afa.stream_probe(nb, 24, 17, 40, local_rank)
             eb.close()
-            rowb["achieved_GBs"] = rowb["frac"] * HBM_PEAK_GBS
+            rowb["achieved_GBs"] = rowb["algorithmic_GBs"]
             rowb["peak_measured_GBs_164B"] = nb * 164 / usb / 1e3
             rowb["frac_of_measured"] = rowb["achieved_GBs"] / rowb["peak_measured_GBs_164B"]
             rowb["frac_of_6290"] = rowb["achieved_GBs"] / 6290.0      # the guide's achievable-from-HBM figure
+            rowb["resident_in"] = "state in infinity_cache (cache policy 1), inputs and outputs from hbm"
             out["roofline"]["beyond_cache"] = rowb
+            # THE HBM row: 2^23 vehicles.  The state alone is 436 MB: nothing a step touches is still on-die when the next
+            # step comes for it, every algorithmic byte crosses the HBM interface, and the fabric-side counters ARE HBM
+            # bytes here (profiles/r05_bc23_summary.json: PMC / algorithmic).  frac = algorithmic bytes / time / 8 TB/s;
+            # frac_of_probe = against what afe_stream_probe streams in the same launch shape at the same size in this run.
+            try:
+                nh = 8 << 20
+                eh, rowh = shard_row(afa, nh, local_rank, sync, barrier, reduce_max, 100)
+                eh.sync()
+                ush = afa.stream_probe(nh, 24, 17, 20, local_rank)
+                eh.close()
+                pmc, pmc_src = committed_json("r*_bc23_summary.json", lambda d: d["per_step"]["pmc_over_algorithmic"])
+                out["roofline"]["hbm_streaming"] = {
+                    "vehicles": nh, "us_per_step": rowh["us_per_step"], "vsteps_per_s": rowh["vsteps_per_s"], "achieved": rowh["algorithmic_GBs"], "unit": "GB/s",
+                    "frac": rowh["algorithmic_GBs"] / HBM_PEAK_GBS, "probe_GBs": nh * 164 / ush / 1e3, "ratio_to_stream_probe": rowh["algorithmic_GBs"] / (nh * 164 / ush / 1e3),
+                    "frac_of_6290": rowh["algorithmic_GBs"] / 6290.0, "pmc_over_algorithmic": pmc, "pmc_from": pmc_src,
+                    "working_set_bytes": nh * e_footprint, "resident_in": "hbm", "stepping": rowh["stepping"], "block_steps": rowh["block_steps"], "repeats": rowh["repeats"],
+                    "note": "launched kernels, two halves on two streams, cache policy by size (afe_set_cache_policy automatic); bounded by the device's "
+                            "write path: read-only streams reach 6.6-6.8 TB/s on these boxes, write-only 4.4-4.9 (profiles/r04_hbm_probe_2p23.txt).  probe_GBs is "
+                            "afe_stream_probe at the same size in this run -- a PLAIN streaming kernel (default cache policy, one stream), not a ceiling: the step "
+                            "kernels' nt hints and two streams can beat it (ratio_to_stream_probe > 1); frac_of_6290 is against the guide's achievable HBM figure"}
+            except Exception as ex:            # (a box short of memory must not cost the line)
+                out["roofline"]["hbm_streaming"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             # the north-star shard: one GPU's share of config 4 on eight (131,072 vehicles), and its neighbours
             sweep = []
             for n in (1024, 4096, 65536, 131072, 262144, 524288, 1 << 20, 2 << 20):
@@ -1125,29 +1303,42 @@ def main():
                 es.set_split_stepping(1)
                 tf = median([time_steps(es, k, 2, sync, barrier) for _ in range(3)])
                 t50 = median([time_steps(es, k, 50, sync, barrier) for _ in range(3)])
-                fr = lambda t: n * bytes_n / (t / k) / 1e9 / HBM_PEAK_GBS
-                row.update({"launches": {"us_per_step": t1 / k * 1e6, "vsteps_per_s": n * k / t1, "frac": fr(t1)},
-                            "split_launches": {"us_per_step": t2 / k * 1e6, "vsteps_per_s": n * k / t2, "frac": fr(t2)},
+                fr = lambda t: n * bytes_n / (t / k) / 1e9
+                row.update({"launches": {"us_per_step": t1 / k * 1e6, "vsteps_per_s": n * k / t1, "algorithmic_GBs": fr(t1)},
+                            "split_launches": {"us_per_step": t2 / k * 1e6, "vsteps_per_s": n * k / t2, "algorithmic_GBs": fr(t2)},
                             "fused2": {"us_per_step": tf / k * 1e6, "vsteps_per_s": n * k / tf},
                             "fused50": {"us_per_step": t50 / k * 1e6, "vsteps_per_s": n * k / t50}})
                 sweep.append(row)
                 es.close()
             out["sweep"] = sweep
-            out["sweep_note"] = ("per size: the engine's automatic mode (top level: us_per_step, vsteps_per_s, frac = algorithmic bytes / time / 8 TB/s, "
+            out["sweep_note"] = ("per size: the headline's stepping (top level: us_per_step, vsteps_per_s, algorithmic_GBs; bound / resident_in say what the rate "
+                                 "is a fraction OF -- the L2s' 34.5 TB/s for working sets that fit them (l2_frac; those rows are latency-bound), 8 TB/s beyond (frac); "
                                  "median of bracketed 400-step blocks), then the same shard stepped by launches on one stream, by launches on two streams "
                                  "(afe_set_split_stepping 2), with two steps per launch (fused2: nothing is observable between 500 Hz logic ticks) and with "
                                  "50 steps per launch (fused50: state in registers, open-loop commands).  131,072 vehicles is one GPU's shard of BASELINE "
                                  "config 4 on 8 GPUs")
             ns = [r for r in sweep if r["vehicles"] == 131072][0]
+            bytes_ns = ns["algorithmic_GBs"] * 1e9 * ns["us_per_step"] * 1e-6 / 131072
             ek, rowk = shard_row(afa, 131072, local_rank, sync, barrier, reduce_max, args.steps)
             ek.close()
-            out["north_star_shard"] = {"vehicles_per_gpu": 131072, "us_per_step": ns["us_per_step"], "vsteps_per_s_per_gpu": ns["vsteps_per_s"],
-                                       "us_per_step_k_blocks": rowk["us_per_step"], "k": args.steps,
-                                       "frac": ns["frac"], "launch_mode_frac": ns["launches"]["frac"],
-                                       "note": "one GPU's shard of the 1M-vehicle ensemble on 8 GPUs, measured on this one GPU; shards do not communicate while stepping "
-                                               "(no data-path collective), so 8 ranks deliver 8x this rate up to barrier skew -- a projection until the driver's --gpus 8 run.  "
-                                               "frac is algorithmic bytes / time / 8 TB/s and can exceed 1 here: the shard's 19 MB live in the XCDs' L2s, HBM sees about one byte per "
-                                               "vehicle-step (profiles/r04e_ns_summary.json: 1.5 B)"}
+            # what ONE GPU delivers on the shard a rank of an N-GPU run of config 4 holds, in the driver's own protocol (blocks of
+            # K steps): the figures a first multi-GPU run is judged against (tools/expected_rates.py -> profiles/expected_rates.json)
+            shard_rates = {"131072": {"us_per_step_k_blocks": rowk["us_per_step"], "vsteps_per_s": rowk["vsteps_per_s"]}}
+            for n_sh in (262144, 524288):
+                esh, rsh = shard_row(afa, n_sh, local_rank, sync, barrier, reduce_max, args.steps)
+                esh.close()
+                shard_rates[str(n_sh)] = {"us_per_step_k_blocks": rsh["us_per_step"], "vsteps_per_s": rsh["vsteps_per_s"]}
+            out["strong_shard_rates_one_gpu"] = {"k": args.steps, "rows": shard_rates}
+            ns_row = {"vehicles_per_gpu": 131072, "us_per_step": ns["us_per_step"], "vsteps_per_s_per_gpu": ns["vsteps_per_s"],
+                      "us_per_step_k_blocks": rowk["us_per_step"], "k": args.steps, "launch_mode_us_per_step": ns["launches"]["us_per_step"],
+                      "note": "one GPU's shard of the 1M-vehicle ensemble on 8 GPUs, measured on this one GPU; shards do not communicate while stepping "
+                              "(no data-path collective), so 8 ranks deliver 8x this rate up to barrier skew -- a projection until the driver's --gpus 8 run.  "
+                              "No HBM fraction: the shard's 19 MB live in the XCDs' L2s (1.6 B per vehicle-step reach the fabric: profiles/r05_ns_summary.json); "
+                              "two worker waves share every SIMD and the step is bound by vector-instruction issue: valu_busy_frac = the share of a SIMD's cycles in "
+                              "which a vector instruction of one of its two waves executes (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave x 2, committed counters of "
+                              "this grid, idle polls between blocks inside); l2_frac = algorithmic bytes against the L2s' 34.5 TB/s"}
+            ns_row.update(bound_fields(131072, bytes_ns, ns["us_per_step"] * 1e-6, committed_ns_profile()))
+            out["north_star_shard"] = ns_row
             # config 2 closed on the GPU: on-device onboard rates logic, hover command
             closed = []
             for n in (4096, 131072, 1 << 20):
@@ -1161,13 +1352,30 @@ def main():
                 es.set_step_mode(afa.AFE_STEP_LAUNCH)
                 t10 = median([time_steps(es, k, 10, sync, barrier) for _ in range(3)])
                 b_mean, _ = mean_bytes_per_step(es, afa, k)   # state, force, commands; on ticks IMU, filter state, rate commands
-                closed.append({"vehicles": n, "vsteps_per_s": n * k / t1, "us_per_step": t1 / k * 1e6,
-                               "algorithmic_bytes_per_vehicle_step": b_mean, "achieved_GBs": n * b_mean / (t1 / k) / 1e9,
-                               "frac": n * b_mean / (t1 / k) / 1e9 / HBM_PEAK_GBS, "vsteps_per_s_fused10": n * k / t10,
-                               "us_per_step_auto": ta / k * 1e6, "vsteps_per_s_auto": n * k / ta,
-                               "bound": "latency (state in the XCDs' L2s)" if n * b_mean < 32e6 else "memory"})
+                crow = {"vehicles": n, "vsteps_per_s": n * k / t1, "us_per_step": t1 / k * 1e6,
+                        "algorithmic_bytes_per_vehicle_step": b_mean, "achieved_GBs": n * b_mean / (t1 / k) / 1e9,
+                        "vsteps_per_s_fused10": n * k / t10, "us_per_step_auto": ta / k * 1e6, "vsteps_per_s_auto": n * k / ta}
+                crow.update(bound_fields(n, b_mean, t1 / k, None))
+                closed.append(crow)
                 es.close()
             out["closed_loop_on_device"] = closed
+            # PCIe-inclusive (never `value`): a host that hands the state over and takes it back around EVERY step -- what the
+            # boundary costs when the inputs are not resident (the engine's design is that they are)
+            ep = build_shard(afa, n_local, 0, n_local, local_rank)
+            ep.set_step_mode(afa.AFE_STEP_LAUNCH)
+            stp = ep.get_state(dtype=np.float32)
+            tp = []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                ep.set_state(stp["pos"], stp["vel"], stp["att"], stp["ang_vel"], None, dtype=np.float32)
+                ep.step(DT_US, 1)
+                stp = ep.get_state(dtype=np.float32)
+                tp.append(time.perf_counter() - t0)
+            ep.close()
+            out["pcie_inclusive"] = {"vehicles": n_local, "ms_per_step": min(tp) * 1e3, "vsteps_per_s": n_local / min(tp),
+                                     "bytes_over_the_bus_per_step": n_local * (13 * 4 + 17 * 4),
+                                     "note": "afe_set_state_f32 (pos, vel, att, ang_vel) + one step + afe_get_state_f32 (with rotor speeds) per step, "
+                                             "pageable numpy buffers through the ctypes host; not the headline: inputs are resident there"}
             out["disturbance_sweep"] = disturbance_sweep(afa, local_rank)
             out["companions"] = companion_rows(afa, n_local, local_rank, sync, barrier, split)
             out["perception_rows"] = perception_rows(afa)

@@ -136,7 +136,7 @@ const char *afe_status_string(int status);
 int afe_abi_version(void);
 /* 1 when the loaded library was built with -DAFE_DEV_HOOKS (the kernel lab's measurement variables of tools/ are
  * read), 0 for the release build, which reads exactly six environment variables:
- * AFE_PERSIST_AQL, AFE_FORCE_STEP_MODE, AFE_FORCE_SPLIT, AFE_FORCE_HOST_ARENA, AFE_CACHE_POLICY, AFE_PERSIST_DEBUG. */
+ * AFE_PERSIST_AQL, AFE_FORCE_STEP_MODE, AFE_FORCE_SPLIT, AFE_FORCE_HOST_ARENA, AFE_PERSIST_DEBUG, AFE_GRID_LOG. */
 int afe_has_dev_hooks(void);
 /* Build self-check (no GPU needed): byte offset and size of each of the four by-value arguments of the resident step
  * kernel -- StepView, DevParams, DevLogic, PersistArgs -- as the HOST packs them for a dispatch on the engine's own

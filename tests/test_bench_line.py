@@ -1,5 +1,8 @@
 """bench.py's printed line: the driver parses ONE JSON line and lost a 20 kB one in round 3 (BENCH_r03.json parsed:
-null).  compact_line keeps it below LINE_LIMIT whatever the full record holds; the full record goes to the side file."""
+null).  compact_line keeps it below LINE_LIMIT whatever the full record holds; the full record goes to the side file.
+Round 5 adds what the line must NOT say: no figure above 1 may be labelled a fraction of the HBM peak except the
+headline's own `frac` (which states where its working set lives), rows whose working set fits the L2s carry no HBM
+fraction at all, and the row that really streams from HBM (2^23 vehicles) is in the line."""
 import copy
 import json
 import os
@@ -12,20 +15,19 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def full_record():
-    """round 3's full 20 kB record (committed), with the keys this round adds"""
-    full = json.load(open(os.path.join(ROOT, "profiles", "r03c_bench_line_k20.json")))
-    full["reference_noise_streams"] = {"value": 4.9674346308e10, "unit": "vehicle-steps/s", "ms_per_step": 0.021109004504978657, "steps": 20,
-                                       "repeats": 124, "algorithmic_bytes_per_vehicle_step": 147.96800000000002, "kernel_us": 21.109004504978657,
-                                       "frac": 0.9187767093150095, "frac_wall": 0.9, "stepping": "persistent", "seed_policy": "AFE_SEED_DECORRELATED",
-                                       "note": "x" * 300}
-    full["config"]["workload_short"] = "w" * 390
-    full["config"]["noise"] = "AFE_SEED_COUNTER (Philox4x32-10 + Box-Muller); the reference's libstdc++ streams: reference_noise_streams"
-    full["config"]["parallelism_short"] = "contiguous shards, 1 rank(s), no data-path collective"
-    full["roofline"]["kernel_short"] = "afe_step_persistent_kernel<float,FEXT,NOISE=counter>"
-    full["north_star_shard"]["us_per_step_k_blocks"] = 3.4123456789
-    if "beyond_cache" in full["roofline"]:
-        full["roofline"]["beyond_cache"]["frac_of_6290"] = 0.8456789123
-    return full
+    """a full record as bench.py wrote it on an MI355X this round (committed: profiles/r05_bench_detail_k20.json, 30+ kB)"""
+    return json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail_k20.json")))
+
+
+def _walk(x, path=""):
+    if isinstance(x, dict):
+        for k, v in x.items():
+            yield from _walk(v, path + "/" + k)
+    elif isinstance(x, list):
+        for i, v in enumerate(x):
+            yield from _walk(v, "%s[%d]" % (path, i))
+    else:
+        yield path, x
 
 
 def test_full_size_record_gives_a_short_line_that_round_trips():
@@ -40,22 +42,47 @@ def test_full_size_record_gives_a_short_line_that_round_trips():
     for k in CONTRACT:
         assert k in back, k
     assert back["value"] == float("%.6g" % full["value"])
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "resident_in", "traffic_is", "hbm_streaming"):
         assert k in back["roofline"], k
     assert back["roofline"]["bound"] == "hbm" and back["roofline"]["peak"] == 8000.0
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "all_cores", "reference_noise_streams"):
         assert k in back["cpu_baseline"], k
     assert set(back["config"]) >= {"workload", "vehicles_per_gpu", "vehicles_total", "stepping"}
     assert "model" not in back["config"]
-    # what the review asked to see in the short line
     assert back["config4_as_stated"]["scaling"] == "strong"
     assert back["north_star_shard"]["vehicles_per_gpu"] == 131072
-    assert back["reference_noise_streams"]["frac"] > 0
+    assert back["counter_noise_policy"]["value"] > 0
     assert all(isinstance(v, float) for v in back["companions"].values())
     assert back["detail"] == bench.DETAIL_FILE
-    # nothing bulky came along
     for k in ("sweep", "sweep_note", "disturbance_sweep", "perception_rows"):
         assert k not in back
+
+
+def test_the_line_labels_nothing_above_one_as_an_hbm_fraction():
+    """round-4 review, "Next round" 1"""
+    line = bench.compact_line(full_record())
+    roof = line["roofline"]
+    # the headline says where its bytes are served from; its traffic figure says what it counts
+    assert roof["resident_in"] == "infinity_cache" and roof["working_set_bytes"] < roof["infinity_cache_bytes"]
+    assert "not HBM" in roof["traffic_is"]
+    # the true HBM row: 2^23 vehicles, a fraction of 8 000 GB/s below 1, the PMC bytes equal to the algorithmic ones
+    hs = roof["hbm_streaming"]
+    assert hs["vehicles"] == 1 << 23 and 0.5 < hs["frac"] < 1.0 and abs(hs["achieved"] / 8000.0 - hs["frac"]) < 1e-3
+    assert 0.95 < hs["pmc_over_algorithmic"] < 1.10
+    # rows that live in the L2s carry no HBM fraction but a bound, an L2-side rate and the vector pipes' share
+    ns = line["north_star_shard"]
+    assert "frac" not in ns and "launch_mode_frac" not in ns
+    assert ns["resident_in"] == "l2" and ns["bound"] in ("valu_issue", "latency") and 0 < ns["l2_frac"] < 1 and 0 < ns["valu_busy_frac"] <= 1.0
+    for row in line["closed_loop_on_device"]:
+        if row["resident_in"] == "l2":
+            assert "frac" not in row and row["bound"] in ("latency", "valu_issue")
+        else:
+            assert row["frac"] <= 1.0
+    # every key called frac / frac_* anywhere in the line is a number not above 1 -- ratios to the plain stream probe are named ratios
+    for path, v in _walk(line):
+        key = path.rsplit("/", 1)[-1]
+        if key.startswith("frac") or key.endswith("_frac") or key == "frac":
+            assert v is None or v <= 1.0, (path, v)
 
 
 def test_hostile_strings_and_missing_parts_still_fit():
@@ -78,6 +105,7 @@ def test_hostile_strings_and_missing_parts_still_fit():
     bare["config4_as_stated"] = None
     bare["roofline"] = dict(bare["roofline"], peak_measured=None, launch_mode=None, per_kernel=None)
     bare["roofline"].pop("beyond_cache", None)
+    bare["roofline"].pop("hbm_streaming", None)
     back = json.loads(json.dumps(bench.compact_line(bare)))
     assert back["value"] > 0 and "cpu_baseline" not in back and "config4_as_stated" not in back
 
@@ -87,8 +115,9 @@ def test_non_finite_numbers_do_not_break_the_parser():
     full["roofline"]["traffic"] = float("nan")
     full["ms_per_step_max"] = float("inf")
     text = json.dumps(bench.compact_line(full))
-    assert "NaN" not in text and "Infinity" not in text
-    json.loads(text)
+    def refuse(token):          # json's hook for the bare tokens NaN / Infinity / -Infinity (the words may appear inside strings: "Infinity Cache")
+        raise AssertionError("non-finite token %s in the line" % token)
+    json.loads(text, parse_constant=refuse)
 
 
 def test_side_file_holds_the_full_record(tmp_path, monkeypatch):
@@ -98,3 +127,18 @@ def test_side_file_holds_the_full_record(tmp_path, monkeypatch):
     name = bench.write_detail(full)
     for d in (tmp_path, tmp_path / "gpurun_out"):
         assert json.load(open(d / name)) == full
+
+
+def test_bound_fields_say_what_a_rate_is_a_fraction_of():
+    ns = {"valu_instructions_per_wave_step": 460.0, "valu_active_frac": 0.39, "simd_valu_busy_frac": 0.78, "counters_from": "profiles/x.json"}
+    small = bench.bound_fields(4096, 144.0, 1.6e-6, ns)                      # one wave on 64 of 1 024 SIMDs
+    shard = bench.bound_fields(131072, 144.0, 2.0e-6, ns)                    # two waves per SIMD
+    head = bench.bound_fields(1 << 20, 144.0, 19.5e-6, ns)
+    big = bench.bound_fields(1 << 23, 144.0, 212e-6, ns)
+    assert small["resident_in"] == "l2" and small["bound"] == "latency" and "frac" not in small
+    assert shard["resident_in"] == "l2" and shard["bound"] == "valu_issue" and shard["valu_busy_frac"] == 0.78 and "frac" not in shard
+    quarter = bench.bound_fields(262144, 148.0, 3.8e-6, ns)                  # 28 MB of distinct bytes: still the L2s', four waves per SIMD
+    assert quarter["resident_in"] == "l2" and quarter["bound"] == "valu_issue" and "frac" not in quarter and "valu_busy_frac" not in quarter
+    assert head == {"bound": "hbm", "resident_in": "infinity_cache", "frac": head["frac"]} and 0.9 < head["frac"] < 1.0
+    assert big["resident_in"] == "hbm" and 0.6 < big["frac"] < 0.8
+    assert bench.residency(109e6) == "infinity_cache" and bench.residency(19e6) == "l2" and bench.residency(905e6) == "hbm"

@@ -46,7 +46,7 @@ def test_bench_with_two_ranks_on_one_gpu_prints_one_consistent_line(tmp_path):
     s = d["config4_as_stated"]
     assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["vehicles_per_gpu"] == 524288 and s["vehicles_total"] == 1048576
     assert s["value"] == pytest.approx(1048576 / (s["ms_per_step"] * 1e-3), rel=1e-4)
-    assert d["reference_noise_streams"]["value"] > 0
+    assert d["counter_noise_policy"]["value"] > 0          # (the headline runs on the reference's streams; the other policy beside it)
     assert "cpu_baseline" not in d                     # rank 0 at N = 1 only
     detail = json.load(open(os.path.join(ROOT, d["detail"])))
     assert detail["ms_per_step_rank0_own"] <= detail["ms_per_step_max"] * (1 + 1e-9)

@@ -356,20 +356,23 @@ def test_full_size_properties_1m_vehicles():
     assert abs(float(gyro[2].std()) - 0.1) < 2e-3
 
 
-def test_full_size_on_the_bench_workload_itself():
+@pytest.mark.parametrize("exact_streams", [True, False])
+def test_full_size_on_the_bench_workload_itself(exact_streams):
     """The ensemble bench.py times, as bench.py builds it (bench.build_shard): 2^20 vehicles on the 4 m lattice out to
-    (4.1 km, 4.1 km) -- where an fp32 position ulp is 0.24-0.49 mm --, the on-device gust process, counter-based IMU noise,
-    the engine's automatic stepping (one resident grid).  150 steps (two gust epochs); a 512-vehicle subsample spread over
-    the whole lattice against the checker flown through the same process (ora_step_batch_counter)."""
+    (4.1 km, 4.1 km) -- where an fp32 position ulp is 0.24-0.49 mm --, the on-device gust process, IMU noise under the
+    headline's policy (the reference's per-vehicle libstdc++ streams, seed 1 + global index: engine words bit-exact) and
+    under the counter-based one, the headline's stepping (one resident grid).  150 steps (two gust epochs); a 512-vehicle
+    subsample spread over the whole lattice against the checker flown through the same process (ora_step_batch_counter)."""
     import bench
     from oracle import oracle_py as ora
     n, steps = 1 << 20, 150
-    e = bench.build_shard(afa, n, 0, n, 0)
+    e = bench.build_shard(afa, n, 0, n, 0, exact_stream=exact_streams)
     p0 = e.get_state()["pos"]
     e.step(1000, steps)
     st = e.get_state()
     gyro, acc = e.get_imu()
     force = e.get_external_force()
+    words = e.get_rng_state()
     e.close()
     assert p0[0].max() == 4092.0 and p0[1].max() == 4092.0
     idx = np.sort((np.arange(512) * 2053 + 7) % n)        # every column and row band of the lattice
@@ -383,14 +386,19 @@ def test_full_size_on_the_bench_workload_itself():
         one = ora.Batch(1, [ora.params_from_type(5)])
         for f in ("pos", "vel", "att", "ang_vel", "motor_speed", "motor_cmd"):
             getattr(one, f)[:] = getattr(b, f)[:, k:k + 1]
-        ora.step_counter(one, 1000, steps, ticks, counter_noise=True, seed=bench.NOISE_SEED, first_global=int(g), tick_base=0,
+        one.rng[:] = 1 + int(g)                     # AFE_SEED_DECORRELATED: std::default_random_engine(1 + global index)
+        ora.step_counter(one, 1000, steps, ticks, counter_noise=not exact_streams, seed=bench.NOISE_SEED, first_global=int(g), tick_base=0,
                          gust_seed=bench.GUST_SEED, gust_period_us=bench.GUST_PERIOD_US, t0_us=0, n_global=n, sigma_max=bench.GUST_SIGMA_MAX)
         for f in ("pos", "vel", "att", "ang_vel", "ext_force", "gyro", "acc"):
             getattr(b, f)[:, k:k + 1] = getattr(one, f)
+        b.rng[k] = one.rng[0]
+    if exact_streams:
+        np.testing.assert_array_equal(words[idx], b.rng)      # 75 ticks x 6 normals per vehicle: every engine word where libstdc++ leaves it
     for k, ref in dict(pos=b.pos, vel=b.vel, att=b.att, ang_vel=b.ang_vel, gyro=b.gyro, acc=b.acc).items():
         got = dict(st, gyro=gyro, acc=acc)[k]
         # (floors: as in the test above -- rates and gyro at the general floor, exact-zero torque; v_z of a hovering vehicle at 0.1)
-        assert record_parity("bench workload: 2^20 vehicles on the 4 km lattice x 150 steps, 512-vehicle subsample", afa.AFE_F32, k, got[:, idx], ref,
+        assert record_parity("bench workload (%s): 2^20 vehicles on the 4 km lattice x 150 steps, 512-vehicle subsample" % ("libstdc++ streams" if exact_streams else "counter noise"),
+                             afa.AFE_F32, k, got[:, idx], ref,
                              floor=0.1 if k == "vel" else None) <= F32_TOL, k
     assert np.abs(st["ang_vel"]).max() == 0.0           # open loop, force-only gusts: no vehicle of the 2^20 ever turns, as in the reference
     assert np.abs(force[:, idx] - b.ext_force).max() <= 1e-6 * 0.5

@@ -12,7 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-B="$ROOT/bench.py --headline-only --vehicles $N"
+B="$ROOT/bench.py --headline-only --vehicles $N ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $B --steps 2000 --warmup 200 > $OUT/prof_$TAG.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_k20_$TAG -- python3 $B --steps 20 --warmup 5 > $OUT/prof_k20_$TAG.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $B --steps 200 --warmup 20 > $OUT/pmc_fetch_$TAG.log 2>&1

@@ -13,7 +13,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-B="$ROOT/bench.py --headline-only --vehicles $N"
+B="$ROOT/bench.py --headline-only --vehicles $N ${BENCH_EXTRA:-}"
 rm -f $OUT/gridlog_*_$TAG.csv
 AFE_GRID_LOG=$OUT/gridlog_k20_$TAG.csv rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_k20_$TAG -- python3 $B --steps 20 --warmup 5 > $OUT/prof_k20_$TAG.log 2>&1
 AFE_GRID_LOG=$OUT/gridlog_$TAG.csv rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $B --steps 2000 --warmup 200 > $OUT/prof_$TAG.log 2>&1

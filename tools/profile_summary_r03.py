@@ -17,6 +17,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from pmc_factors import factors
+FETCH_FACTOR, WRITE_FACTOR, FACTOR_SOURCE = factors()
 tag = sys.argv[1]
 note = sys.argv[2] if len(sys.argv) > 2 else ""
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
@@ -56,8 +59,10 @@ def counter_per_launch(dirname):
     return agg
 
 
-summary = {"build": note, "tag": tag, "script": "tools/profile_r03.sh %s %d" % (tag, N), "vehicles": N,
-           "kernel": "afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=2 (counter), LOGIC=0, RESIDENT=0> (one launch per synchronised block of steps)"}
+summary = {"build": note, "tag": tag, "script": "tools/profile_r03.sh %s %d" % (tag, N), "vehicles": N, "noise_policy": sys.argv[6] if len(sys.argv) > 6 else "counter",
+           "algorithmic_bytes_per_vehicle_step": BYTES_MEAN,
+           "kernel": "afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=%s, LOGIC=0, RESIDENT=0> (one launch per synchronised block of steps)"
+                     % ("1 (libstdc++ streams)" if (len(sys.argv) > 6 and sys.argv[6] == "reference_streams") else "2 (counter)")}
 for src, dst in (("prof_%s" % tag, "%s_kernel_stats.csv" % tag), ("prof_k20_%s" % tag, "%s_k20_kernel_stats.csv" % tag),
                  ("prof_full_%s" % tag, "%s_full_kernel_stats.csv" % tag)):
     f = one(src + "/**/*_kernel_stats.csv")
@@ -69,6 +74,7 @@ for src, dst in (("prof_%s" % tag, "%s_kernel_stats.csv" % tag), ("prof_k20_%s" 
 
 # (round 4: a grid is retired after 512 steps, so a 2000-step block is launches of 512, 512, 512 and 464 steps: the median launch serves 512)
 LONG_STEPS = int(sys.argv[5]) if len(sys.argv) > 5 else 2000
+POLICY = sys.argv[6] if len(sys.argv) > 6 else "counter"          # the bench's noise policy in these passes: "reference_streams" | "counter"
 for name, src, steps in (("blocks_of_2000_steps", "prof_%s" % tag, LONG_STEPS), ("blocks_of_20_steps", "prof_k20_%s" % tag, 20)):
     d = launches(src)
     if not d:
@@ -81,12 +87,13 @@ steps = 200
 fetch, write, sq = counter_per_launch("pmc_fetch_%s" % tag), counter_per_launch("pmc_write_%s" % tag), counter_per_launch("pmc_sq_%s" % tag)
 if fetch.get("FETCH_SIZE") and write.get("WRITE_SIZE"):
     fs, ws = median(fetch["FETCH_SIZE"]), median(write["WRITE_SIZE"])      # the 200-step blocks outnumber the warm-up launch
-    per_step = (2 * 1024 * fs + 1024 * ws) / steps
+    per_step = (FETCH_FACTOR * 1024 * fs + WRITE_FACTOR * 1024 * ws) / steps
     summary["traffic"] = {"FETCH_SIZE_KiB_per_launch": fs, "WRITE_SIZE_KiB_per_launch": ws, "steps_per_launch": steps,
-                          "hbm_bytes_per_step": per_step, "hbm_bytes_per_vehicle_step": per_step / N,
+                          "fabric_bytes_per_step": per_step, "fabric_bytes_per_vehicle_step": per_step / N, "counter_factors": {"FETCH_SIZE": FETCH_FACTOR, "WRITE_SIZE": WRITE_FACTOR, "source": FACTOR_SOURCE},
+                          "what": "bytes through the L2s' fabric side (TCC_EA0 requests): Infinity-Cache hits are counted, so this is L2 <-> Infinity Cache / HBM traffic, not HBM traffic",
                           "algorithmic_bytes_per_step": N * BYTES_MEAN, "ratio": per_step / (N * BYTES_MEAN)}
-    if N == 1 << 20:
-        json.dump({"workload": {"vehicles_per_gpu": N, "fext": True, "noise": True, "dt_us": 1000, "logic_period_s": 0.002},
+    if N == 1 << 20 and (len(sys.argv) <= 7 or sys.argv[7] != "no-traffic-json"):
+        json.dump({"workload": {"vehicles_per_gpu": N, "fext": True, "noise": True, "noise_policy": POLICY, "dt_us": 1000, "logic_period_s": 0.002},
                    "traffic_bytes_per_step": per_step,
                    "traffic_bytes_per_launch": per_step,
                    "rocprof_kernel_us_per_step": {"blocks_of_20_steps": summary.get("blocks_of_20_steps", {}).get("us_per_step"),
@@ -94,7 +101,7 @@ if fetch.get("FETCH_SIZE") and write.get("WRITE_SIZE"):
                                                   "source": "profiles/%s_k20_kernel_stats.csv, profiles/%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats; "
                                                             "median duration of the resident grid's launches / the steps each served)" % (tag, tag)},
                    "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over resident-grid launches of %d steps, separate passes, "
-                             "FETCH_SIZE x2 gfx950 correction)" % (tag, steps)}, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+                             "FETCH_SIZE / WRITE_SIZE scaled by the factors measured on known dword streams: profiles/*_fetch_calibration.json)" % (tag, steps)}, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 if sq.get("SQ_WAVES"):
     rec = {c: median(v) for c, v in sorted(sq.items())}
     waves = rec["SQ_WAVES"]
@@ -102,5 +109,10 @@ if sq.get("SQ_WAVES"):
     summary["valu_instructions_per_wave_and_step"] = rec.get("SQ_INSTS_VALU", 0) / waves / steps
     summary["salu_instructions_per_wave_and_step"] = rec.get("SQ_INSTS_SALU", 0) / waves / steps
     summary["note_sq"] = "a wave of the resident grid steps ceil(chunks / waves) chunks of 64 vehicles per step; the pump wave is one of SQ_WAVES"
+foot = N * (52.0 + 16.0 + 12.0 + 24.0 + (4.0 if POLICY == "reference_streams" else 0.0))
+summary["working_set_bytes"] = foot
+summary["resident_in"] = "l2" if foot <= (32 << 20) else ("infinity_cache" if foot <= 0.94 * (256 << 20) else "hbm")
+summary["note_frac"] = ("frac_of_8TBs is algorithmic bytes / kernel time against the HBM peak; with the working set resident in the Infinity Cache the bytes are served "
+                        "on-die and the figure can exceed 1 -- the HBM row is profiles/r05_bc23_summary.json (2^23 vehicles)")
 json.dump(summary, open(os.path.join(prof, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:4000])

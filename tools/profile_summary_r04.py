@@ -20,6 +20,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from pmc_factors import factors
+FETCH_FACTOR, WRITE_FACTOR, FACTOR_SOURCE = factors()
 tag = sys.argv[1]
 note = sys.argv[2] if len(sys.argv) > 2 else ""
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
@@ -77,7 +80,8 @@ def counter_per_dispatch(dirname):
 
 
 summary = {"build": note, "tag": tag, "script": "tools/profile_r04.sh %s %d" % (tag, N), "vehicles": N,
-           "kernel": "afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=2 (counter), LOGIC=0, RESIDENT=0> on the engine's own AQL queue; "
+           "noise_policy": sys.argv[5] if len(sys.argv) > 5 else "counter",
+           "kernel": "afe::afe_step_persistent_kernel<float, FEXT=1, NOISE (by policy), LOGIC=0, RESIDENT=0> on the engine's own AQL queue; "
                      "a dispatch serves every step authorised until it parks (AFE_GRID_LOG gives the steps per dispatch)",
            "algorithmic_bytes_per_vehicle_step": BYTES_MEAN}
 for src, dst in (("prof_%s" % tag, "%s_kernel_stats.csv" % tag), ("prof_k20_%s" % tag, "%s_k20_kernel_stats.csv" % tag),
@@ -127,11 +131,12 @@ for cname, src, log in (("FETCH_SIZE", "pmc_fetch_%s" % tag, "gridlog_fetch_%s.c
 if len(steps_of) == 2:
     fs, fst = steps_of["FETCH_SIZE"]
     ws, wst = steps_of["WRITE_SIZE"]
-    per_step = 2 * 1024 * fs / fst + 1024 * ws / wst
+    per_step = FETCH_FACTOR * 1024 * fs / fst + WRITE_FACTOR * 1024 * ws / wst
     summary["traffic"] = {"FETCH_SIZE_KiB_per_step": fs / fst, "WRITE_SIZE_KiB_per_step": ws / wst, "steps_counted": [fst, wst],
-                          "hbm_bytes_per_step": per_step, "hbm_bytes_per_vehicle_step": per_step / N,
+                          "fabric_bytes_per_step": per_step, "fabric_bytes_per_vehicle_step": per_step / N, "counter_factors": {"FETCH_SIZE": FETCH_FACTOR, "WRITE_SIZE": WRITE_FACTOR, "source": FACTOR_SOURCE},
+                          "what": "bytes through the L2s' fabric side (TCC_EA0 requests): Infinity-Cache hits are counted, so this is L2 <-> Infinity Cache / HBM traffic, not HBM traffic",
                           "algorithmic_bytes_per_step": N * BYTES_MEAN, "ratio": per_step / (N * BYTES_MEAN)}
-    if N == 1 << 20:
+    if N == 1 << 20 and False:      # (round 5: the 2^20 record comes from tools/profile_summary_r03.py -- the grid is launched per block there)
         k20 = summary.get("blocks_of_20_steps", {}).get("resident_through_the_timed_blocks", {}).get("us_per_step")
         k2000 = summary.get("blocks_of_2000_steps", {}).get("resident_through_the_timed_blocks", {}).get("us_per_step")
         json.dump({"workload": {"vehicles_per_gpu": N, "fext": True, "noise": True, "dt_us": 1000, "logic_period_s": 0.002},
@@ -140,7 +145,7 @@ if len(steps_of) == 2:
                                                   "source": "profiles/%s_summary.json (rocprofv3 --kernel-trace: the resident grid's dispatch that lived through the timed "
                                                             "blocks, duration / steps served)" % tag},
                    "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summed over the resident grid's dispatches / steps served, separate passes, "
-                             "FETCH_SIZE x2 gfx950 correction)" % tag}, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+                             "FETCH_SIZE / WRITE_SIZE scaled by the factors measured on known dword streams: profiles/*_fetch_calibration.json)" % tag}, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 sq, g = counter_per_dispatch("pmc_sq_%s" % tag), gridlog("gridlog_sq_%s.csv" % tag)
 if sq.get("SQ_WAVES") and len(sq["SQ_WAVES"]) == len(g) + 1:
     sq = {k: v[1:] for k, v in sq.items()}     # the primer
@@ -151,6 +156,16 @@ if sq.get("SQ_WAVES") and len(sq["SQ_WAVES"]) == len(g):
     summary["sq_totals"] = rec
     summary["valu_instructions_per_wave_and_step"] = rec.get("SQ_INSTS_VALU", 0) / waves / st
     summary["salu_instructions_per_wave_and_step"] = rec.get("SQ_INSTS_SALU", 0) / waves / st
+    wc = max(1.0, rec.get("SQ_WAVE_CYCLES", 0))
+    # what bounds a grid whose state lives in the XCDs' L2s (round-4 review): share of the waves' resident cycles in which
+    # a vector instruction is executing, and in which the wave waits for anything / for an instruction's operands
+    summary["valu_active_frac_of_wave_cycles"] = rec.get("SQ_ACTIVE_INST_VALU", 0) / wc
+    summary["wait_any_frac_of_wave_cycles"] = rec.get("SQ_WAIT_ANY", 0) / wc
+    summary["wait_inst_any_frac_of_wave_cycles"] = rec.get("SQ_WAIT_INST_ANY", 0) / wc
+    # a worker wave shares its SIMD with (workers / 1024 - 1) others: the SIMD's vector pipe is busy that many times the per-wave share
+    workers_per_simd = max(1.0, (waves - 1) / 1024.0)
+    summary["worker_waves_per_simd"] = workers_per_simd
+    summary["simd_valu_busy_frac"] = summary["valu_active_frac_of_wave_cycles"] * workers_per_simd
     summary["note_sq"] = "a wave of the resident grid steps ceil(chunks / waves) chunks of 64 vehicles per step; the pump wave is one of SQ_WAVES; idle polling between blocks is inside"
 json.dump(summary, open(os.path.join(prof, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:5000])

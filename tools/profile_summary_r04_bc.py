@@ -8,8 +8,12 @@ both halves concurrently): wall microseconds from the trace, algorithmic TB/s, f
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from pmc_factors import factors
+FETCH_FACTOR, WRITE_FACTOR, FACTOR_SOURCE = factors()
 tag, note = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 22
+BYTES = float(sys.argv[4]) if len(sys.argv) > 4 else 144.0      # algorithmic bytes per vehicle-step of the passes' noise policy (148: libstdc++ streams)
 out, prof = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -45,7 +49,7 @@ for k, durs in per_kernel.items():
     fs, ws = counters["FETCH_SIZE"].get(k), counters["WRITE_SIZE"].get(k)
     rec = {"launches": len(durs), "avg_us": sum(body) / len(body) / 1e3, "vehicles_per_launch": N // halves}
     if fs and ws:
-        fb, wb = 2 * 1024 * sum(fs[len(fs) // 5:]) / len(fs[len(fs) // 5:]), 1024 * sum(ws[len(ws) // 5:]) / len(ws[len(ws) // 5:])
+        fb, wb = FETCH_FACTOR * 1024 * sum(fs[len(fs) // 5:]) / len(fs[len(fs) // 5:]), WRITE_FACTOR * 1024 * sum(ws[len(ws) // 5:]) / len(ws[len(ws) // 5:])
         rec.update({"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "fetch_bytes_per_vehicle": fb / (N // halves),
                     "write_bytes_per_vehicle": wb / (N // halves), "traffic_GBs_in_the_launch": (fb + wb) / (rec["avg_us"] * 1e-6) / 1e9})
     summary["kernels"][k] = rec
@@ -58,7 +62,13 @@ if trace:
     traffic = sum(r.get("fetch_bytes_per_launch", 0) + r.get("write_bytes_per_launch", 0) for r in summary["kernels"].values()) / max(1, len(summary["kernels"])) * halves
     summary["per_step"] = {"us_trace_span_per_step": us, "note": "first start to last end of the launches past the warm-up / steps (host gaps between blocks inside)",
                            "pmc_bytes_per_step_mean_of_the_two_kernels": traffic, "pmc_bytes_per_vehicle_step": traffic / N,
-                           "algorithmic_bytes_per_vehicle_step": 144.0, "algorithmic_GBs": N * 144.0 / (us * 1e-6) / 1e9,
-                           "frac_of_8000": N * 144.0 / (us * 1e-6) / 1e9 / 8000.0, "frac_of_6290": N * 144.0 / (us * 1e-6) / 1e9 / 6290.0}
+                           "algorithmic_bytes_per_vehicle_step": BYTES, "algorithmic_GBs": N * BYTES / (us * 1e-6) / 1e9,
+                           "frac_of_8000": N * BYTES / (us * 1e-6) / 1e9 / 8000.0, "frac_of_6290": N * BYTES / (us * 1e-6) / 1e9 / 6290.0}
+summary["counter_factors"] = {"FETCH_SIZE": FETCH_FACTOR, "WRITE_SIZE": WRITE_FACTOR, "source": FACTOR_SOURCE}
+if "per_step" in summary:
+    ps = summary["per_step"]
+    ps["pmc_over_algorithmic"] = ps["pmc_bytes_per_vehicle_step"] / ps["algorithmic_bytes_per_vehicle_step"]
+    ps["what"] = ("beyond the 256 MiB Infinity Cache nothing survives from one step to the next, so the fabric-side counters ARE HBM traffic here "
+                  "(state 52 B x %d vehicles = %.0f MB)" % (N, 52.0 * N / 1e6))
 json.dump(summary, open(os.path.join(prof, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3500])
