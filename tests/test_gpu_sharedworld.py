@@ -543,6 +543,60 @@ def test_device_view_never_writes_past_the_callers_struct():
         assert not e.persistent_running
 
 
+def test_a_world_that_scatters_leaves_thousands_of_queries_over_and_is_still_answered_in_milliseconds():
+    """Round-4 advisor: the query kernel's last workgroup used to brute-force EVERY leftover query, one after the other, on
+    one compute unit -- n_left x n_all distance evaluations; 10^4 leftovers among 10^6 points would hold the stream for
+    0.4 s, and the host learnt about leftovers only after a query had finished.  Now the in-kernel tail takes at most 32
+    and one conditional launch behind every query shares larger lists over the device.  A dense core of 2^18 vehicles
+    (600 m square) plus a halo of 6 000 vehicles ~77 m apart over 6 km (the grid's cells are sized for the core: six
+    rings reach 20 m, and the halo beyond 6 sigma is clamped into boundary cells): every halo query is left over; every
+    answer is the brute-force definition's, and the query -- the FIRST one of this world included -- takes milliseconds."""
+    import time
+    import torch
+    rng = np.random.default_rng(41)
+    n_core, n_far = 1 << 18, 6000
+    core = np.stack([rng.uniform(0, 600, n_core), rng.uniform(0, 600, n_core), rng.uniform(1, 4, n_core)])
+    far = np.stack([rng.uniform(-2700, 3300, n_far), rng.uniform(-2700, 3300, n_far), rng.uniform(1, 4, n_far)])     # a halo 77 m apart: 20x the six rings' reach
+    pos = np.concatenate([core, far], axis=1).astype(np.float32)
+    perm = rng.permutation(pos.shape[1])
+    pos = np.ascontiguousarray(pos[:, perm])
+    n = pos.shape[1]
+    world = torch.from_numpy(pos).cuda()
+    with afa.Ensemble(n) as e:
+        e.set_type_table([afa.params_from_type(5)])
+        e.set_state(pos=pos.astype(np.float64))
+        d2_t = torch.empty(n, dtype=torch.float32, device="cuda")
+        idx_t = torch.empty(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e.nearest_neighbour(world.data_ptr(), n, d2_t.data_ptr(), idx_t.data_ptr())       # the first query of this world
+        e.sync()
+        first_ms = (time.perf_counter() - t0) * 1e3
+        info = e.neighbour_grid_info()
+        assert info["n_bruteforce"] > 1000, info                     # thousands left over by the rings: the conditional launch's work
+        assert first_ms < 250.0, first_ms                             # (sort scratch allocation included; the old tail: ~0.4 s per 10^4 leftovers at 10^6 points)
+        ev0, ev1 = e.event(), e.event()
+        e.record(ev0)
+        for _ in range(5):
+            e.nearest_neighbour(world.data_ptr(), n, d2_t.data_ptr(), idx_t.data_ptr())
+        e.record(ev1)
+        ms = e.elapsed_ms(ev0, ev1) / 5
+        assert ms < 20.0, ms
+        d2, idx = d2_t.cpu().numpy(), idx_t.cpu().numpy()
+        far_ids = np.nonzero(np.isin(perm, np.arange(n_core, n)))[0]
+        q = np.unique(np.concatenate([far_ids, rng.choice(n, 2048, replace=False)])).astype(np.int32)
+        q_t = torch.from_numpy(q).cuda()
+        bd = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+        bi = torch.full((n,), -2, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        e.nearest_neighbour_bruteforce(world.data_ptr(), n, q_t.data_ptr(), q.size, bd.data_ptr(), bi.data_ptr())
+        e.sync()
+        np.testing.assert_array_equal(idx[q], bi.cpu().numpy()[q])
+        np.testing.assert_array_equal(d2[q], bd.cpu().numpy()[q])
+    from tests.scenarios import MEASUREMENTS
+    MEASUREMENTS["neighbour_query_scattered_world"] = {"vehicles": n, "left_over_by_the_rings": int(info["n_bruteforce"]), "first_query_ms": first_ms, "ms_per_query": ms}
+
+
 def test_group_gathers_by_staged_copies_too():
     """round-3 / round-4 advisor: a pair of devices without peer access must not refuse the group, and the copies between
     such a pair must be the runtime's peer copies (hipMemcpyPeerAsync, staged through the host where the devices cannot
