@@ -209,6 +209,23 @@ def committed_ns_profile(exact_stream=None):
     return None
 
 
+def scaling_check(exp, exp_src, world, n_local, value, n_strong, strong_value):
+    """This run's per-GPU rates beside what ONE GPU measured on the same shards with the same arguments
+    (profiles/expected_rates.json, tools/expected_rates.py): shards do not communicate while stepping, so a ratio near 1 is
+    linear scaling and anything well below it is the collectives between blocks, barrier skew or a slow device."""
+    if not exp or world < 2:
+        return None
+    sc = {"from": exp_src, "n_gpus": world}
+    w = (exp.get("weak_per_gpu") or {}).get(str(n_local))
+    if w and value:
+        sc["weak"] = {"vehicles_per_gpu": n_local, "expected_per_gpu": w["vsteps_per_s"], "measured_per_gpu": value / world, "ratio": value / world / w["vsteps_per_s"]}
+    st = (exp.get("strong_shard") or {}).get(str(n_strong))
+    if st and strong_value:
+        sc["strong"] = {"vehicles_per_gpu": n_strong, "expected_per_gpu": st["vsteps_per_s"], "measured_per_gpu": strong_value / world,
+                        "ratio": strong_value / world / st["vsteps_per_s"]}
+    return sc if ("weak" in sc or "strong" in sc) else None
+
+
 def committed_json(pattern, pick):
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
@@ -1227,15 +1244,8 @@ def main():
         }
         if world > 1:
             exp, exp_src = committed_json("expected_rates.json", lambda d: d)
-            if exp:
-                sc = {"from": exp_src, "what": "per-GPU rate of this run against what ONE GPU measured on the same shard with the same arguments (independent shards: ratio 1 = linear scaling)"}
-                w = (exp.get("weak_per_gpu") or {}).get(str(n_local))
-                if w:
-                    sc["weak"] = {"vehicles_per_gpu": n_local, "expected_per_gpu": w["vsteps_per_s"], "measured_per_gpu": value / world, "ratio": value / world / w["vsteps_per_s"]}
-                st_ = (exp.get("strong_shard") or {}).get(str(n_strong))
-                if st_ and strong:
-                    sc["strong"] = {"vehicles_per_gpu": n_strong, "expected_per_gpu": st_["vsteps_per_s"], "measured_per_gpu": strong["value"] / world,
-                                    "ratio": strong["value"] / world / st_["vsteps_per_s"]}
+            sc = scaling_check(exp, exp_src, world, n_local, value, n_strong, strong["value"] if strong else None)
+            if sc:
                 out["scaling_check"] = sc
         # rows whose bytes are served by the Infinity Cache: their ceiling is what a pure streaming kernel of the step kernel's
         # shape reaches at the same size and residency in this run (afe_stream_probe), not the HBM peak -- frac_of_probe

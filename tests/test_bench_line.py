@@ -142,3 +142,19 @@ def test_bound_fields_say_what_a_rate_is_a_fraction_of():
     assert head == {"bound": "hbm", "resident_in": "infinity_cache", "frac": head["frac"]} and 0.9 < head["frac"] < 1.0
     assert big["resident_in"] == "hbm" and 0.6 < big["frac"] < 0.8
     assert bench.residency(109e6) == "infinity_cache" and bench.residency(19e6) == "l2" and bench.residency(905e6) == "hbm"
+
+
+def test_scaling_check_puts_a_multi_gpu_run_beside_the_one_gpu_shard_rates():
+    """round-4 review, "Next round" 3d: a first --gpus N run is judged against what one GPU delivers on the same shard"""
+    exp = json.load(open(os.path.join(ROOT, "profiles", "expected_rates.json")))
+    assert set(exp["strong_shard"]) >= {"131072", "262144", "524288", "1048576"} and "1048576" in exp["weak_per_gpu"]
+    one = exp["weak_per_gpu"]["1048576"]["vsteps_per_s"]
+    shard = exp["strong_shard"]["131072"]["vsteps_per_s"]
+    sc = bench.scaling_check(exp, "profiles/expected_rates.json", 8, 1 << 20, 8 * 0.95 * one, 131072, 8 * 0.5 * shard)
+    assert sc["n_gpus"] == 8
+    assert abs(sc["weak"]["ratio"] - 0.95) < 1e-9 and sc["weak"]["measured_per_gpu"] == 0.95 * one
+    assert abs(sc["strong"]["ratio"] - 0.5) < 1e-9 and sc["strong"]["vehicles_per_gpu"] == 131072
+    assert bench.scaling_check(exp, "x", 1, 1 << 20, one, 1 << 20, one) is None           # one GPU: nothing to compare
+    assert bench.scaling_check(None, None, 8, 1 << 20, one, 131072, shard) is None       # no committed rates
+    line = bench.compact_line(dict(full_record(), scaling_check=sc))
+    assert line["scaling_check"]["strong"]["ratio"] == 0.5
