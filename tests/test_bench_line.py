@@ -45,7 +45,7 @@ def test_full_size_record_gives_a_short_line_that_round_trips():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "resident_in", "traffic_is", "hbm_streaming"):
         assert k in back["roofline"], k
     assert back["roofline"]["bound"] == "hbm" and back["roofline"]["peak"] == 8000.0
-    for k in ("value", "unit", "cores", "kind", "sample", "all_cores", "reference_noise_streams"):
+    for k in ("value", "unit", "cores", "kind", "sample", "all_cores"):
         assert k in back["cpu_baseline"], k
     assert set(back["config"]) >= {"workload", "vehicles_per_gpu", "vehicles_total", "stepping"}
     assert "model" not in back["config"]
