@@ -690,10 +690,12 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
   // Quadcopter_T.hpp:100, widened at Quadcopter_T.cpp:98)
   R cmd[4];
 #pragma unroll
-  for (int m = 0; m < 4; m++) { cmd[m] = (R)cmd_f[m]; if (cmd[m] < 0) cmd[m] = 0; }
-  // (a motor without lag below: clamp(cmd', w_min, w_max) with cmd' = max(0, cmd) is the MEDIAN of the three -- one v_med3
-  // instead of two compares and two selects per motor; a NaN command stays NaN as through the reference's comparisons,
-  // where v_med3 alone would return the lower bound.  Round 5, same box: 1 % at every size, tools/ab_probe.py)
+  for (int m = 0; m < 4; m++) cmd[m] = (R)cmd_f[m];     // (clamped at zero where it is used: the lagged branch below)
+  // A motor without lag: clamp(max(0, cmd), w_min, w_max) is the MEDIAN of (cmd, max(w_min, 0), w_max) -- one v_med3
+  // instead of three compares and three selects per motor (a compare costs 2.4 and a select 1.8 plain instructions of
+  // issue on this chip, tools/valu_rate_probe.hip); no rounding is involved, and a NaN command stays NaN as it does
+  // through the reference's comparisons (v_med3 alone would return the lower bound).  tools/ab_probe.py, same box: 1-2 %.
+  const R wlo = P.wmin > (R)0 ? P.wmin : (R)0;
 
   // SINGLE: one sub-step per launch (the per-step-observable mode): no loop
   const int n_steps = SINGLE ? 1 : n_steps_arg;
@@ -734,9 +736,10 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
       R w;
       R rotor_tz = 0;                                        // (ang_acc * J) * spin, :78-79
       if (!lagged) {
-        w = cmd[m];                                          // :60 with c = 0
-        w = w != w ? w : m_med3(w, P.wmin, P.wmax);          // :62-66 (no rounding; a NaN stays a NaN)
+        w = cmd[m];                                          // :48-50, :60 with c = 0,
+        w = w != w ? w : m_med3(w, wlo, P.wmax);             // :62-66
       } else {
+        if (cmd[m] < 0) cmd[m] = 0;                          // :48-50
         const R old = ms[m];
         R dw;
         if (sizeof(R) == 8) {
