@@ -841,7 +841,7 @@ def compact_line(full):
                       "vehicles_per_gpu": cfg.get("vehicles_per_gpu"), "vehicles_total": cfg.get("vehicles_total"),
                       "dt_us": cfg.get("dt_us"), "steps_per_call": cfg.get("steps_per_call"), "stepping": cfg.get("stepping"),
                       "noise": cfg.get("noise"), "parallelism": cfg.get("parallelism_short", cfg.get("parallelism"))}
-    line.update(_pick(full, ("repeats", "ms_per_step_min", "ms_per_step_max")) or {})
+    line.update(_pick(full, ("repeats", "ms_per_step_min", "ms_per_step_max", "headline_note")) or {})
     r = _pick(roof, ("bound", "resident_in", "working_set_bytes", "infinity_cache_bytes", "achieved", "peak", "unit", "frac", "traffic", "traffic_is",
                      "traffic_source", "kernel_us", "kernel_us_min", "kernel_us_max",
                      "kernel_us_rocprof", "algorithmic_bytes_per_vehicle_step")) or {}
@@ -1164,6 +1164,8 @@ def main():
             "ms_per_step_max": max(blocks) / args.steps * 1e3,
             "ms_per_step_rank0_own": median(own_blocks) / args.steps * 1e3,     # `ms_per_step` is the MAX over ranks, block by block
             "higher_is_better": True,
+            "headline_note": ("since round 5 `value` is measured on the reference's own libstdc++ noise streams; rounds 1-4 quoted the counter-based "
+                              "generator, which is the counter_noise_policy row here") if HEADLINE_EXACT_STREAMS else None,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
