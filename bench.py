@@ -870,7 +870,7 @@ def compact_line(full):
     cb = full.get("cpu_baseline")
     if cb:
         c = _pick(cb, ("value", "unit", "cores", "kind"))
-        c["sample"] = str(cb.get("sample", ""))[:200]
+        c["sample"] = str(cb.get("sample", ""))[:150]
         if cb.get("all_cores"):
             c["all_cores"] = _pick(cb["all_cores"], ("value", "cores", "speedup_over_one_thread"))
         if cb.get("other_noise_policy"):
@@ -1164,8 +1164,8 @@ def main():
             "ms_per_step_max": max(blocks) / args.steps * 1e3,
             "ms_per_step_rank0_own": median(own_blocks) / args.steps * 1e3,     # `ms_per_step` is the MAX over ranks, block by block
             "higher_is_better": True,
-            "headline_note": ("since round 5 `value` is measured on the reference's own libstdc++ noise streams; rounds 1-4 quoted the counter-based "
-                              "generator, which is the counter_noise_policy row here") if HEADLINE_EXACT_STREAMS else None,
+            "headline_note": ("since round 5 `value` runs on the reference's libstdc++ noise streams; rounds 1-4 quoted the counter generator "
+                              "(= counter_noise_policy here)") if HEADLINE_EXACT_STREAMS else None,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
@@ -1174,8 +1174,8 @@ def main():
                 "workload_short": "BASELINE config 4 per GPU: %d hovering CF_MINIQUAD vehicles, per-vehicle wind gusts (on-device gust process, sigma 0..0.5 N, "
                                   "100 ms epochs), IMU synthesis + Gaussian noise at the 500 Hz logic gate, one afe_step call per 1 ms step, state "
                                   "through memory every step (no temporal fusion)" % n_local,
-                "noise": ("AFE_SEED_DECORRELATED: the reference's per-vehicle std::minstd_rand0 + std::normal_distribution streams, words bit-exact; the "
-                          "counter-based generator: counter_noise_policy" if HEADLINE_EXACT_STREAMS else
+                "noise": ("AFE_SEED_DECORRELATED: the reference's per-vehicle libstdc++ streams, words bit-exact (counter generator: counter_noise_policy)"
+                          if HEADLINE_EXACT_STREAMS else
                           "AFE_SEED_COUNTER (Philox4x32-10 + Box-Muller); the reference's libstdc++ streams: reference_noise_streams"),
                 "parallelism_short": "contiguous shards, %d rank(s), no data-path collective" % world,
                 "workload": "config 4: hovering CF_MINIQUAD ensemble, per-vehicle wind gusts from the on-device gust process (sigma swept 0..0.5 N over "
@@ -1212,7 +1212,7 @@ def main():
                 "peak_measured": probe,
                 "frac_of_measured": None if probe is None else achieved / probe["GBs_164B"],
                 "traffic": traffic,
-                "traffic_is": "L2-fabric bytes per step (FETCH_SIZE / WRITE_SIZE count Infinity-Cache hits): L2 <-> Infinity Cache traffic here, not HBM bytes",
+                "traffic_is": "L2-fabric bytes per step (FETCH/WRITE_SIZE count Infinity-Cache hits): not HBM bytes here",
                 "traffic_source": traffic_src,
                 "kernel_short": ("afe_step_persistent_kernel<float,FEXT,NOISE=%s>" % ("libstdc++ streams" if HEADLINE_EXACT_STREAMS else "counter")) if persistent else "afe_step_kernel<float,FEXT,NOISE 0/1,SINGLE>",
                 "kernel": (("afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=%s, LOGIC=0>: one launch serves every step between two " % ("1 (libstdc++ streams)" if HEADLINE_EXACT_STREAMS else "2 (counter)")) +
