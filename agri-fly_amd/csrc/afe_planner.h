@@ -29,6 +29,12 @@ struct PlannerBatch {
   const uint16_t *images;        // [n_images][height][width]
   uint16_t *images_t;            // [n_images][width][height] scratch, filled by launch_rappids
   int64_t n_images;
+  // Per 64-pixel word of every image (only when width % 64 == 0, else null), filled by launch_rappids together with the
+  // transpose: low half = the smallest depth above `ignore` (the vehicle's own radius in counts; 0xffff if none), high
+  // half = the largest depth, or 0xffff if a pixel at or below `ignore` is among the 64.  Both bit images of a pyramid
+  // ask "ignore < d < hi" of every pixel: a word whose smallest such depth is >= hi is all zeros, one whose high half is
+  // < hi all ones -- only the words a depth edge at `hi` runs through are looked at pixel by pixel (build_mask_sum).
+  uint32_t *sums;                // [n_images][height][width / 64]
   const int32_t *image_index;    // [n] or null (image i for planner i)
   const double *vel0, *acc0, *grav;  // planar [3][n], camera-fixed frame
   const double *cost_vec;        // planar [3][n] or null (cfg.cost_vec for all)
@@ -38,7 +44,8 @@ struct PlannerBatch {
   double *cand_cost;             // [n][n_candidates] scratch: cost of every candidate
   uint8_t *cand_bits;            // [n][n_candidates] scratch: input-feasible / velocity-admissible bits
   CandSections *cand_sections;   // [n][n_candidates] scratch, filled for the admissible candidates
-  PlannerPyramid *pyramids;      // [n][max_pyramids] scratch
+  PlannerPyramid *pyramids;      // [n][max_pyramids] scratch; up to 64 pyramids per plan: in the order they were made
+  uint8_t *pyr_order;            // [n][64]: an interrupted planner's pyramid order by depth (slot numbers), see PyrKeys
   int max_pyramids;
   PlanOutput *out;               // [n]
   uint8_t *flags;                // [n][n_candidates] or null

@@ -31,18 +31,25 @@ namespace {
 
 // -DAFE_PLANNER_PROFILE: per-phase cycle totals (s_memtime), printed by launch_rappids; development only
 #ifdef AFE_PLANNER_PROFILE
-__device__ unsigned long long g_prof[24];   // [8]: the longest planner (cycles); [9] scan chunks examined, [10] of them holding a marked pixel, [11] scan calls
+__device__ unsigned long long g_prof[40];   // [8]: the longest planner (cycles); [9] scan chunks examined, [10] of them holding a marked pixel, [11] scan calls
 #define PL_T0(var) const unsigned long long var = __builtin_readcyclecounter()
-__device__ unsigned long long g_longest[24];   // the same slots, of the longest planner alone
+__device__ unsigned long long g_longest[40];   // the same slots, of the longest planner alone
 __shared__ unsigned long long s_mine[24];
 #define PL_T1(var, slot) do { if (threadIdx.x == 0) { const unsigned long long d_ = __builtin_readcyclecounter() - var; atomicAdd(&g_prof[slot], d_); s_mine[slot] += d_; } } while (0)
 #define PL_COUNT(slot, n) do { if (threadIdx.x == 0) { atomicAdd(&g_prof[slot], (unsigned long long)(n)); s_mine[slot] += (unsigned long long)(n); } } while (0)
+struct PlScope {      // a phase's cycles however it is left (early returns included)
+  unsigned long long t0; int slot;
+  __device__ PlScope(int s) : t0(__builtin_readcyclecounter()), slot(s) {}
+  __device__ ~PlScope() { if (threadIdx.x == 0) { const unsigned long long d_ = __builtin_readcyclecounter() - t0; atomicAdd(&g_prof[slot], d_); } }
+};
+#define PL_SCOPE(name, slot) PlScope name(slot)
 #ifndef AFE_PLANNER_PROFILE_SCANS   // the per-chunk counters sit in the innermost loops and slow the kernel several times
 #define PL_COUNT_SCAN(slot, n)
 #else
 #define PL_COUNT_SCAN(slot, n) PL_COUNT(slot, n)
 #endif
 #else
+#define PL_SCOPE(name, slot)
 #define PL_T0(var)
 #define PL_T1(var, slot)
 #define PL_COUNT(slot, n)
@@ -429,18 +436,9 @@ __device__ __forceinline__ int div_small(int i, int inner, unsigned magic) {
 constexpr int kSweepBatch = 8;
 
 // mask(x, y) = lo < d(x, y) < hi for the whole image
-__device__ __forceinline__ unsigned in_open_range(unsigned d, unsigned lo1, unsigned span) {
-  return (d - lo1) < span ? 1u : 0u;          // lo < d < hi with lo1 = lo + 1, span = hi - lo - 1 (unsigned wrap)
-}
-__device__ __forceinline__ unsigned range_bits8(const uint4 q, unsigned lo1, unsigned span) {
-  return in_open_range(q.x & 0xffffu, lo1, span) | in_open_range(q.x >> 16, lo1, span) << 1 |
-         in_open_range(q.y & 0xffffu, lo1, span) << 2 | in_open_range(q.y >> 16, lo1, span) << 3 |
-         in_open_range(q.z & 0xffffu, lo1, span) << 4 | in_open_range(q.z >> 16, lo1, span) << 5 |
-         in_open_range(q.w & 0xffffu, lo1, span) << 6 | in_open_range(q.w >> 16, lo1, span) << 7;
-}
-
 // WANT_MIN: also return the smallest marked depth (65535 if none) -- the shrink scans stop where
-// even that depth could not reach an edge any more
+// even that depth could not reach an edge any more.  (Images whose rows are not whole 64-pixel words, or too large for
+// the summaries' list in LDS; everything else goes through build_mask_sum below.)
 template <bool WANT_MIN>
 __device__ AFE_NI_MASK int build_mask(const uint16_t *__restrict__ img, int W, int H, int lane, uint64_t *mask, int WW, uint16_t lo,
                           uint16_t hi) {
@@ -452,39 +450,6 @@ __device__ AFE_NI_MASK int build_mask(const uint16_t *__restrict__ img, int W, i
   // previous image are done before it is overwritten, and the new image is complete (and the
   // compiler may not move LDS reads across) before anyone looks at it.
   __syncthreads();
-  if ((W & 63) == 0 && hi > lo) {
-    // rows are whole 64-pixel words, so the image is one linear run of them: every lane takes
-    // 8 pixels (16 B) per load and writes their 8 bits as one BYTE of the little-endian bit image
-    const uint4 *src = (const uint4 *)img;       // 16-byte aligned: hipMalloc base + k * W * H * 2
-    uint8_t *bytes = (uint8_t *)mask;
-    const int nvec = (W * H) >> 3;
-    const unsigned lo1 = (unsigned)lo + 1u, span = (unsigned)hi - (unsigned)lo - 1u;
-    for (int v0 = 0; v0 < nvec; v0 += 64 * kSweepBatch) {
-      uint4 q[kSweepBatch];
-#pragma unroll
-      for (int u = 0; u < kSweepBatch; u++) {
-        const int v = v0 + 64 * u + lane;
-        q[u] = make_uint4(0, 0, 0, 0);
-        if (v < nvec) q[u] = src[v];
-      }
-#pragma unroll
-      for (int u = 0; u < kSweepBatch; u++) {
-        const int v = v0 + 64 * u + lane;
-        if (v < nvec) {
-          const unsigned bits = range_bits8(q[u], lo1, span);
-          bytes[v] = (uint8_t)bits;
-          if (WANT_MIN && bits) {
-            const unsigned px[8] = {q[u].x & 0xffffu, q[u].x >> 16, q[u].y & 0xffffu, q[u].y >> 16,
-                                    q[u].z & 0xffffu, q[u].z >> 16, q[u].w & 0xffffu, q[u].w >> 16};
-#pragma unroll
-            for (int j = 0; j < 8; j++) if ((bits >> j) & 1u) lane_min = PL_MIN(lane_min, (int)px[j]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    return WANT_MIN ? wave_min_i32(lane_min) : 65535;
-  }
   const int n = WW * H;
   const unsigned magic = div_magic(WW);
   for (int c0 = 0; c0 < n; c0 += kSweepBatch) {
@@ -509,6 +474,103 @@ __device__ AFE_NI_MASK int build_mask(const uint16_t *__restrict__ img, int W, i
       }
     }
   }
+  __syncthreads();
+  return WANT_MIN ? wave_min_i32(lane_min) : 65535;
+}
+
+// ---- the bit image from per-word summaries (round 6) --------------------------------------------------
+// PlannerBatch::sums holds, per 64-pixel word of the image, the smallest depth above `ignore` and the largest depth (or
+// 0xffff when a pixel at or below `ignore` sits in the word).  Both questions build_mask answers are "ignore < d < hi":
+// a word whose smallest such depth is >= hi is all zeros, a word whose largest depth is < hi (and that holds no ignored
+// pixel) is all ones; only the words a depth edge at `hi` runs through -- a tenth of an orchard view -- need their
+// pixels.  Lane l decides word base + l from one dword; the undecided words of the batch are then taken eight at a
+// time, eight lanes per word (one 16-byte vector = one byte of the bit image each), the k-th undecided word found by
+// a push (ds_permute: word of rank k -> lane 8k) and a pull (ds_bpermute from lane & ~7) through the LDS crossbar, no
+// LDS memory.  The range test itself is packed 16-bit arithmetic: t = d - (lo + 1) wraps the depths at or below lo
+// ABOVE every depth in range, u = sat(t - (span - 1)) is zero exactly for t < span, min(u, 1) is the NOT-in-range
+// bit of both halves of a dword: 4 vector instructions per two pixels instead of 10.
+// (the three instructions themselves: from the builtins the compiler rebuilds the comparison -- two v_cmp, two
+// v_cndmask and a v_perm per dword)
+__device__ __forceinline__ unsigned not_in_range2(unsigned two_px, unsigned lo1, unsigned span1) {
+  unsigned t, u, n;
+  asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t) : "v"(two_px), "s"(lo1));
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(u) : "v"(t), "s"(span1));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(n) : "v"(u), "s"(0x00010001u));
+  return n;
+}
+// the 8 bits of 8 pixels (bit j = pixel j is in (lo, hi)); lo1 = lo + 1, span1 = hi - lo - 2 (>= 0: the caller knows a depth in range exists)
+__device__ __forceinline__ unsigned range_bits8_packed(const uint4 q, unsigned lo1, unsigned span1) {
+  unsigned acc = not_in_range2(q.x, lo1, span1);
+  acc |= not_in_range2(q.y, lo1, span1) << 2;
+  acc |= not_in_range2(q.z, lo1, span1) << 4;
+  acc |= not_in_range2(q.w, lo1, span1) << 6;
+  return ~(acc | (acc >> 15)) & 0xffu;      // low halves sit at bits 0, 2, 4, 6, high halves at 16, 18, 20, 22
+}
+
+// Memory round trips, not instructions, are what a planner's wave spends its time on (four waves share a SIMD and each
+// has a few dozen vector instructions between two waits): the summaries arrive kSumBatch batches of 64 words at a time
+// (one wait), the undecided words go to a list in LDS behind the bit image (kSumList entries; emptied when full), and the
+// list is worked off 8 * kSumGroups words per trip -- for an orchard view five waits per bit image instead of nineteen.
+constexpr int kSumBatch = 10, kSumGroups = 8, kSumList = 256;
+
+__device__ __forceinline__ void sum_list_flush(const uint4 *__restrict__ src, uint8_t *bytes, const uint16_t *list, int count, int lane,
+                                               unsigned lo1, unsigned span1) {
+  for (int g = 0; g < count; g += 8 * kSumGroups) {
+    uint4 q[kSumGroups];
+    int vec[kSumGroups];
+#pragma unroll
+    for (int u = 0; u < kSumGroups; u++) {
+      const int idx = g + 8 * u + (lane >> 3);
+      vec[u] = -1;
+      q[u] = make_uint4(0, 0, 0, 0);
+      if (idx < count) { vec[u] = (int)list[idx] * 8 + (lane & 7); q[u] = src[vec[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kSumGroups; u++)
+      if (vec[u] >= 0) bytes[vec[u]] = (uint8_t)range_bits8_packed(q[u], lo1, span1);
+  }
+}
+
+template <bool WANT_MIN>
+__device__ AFE_NI_MASK int build_mask_sum(const uint16_t *__restrict__ img, const uint32_t *__restrict__ sums, int nwords, int lane,
+                                          uint64_t *mask, uint16_t lo, uint16_t hi) {
+  PL_UNIFORM(nwords);
+  { int l = lo, h = hi; PL_UNIFORM(l); PL_UNIFORM(h); lo = (uint16_t)l; hi = (uint16_t)h; }
+  int lane_min = 65535;
+  __syncthreads();                      // readers of the previous image are done (see build_mask)
+  const uint4 *src = (const uint4 *)img;
+  uint8_t *bytes = (uint8_t *)mask;
+  uint16_t *list = (uint16_t *)(mask + nwords);
+  const unsigned lo1s = (lo + 1u) & 0xffffu, sp1s = ((unsigned)hi - (unsigned)lo - 2u) & 0xffffu;
+  const unsigned lo1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lo1s | (lo1s << 16))), span1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(sp1s | (sp1s << 16)));
+  int count = 0;
+  for (int base0 = 0; base0 < nwords; base0 += 64 * kSumBatch) {
+    unsigned sm[kSumBatch];
+#pragma unroll
+    for (int u = 0; u < kSumBatch; u++) {
+      const int w = base0 + 64 * u + lane;
+      sm[u] = 0xffffffffu;
+      if (w < nwords) sm[u] = sums[w];
+    }
+#pragma unroll
+    for (int u = 0; u < kSumBatch; u++) {
+      const int w = base0 + 64 * u + lane;
+      const bool valid = w < nwords;
+      const unsigned mn = sm[u] & 0xffffu, mxe = sm[u] >> 16;
+      const bool zero = mn >= (unsigned)hi, ones = mxe < (unsigned)hi;
+      const bool open = valid && !zero && !ones;      // (then lo < mn < hi: hi >= lo + 2)
+      if (valid && !open) mask[w] = ones ? ~0ull : 0ull;
+      if (WANT_MIN && !zero) lane_min = PL_MIN(lane_min, (int)mn);    // the word's smallest depth above lo is below hi: it is marked
+      const uint64_t b = __ballot(open);
+      if (!b) continue;
+      const int cnt = __popcll(b);
+      if (count + cnt > kSumList) { sum_list_flush(src, bytes, list, count, lane, lo1, span1); count = 0; }
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+      if (open) list[count + rank] = (uint16_t)w;
+      count += cnt;
+    }
+  }
+  sum_list_flush(src, bytes, list, count, lane, lo1, span1);
   __syncthreads();
   return WANT_MIN ? wave_min_i32(lane_min) : 65535;
 }
@@ -620,7 +682,10 @@ enum { SIDE_RIGHT = 0, SIDE_LEFT = 1, SIDE_TOP = 2, SIDE_BOTTOM = 3 };
 // Scans walk `total` pixels in chunks of 64; kScanBatch chunks are loaded together (the loads do
 // not depend on the edges) and then resolved one after the other, so one memory latency is paid
 // per batch instead of per chunk.  i / inner for i < 2^24, inner <= 2^15 as a multiply-high.
-constexpr int kScanBatch = 4;
+#ifndef AFE_SCAN_BATCH
+#define AFE_SCAN_BATCH 4
+#endif
+constexpr int kScanBatch = AFE_SCAN_BATCH;
 
 template <int SIDE>
 __device__ AFE_NI_SIDE bool side_scan(const uint16_t *__restrict__ src, int sx, int sy, const uint64_t *mask, int WW, int lane,
@@ -821,7 +886,7 @@ __device__ AFE_NI_CORNER bool corner_scan(const uint16_t *__restrict__ img, int 
 
 // DIP.cpp:456-970, executed by one wave (lane = 0..63, everything but the scans is uniform)
 __device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restrict__ img,
-                                const uint16_t *__restrict__ imgT, uint64_t *mask, int lane, int x0, int y0,
+                                const uint16_t *__restrict__ imgT, const uint32_t *__restrict__ sums, uint64_t *mask, int lane, int x0, int y0,
                                 double minimumDepth, PlannerPyramid &out) {
 #pragma clang fp contract(off)
   PL_COUNT(22, 1);
@@ -853,7 +918,9 @@ __device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uin
   if (x0 - initR < edgeOff) { L = edgeOff; R = L + 2 * initR; }
   else { R = PL_MIN(W - edgeOff - 1, x0 + initR); L = R - 2 * initR; }
   const uint16_t ignore = (uint16_t)(c.true_vehicle_radius / c.depth_scale);
+  PL_SCOPE(sc_all, 24);
   {  // :505-518, any pixel of [L,R) x [T,B) nearer than minDepthPix
+    PL_SCOPE(sc_seed, 25);
     // (the answer does not depend on the order the pixels are looked at: eight chunks of 64 are loaded together,
     // one memory round trip per 512 pixels instead of eight -- a plan in a cluttered image asks this ~90 times)
     const int w = R - L, total = w * (B - T);
@@ -879,7 +946,8 @@ __device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uin
   // spiral expansion, :520-600, on the bit image "nearer than minDepthPix"
   const int WW = (W + 63) >> 6;
   PL_T0(t_m1);
-  build_mask<false>(img, W, H, lane, mask, WW, ignore, minDepthPix);
+  if (sums) build_mask_sum<false>(img, sums, WW * H, lane, mask, ignore, minDepthPix);
+  else build_mask<false>(img, W, H, lane, mask, WW, ignore, minDepthPix);
   PL_T1(t_m1, 1);
   PL_T0(t_ring);
   const int L0 = L, T0 = T, R0 = R, B0 = B;
@@ -929,6 +997,7 @@ __device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uin
   // plus the examined prefixes of the blocked lines
   int laneMin = 65535;
   {
+    PL_SCOPE(sc_maxd, 26);
     if ((W & 63) == 0) {
       // 8 pixels (one 16-byte vector, never straddling a row since W % 8 == 0) per lane per load,
       // only the vectors that overlap columns L..R.  A vector that lies wholly inside the counted
@@ -1008,7 +1077,9 @@ __device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uin
   // shrink by the vehicle radius, :602-940, on the bit image "ignore < d < maxDepth"
   // dmin: the nearest marked pixel anywhere; (distance from an edge) * dmin >= num means no pixel
   // at that distance or beyond can move the edge (num / d <= num / dmin), so a scan stops there
-  const int dmin = build_mask<true>(img, W, H, lane, mask, WW, ignore, maxDepth);
+  PL_SCOPE(sc_shrink, 27);
+  const int dmin = sums ? build_mask_sum<true>(img, sums, WW * H, lane, mask, ignore, maxDepth)
+                        : build_mask<true>(img, W, H, lane, mask, WW, ignore, maxDepth);
   Shrink s = {W - 1 - edgeOff, edgeOff, edgeOff, H - 1 - edgeOff};
   const int num = (int)(c.focal_length * c.planning_vehicle_radius / c.depth_scale);
   const int ny = B - T + 1, nx = R - L + 1;
@@ -1137,10 +1208,27 @@ __device__ void monotonic_sections(const Poly &p, double tf, CandSections &out) 
   }
 }
 
+// The plan's pyramid list, sorted by depth (DIP.cpp:269-271), as the wave holds it when a plan may have at most 64
+// pyramids (REGKEYS): lane q keeps what FindContainingPyramid reads of the q-th pyramid -- depth and the four edges --
+// and the number of its record in HBM (records stay in the order the pyramids were made: nothing is moved on an
+// insert; only the normals are ever read back).  "First pyramid at or beyond this depth that contains the pixel"
+// is then one comparison per lane and a ballot instead of a walk over up to 64 records in memory, and an insert is
+// a shift by one lane.  (Round 5 profile: the walk and the insert's record moves were 15 % of a plan's cycles.)
+struct PyrKeys {
+  double depth;
+  int right, top, left, bottom, slot;
+};
+__device__ __forceinline__ double shfl_up1_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__shfl_up((int)(unsigned)u, 1), hi = (unsigned)__shfl_up((int)(unsigned)(u >> 32), 1);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // IsCollisionFree (DIP.cpp:214-301) on the candidate's sections
+template <bool REGKEYS>
 __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restrict__ img,
-                               const uint16_t *__restrict__ imgT, uint64_t *mask_lds, int lane, const Poly &p,
-                               const CandSections &first, PlannerPyramid *pyr, int &nPyr, int maxPyr) {
+                               const uint16_t *__restrict__ imgT, const uint32_t *__restrict__ sums, uint64_t *mask_lds, int lane, const Poly &p,
+                               const CandSections &first, PlannerPyramid *pyr, PyrKeys &keys, int &nPyr, int maxPyr) {
 #pragma clang fp contract(off)
   Section sec[16];   // pending sections (a std::vector in the reference; 16 like the CPU checker)
   int ns = first.n;
@@ -1160,7 +1248,13 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
     // FindContainingPyramid, DIP.cpp:356-380
     int at = -1;
     PL_T0(t_find);
-    {
+    if (REGKEYS) {
+      // the pyramids nearer than ez are a prefix of the sorted list: "from the first at or beyond ez on" is "not nearer"
+      const bool mine = lane < nPyr && !(keys.depth < ez) && keys.left + cfg.pixel_buffer < px && px < keys.right - cfg.pixel_buffer &&
+                        keys.top + cfg.pixel_buffer < py && py < keys.bottom - cfg.pixel_buffer;
+      const uint64_t holds = __ballot(mine);
+      if (holds) at = (int)__ffsll((unsigned long long)holds) - 1;
+    } else {
       int first = 0;
       while (first < nPyr && pyr[first].depth < ez) first++;
       for (int q = first; q < nPyr; q++)
@@ -1171,19 +1265,29 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
     if (at < 0) {
       if (nPyr >= maxPyr) return false;                        // _maxNumPyramids, :255-260
       PlannerPyramid fresh;
-      if (!inflate_pyramid(cfg, img, imgT, mask_lds, lane, (int)px, (int)py, ez, fresh)) return false;
+      if (!inflate_pyramid(cfg, img, imgT, sums, mask_lds, lane, (int)px, (int)py, ez, fresh)) return false;
       PL_T0(t_ins);
       int idx = 0;                                             // std::lower_bound + insert, :269-271
-      while (idx < nPyr && pyr[idx].depth < fresh.depth) idx++;
-      for (int q = nPyr; q > idx; q--) pyr[q] = pyr[q - 1];
-      pyr[idx] = fresh;
+      if (REGKEYS) {
+        idx = __popcll(__ballot(lane < nPyr && keys.depth < fresh.depth));   // (a prefix again)
+        const double d_up = shfl_up1_f64(keys.depth);
+        const int r_up = __shfl_up(keys.right, 1), t_up = __shfl_up(keys.top, 1), l_up = __shfl_up(keys.left, 1),
+                  b_up = __shfl_up(keys.bottom, 1), s_up = __shfl_up(keys.slot, 1);
+        if (lane > idx) { keys.depth = d_up; keys.right = r_up; keys.top = t_up; keys.left = l_up; keys.bottom = b_up; keys.slot = s_up; }
+        if (lane == idx) { keys.depth = fresh.depth; keys.right = fresh.right; keys.top = fresh.top; keys.left = fresh.left; keys.bottom = fresh.bottom; keys.slot = nPyr; }
+        pyr[nPyr] = fresh;          // every lane writes the same record (and reads back only what it wrote itself)
+      } else {
+        while (idx < nPyr && pyr[idx].depth < fresh.depth) idx++;
+        for (int q = nPyr; q > idx; q--) pyr[q] = pyr[q - 1];
+        pyr[idx] = fresh;
+      }
       nPyr++;
       at = idx;
       PL_T1(t_ins, 18);
     }
     double tcol;
     PL_T0(t_deep);
-    const bool hits = deepest_collision_time(p, m, pyr[at], lane, tcol);
+    const bool hits = deepest_collision_time(p, m, pyr[REGKEYS ? __builtin_amdgcn_readlane(keys.slot, at) : at], lane, tcol);
     PL_T1(t_deep, 19);
     PL_COUNT(20, 1);
     if (hits) {
@@ -1273,6 +1377,8 @@ __global__ void __launch_bounds__(256) afe_rappids_candidates_kernel(const Plann
 #ifndef AFE_PLANNER_WAVES
 #define AFE_PLANNER_WAVES 4
 #endif
+// REGKEYS: at most 64 pyramids per plan -- the sorted list lives in the wave's lanes (PyrKeys)
+template <bool REGKEYS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFE_PLANNER_WAVES, AFE_PLANNER_WAVES)))
 afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
 #pragma clang fp contract(off)
@@ -1298,12 +1404,14 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
   const int64_t img_off = (int64_t)(b.image_index ? b.image_index[i] : i) * cfg.width * cfg.height;
   const uint16_t *img = b.images + img_off;
   const uint16_t *imgT = b.images_t + img_off;
+  const uint32_t *sums = b.sums ? b.sums + (img_off >> 6) : nullptr;      // one dword per 64 pixels
   const double *samples = b.samples + (int64_t)(b.sample_table ? b.sample_table[i] : 0) * b.n_candidates * 4;
   const double *cand_cost = b.cand_cost + i * b.n_candidates;
   const uint8_t *cand_bits = b.cand_bits + i * b.n_candidates;
   const CandSections *__restrict__ cand_sections = b.cand_sections + i * b.n_candidates;
   PlannerPyramid *pyr = b.pyramids + i * b.max_pyramids;
   PlanOutput *out = b.out + i;
+  PyrKeys keys = {0.0, 0, 0, 0, 0, 0};
   int nPyr = 0;
   int n_cost = 0, n_feasible = 0, n_velocity = 0, n_free = 0, best_index = -1;
   double bestCost = 1.7976931348623157e308;
@@ -1314,6 +1422,11 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
     start_base = rs->base; start_lane = rs->lane;
     best_index = rs->best_index; n_cost = rs->n_cost; n_feasible = rs->n_feasible; n_velocity = rs->n_velocity; n_free = rs->n_free;
     nPyr = rs->n_pyr; bestCost = rs->best_cost;
+    if (REGKEYS && lane < nPyr) {      // the sorted list as the interrupted launch left it
+      keys.slot = b.pyr_order[i * 64 + lane];
+      const PlannerPyramid &P = pyr[keys.slot];
+      keys.depth = P.depth; keys.right = P.right; keys.top = P.top; keys.left = P.left; keys.bottom = P.bottom;
+    }
   } else if (lane == 0) {             // the "nothing found" answer; overwritten below
     out->tf = 0;
     for (int q = 0; q < 6; q++) for (int a = 0; a < 3; a++) out->coeffs[q][a] = 0;
@@ -1353,7 +1466,7 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
           candidate_poly(k, p);
           PL_T1(t_regen, 21);
           PL_T0(t_cf);
-          const bool cfree = collision_free(cfg, img, imgT, mask_lds, lane, p, cand_sections[base + l], pyr, nPyr, b.max_pyramids);
+          const bool cfree = collision_free<REGKEYS>(cfg, img, imgT, sums, mask_lds, lane, p, cand_sections[base + l], pyr, keys, nPyr, b.max_pyramids);
           PL_T1(t_cf, 6);
           if (cfree) {
             result |= 8;
@@ -1388,6 +1501,7 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
             b.bin_list[(int64_t)bin * b.n + at] = (int32_t)i;
           }
         }
+        if (REGKEYS && lane < nPyr) b.pyr_order[i * 64 + lane] = (uint8_t)keys.slot;
         if (lane == 0) {
           rs->done = 0;
           rs->base = l == 63 ? base + 64 : base;
@@ -1424,37 +1538,66 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
 #endif
 }
 
-// images [n][H][W] -> images_t [n][W][H] through 32x32 LDS tiles
-__global__ void __launch_bounds__(256) afe_transpose_images_kernel(const uint16_t *__restrict__ src,
-                                                                   uint16_t *__restrict__ dst, int W, int H) {
-  __shared__ uint16_t tile[32][33];
+// images [n][H][W] -> images_t [n][W][H] through 64 x 32 LDS tiles, and -- `sums` given (width % 64 == 0) -- the
+// per-word summaries of PlannerBatch::sums on the way: a tile row IS one 64-pixel word of the bit images.
+__global__ void __launch_bounds__(256) afe_prepare_images_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+                                                                 uint32_t *__restrict__ sums, int W, int H, unsigned ignore) {
+  __shared__ uint16_t tile[32][66];
   const int64_t off = (int64_t)blockIdx.z * W * H;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int x = blockIdx.x * 32 + tx;
-  for (int r = ty; r < 32; r += 8) {
-    const int y = blockIdx.y * 32 + r;
-    if (x < W && y < H) tile[r][tx] = src[off + (int64_t)y * W + x];
+  const int t = threadIdx.x;
+  {
+    const int tx = t & 63, x = blockIdx.x * 64 + tx;
+    for (int r = t >> 6; r < 32; r += 4) {
+      const int y = blockIdx.y * 32 + r;
+      tile[r][tx] = (x < W && y < H) ? src[off + (int64_t)y * W + x] : (uint16_t)0;
+    }
   }
   __syncthreads();
-  const int yo = blockIdx.y * 32 + tx;
-  for (int r = ty; r < 32; r += 8) {
-    const int xo = blockIdx.x * 32 + r;
-    if (xo < W && yo < H) dst[off + (int64_t)xo * H + yo] = tile[tx][r];
+  {
+    const int ty = t & 31, yo = blockIdx.y * 32 + ty;
+    for (int c = t >> 5; c < 64; c += 8) {
+      const int xo = blockIdx.x * 64 + c;
+      if (xo < W && yo < H) dst[off + (int64_t)xo * H + yo] = tile[ty][c];
+    }
+  }
+  if (sums) {
+    // row r of the tile, eight lanes with eight pixels each
+    const int r = t >> 3, seg = t & 7, y = blockIdx.y * 32 + r;
+    unsigned mn = 0xffffu, mx = 0u;
+    bool ign = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const unsigned d = tile[r][8 * seg + j];
+      if (d > ignore) mn = d < mn ? d : mn; else ign = true;
+      mx = d > mx ? d : mx;
+    }
+    unsigned packed = mn | ((ign ? 0xffffu : mx) << 16);
+#pragma unroll
+    for (int m = 1; m <= 4; m <<= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)packed, m);
+      const unsigned lo = (o & 0xffffu) < (packed & 0xffffu) ? (o & 0xffffu) : (packed & 0xffffu);
+      const unsigned hi = (o >> 16) > (packed >> 16) ? (o >> 16) : (packed >> 16);
+      packed = lo | (hi << 16);
+    }
+    if (seg == 0 && y < H) sums[((int64_t)blockIdx.z * H + y) * (W >> 6) + blockIdx.x] = packed;
   }
 }
 
 int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream) {
   if (b.n <= 0) return 0;
   // grid.z is limited to 65535: one launch per run of that many images (config 3 has one image per planner, 65536)
+  const unsigned ignore = (unsigned)(uint16_t)(cfg.true_vehicle_radius / cfg.depth_scale);     // as inflate_pyramid forms it
   for (int64_t i0 = 0; i0 < b.n_images; i0 += 65535) {
     const int64_t cnt = (b.n_images - i0) < 65535 ? (b.n_images - i0) : 65535;
     const int64_t off = i0 * cfg.width * cfg.height;
-    hipLaunchKernelGGL(afe_transpose_images_kernel, dim3((cfg.width + 31) / 32, (cfg.height + 31) / 32, (unsigned)cnt),
-                       dim3(256), 0, (hipStream_t)stream, b.images + off, b.images_t + off, cfg.width, cfg.height);
+    hipLaunchKernelGGL(afe_prepare_images_kernel, dim3((cfg.width + 63) / 64, (cfg.height + 31) / 32, (unsigned)cnt),
+                       dim3(256), 0, (hipStream_t)stream, b.images + off, b.images_t + off, b.sums ? b.sums + (off >> 6) : nullptr,
+                       cfg.width, cfg.height, ignore);
   }
-  const unsigned mask_bytes = (unsigned)(((cfg.width + 63) >> 6) * cfg.height) * (unsigned)sizeof(uint64_t);
+  // the bit image, and behind it the list of undecided words of build_mask_sum
+  const unsigned mask_bytes = (unsigned)(((cfg.width + 63) >> 6) * cfg.height) * (unsigned)sizeof(uint64_t) + (b.sums ? kSumList * (unsigned)sizeof(uint16_t) : 0u);
 #ifdef AFE_PLANNER_PROFILE
-  unsigned long long zero[24] = {0};
+  unsigned long long zero[40] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero));
 #endif
   const int64_t n_cand = b.n * b.n_candidates;
@@ -1470,6 +1613,7 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   //   * longest first (below): 210 -> 152 ms on the cluttered views, 50.6 -> 29 ms on the config-3 shape.
   PlannerBatch bb = b;
   bb.ordered = 0;
+  void (*search)(const PlannerConfig, const PlannerBatch) = (b.max_pyramids <= 64 && b.pyr_order) ? afe_rappids_search_kernel<true> : afe_rappids_search_kernel<false>;
   int64_t rounds_from = INT64_MAX;
   if (const char *env = afe_dev_env("AFE_PLANNER_ROUNDS_FROM")) rounds_from = std::strtoll(env, nullptr, 10);
   // Longest first: a short sizing round (every planner works for at most `sizing` microseconds; most finish), then ONE
@@ -1482,12 +1626,12 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   if (b.resume && b.bin_count && b.n > lpt_from && b.n <= rounds_from) {
     (void)hipMemsetAsync(b.bin_count, 0, PlannerBatch::kBins * sizeof(int32_t), (hipStream_t)stream);
     bb.round = 0; bb.budget_ticks = sizing_us * 100u;
-    hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
+    hipLaunchKernelGGL(search, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
     bb.round = 1; bb.budget_ticks = 0; bb.ordered = 1;
-    hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
+    hipLaunchKernelGGL(search, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
   } else if (!b.resume || b.n <= rounds_from) {
     bb.resume = nullptr; bb.budget_ticks = 0; bb.round = 0; bb.bin_count = nullptr;
-    hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
+    hipLaunchKernelGGL(search, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
   } else {
     bb.bin_count = nullptr;
     unsigned budgets_us[16] = {1000, 2000, 4000, 8000, 16000, 32000};
@@ -1503,16 +1647,18 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
     for (int r = 0; r <= n_rounds; r++) {
       bb.round = r;
       bb.budget_ticks = r < n_rounds ? budgets_us[r] * 100u : 0u;
-      hipLaunchKernelGGL(afe_rappids_search_kernel, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
+      hipLaunchKernelGGL(search, dim3((unsigned)b.n), dim3(64), mask_bytes, (hipStream_t)stream, cfg, bb);
     }
   }
 #ifdef AFE_PLANNER_PROFILE
-  unsigned long long prof[24];
+  unsigned long long prof[40];
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_prof), sizeof(prof));
   fprintf(stderr, "planner profile (cycles per planner): total %.0f | collision_free %.0f | inflate: mask1 %.0f expansion(all) %.0f "
           "sides+mask2 %.0f corners %.0f | completed pyramids/planner %.2f ringloop %.0f | longest planner %.0f | scan chunks/planner %.0f, holding a marked pixel %.0f\n", (double)prof[0] / b.n, (double)prof[6] / b.n,
           (double)prof[1] / b.n, (double)prof[2] / b.n, (double)prof[3] / b.n, (double)prof[4] / b.n, (double)prof[5] / b.n, (double)prof[7] / b.n, (double)prof[8], (double)prof[9] / b.n, (double)prof[10] / b.n);
+  fprintf(stderr, "  per planner (scoped, early exits included): inflate %.0f | seed check %.0f | max-depth sweep %.0f | mask2 + scans %.0f\n",
+          (double)prof[24] / b.n, (double)prof[25] / b.n, (double)prof[26] / b.n, (double)prof[27] / b.n);
   fprintf(stderr, "  per planner: inflate calls %.2f, refused at the seed rectangle %.2f, refused inside a scan %.2f\n", (double)prof[22] / b.n, (double)prof[23] / b.n, (double)prof[16] / b.n);
   fprintf(stderr, "  per planner: regenerate %.0f | sections(unused) %.0f | find pyramid %.0f | insert %.0f | section quartics %.0f (%.1f of them)\n",
           (double)prof[21] / b.n, (double)prof[16] / b.n, (double)prof[17] / b.n, (double)prof[18] / b.n, (double)prof[19] / b.n, (double)prof[20] / b.n);

@@ -62,7 +62,7 @@ struct ScratchSlot {
   size_t cap = 0;
 };
 std::mutex g_scratch_mutex;
-ScratchSlot g_scratch[18];
+ScratchSlot g_scratch[20];
 int g_scratch_device = -1;
 
 void release_scratch_locked() {
@@ -140,7 +140,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   if (g_scratch_device != device) { release_scratch_locked(); (void)hipSetDevice(device); g_scratch_device = device; }
   const size_t px = (size_t)cfg->width * cfg->height;
   DevBuf d_img(0), d_imgT(1), d_cc(2), d_cb(3), d_cs(4), d_idx(5), d_v(6), d_a(7), d_g(8), d_c(9), d_s(10), d_t(11), d_pyr(12), d_out(13),
-      d_flags(14), d_resume(15), d_bins(16);
+      d_flags(14), d_resume(15), d_bins(16), d_sums(17), d_order(18);
   if ((!depth_on_device && !d_img.upload(depth_images, (size_t)n_images * px * 2)) || !d_v.upload(vel0, (size_t)n * 24) ||
       !d_a.upload(acc0, (size_t)n * 24) || !d_g.upload(grav, (size_t)n * 24) ||
       !d_s.upload(samples, (size_t)n_tables * n_candidates * 32))
@@ -155,11 +155,17 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   if (flags && !d_flags.alloc((size_t)n * n_candidates)) return AFE_ERR_HIP;
   if (!d_resume.alloc((size_t)n * sizeof(PlannerBatch::Resume))) return AFE_ERR_HIP;
   if (!d_bins.alloc(((size_t)n * PlannerBatch::kBins + 64) * sizeof(int32_t))) return AFE_ERR_HIP;
+  // the per-word summaries need rows of whole 64-pixel words (and 512 B of LDS behind the bit image for their list)
+  const bool whole_words = (cfg->width & 63) == 0 && (px >> 6) * 8 + 512 <= 65536;
+  if (whole_words && !d_sums.alloc((size_t)n_images * (px >> 6) * sizeof(uint32_t))) return AFE_ERR_HIP;
+  if (cfg->max_pyramids <= 64 && !d_order.alloc((size_t)n * 64)) return AFE_ERR_HIP;
 
   PlannerBatch b;
   b.n = n;
   b.images = depth_on_device ? depth_images : (const uint16_t *)d_img.p;
   b.images_t = (uint16_t *)d_imgT.p;
+  b.sums = whole_words ? (uint32_t *)d_sums.p : nullptr;
+  b.pyr_order = cfg->max_pyramids <= 64 ? (uint8_t *)d_order.p : nullptr;
   b.cand_cost = (double *)d_cc.p;
   b.cand_bits = (uint8_t *)d_cb.p;
   b.cand_sections = (CandSections *)d_cs.p;

@@ -55,6 +55,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+def _load_provenance():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("afe_provenance", os.path.join(ROOT, "agri-fly_amd", "provenance.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+PROV = _load_provenance()      # which kernel sources a committed counter summary was taken on (round-5 review item 5)
+STALE = []                     # committed summaries this run refused to borrow from: their kernels have been edited since
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 DT_US = 1000
 LOGIC_PERIOD = 1.0 / 500.0
@@ -186,7 +197,9 @@ def bound_fields(n, bytes_per_vehicle_step, seconds_per_step, ns_profile=None):
     if where == "l2":
         waves_per_simd = ((n + 63) // 64) / float(SIMDS)
         out = {"bound": "valu_issue" if waves_per_simd >= 1.5 else "latency", "resident_in": "l2", "l2_GBs": rate, "l2_frac": rate / L2_PEAK_GBS}
-        if ns_profile and n == 131072:
+        if ns_profile and n == 131072 and ns_profile.get("counters_stale"):
+            out.update({"counters_stale": True})
+        elif ns_profile and n == 131072:
             out.update({"valu_busy_frac": ns_profile.get("simd_valu_busy_frac"), "valu_active_frac_per_wave": ns_profile.get("valu_active_frac"),
                         "valu_instructions_per_wave_step": ns_profile.get("valu_instructions_per_wave_step"), "counters_from": ns_profile.get("counters_from")})
         return out
@@ -201,12 +214,21 @@ def committed_ns_profile(exact_stream=None):
         try:
             d = json.load(open(f))
             if d.get("valu_active_frac_of_wave_cycles") and d.get("noise_policy", "counter") == want:
+                if not PROV.taken_on_this_tree(d, PROV.STEP_KERNEL):       # the newest summary is of another kernel: nothing older is better
+                    _stale(f)
+                    return {"counters_stale": True, "stale_summary": os.path.relpath(f, ROOT)}
                 return {"valu_active_frac": d["valu_active_frac_of_wave_cycles"], "wait_any_frac": d.get("wait_any_frac_of_wave_cycles"),
                         "simd_valu_busy_frac": d.get("simd_valu_busy_frac"),
                         "valu_instructions_per_wave_step": d.get("valu_instructions_per_wave_and_step"), "counters_from": os.path.relpath(f, ROOT)}
         except (OSError, ValueError):
             pass
     return None
+
+
+def _stale(path):
+    rel = os.path.relpath(path, ROOT)
+    if rel not in STALE:
+        STALE.append(rel)
 
 
 def scaling_check(exp, exp_src, world, n_local, value, n_strong, strong_value):
@@ -216,7 +238,7 @@ def scaling_check(exp, exp_src, world, n_local, value, n_strong, strong_value):
     if not exp or world < 2:
         return None
     sc = {"from": exp_src, "n_gpus": world}
-    w = (exp.get("weak_per_gpu") or {}).get(str(n_local))
+    w = (exp.get("weak_per_gpu") or {}).get(str(n_local)) or (exp.get("strong_shard") or {}).get(str(n_local))     # (one GPU on a shard of that size, same protocol)
     if w and value:
         sc["weak"] = {"vehicles_per_gpu": n_local, "expected_per_gpu": w["vsteps_per_s"], "measured_per_gpu": value / world, "ratio": value / world / w["vsteps_per_s"]}
     st = (exp.get("strong_shard") or {}).get(str(n_strong))
@@ -226,12 +248,18 @@ def scaling_check(exp, exp_src, world, n_local, value, n_strong, strong_value):
     return sc if ("weak" in sc or "strong" in sc) else None
 
 
-def committed_json(pattern, pick):
+def committed_json(pattern, pick, sources=None):
+    """the newest committed summary matching `pattern` that `pick` accepts; with `sources` (agri-fly_amd/provenance.py) only
+    if it was taken on the kernel sources of this tree -- otherwise (None, None) and the file is listed in STALE"""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
-            r = pick(json.load(open(f)))
+            d = json.load(open(f))
+            r = pick(d)
             if r is not None:
+                if sources is not None and not PROV.taken_on_this_tree(d, sources):
+                    _stale(f)
+                    return None, None
                 return r, os.path.relpath(f, ROOT)
         except (OSError, ValueError, KeyError, TypeError):
             pass
@@ -360,6 +388,9 @@ def committed_traffic(n_local, exact_stream):
         w = t["workload"]
         policy = w.get("noise_policy", "counter")
         if w["vehicles_per_gpu"] == n_local and w["dt_us"] == DT_US and w["fext"] and w["noise"] and policy == ("reference_streams" if exact_stream else "counter"):
+            if not PROV.taken_on_this_tree(t, PROV.STEP_KERNEL):
+                _stale(path)
+                return None, None, None
             return t.get("traffic_bytes_per_step", t["traffic_bytes_per_launch"]), t["source"], t.get("rocprof_kernel_us_per_step")
     except (OSError, KeyError, ValueError):
         pass
@@ -474,8 +505,8 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
     ray_flops = 9 * 2 + 6 + 4          # direction = R (u, v, 1), final floor(z / scale)
     fp64_flops = st["tri_fp64_tests_per_ray"] * mt_flops + rays * ray_flops
     node_bytes = st["nodes_per_wave"] * 64.0 + st["tri_box_tests_per_wave"] * 96.0   # scalar loads, served by L2
-    rpmc, rsrc = committed_json("r*_render_pmc.json", lambda d: d if d.get("valu_issue_fraction_of_busy_cycles") else None)
-    ppmc, psrc = committed_json("r*_planner_pmc.json", lambda d: d if d.get("valu_issue_fraction_of_busy_cycles") else None)
+    rpmc, rsrc = committed_json("r*_render_pmc.json", lambda d: d if d.get("valu_issue_fraction_of_busy_cycles") else None, PROV.RENDER_KERNEL)
+    ppmc, psrc = committed_json("r*_planner_pmc.json", lambda d: d if d.get("valu_issue_fraction_of_busy_cycles") else None, PROV.PLANNER_KERNEL)
     rpmc, ppmc = rpmc or {}, ppmc or {}
     render_roofline = {
         "bound": "vector-instruction issue (a vector instruction issues in most of the SIMDs' busy cycles: the committed SQ counters below), not HBM and not fp64 throughput",
@@ -516,6 +547,147 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
                     "bit-identical to the CPU checkers in tests/test_gpu_render.py / test_gpu_planner.py"}
 
 
+def _rot64(q):
+    """Rotation.hpp:196-220 for planar quaternions [4, n] -> [3, 3, n]"""
+    r0, r1, r2, r3 = q[0] * q[0], q[1] * q[1], q[2] * q[2], q[3] * q[3]
+    return np.array([[r0 + r1 - r2 - r3, 2 * q[1] * q[2] - 2 * q[0] * q[3], 2 * q[1] * q[3] + 2 * q[0] * q[2]],
+                     [2 * q[1] * q[2] + 2 * q[0] * q[3], r0 - r1 + r2 - r3, 2 * q[2] * q[3] - 2 * q[0] * q[1]],
+                     [2 * q[1] * q[3] - 2 * q[0] * q[2], 2 * q[2] * q[3] + 2 * q[0] * q[1], r0 - r1 - r2 + r3]])
+
+
+def _qmul64(a, b):
+    """Rotation.hpp:124-131 (this = a, r1 = b)"""
+    return np.stack([b[0] * a[0] - b[1] * a[1] - b[2] * a[2] - b[3] * a[3], b[1] * a[0] + b[0] * a[1] + b[3] * a[2] - b[2] * a[3],
+                     b[2] * a[0] - b[3] * a[1] + b[0] * a[2] + b[1] * a[3], b[3] * a[0] + b[2] * a[1] - b[1] * a[2] + b[0] * a[3]])
+
+
+def config3_row(afa, device=0, n=65536, frames=3, n_candidates=192, steps_per_frame=30):
+    """BASELINE config 3 AT ITS SIZE in the metric's unit: 65 536 vehicles with the RAPPIDS planner in the loop, the device
+    side of one camera frame as tests/test_gpu_configs_full.py::test_config3_65536_vehicles_planner_in_the_loop flies it
+    (tests/orchard_flight.py: the 6 x 10-tree orchard, vehicles west of it facing +x, 192 candidates, main.cpp's cost
+    function towards a goal east of the orchard, a plan every 3rd offboard tick = 30 steps of 1 ms):
+        30 steps of physics + IMU + on-device rates logic  ->  one depth image per vehicle from engine state (10 GB, stays
+        in HBM)  ->  one plan per vehicle on its own image.
+    The offboard tracking controller between two frames is host code outside SURVEY 8 (caller side) and is not timed: the
+    rate command stays the hover command, as in the first 40 ms of the test.  vsteps_per_s = n x 30 / (physics + render + plan)."""
+    sc = afa.scenarios
+    rows, cols, altitude = 6, 10, 1.2
+    tris = sc.orchard_mesh(rows=rows, cols=cols, seed=0)
+    scene = afa.Scene(tris, device=device)
+    cam = afa.camera_default(320, 240)
+    mount = afa.camera_default_mount()
+    params = afa.params_from_type(5)
+    rng = np.random.default_rng(0)
+    lane = rng.integers(0, rows - 1, n)
+    on_row = rng.random(n) < 0.5
+    y0 = np.where(on_row, lane * 4.0 + rng.uniform(-0.3, 0.3, n), lane * 4.0 + 2.0 + rng.uniform(-0.8, 0.8, n))
+    pos0 = np.stack([np.full(n, -4.0) + rng.uniform(-1, 0, n), y0, np.full(n, altitude)])
+    goal = np.stack([np.full(n, (cols - 1) * 3.0 + 8.0), y0, np.full(n, altitude)])
+    att0 = np.tile(np.array([[1.0], [0.0], [0.0], [0.0]]), (1, n))
+    e = afa.Ensemble(n, precision=afa.AFE_F32, device=device)
+    e.set_type_table([params])
+    e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+    e.set_rates_logic([afa.rates_logic_params_from_type(5)])
+    e.set_state(pos0, np.zeros((3, n)), att0, np.zeros((3, n)), np.full((4, n), sc.hover_speed(params)))
+    e.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
+    buf = afa.DeviceBuffer(n * 240 * 320 * 2, device=device)
+    cfg = afa.planner_default_config(320, 240, cam.depth_scale, cam.focal_length, 2 * params.arm_length, 3 * params.arm_length, 0.5)   # main.cpp:167-169
+    cfg.cost_type = 1
+    samples = afa.planner_samples(0, 320, 240, n_candidates)
+    rec = []
+    for f in range(frames + 1):                 # the first frame is warm-up (scratch allocation of the planner)
+        t0 = time.perf_counter()
+        e.step(1000, steps_per_frame)
+        e.sync()
+        ms_phys = (time.perf_counter() - t0) * 1e3
+        st = e.get_state()
+        pos, vel, att = st["pos"], st["vel"], st["att"]
+        R_att = _rot64(att)
+        R_cam = _rot64(_qmul64(att, np.tile(mount[:, None], (1, n))))
+        inv = lambda R, v: np.einsum("jin,jn->in", R, v)
+        e3 = np.zeros((3, n))
+        e3[2] = 1
+        vel_c = inv(R_cam, vel)
+        acc_c = inv(R_cam, np.einsum("ijn,jn->in", R_att, e3) * 9.81 - np.array([[0], [0], [9.81]]))
+        grav_c = inv(R_cam, np.tile(np.array([[0.0], [0.0], [-9.81]]), (1, n)))
+        goal_c = inv(R_cam, goal - pos)
+        ms_r = scene.render_engine(e, cam, mount, out=buf)
+        out, _, ms_p = afa.rappids_plan(cfg, buf, vel_c, acc_c, grav_c, samples, cost_vec=goal_c, device=device)
+        if f:
+            plans = afa.plans_as_array(out)
+            rec.append({"physics_ms": ms_phys, "render_ms": ms_r, "plan_ms": ms_p, "found": float(plans["found"].mean()),
+                        "pyramids_per_plan": float(plans["n_pyramids"].mean()), "collision_checks_per_plan": float(plans["n_collision_checks"].mean())})
+    buf.close()
+    e.close()
+    scene.close()
+    afa.planner_release_scratch()
+    m = {k: median([r[k] for r in rec]) for k in rec[0]}
+    frame_ms = m["physics_ms"] + m["render_ms"] + m["plan_ms"]
+    return {"vehicles": n, "frames_timed": frames, "steps_per_frame": steps_per_frame, "candidates": n_candidates, "triangles": int(len(tris)),
+            "frame_ms": frame_ms, "physics_ms": m["physics_ms"], "render_ms": m["render_ms"], "plan_ms": m["plan_ms"],
+            "vsteps_per_s": n * steps_per_frame / (frame_ms * 1e-3), "rays_per_s": n * 76800 / (m["render_ms"] * 1e-3), "plans_per_s": n / (m["plan_ms"] * 1e-3),
+            "fraction_found": m["found"], "pyramids_per_plan": m["pyramids_per_plan"], "collision_checks_per_plan": m["collision_checks_per_plan"],
+            "bound": "perception: depth camera (vector issue) + planner search; the physics is %.1f %% of the frame" % (100 * m["physics_ms"] / frame_ms)}
+
+
+def config5_row(afa, device=0, n=262144, frames=2, shard=32768, steps_per_frame=33):
+    """BASELINE config 5 AT ITS SIZE in the metric's unit: 262 144 vehicles + depth raycast against the orchard triangle mesh
+    (32 x 32 trees), the device side of one camera frame as tests/test_gpu_configs_full.py::test_config5_... runs it: 33 steps
+    of physics + IMU + rates logic (one 30 Hz camera period), then every vehicle's 320 x 240 depth image from engine state,
+    in eight chunks of 32 768 views (one GPU's share of the 8-GPU split: a 5 GB image buffer)."""
+    sc = afa.scenarios
+    tris = sc.orchard_mesh(rows=32, cols=32, seed=1)
+    scene = afa.Scene(tris, device=device)
+    info = scene.info()
+    cam = afa.camera_default(320, 240)
+    mount = afa.camera_default_mount()
+    rng = np.random.default_rng(5)
+    lo, hi = info["bounds"][:3], info["bounds"][3:]
+    pos = np.stack([rng.uniform(lo[0] + 2, hi[0] - 2, n), rng.uniform(lo[1] + 2, hi[1] - 2, n), rng.uniform(0.5, 3.0, n)])
+    att = sc.random_attitudes(rng, n, max_tilt_deg=20.0)
+    params = afa.params_from_type(5)
+    e = afa.Ensemble(n, precision=afa.AFE_F32, device=device)
+    e.set_type_table([params])
+    e.set_imu_noise(True, 0.1, 0.2, afa.AFE_SEED_DECORRELATED)
+    e.set_rates_logic([afa.rates_logic_params_from_type(5)])
+    e.set_state(pos, rng.normal(0, 0.5, (3, n)), att, np.zeros((3, n)), np.full((4, n), sc.hover_speed(params)))
+    e.set_rates_commands(np.full(n, 9.81, np.float32), np.zeros((3, n), np.float32))
+    buf = afa.DeviceBuffer(shard * 240 * 320 * 2, device=device)
+    rec = []
+    for f in range(frames + 1):
+        t0 = time.perf_counter()
+        e.step(1000, steps_per_frame)
+        e.sync()
+        ms_phys = (time.perf_counter() - t0) * 1e3
+        ms_r = sum(scene.render_engine(e, cam, mount, first=c * shard, count=shard, out=buf) for c in range(n // shard))
+        if f:
+            rec.append({"physics_ms": ms_phys, "render_ms": ms_r})
+    # traversal counters of a sample of this frame's views (counting build of the kernel)
+    st = e.get_state()
+    k = 256
+    pick = np.sort(rng.choice(n, k, replace=False))
+    stats, _ = scene.render_stats(cam, st["pos"][:, pick], st["att"][:, pick], mount)
+    buf.close()
+    e.close()
+    scene.close()
+    m = {q: median([r[q] for r in rec]) for q in rec[0]}
+    frame_ms = m["physics_ms"] + m["render_ms"]
+    return {"vehicles": n, "frames_timed": frames, "steps_per_frame": steps_per_frame, "triangles": int(info["n_tri"]), "bvh_nodes": int(info["n_nodes"]),
+            "views_per_chunk": shard, "frame_ms": frame_ms, "physics_ms": m["physics_ms"], "render_ms": m["render_ms"],
+            "vsteps_per_s": n * steps_per_frame / (frame_ms * 1e-3), "rays_per_s": n * 76800 / (m["render_ms"] * 1e-3),
+            "per_ray": render_per_ray(stats),
+            "bound": "depth camera (vector issue); the physics is %.1f %% of the frame" % (100 * m["physics_ms"] / frame_ms)}
+
+
+def render_per_ray(st):
+    """what one ray of the depth camera costs in tree work (the counting build's totals over a batch): nodes its wave visits
+    (one node per wave step, shared by the 64 rays of the tile), triangle-box tests and double-precision triangle tests"""
+    rays, waves = float(st["rays"]), float(st["waves"])
+    return {"nodes_visited_per_wave": st["nodes_per_wave"] / waves, "nodes_visited_per_ray": st["nodes_per_wave"] / rays,
+            "triangle_box_tests_per_ray": st["tri_box_tests_per_ray"] / rays, "fp64_triangle_tests_per_ray": st["tri_fp64_tests_per_ray"] / rays,
+            "triangle_box_tests_per_wave": st["tri_box_tests_per_wave"] / waves, "fp64_triangle_tests_per_wave": st["tri_fp64_tests_per_wave"] / waves}
+
+
 def host_cores():
     """(threads this process may run on, cgroup CPU quota in cores or None, CPU model): os.cpu_count() is the HOST's count --
     a container is often given a slice of it (round 4: 256 reported, 8 usable)"""
@@ -547,7 +719,7 @@ def host_cores():
     return affinity, quota, model
 
 
-def cpu_baseline(afa, budget_vehicle_steps=20_000_000):
+def cpu_baseline(afa, budget_vehicle_steps=20_000_000, all_cores=True):
     """the oracle (double, scalar C) on a bounded sample of the same workload; test infrastructure used here only as the
     reported baseline.  Three legs, ~10 s together: one thread under the headline's noise policy (cpu_baseline.value: the same
     workload as `value`), one thread under the other policy, and every core this process may use (OpenMP over vehicles, >= 64 vehicles per thread, vehicles outer /
@@ -592,7 +764,7 @@ def cpu_baseline(afa, budget_vehicle_steps=20_000_000):
                                  "sample": "%d vehicles x %d steps, %s, 1 thread, %.1f s" % (n, steps_x, names[not head_counter], dtx)}
     # the same port on every core this process may use, SURVEY 8d CPU-baseline (ii)
     threads = max(1, min(affinity, int(np.ceil(quota)) if quota else affinity))
-    if threads > 1:
+    if threads > 1 and all_cores:
         n_mt = max(n, 64 * threads)
         bm = batch(n_mt)
         oracle_py.lib().ora_set_batch_threads(threads)
@@ -881,14 +1053,14 @@ def compact_line(full):
         line["cpu_baseline"] = c
     st = full.get("config4_as_stated")
     if st:
-        c4 = _pick(st, ("scaling", "vehicles_total", "vehicles_per_gpu", "n_gpus", "value", "unit", "ms_per_step", "stepping", "bound", "resident_in", "frac", "l2_GBs", "l2_frac", "valu_busy_frac"))
+        c4 = _pick(st, ("scaling", "vehicles_total", "vehicles_per_gpu", "n_gpus", "value", "unit", "ms_per_step", "stepping", "bound", "resident_in", "frac", "l2_GBs", "l2_frac", "valu_busy_frac", "counters_stale"))
         if st.get("steady_state"):
             c4["steady_state"] = _pick(st["steady_state"], ("steps", "ms_per_step", "value"))
         line["config4_as_stated"] = c4
     ns = full.get("north_star_shard")
     if ns:
         line["north_star_shard"] = _pick(ns, ("vehicles_per_gpu", "us_per_step", "us_per_step_k_blocks", "vsteps_per_s_per_gpu", "bound", "resident_in", "l2_GBs", "l2_frac",
-                                              "valu_busy_frac", "valu_active_frac_per_wave", "valu_instructions_per_wave_step", "counters_from", "launch_mode_us_per_step"))
+                                              "valu_busy_frac", "valu_active_frac_per_wave", "valu_instructions_per_wave_step", "counters_from", "counters_stale", "launch_mode_us_per_step"))
     rn = full.get("counter_noise_policy")
     if rn:
         line["counter_noise_policy"] = _pick(rn, ("value", "unit", "ms_per_step", "algorithmic_bytes_per_vehicle_step", "kernel_us", "achieved_GBs", "ratio_to_stream_probe", "resident_in", "stepping", "seed_policy"))
@@ -904,15 +1076,27 @@ def compact_line(full):
     pr = full.get("perception_rows")
     if pr and "depth_camera" in pr:
         dc, rp = pr["depth_camera"], pr["rappids_planner"]
-        line["perception"] = {"depth_camera": {"views": dc["views"], "ms": dc["kernel_ms"], "rays_per_s": dc["rays_per_s"], "bound": "valu issue",
-                                               "valu_issue_frac": dc["roofline"].get("valu_issue_fraction_of_busy_cycles"),
-                                               "valu_instructions_per_ray": dc["roofline"].get("valu_instructions_per_ray"),
-                                               "counters_from": dc["roofline"].get("counters_from")},
-                              "planner": {"planners": rp["config3_size"]["planners"], "ms": rp["config3_size"]["kernel_ms"], "plans_per_s": rp["config3_size"]["plans_per_s"],
-                                          "bound": "latency (one wave per sequential search)", "valu_issue_frac": rp["roofline"].get("valu_issue_fraction_of_busy_cycles"),
-                                          "valu_instructions_per_plan": rp["roofline"].get("valu_instructions_per_plan"),
-                                          "counters_from": rp["roofline"].get("counters_from")},
-                              "frame_ms_4096_vehicles": pr["closed_perception_loop_frame"]["frame_ms"]}
+        dcr, rpr = dc["roofline"], rp["roofline"]
+        cam = {"views": dc["views"], "ms": dc["kernel_ms"], "rays_per_s": dc["rays_per_s"], "bound": "valu issue",
+               "valu_issue_frac": dcr.get("valu_issue_fraction_of_busy_cycles"), "valu_per_ray": dcr.get("valu_instructions_per_ray"),
+               "floor_valu_per_ray": dcr.get("floor_valu_per_ray"), "nodes_per_wave": (dcr.get("per_wave_of_64_rays") or {}).get("nodes_visited"),
+               "tri_box_per_wave": (dcr.get("per_wave_of_64_rays") or {}).get("triangle_box_tests"),
+               "tri_fp64_per_wave": (dcr.get("per_wave_of_64_rays") or {}).get("fp64_triangle_tests_executed"),
+               "counters_from": dcr.get("counters_from")}
+        pln = {"planners": rp["config3_size"]["planners"], "ms": rp["config3_size"]["kernel_ms"], "plans_per_s": rp["config3_size"]["plans_per_s"],
+               "bound": "latency", "valu_issue_frac": rpr.get("valu_issue_fraction_of_busy_cycles"),
+               "valu_per_plan": rpr.get("valu_instructions_per_plan"), "counters_from": rpr.get("counters_from")}
+        for row in (cam, pln):
+            if row["counters_from"] is None:
+                row["counters_stale"] = True
+        line["perception"] = {"depth_camera": cam, "planner": pln}
+    for key in ("config3", "config5"):           # BASELINE configs 3 and 5 at their size, in the metric's unit
+        row = full.get(key)
+        if row:
+            line[key] = _pick(row, ("vehicles", "frame_ms", "physics_ms", "render_ms", "plan_ms", "vsteps_per_s", "rays_per_s", "plans_per_s", "bound_short",
+                                    "valu_issue_frac", "valu_per_ray", "valu_per_plan", "counters_stale", "error"))
+    if full.get("counters_stale"):
+        line["counters_stale"] = [str(x)[:48] for x in full["counters_stale"]][:6]
     sw = full.get("shared_world")
     if sw:
         if "error" in sw:
@@ -926,8 +1110,8 @@ def compact_line(full):
         line["config1_host_in_loop"] = _pick(c1, ("us_per_step", "realtime_factor", "error"))
     line["detail"] = full.get("detail", DETAIL_FILE)
     line = _r(line)
-    for victim in ("config1_host_in_loop", "perception", "closed_loop_on_device", "shared_world", "companions", "counter_noise_policy",
-                   "north_star_shard", "config4_as_stated"):
+    for victim in ("config1_host_in_loop", "closed_loop_on_device", "shared_world", "companions", "counter_noise_policy",
+                   "north_star_shard", "config4_as_stated", "perception", "config5", "config3"):
         if len(json.dumps(line)) <= LINE_LIMIT:
             break
         line.pop(victim, None)
@@ -972,11 +1156,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-shared-world", action="store_true")
+    ap.add_argument("--no-perception", action="store_true", help="skip the config-3 / config-5 rows")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed cadence (for rocprofv3 passes: no comparisons, no per-kernel breakdown, no sweep)")
     ap.add_argument("--step-mode", choices=("auto", "launch", "persistent"), default="auto")
     ap.add_argument("--noise", choices=("reference", "counter"), default=None,
                     help="the headline's IMU noise: the reference's per-vehicle libstdc++ streams (default) or the counter-based generator")
+    ap.add_argument("--perception-only", action="store_true",
+                    help="development: only the config-3 / config-5 rows (and the perception component rows) as one JSON object")
     ap.add_argument("--watchdog", type=int, default=240, help="seconds the shared-world part may take before the line is printed without it")
     args = ap.parse_args()
 
@@ -1038,6 +1225,10 @@ def main():
         return float(t.item())
 
     afa = importlib.import_module("agri-fly_amd")
+    if args.perception_only:
+        rows = {"config3": config3_row(afa, local_rank), "config5": config5_row(afa, local_rank)}
+        print(json.dumps(_r(rows)))
+        return
     n_local = args.vehicles
     mode = {"auto": headline_mode(afa, n_local), "launch": afa.AFE_STEP_LAUNCH, "persistent": afa.AFE_STEP_PERSISTENT}[args.step_mode]
     n_global = n_local * world
@@ -1286,7 +1477,7 @@ def main():
                 eh.sync()
                 ush = afa.stream_probe(nh, 24, 17, 20, local_rank)
                 eh.close()
-                pmc, pmc_src = committed_json("r*_bc23_summary.json", lambda d: d["per_step"]["pmc_over_algorithmic"])
+                pmc, pmc_src = committed_json("r*_bc23_summary.json", lambda d: d["per_step"]["pmc_over_algorithmic"], PROV.STEP_KERNEL)
                 out["roofline"]["hbm_streaming"] = {
                     "vehicles": nh, "us_per_step": rowh["us_per_step"], "vsteps_per_s": rowh["vsteps_per_s"], "achieved": rowh["algorithmic_GBs"], "unit": "GB/s",
                     "frac": rowh["algorithmic_GBs"] / HBM_PEAK_GBS, "probe_GBs": nh * 164 / ush / 1e3, "ratio_to_stream_probe": rowh["algorithmic_GBs"] / (nh * 164 / ush / 1e3),
@@ -1396,8 +1587,31 @@ def main():
             out["companions"] = companion_rows(afa, n_local, local_rank, sync, barrier, split)
             out["perception_rows"] = perception_rows(afa)
             out["config1_host_in_loop"] = config1_row()
-        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
-            out["cpu_baseline"] = cpu_baseline(afa)
+        if world == 1 and not args.no_perception and not args.headline_only:
+            # BASELINE configs 3 and 5 at their size, in the metric's unit: for these two the perception kernels ARE the hot path
+            # (round-5 review item 1).  The SQ-counter figures ride along only while the committed summaries are of this tree's kernels.
+            pr = out.get("perception_rows") or {}
+            rr = (pr.get("depth_camera") or {}).get("roofline") or {}
+            pl = (pr.get("rappids_planner") or {}).get("roofline") or {}
+            for key, fn in (("config3", config3_row), ("config5", config5_row)):
+                try:
+                    row = fn(afa, local_rank)
+                    row["valu_issue_frac"] = rr.get("valu_issue_fraction_of_busy_cycles")      # the camera bounds both frames
+                    row["valu_per_ray"] = rr.get("valu_instructions_per_ray")
+                    if key == "config3":
+                        row["valu_per_plan"] = pl.get("valu_instructions_per_plan")
+                    if rr.get("counters_from") is None or (key == "config3" and pl.get("counters_from") is None):
+                        row["counters_stale"] = True
+                    row["bound_short"] = "depth camera: valu issue" if key == "config5" else "depth camera: valu issue; planner: latency"
+                except Exception as ex:            # (a box short of memory must not cost the line)
+                    row = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                out[key] = row
+        if not args.no_cpu_baseline and not args.headline_only:
+            # (N > 1: rank 0 alone, after its timed region -- the other ranks go on to the shared-world part and meet rank 0
+            # there; a shorter sample and no all-cores leg, the cores are busy with the other ranks' processes)
+            out["cpu_baseline"] = cpu_baseline(afa) if world == 1 else cpu_baseline(afa, budget_vehicle_steps=6_000_000, all_cores=False)
+        if STALE:
+            out["counters_stale"] = list(STALE)
     # The headline is measured.  What follows (the shared-world exchange: a second communicator, collectives at
     # query cadence) must never cost the line already in hand: if it has not finished within the watchdog's
     # time -- a rank stuck in a collective, whatever the cause -- rank 0 prints the line with the failure

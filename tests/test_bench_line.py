@@ -158,3 +158,62 @@ def test_scaling_check_puts_a_multi_gpu_run_beside_the_one_gpu_shard_rates():
     assert bench.scaling_check(None, None, 8, 1 << 20, one, 131072, shard) is None       # no committed rates
     line = bench.compact_line(dict(full_record(), scaling_check=sc))
     assert line["scaling_check"]["strong"]["ratio"] == 0.5
+
+
+def _fake_profiles(tmp_path, monkeypatch, sources):
+    """a profiles/ directory holding one planner and one north-star summary that claim the given kernel-source hashes"""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    json.dump({"valu_issue_fraction_of_busy_cycles": 0.5, "per_plan": {"valu_instructions": 4.0e5}, "kernel_sources": sources},
+              open(prof / "r99_planner_pmc.json", "w"))
+    json.dump({"valu_active_frac_of_wave_cycles": 0.38, "simd_valu_busy_frac": 0.76, "valu_instructions_per_wave_and_step": 556.0,
+               "noise_policy": "reference_streams", "kernel_sources": sources}, open(prof / "r99_ns_summary.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "STALE", [])
+
+
+def test_borrowed_counters_ride_along_only_while_the_kernel_sources_match(tmp_path, monkeypatch):
+    """round-5 review item 5: every committed summary records sha256 of the kernel sources it was taken on; bench.py borrows
+    from it only while they are the tree's, and says counters_stale otherwise"""
+    now = bench.PROV.kernel_source_hashes()
+    assert all(now.values()) and set(now) >= set(bench.PROV.STEP_KERNEL + bench.PROV.PLANNER_KERNEL + bench.PROV.RENDER_KERNEL)
+    _fake_profiles(tmp_path, monkeypatch, now)
+    pick = lambda d: d if d.get("valu_issue_fraction_of_busy_cycles") else None
+    rec, src = bench.committed_json("r*_planner_pmc.json", pick, bench.PROV.PLANNER_KERNEL)
+    assert rec["per_plan"]["valu_instructions"] == 4.0e5 and src == os.path.join("profiles", "r99_planner_pmc.json")
+    ns = bench.committed_ns_profile(True)
+    assert ns["simd_valu_busy_frac"] == 0.76 and ns["counters_from"].endswith("r99_ns_summary.json") and not bench.STALE
+    row = bench.bound_fields(131072, 148.0, 2.5e-6, ns)
+    assert row["valu_busy_frac"] == 0.76 and "counters_stale" not in row
+
+
+def test_an_edited_kernel_drops_the_borrowed_counters(tmp_path, monkeypatch):
+    now = bench.PROV.kernel_source_hashes()
+    edited = dict(now, **{"afe_planner.hip": "0" * 16, "afe_kernels.hip": "f" * 16})
+    _fake_profiles(tmp_path, monkeypatch, edited)
+    pick = lambda d: d if d.get("valu_issue_fraction_of_busy_cycles") else None
+    assert bench.committed_json("r*_planner_pmc.json", pick, bench.PROV.PLANNER_KERNEL) == (None, None)
+    ns = bench.committed_ns_profile(True)
+    assert ns.get("counters_stale") and "simd_valu_busy_frac" not in ns
+    assert sorted(bench.STALE) == [os.path.join("profiles", "r99_ns_summary.json"), os.path.join("profiles", "r99_planner_pmc.json")]
+    row = bench.bound_fields(131072, 148.0, 2.5e-6, ns)
+    assert row["counters_stale"] is True and "valu_busy_frac" not in row and "counters_from" not in row
+    # a summary without hashes (rounds 1-5) is stale by definition; without the `sources` argument nothing is checked
+    json.dump({"valu_issue_fraction_of_busy_cycles": 0.5}, open(tmp_path / "profiles" / "r98_render_pmc.json", "w"))
+    assert bench.committed_json("r*_render_pmc.json", pick, bench.PROV.RENDER_KERNEL) == (None, None)
+    assert bench.committed_json("r*_render_pmc.json", pick)[0] is not None
+    # and the printed line says so instead of printing last round's fractions
+    full = full_record()
+    full["counters_stale"] = list(bench.STALE)
+    full["north_star_shard"] = dict({k: v for k, v in full["north_star_shard"].items() if not k.startswith("valu_") and k != "counters_from"}, counters_stale=True)
+    full["config3"] = {"vehicles": 65536, "frame_ms": 98.9, "physics_ms": 0.13, "render_ms": 77.8, "plan_ms": 21.0, "vsteps_per_s": 1.99e7,
+                       "rays_per_s": 6.5e10, "plans_per_s": 3.1e6, "bound_short": "depth camera: valu issue; planner: latency", "counters_stale": True}
+    full["config5"] = {"vehicles": 262144, "frame_ms": 402.0, "physics_ms": 0.2, "render_ms": 401.7, "vsteps_per_s": 2.15e7, "rays_per_s": 5.0e10,
+                       "bound_short": "depth camera: valu issue", "counters_stale": True}
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    assert line["counters_stale"] and line["north_star_shard"]["counters_stale"] is True and "valu_busy_frac" not in line["north_star_shard"]
+    for key, n in (("config3", 65536), ("config5", 262144)):
+        assert line[key]["vehicles"] == n and line[key]["vsteps_per_s"] > 1e7 and line[key]["counters_stale"] is True
+        assert "valu_issue_frac" not in line[key]
+    assert line["config3"]["plan_ms"] == 21.0 and "plan_ms" not in line["config5"]

@@ -47,7 +47,14 @@ def test_bench_with_two_ranks_on_one_gpu_prints_one_consistent_line(tmp_path):
     assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["vehicles_per_gpu"] == 524288 and s["vehicles_total"] == 1048576
     assert s["value"] == pytest.approx(1048576 / (s["ms_per_step"] * 1e-3), rel=1e-4)
     assert d["counter_noise_policy"]["value"] > 0          # (the headline runs on the reference's streams; the other policy beside it)
-    assert "cpu_baseline" not in d                     # rank 0 at N = 1 only
+    # the N > 1 line is complete (round-5 review item 4): roofline, cpu_baseline (rank 0, a bounded one-thread sample) and scaling_check
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] == "port" and cb["unit"] == "vehicle-steps/s" and cb["sample"]
+    sc = d["scaling_check"]
+    assert sc["n_gpus"] == 2 and sc["weak"]["vehicles_per_gpu"] == 131072 and sc["strong"]["vehicles_per_gpu"] == 524288
+    assert sc["weak"]["measured_per_gpu"] == pytest.approx(d["value"] / 2, rel=1e-4)
     detail = json.load(open(os.path.join(ROOT, d["detail"])))
     assert detail["ms_per_step_rank0_own"] <= detail["ms_per_step_max"] * (1 + 1e-9)
     assert detail["config"]["vehicles_total"] == 262144

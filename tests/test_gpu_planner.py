@@ -59,6 +59,34 @@ def test_planner_matches_oracle_varied_states_and_images(ora):
     assert max(r[0].n_pyramids for r in refs) >= 3
 
 
+def test_pyramid_list_in_lanes_and_in_memory_plan_the_same():
+    """Up to 64 pyramids per plan the wave keeps the sorted pyramid list in its lanes (PyrKeys, afe_planner.hip); a larger
+    limit takes the list in HBM.  No plan here comes near either limit, so both must give the same bytes -- on cluttered
+    orchard views, where plans hold a dozen pyramids and insert in the middle of the list."""
+    rng = np.random.default_rng(23)
+    n, m, n_img = 600, 256, 12
+    scene = afa.Scene(afa.scenarios.orchard_mesh(rows=8, cols=8, seed=5))
+    cam = afa.camera_default(320, 240)
+    pos = np.stack([rng.uniform(-3, 25, n_img), rng.uniform(-3, 30, n_img), rng.uniform(0.8, 2.5, n_img)])
+    yaw = rng.uniform(-np.pi, np.pi, n_img)
+    att = np.stack([np.cos(yaw / 2), 0 * yaw, 0 * yaw, np.sin(yaw / 2)])
+    images, _ = scene.render(cam, pos, att, afa.camera_default_mount())
+    images = np.asarray(images).reshape(n_img, 240, 320)
+    idx = rng.integers(0, n_img, n).astype(np.int32)
+    vel0 = np.stack([rng.normal(0, 0.4, n), rng.normal(0, 0.2, n), rng.uniform(0, 2.0, n)])
+    acc0 = rng.normal(0, 0.3, (3, n))
+    grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n))
+    samples = afa.planner_samples(0, 320, 240, m)
+    res = []
+    for limit in (64, 100):
+        cfg = afa.planner_default_config(320, 240, 10.0 / 256.0, 160.0, 0.116, 0.174, 0.5)
+        cfg.max_pyramids = limit
+        out, flags, _ = afa.rappids_plan(cfg, images, vel0, acc0, grav, samples, image_index=idx, want_flags=True)
+        res.append((np.frombuffer(bytes(out), np.uint8).copy(), flags.copy(), max(o.n_pyramids for o in out)))
+    assert 8 <= res[0][2] < 64
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 def test_a_big_batch_starts_its_longest_planners_first_and_plans_the_same():
     """The release library's own use of the interruptible search: from 16 385 planners up a batch runs a 0.4 ms sizing
     round and then ONE finishing round that starts the interrupted planners longest first (launch_rappids).  20 000

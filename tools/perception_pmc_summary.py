@@ -4,6 +4,9 @@ profiles/<tag>_planner_pmc.json, profiles/<tag>_render_pmc.json: what bounds eac
 busy cycles in which a vector instruction issues), instructions per plan / per ray, and the rates.
     python tools/perception_pmc_summary.py <tag>
 bench.py reads the two files for the `perception` rows' bound and fraction (counters cannot be read inside the run)."""
+import sys as _sys, os as _os
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _provenance import STEP_KERNEL, PLANNER_KERNEL, RENDER_KERNEL, kernel_source_hashes
 import collections
 import csv
 import glob
@@ -72,6 +75,7 @@ if c:
                     "compute unit's busy cycles and in %.0f %% of a wave's resident cycles (it waits in %.0f %% of them)"
                     % (rec["per_plan"]["valu_instructions"], 100 * rec["valu_issue_fraction_of_busy_cycles"], 100 * rec["valu_active_frac_of_wave_cycles"],
                        100 * (rec["wait_any_frac_of_wave_cycles"] or 0)))
+    rec["kernel_sources"] = kernel_source_hashes(PLANNER_KERNEL)
     json.dump(rec, open(os.path.join(prof, "%s_planner_pmc.json" % tag), "w"), indent=1)
     print(json.dumps(rec, indent=1)[:2500])
 
@@ -94,5 +98,6 @@ if c:
     rec.update(fractions(c))
     rec["bound"] = ("vector-instruction issue: a vector instruction is executing in %.0f %% of a compute unit's busy cycles (%.0f per wave of 64 rays, %.1f per ray)"
                     % (100 * rec["valu_issue_fraction_of_busy_cycles"], rec["per_wave_of_64_rays"]["valu_instructions"], rec["per_ray"]["valu_instructions"]))
+    rec["kernel_sources"] = kernel_source_hashes(RENDER_KERNEL)
     json.dump(rec, open(os.path.join(prof, "%s_render_pmc.json" % tag), "w"), indent=1)
     print(json.dumps(rec, indent=1)[:2500])

@@ -8,6 +8,9 @@
                                 (separate passes; FETCH_SIZE x 2 per the gfx950 note of MI355X_MICROARCH.md, KiB units),
                                 SQ counters per wave and step
   profiles/traffic.json         PMC HBM bytes per step of the bench workload (read by bench.py) -- only for 2^20 vehicles"""
+import sys as _sys, os as _os
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _provenance import STEP_KERNEL, PLANNER_KERNEL, RENDER_KERNEL, kernel_source_hashes
 import collections
 import csv
 import glob
@@ -94,6 +97,7 @@ if fetch.get("FETCH_SIZE") and write.get("WRITE_SIZE"):
                           "algorithmic_bytes_per_step": N * BYTES_MEAN, "ratio": per_step / (N * BYTES_MEAN)}
     if N == 1 << 20 and (len(sys.argv) <= 7 or sys.argv[7] != "no-traffic-json"):
         json.dump({"workload": {"vehicles_per_gpu": N, "fext": True, "noise": True, "noise_policy": POLICY, "dt_us": 1000, "logic_period_s": 0.002},
+                   "kernel_sources": kernel_source_hashes(STEP_KERNEL),
                    "traffic_bytes_per_step": per_step,
                    "traffic_bytes_per_launch": per_step,
                    "rocprof_kernel_us_per_step": {"blocks_of_20_steps": summary.get("blocks_of_20_steps", {}).get("us_per_step"),
@@ -114,5 +118,6 @@ summary["working_set_bytes"] = foot
 summary["resident_in"] = "l2" if foot <= (32 << 20) else ("infinity_cache" if foot <= 0.94 * (256 << 20) else "hbm")
 summary["note_frac"] = ("frac_of_8TBs is algorithmic bytes / kernel time against the HBM peak; with the working set resident in the Infinity Cache the bytes are served "
                         "on-die and the figure can exceed 1 -- the HBM row is profiles/r05_bc23_summary.json (2^23 vehicles)")
+summary["kernel_sources"] = kernel_source_hashes(STEP_KERNEL)       # bench.py borrows from this file only while these match the tree
 json.dump(summary, open(os.path.join(prof, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:4000])

@@ -11,6 +11,9 @@
   profiles/traffic.json                  PMC bytes per step + rocprof us per step of the bench workload (read by bench.py) -- 2^20 only
 A resident grid now survives afe_sync: one dispatch serves every block of steps until something parks it (an entry point
 that needs the stream, or 200 us without a new step), so a trace row's duration is meaningful only per step served."""
+import sys as _sys, os as _os
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _provenance import STEP_KERNEL, PLANNER_KERNEL, RENDER_KERNEL, kernel_source_hashes
 import collections
 import csv
 import glob
@@ -167,5 +170,6 @@ if sq.get("SQ_WAVES") and len(sq["SQ_WAVES"]) == len(g):
     summary["worker_waves_per_simd"] = workers_per_simd
     summary["simd_valu_busy_frac"] = summary["valu_active_frac_of_wave_cycles"] * workers_per_simd
     summary["note_sq"] = "a wave of the resident grid steps ceil(chunks / waves) chunks of 64 vehicles per step; the pump wave is one of SQ_WAVES; idle polling between blocks is inside"
+summary["kernel_sources"] = kernel_source_hashes(STEP_KERNEL)       # bench.py borrows from this file only while these match the tree
 json.dump(summary, open(os.path.join(prof, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:5000])

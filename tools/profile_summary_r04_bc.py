@@ -5,6 +5,9 @@ cache-policy hints by size).  Per step kernel: launches, average duration, FETCH
 gfx950 note of MI355X_MICROARCH.md) per launch and per vehicle; per step (an off-tick and an on-tick launch pair alternate,
 both halves concurrently): wall microseconds from the trace, algorithmic TB/s, fraction of 8 TB/s and of the guide's 6.29.
     python tools/profile_summary_r04_bc.py <tag> "<note>" [vehicles]"""
+import sys as _sys, os as _os
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _provenance import STEP_KERNEL, PLANNER_KERNEL, RENDER_KERNEL, kernel_source_hashes
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -70,5 +73,6 @@ if "per_step" in summary:
     ps["pmc_over_algorithmic"] = ps["pmc_bytes_per_vehicle_step"] / ps["algorithmic_bytes_per_vehicle_step"]
     ps["what"] = ("beyond the 256 MiB Infinity Cache nothing survives from one step to the next, so the fabric-side counters ARE HBM traffic here "
                   "(state 52 B x %d vehicles = %.0f MB)" % (N, 52.0 * N / 1e6))
+summary["kernel_sources"] = kernel_source_hashes(STEP_KERNEL)       # bench.py borrows from this file only while these match the tree
 json.dump(summary, open(os.path.join(prof, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3500])
