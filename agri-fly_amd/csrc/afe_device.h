@@ -30,6 +30,10 @@ struct alignas(16) DevParams {
   R wmax;
   R drag[3];   // _linDragCoeffB
   float Rimu[9];  // _R_inverse (float in the reference too)
+  // kf / mass in the host's double, for the fp32 kernel: the vertical chain  sum k_f w|w| -> / m -> - 9.81  is two 9.81 m/s^2
+  // terms that cancel on a hovering vehicle; that one product chain is carried in double registers (run_vehicle), which needs
+  // its constant unrounded.  (A scalar-register pair of the kernel-argument segment: an fp64 operand as it is.)
+  double kf_over_mass_d;
 };
 static_assert(sizeof(DevParams<float>) % 16 == 0, "DevParams<float> size");
 static_assert(sizeof(DevParams<double>) % 16 == 0, "DevParams<double> size");

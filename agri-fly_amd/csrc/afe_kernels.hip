@@ -723,6 +723,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     }
     // ---- 4 motors: Motor::Run, Motor.cpp:39-84 ----
     R Fz = 0;                       // totalForce_b (thrust axes are all +z)
+    double W2_d = 0;                // sum w|w| in double, fp32 kernel only (see accz)
     R Tx = 0, Ty = 0, Tz = 0;       // totalTorque_b
     R Lm[4] = {0, 0, 0, 0};         // rotor angular momenta (about z)
     const R c = P.c_lag;
@@ -763,6 +764,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
         Lm[m] = (w * P.Jm) * spin;                           // Motor.cpp:68
       }
       ms[m] = w;
+      if (sizeof(R) == 4) { const double wd = (double)w; W2_d = __builtin_fma(wd, __builtin_fabs(wd), W2_d); }   // sum w|w| in double (see accz)
       const R thrust = P.kf * w * m_abs(w);                  // :70 (along +z)
       const R aero = -P.ktau * w * m_abs(w);                 // :73 (along spin*z)
       // torque = aero*axis + p x (0,0,thrust) - ang_acc*J*axis   :71-79
@@ -808,7 +810,23 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     // acceleration, Quadcopter_T.cpp:131-132
     R accx = div_mass(fm(Rm[2], Fbz, fm(Rm[1], Fby, Rm[0] * Fbx)) + fex, P.mass, P.inv_mass);
     R accy = div_mass(fm(Rm[5], Fbz, fm(Rm[4], Fby, Rm[3] * Fbx)) + fey, P.mass, P.inv_mass);
-    R accz = R(-9.81) + div_mass(fm(Rm[8], Fbz, fm(Rm[7], Fby, Rm[6] * Fbx)) + fez, P.mass, P.inv_mass);
+    R accz, nvz;
+    if (sizeof(R) == 4) {
+      // The vertical chain in double registers (SURVEY 7.2's escape hatch; round-5 review item 3).  On a hovering vehicle
+      // R22 sum k_f w|w| / m and 9.81 cancel; in fp32 the rounding of k_f, of the four products and of 1/m leaves ~1.5e-6 m/s^2
+      // of bias against g, the SAME on every vehicle that holds the hover command, and v_z integrates it: 1.6e-7 m/s after
+      // 0.1 s, 2e-5 of the 0.01 m/s floor the velocity of a vehicle at rest is judged at.  So the thrust term alone goes
+      // through double: sum w|w| (four FMAs), times kf / m (the host's double), times R22, minus 9.81; drag and the external
+      // force -- no cancellation there -- stay fp32.  17 fp64 instructions per step; the state stays fp32 (v_z is rounded
+      // once, when it is stored).
+      const R rest = fm(Rm[8], P.drag[2] * (-vbz), fm(Rm[7], Fby, Rm[6] * Fbx)) + fez;
+      const double accz_d = __builtin_fma((double)Rm[8], P.kf_over_mass_d * W2_d, -9.81) + (double)(rest * P.inv_mass);
+      accz = (R)accz_d;
+      nvz = (R)((double)vz + (double)dt * accz_d);         // :141, rounded once
+    } else {
+      accz = R(-9.81) + div_mass(fm(Rm[8], Fbz, fm(Rm[7], Fby, Rm[6] * Fbx)) + fez, P.mass, P.inv_mass);
+      nvz = fm(dt, accz, vz);
+    }
 
     // integration, Quadcopter_T.cpp:140-143 (old vel / old angVel / old att)
     // p + v dt + 0.5 a dt^2 = p + dt (v + (0.5 dt) a): two FMAs per axis
@@ -816,7 +834,7 @@ __device__ __forceinline__ void run_vehicle(const StepView<R> &v, const DevParam
     R npx = fm(dt, fm(hdt, accx, vx), px);
     R npy = fm(dt, fm(hdt, accy, vy), py);
     R npz = fm(dt, fm(hdt, accz, vz), pz);
-    R nvx = fm(dt, accx, vx), nvy = fm(dt, accy, vy), nvz = fm(dt, accz, vz);
+    R nvx = fm(dt, accx, vx), nvy = fm(dt, accy, vy);
     R d0, d1, d2, d3;
     rotvec_to_quat(dt * wx, dt * wy, dt * wz, d0, d1, d2, d3);
     // att * dq, Rotation.hpp:124-131 (this = att, r1 = dq)

@@ -138,6 +138,7 @@ void to_device_params(const HostParams &h, double dt, DevParams<R> &d) {
   d.wmin = (R)h.wmin;
   d.wmax = (R)h.wmax;
   for (int k = 0; k < 3; k++) d.drag[k] = (R)h.drag[k];
+  d.kf_over_mass_d = h.kf / h.mass;
 }
 template void to_device_params<float>(const HostParams &, double, DevParams<float> &);
 template void to_device_params<double>(const HostParams &, double, DevParams<double> &);

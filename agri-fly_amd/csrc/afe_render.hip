@@ -260,6 +260,7 @@ constexpr int kTileW = AFE_TILE_W, kTileH = AFE_TILE_H, kStack = 32;
 #define AFE_ENTRY_GROUP 2
 #endif
 constexpr int kEntryGroup = AFE_ENTRY_GROUP;
+constexpr uint32_t kNoEntry = 0xffffffffu;     // afe_tile_entry_kernel: no node of the tree is within range of this tile group
 
 struct PoseArgs {
   const void *pos, *att;      // planar, `stride` elements between components
@@ -411,7 +412,7 @@ struct RayState {
   float best_f;
 };
 
-struct WalkCounters { unsigned top = 0, nodes = 0, tri_wave_box = 0, tri_wave_mt = 0, tri_lane_box = 0, tri_lane_mt = 0; };
+struct WalkCounters { unsigned winner = 0xffffffffu, nodes = 0, tri_wave_box = 0, tri_wave_mt = 0, tri_lane_box = 0, tri_lane_mt = 0; };
 
 __device__ __forceinline__ float as_float(uint32_t u) { return __builtin_bit_cast(float, u); }
 // v_writelane_b32 (this compiler has the read side as a builtin, the write side only as the intrinsic)
@@ -470,7 +471,7 @@ __device__ __forceinline__ void leaf_triangles(const RenderArgs &a, RayState &ra
       if (COUNT) { cnt.tri_wave_mt += 1; cnt.tri_lane_mt += me ? 1 : 0; }
       if (me) {
         const double th = ray_triangle(ray.o, ray.d, T);
-        if (th < ray.best) { ray.best = th; ray.best_f = __double2float_ru(th); }
+        if (th < ray.best) { ray.best = th; ray.best_f = __double2float_ru(th); if (COUNT) cnt.winner = first + k; }
       }
     }
   }
@@ -499,7 +500,7 @@ __device__ __forceinline__ void walk(const RenderArgs &a, const PairNode *tree, 
   for (;;) {
     const u32x16 R = *reinterpret_cast<const u32x16 *>(reinterpret_cast<const char *>(tree) + cur);
     const uint32_t meta = R[14];
-    if (COUNT) { cnt.nodes += 1; if ((meta >> 24) <= 8u) cnt.top += 1; }
+    if (COUNT) cnt.nodes += 1;
     const bool bl = node_box_reached<ORDERED>((f32x2){as_float(R[0]), as_float(R[1])}, (f32x2){as_float(R[2]), as_float(R[3])},
                                               (f32x2){as_float(R[4]), as_float(R[5])}, br, ray.best_f);
     const bool bR = node_box_reached<ORDERED>((f32x2){as_float(R[6]), as_float(R[7])}, (f32x2){as_float(R[8]), as_float(R[9])},
@@ -601,7 +602,12 @@ __global__ void __launch_bounds__(64) afe_tile_entry_kernel(RenderArgs a, uint32
     const unsigned cl = (P.meta >> 8) & 255u, cr = (P.meta >> 16) & 255u;
     if (hl && !hr && cl == 0) cur = P.left;
     else if (hr && !hl && cr == 0) cur = P.right;
-    else break;
+    else {
+      // neither child within the camera's range for any ray of the group (sky, or an orchard that ends before the far
+      // plane): there is nothing to walk -- the tiles go straight to their answer (round 6)
+      if (!hl && !hr) cur = kNoEntry;
+      break;
+    }
   }
   entry[logical] = cur;
 }
@@ -669,7 +675,8 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
     const float *tb = a.tribox + (int64_t)neg * a.n_tri * 8;
     if (a.n_big) leaf_triangles<COUNT, true>(a, ray, br, tb, a.big_first, a.n_big, __ballot(in_image), cnt);
     const int64_t group = view * a.groups_per_view + (int64_t)((tile / a.tiles_x) / kEntryGroup) * a.groups_x + (tile % a.tiles_x) / kEntryGroup;
-    walk<COUNT, true>(a, a.pairs + (int64_t)neg * a.n_pairs, tb, ray, br, in_image, neg, cnt, a.entry ? a.entry[group] : 0u);
+    const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.entry ? a.entry[group] : 0u));
+    if (start != kNoEntry) walk<COUNT, true>(a, a.pairs + (int64_t)neg * a.n_pairs, tb, ray, br, in_image, neg, cnt, start);
   } else {
     for (int k = 0; k < 3; k++) {
       br.scale[k] = (f32x2){ray.inv[k], ray.inv[k]};
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
     walk<COUNT, false>(a, a.pairs, a.tribox, ray, br, in_image, neg, cnt, 0u);
   }
   const double best = ray.best;
-  const unsigned c_top = cnt.top, c_nodes = cnt.nodes, c_tri_wave_box = cnt.tri_wave_box, c_tri_wave_mt = cnt.tri_wave_mt,
+  const unsigned c_winner = cnt.winner, c_nodes = cnt.nodes, c_tri_wave_box = cnt.tri_wave_box, c_tri_wave_mt = cnt.tri_wave_mt,
                  c_tri_lane_box = cnt.tri_lane_box, c_tri_lane_mt = cnt.tri_lane_mt;
 
   uint16_t count = (uint16_t)a.max_count;
@@ -696,6 +703,13 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
     for (int sft = 32; sft >= 1; sft >>= 1) {
       lane_box += __shfl_xor(lane_box, sft); lane_mt += __shfl_xor(lane_mt, sft); rays += __shfl_xor(rays, sft);
     }
+    // the triangles this tile really shows: distinct winners among its rays (what no traversal could avoid testing)
+    unsigned visible = 0;
+    for (uint64_t todo = __ballot(in_image && best < INFINITY && c_winner != 0xffffffffu); todo;) {
+      const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)c_winner, (int)__ffsll((unsigned long long)todo) - 1);
+      todo &= ~__ballot(c_winner == w0);
+      visible++;
+    }
     if (lane == 0) {
       atomicAdd(&a.counters[0], (unsigned long long)c_nodes);
       atomicAdd(&a.counters[1], (unsigned long long)c_tri_wave_box);
@@ -704,7 +718,7 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
       atomicAdd(&a.counters[4], (unsigned long long)lane_mt);
       atomicAdd(&a.counters[5], (unsigned long long)rays);
       atomicAdd(&a.counters[6], 1ull);
-      atomicAdd(&a.counters[7], (unsigned long long)c_top);
+      atomicAdd(&a.counters[7], (unsigned long long)visible);
     }
   }
 }
@@ -1117,7 +1131,7 @@ extern "C" int afe_render_depth(afe_scene *s, const afe_camera *cam, int64_t n_v
 // The counting build of the same kernel over explicit poses: what the traversal did, for the roofline
 // accounting of bench.py.  stats: [0] nodes visited (per wave), [1] triangle box tests (per wave),
 // [2] triangle double-precision tests actually executed (per wave), [3] triangle box tests (per ray),
-// [4] double-precision tests (per ray), [5] rays, [6] waves (8 x 8 tiles), [7] visits of inner nodes of depth <= 8 (per wave).
+// [4] double-precision tests (per ray), [5] rays, [6] waves (8 x 8 tiles), [7] distinct triangles that are some ray's closest hit, summed over the waves.
 extern "C" int afe_render_depth_stats(afe_scene *s, const afe_camera *cam, int64_t n_views, const double *pos,
                                       const double *att, const double mount[4], uint64_t stats[8], float *kernel_ms) {
   if (!s || !camera_ok(cam) || n_views <= 0 || !pos || !att || !stats) return AFE_ERR_INVALID_ARG;

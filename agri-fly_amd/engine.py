@@ -590,7 +590,7 @@ class Scene:
         if rc:
             raise AfeError(rc, library().afe_status_string(rc).decode())
         keys = ("nodes_per_wave", "tri_box_tests_per_wave", "tri_fp64_tests_per_wave", "tri_box_tests_per_ray",
-                "tri_fp64_tests_per_ray", "rays", "waves", "top8_level_nodes_per_wave")
+                "tri_fp64_tests_per_ray", "rays", "waves", "visible_triangles_per_wave")
         return dict(zip(keys, (int(x) for x in st[:8]))), ms.value
 
     def render_engine(self, ensemble, cam, mount=None, first=0, count=None, out=None):

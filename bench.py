@@ -513,6 +513,7 @@ def perception_rows(afa, n_views=512, n_planners=16384, n_candidates=256):
         "valu_issue_fraction_of_busy_cycles": rpmc.get("valu_issue_fraction_of_busy_cycles"),
         "valu_instructions_per_ray": (rpmc.get("per_ray") or {}).get("valu_instructions", (rpmc.get("per_wave") or {}).get("valu_instructions", 0) / 64.0 or None),
         "counters_from": rsrc,
+        "floor_valu_per_ray": render_floor(st)["floor_valu_per_ray"], "floor": render_floor(st),
         "per_ray": {"triangle_box_tests": st["tri_box_tests_per_ray"] / rays, "fp64_triangle_tests": st["tri_fp64_tests_per_ray"] / rays},
         "per_wave_of_64_rays": {"nodes_visited": st["nodes_per_wave"] / waves, "triangle_box_tests": st["tri_box_tests_per_wave"] / waves,
                                 "fp64_triangle_tests_executed": st["tri_fp64_tests_per_wave"] / waves},
@@ -679,13 +680,36 @@ def config5_row(afa, device=0, n=262144, frames=2, shard=32768, steps_per_frame=
             "bound": "depth camera (vector issue); the physics is %.1f %% of the frame" % (100 * m["physics_ms"] / frame_ms)}
 
 
+# Vector instructions of the depth camera's wave by what they are spent on, counted in the gfx950 listing of
+# afe_render_depth_kernel<false> (make -C agri-fly_amd/csrc asm-style listing, ordered walk; round 6): ray set-up + octant vote +
+# quantise / store; one PairNode visit (two boxes: 6 v_pk_fma + min3 / max3 + compares); one triangle's own box; one
+# double-precision Moeller-Trumbore test to the end with the best-hit update (62 fp64 instructions, an IEEE division inside).
+RENDER_VALU = {"ray_setup_and_output": 132, "node_visit": 16, "triangle_box_test": 8, "fp64_triangle_test": 84}
+
+
+def render_floor(st):
+    """What 64 rays cost in vector instructions by the counting build's tallies and the static costs above, and the FLOOR of
+    any traversal that keeps the contract (every pixel's count from the double-precision test of the triangle it shows): ray
+    set-up, ONE fp64 test per triangle a tile really shows, the store -- no node, no box, no test of a hidden triangle."""
+    waves = float(st["waves"])
+    nodes, boxes, mts, vis = (st[k] / waves for k in ("nodes_per_wave", "tri_box_tests_per_wave", "tri_fp64_tests_per_wave", "visible_triangles_per_wave"))
+    c = RENDER_VALU
+    model = c["ray_setup_and_output"] + nodes * c["node_visit"] + boxes * c["triangle_box_test"] + mts * c["fp64_triangle_test"]
+    floor = c["ray_setup_and_output"] + vis * c["fp64_triangle_test"]
+    return {"visible_triangles_per_wave": vis, "valu_per_wave_by_static_costs": model, "valu_per_ray_by_static_costs": model / 64.0,
+            "valu_per_node_visit": c["node_visit"], "floor_valu_per_wave": floor, "floor_valu_per_ray": floor / 64.0, "floor_over_model": floor / model,
+            "traversal_share": (nodes * c["node_visit"] + boxes * c["triangle_box_test"]) / model,
+            "hidden_or_missed_fp64_tests_share": max(0.0, mts - vis) * c["fp64_triangle_test"] / model}
+
+
 def render_per_ray(st):
     """what one ray of the depth camera costs in tree work (the counting build's totals over a batch): nodes its wave visits
     (one node per wave step, shared by the 64 rays of the tile), triangle-box tests and double-precision triangle tests"""
     rays, waves = float(st["rays"]), float(st["waves"])
     return {"nodes_visited_per_wave": st["nodes_per_wave"] / waves, "nodes_visited_per_ray": st["nodes_per_wave"] / rays,
             "triangle_box_tests_per_ray": st["tri_box_tests_per_ray"] / rays, "fp64_triangle_tests_per_ray": st["tri_fp64_tests_per_ray"] / rays,
-            "triangle_box_tests_per_wave": st["tri_box_tests_per_wave"] / waves, "fp64_triangle_tests_per_wave": st["tri_fp64_tests_per_wave"] / waves}
+            "triangle_box_tests_per_wave": st["tri_box_tests_per_wave"] / waves, "fp64_triangle_tests_per_wave": st["tri_fp64_tests_per_wave"] / waves,
+            "floor": render_floor(st)}
 
 
 def host_cores():
@@ -1042,7 +1066,7 @@ def compact_line(full):
     cb = full.get("cpu_baseline")
     if cb:
         c = _pick(cb, ("value", "unit", "cores", "kind"))
-        c["sample"] = str(cb.get("sample", ""))[:150]
+        c["sample"] = str(cb.get("sample", ""))[:110]
         if cb.get("all_cores"):
             c["all_cores"] = _pick(cb["all_cores"], ("value", "cores", "speedup_over_one_thread"))
         if cb.get("other_noise_policy"):
@@ -1089,12 +1113,12 @@ def compact_line(full):
         for row in (cam, pln):
             if row["counters_from"] is None:
                 row["counters_stale"] = True
-        line["perception"] = {"depth_camera": cam, "planner": pln}
+        line["perception"] = {"depth_camera": {k: v for k, v in cam.items() if v is not None}, "planner": {k: v for k, v in pln.items() if v is not None}}
     for key in ("config3", "config5"):           # BASELINE configs 3 and 5 at their size, in the metric's unit
         row = full.get(key)
         if row:
             line[key] = _pick(row, ("vehicles", "frame_ms", "physics_ms", "render_ms", "plan_ms", "vsteps_per_s", "rays_per_s", "plans_per_s", "bound_short",
-                                    "valu_issue_frac", "valu_per_ray", "valu_per_plan", "counters_stale", "error"))
+                                    "valu_issue_frac", "valu_per_ray", "model_valu_per_ray", "floor_valu_per_ray", "valu_per_plan", "counters_stale", "error"))
     if full.get("counters_stale"):
         line["counters_stale"] = [str(x)[:48] for x in full["counters_stale"]][:6]
     sw = full.get("shared_world")
@@ -1355,17 +1379,15 @@ def main():
             "ms_per_step_max": max(blocks) / args.steps * 1e3,
             "ms_per_step_rank0_own": median(own_blocks) / args.steps * 1e3,     # `ms_per_step` is the MAX over ranks, block by block
             "higher_is_better": True,
-            "headline_note": ("since round 5 `value` runs on the reference's libstdc++ noise streams; rounds 1-4 quoted the counter generator "
-                              "(= counter_noise_policy here)") if HEADLINE_EXACT_STREAMS else None,
+            "headline_note": "since round 5 on the reference's noise streams; rounds 1-4 quoted counter_noise_policy" if HEADLINE_EXACT_STREAMS else None,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload_short": "BASELINE config 4 per GPU: %d hovering CF_MINIQUAD vehicles, per-vehicle wind gusts (on-device gust process, sigma 0..0.5 N, "
-                                  "100 ms epochs), IMU synthesis + Gaussian noise at the 500 Hz logic gate, one afe_step call per 1 ms step, state "
-                                  "through memory every step (no temporal fusion)" % n_local,
-                "noise": ("AFE_SEED_DECORRELATED: the reference's per-vehicle libstdc++ streams, words bit-exact (counter generator: counter_noise_policy)"
+                "workload_short": "BASELINE config 4 per GPU: %d hovering CF_MINIQUAD vehicles, per-vehicle wind gusts (sigma 0..0.5 N, 100 ms epochs), IMU "
+                                  "synthesis + noise at the 500 Hz logic gate, one afe_step call per 1 ms step, state through memory every step" % n_local,
+                "noise": ("AFE_SEED_DECORRELATED: the reference's per-vehicle libstdc++ streams, bit-exact"
                           if HEADLINE_EXACT_STREAMS else
                           "AFE_SEED_COUNTER (Philox4x32-10 + Box-Muller); the reference's libstdc++ streams: reference_noise_streams"),
                 "parallelism_short": "contiguous shards, %d rank(s), no data-path collective" % world,
@@ -1403,7 +1425,7 @@ def main():
                 "peak_measured": probe,
                 "frac_of_measured": None if probe is None else achieved / probe["GBs_164B"],
                 "traffic": traffic,
-                "traffic_is": "L2-fabric bytes per step (FETCH/WRITE_SIZE count Infinity-Cache hits): not HBM bytes here",
+                "traffic_is": "L2-fabric bytes per step (Infinity-Cache hits counted): not HBM bytes here",
                 "traffic_source": traffic_src,
                 "kernel_short": ("afe_step_persistent_kernel<float,FEXT,NOISE=%s>" % ("libstdc++ streams" if HEADLINE_EXACT_STREAMS else "counter")) if persistent else "afe_step_kernel<float,FEXT,NOISE 0/1,SINGLE>",
                 "kernel": (("afe::afe_step_persistent_kernel<float, FEXT=1, NOISE=%s, LOGIC=0>: one launch serves every step between two " % ("1 (libstdc++ streams)" if HEADLINE_EXACT_STREAMS else "2 (counter)")) +
@@ -1598,6 +1620,9 @@ def main():
                     row = fn(afa, local_rank)
                     row["valu_issue_frac"] = rr.get("valu_issue_fraction_of_busy_cycles")      # the camera bounds both frames
                     row["valu_per_ray"] = rr.get("valu_instructions_per_ray")
+                    if key == "config5":
+                        row["floor_valu_per_ray"] = row["per_ray"]["floor"]["floor_valu_per_ray"]
+                        row["model_valu_per_ray"] = row["per_ray"]["floor"]["valu_per_ray_by_static_costs"]
                     if key == "config3":
                         row["valu_per_plan"] = pl.get("valu_instructions_per_plan")
                     if rr.get("counters_from") is None or (key == "config3" and pl.get("counters_from") is None):

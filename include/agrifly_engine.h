@@ -410,8 +410,8 @@ int afe_scene_set_walk(afe_scene *s, int mode);
 /* What the traversal did for such a batch (a counting build of the same kernel; the images are
  * discarded): stats[0] BVH nodes visited and [1] triangle box tests / [2] double-precision
  * ray-triangle tests executed, per wave of 64 rays; [3], [4] the same two per participating ray;
- * [5] rays; [6] waves; [7] visits of inner nodes in the top 8 levels of the tree, per wave.  bench.py prices
- * the depth camera against the fp64 vector peak with these. */
+ * [5] rays; [6] waves; [7] the triangles the tiles really show (distinct closest-hit triangles per wave, summed):
+ * the double-precision tests no traversal could avoid.  bench.py states the camera's floor with these. */
 int afe_render_depth_stats(afe_scene *s, const afe_camera *cam, int64_t n_views, const double *pos, const double *att,
                            const double mount[4], uint64_t stats[8], float *kernel_ms);
 

@@ -13,5 +13,5 @@ st, ms2 = scene.render_stats(cam, pos, att, mount)
 print("render 1024 views: %.2f ms (%.3g rays/s); counting build %.2f ms" % (ms, n*76800/ms*1e3, ms2))
 print(st)
 r = st["rays"]; w = st["waves"]
-print("top-8-level node visits per wave %.1f" % (st["top8_level_nodes_per_wave"]/w))
+print("triangles a tile really shows (distinct closest hits per wave) %.2f" % (st["visible_triangles_per_wave"]/w))
 print("per ray: box tests %.1f, fp64 tests %.1f | per wave: nodes %.1f, tri box %.1f, tri fp64 executed %.1f" % (st["tri_box_tests_per_ray"]/r, st["tri_fp64_tests_per_ray"]/r, st["nodes_per_wave"]/w, st["tri_box_tests_per_wave"]/w, st["tri_fp64_tests_per_wave"]/w))
