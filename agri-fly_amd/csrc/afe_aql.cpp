@@ -235,7 +235,8 @@ AqlQueue *aql_open(int hip_device, std::string *why) {
     std::fprintf(stderr, "agrifly_engine: AQL queue: HIP device %d (%04x:%02x:%02x %s) is the HSA agent chosen by %s; %d GPU agent(s):%s\n", hip_device, fa.domain, fa.bus,
                  fa.dev, fa.uuid, rule, fa.n_gpus, fa.seen.c_str());
   (void)a.hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &q->ticks_per_s);
-  st = a.hsa_queue_create(q->gpu, 64, HSA_QUEUE_TYPE_SINGLE, queue_error_cb, q, UINT32_MAX, UINT32_MAX, &q->queue);
+  st = afe_fault("queue_create") ? HSA_STATUS_ERROR_OUT_OF_RESOURCES
+                                 : a.hsa_queue_create(q->gpu, 64, HSA_QUEUE_TYPE_SINGLE, queue_error_cb, q, UINT32_MAX, UINT32_MAX, &q->queue);
   if (st != HSA_STATUS_SUCCESS) { q->queue = nullptr; return bail(hsa_err(a, st, "hsa_queue_create")); }
   (void)a.hsa_amd_profiling_set_profiler_enabled(q->queue, 1);     // begin / end device timestamps on the completion signal
   st = a.hsa_signal_create(0, 0, nullptr, &q->done);
@@ -313,6 +314,7 @@ bool aql_find_kernel(AqlQueue *q, const void *fn, AqlKernel *out, std::string *w
   FindSymbol fs{};
   fs.a = &a; fs.agent = q->gpu; fs.name_kd = kd.c_str();
   st = loader.hsa_ven_amd_loader_iterate_executables(exec_cb, &fs);
+  if (afe_fault("kernel_symbol")) fs.found = false;
   if (!fs.found) { if (why) *why = "kernel descriptor " + kd + " not found in any loaded executable"; return false; }
   *out = fs.k;
   return true;
@@ -324,8 +326,9 @@ uint64_t aql_last_duration_ns(const AqlQueue *q) { return q ? q->last_ns : 0; }
 bool aql_dispatch(AqlQueue *q, const AqlKernel &k, const void *kernarg, size_t bytes, uint32_t workgroups, uint32_t wg_size, std::string *why) {
   Api &a = api();
   if (!q || !a.ok || q->in_flight || !k.object || workgroups == 0) { if (why) *why = "aql_dispatch: queue busy or bad arguments"; return false; }
-  if (bytes != k.kernarg_bytes || bytes > KERNARG_SLOT) {
-    if (why) *why = "kernel-argument segment is " + std::to_string(k.kernarg_bytes) + " bytes in the code object, " + std::to_string(bytes) + " packed by the host";
+  const size_t declared = (size_t)k.kernarg_bytes + (afe_fault("kernarg_size") ? 16u : 0u);
+  if (bytes != declared || bytes > KERNARG_SLOT) {
+    if (why) *why = "kernel-argument segment is " + std::to_string(declared) + " bytes in the code object, " + std::to_string(bytes) + " packed by the host";
     return false;
   }
   if (q->error.load()) { if (why) *why = "the AQL queue reported an error earlier (" + std::to_string(q->error.load()) + ")"; return false; }

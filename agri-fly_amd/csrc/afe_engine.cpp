@@ -200,9 +200,11 @@ int copy_in(afe_engine *e, void *dev, size_t esz, int comps, int64_t first, int6
     __atomic_thread_fence(__ATOMIC_RELEASE);   // ahead of the ring entry / the launch that lets the device read it
     return AFE_OK;
   }
+  hipStream_t st = main_stream(e);                   // (ends a resident grid)
+  if (e->p_failed) return fail(e, AFE_ERR_HIP, e->err);   // a grid that gave up or did not come back: the ensemble may be torn, nothing is written over it
   AFE_HIP(e, hipMemcpy2DAsync((char *)dev + first * esz, e->stride * esz, host, count * esz,
-                              count * esz, comps, hipMemcpyHostToDevice, main_stream(e)));
-  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));  // host buffer may be reused by the caller
+                              count * esz, comps, hipMemcpyHostToDevice, st));
+  AFE_HIP(e, hipStreamSynchronize(st));              // host buffer may be reused by the caller
   return AFE_OK;
 }
 int copy_out(afe_engine *e, const void *dev, size_t esz, int comps, int64_t first, int64_t count, void *host) {
@@ -215,9 +217,11 @@ int copy_out(afe_engine *e, const void *dev, size_t esz, int comps, int64_t firs
       std::memcpy((char *)host + (size_t)c * count * esz, d + ((size_t)c * e->stride + first) * esz, (size_t)count * esz);
     return AFE_OK;
   }
+  hipStream_t st = main_stream(e);                   // (ends a resident grid)
+  if (e->p_failed) return fail(e, AFE_ERR_HIP, e->err);   // ... and a torn ensemble is not handed out as a state
   AFE_HIP(e, hipMemcpy2DAsync(host, count * esz, (const char *)dev + first * esz, e->stride * esz,
-                              count * esz, comps, hipMemcpyDeviceToHost, main_stream(e)));
-  AFE_HIP(e, hipStreamSynchronize(main_stream(e)));
+                              count * esz, comps, hipMemcpyDeviceToHost, st));
+  AFE_HIP(e, hipStreamSynchronize(st));
   return AFE_OK;
 }
 
@@ -768,7 +772,7 @@ int persist_collect(afe_engine *e) {
   const bool was_aql = e->p_on_aql;
   if (e->p_on_aql) {
     std::string why;
-    const int w = afe::aql_wait(e->aql, 120000000ull, &why);     // (the grid's own patience ends long before: 50 ms without progress)
+    const int w = afe_fault("park_timeout") ? 1 : afe::aql_wait(e->aql, 120000000ull, &why);     // (the grid's own patience ends long before: 50 ms without progress)
     if (w != 0) {
       e->p_running = false; e->p_on_aql = false; e->p_failed = true;
       return fail(e, AFE_ERR_HIP, "persistent step kernel on the engine's AQL queue: " + (w > 0 ? std::string("still running after 120 s") : why));
@@ -834,11 +838,13 @@ int persist_park(afe_engine *e) {
 // completion word is written after the marks it summarises: once it stands at p_next the slabs are the host's).
 int quiesce(afe_engine *e) {
   join_streams(e);
+  if (e->p_failed) return fail(e, AFE_ERR_HIP, e->err);     // (host-visible arenas' getters come through here)
   if (e->p_running) {
     volatile unsigned long long *st = p_status(e);
     const auto t0 = std::chrono::steady_clock::now();
+    const bool deaf = afe_fault("sync_answer");      // (fault injection, dev-hooks builds: the host sees neither a park nor an answer)
     for (unsigned spins = 0;; spins++) {
-      if (st[0] != 0) {                          // it has parked (idle host, or a stall): collect, finish what is left
+      if (st[0] != 0 && !deaf) {                 // it has parked (idle host, or a stall): collect, finish what is left
         int rc = persist_collect(e);
         if (rc) return rc;
         if (e->p_resume > e->p_next) { e->p_failed = true; return fail(e, AFE_ERR_HIP, "persistent step kernel ran past the authorised steps"); }
@@ -852,10 +858,10 @@ int quiesce(afe_engine *e) {
         // of its size -- so a request that is left while only part of the workers have answered its marker (through the
         // pump's older word, say, with the slot then overwritten by the next real entry) would leave them misaligned for
         // the life of the grid, and a later request would be "answered" while workers are still stepping.
-        if (st[AFE_PERSIST_SYNC_WORD] >= e->p_next) break;
+        if (st[AFE_PERSIST_SYNC_WORD] >= e->p_next && !deaf) break;
       } else {
-        if (st[1] >= e->p_next) break;             // the pump's sweep already says so: nothing posted, nothing to answer
-        if (e->host_arena && e->p_workers <= AFE_PERSIST_HOST_MARKS) {   // small grids write their marks here themselves: no request, no wait for the pump's sweep
+        if (st[1] >= e->p_next && !deaf) break;    // the pump's sweep already says so: nothing posted, nothing to answer
+        if (e->host_arena && e->p_workers <= AFE_PERSIST_HOST_MARKS && !deaf) {   // small grids write their marks here themselves: no request, no wait for the pump's sweep
           unsigned long long low = ~0ull;
           for (int w = 0; w < e->p_workers; w++) { const unsigned long long d = st[8 + w]; low = d < low ? d : low; }
           if (low >= e->p_next) break;
@@ -866,8 +872,17 @@ int quiesce(afe_engine *e) {
           e->p_sync_posted = e->p_next + 1;
         }
       }
-      if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
-        return fail(e, AFE_ERR_HIP, "persistent step kernel makes no progress");
+      if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(afe_sync_patience_s())) {
+        // Nothing answered and nothing parked: the grid is not going to.  The engine is marked failed (every later call says
+        // so at once instead of spinning another 20 s on the same posted request) and the request is withdrawn.
+        char msg[200];
+        std::snprintf(msg, sizeof(msg), "persistent step kernel makes no progress (waiting for step %llu; request posted for %llu, answered %llu, pump at %llu)",
+                      (unsigned long long)e->p_next, (unsigned long long)(e->p_sync_posted ? e->p_sync_posted - 1 : 0),
+                      (unsigned long long)st[AFE_PERSIST_SYNC_WORD], (unsigned long long)st[1]);
+        e->p_failed = true;
+        e->p_sync_posted = 0;
+        return fail(e, AFE_ERR_HIP, msg);
+      }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     e->p_quiesced = e->p_next;
@@ -1614,6 +1629,7 @@ extern "C" int afe_steps_until_tick(const afe_engine *e, uint64_t dt_us, int *n_
 extern "C" int afe_sync(afe_engine *e) {
   if (!e) return AFE_ERR_INVALID_ARG;
   AFE_HIP(e, hipSetDevice(e->device));
+  if (e->p_failed) return fail(e, AFE_ERR_HIP, e->err);     // a grid that gave up, did not come back or never answered: said at once, nothing is waited for again
   if (e->p_running && e->p_on_aql && !e->view_exported &&
       !(!e->p_prio && persist_refresh_steps() > 0 && (long)(e->p_next - e->p_launch_start) >= persist_refresh_steps())) {     // (an aged grid is retired: persist_step)
     // Every authorised step has run and its stores are acknowledged; the grid STAYS (it lives on the engine's own queue,

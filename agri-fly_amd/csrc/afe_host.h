@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "../../include/agrifly_engine.h"
 #include "afe_device.h"
@@ -23,6 +24,27 @@ inline const char *afe_dev_env(const char *name) {
   (void)name;
   return nullptr;
 #endif
+}
+
+// Fault injection for the failure paths of the resident grid's own queue (tests/test_gpu_fault_paths.py), -DAFE_DEV_HOOKS
+// builds only: AFE_FAULT=<name>[,<name>...] makes the named step fail the way the runtime could --
+//   queue_create   hsa_queue_create refuses            kernel_symbol  the kernel descriptor is not found in the loaded code
+//   kernarg_size   the code object declares another kernel-argument size than the host packs
+//   park_timeout   a parked grid is reported as still running when the wait ends
+//   sync_answer    the host never sees the grid's answer to a sync request (nor its park): afe_sync runs into its patience
+// In the release build this folds to false.
+inline bool afe_fault(const char *name) {
+  const char *s = afe_dev_env("AFE_FAULT");
+  if (!s) return false;
+  const size_t n = std::strlen(name);
+  for (const char *p = s; (p = std::strstr(p, name)) != nullptr; p += n)
+    if ((p == s || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+  return false;
+}
+// how long afe_sync waits for a resident grid that neither answers nor parks (seconds; AFE_SYNC_PATIENCE_S in a dev-hooks build)
+inline int afe_sync_patience_s() {
+  const char *s = afe_dev_env("AFE_SYNC_PATIENCE_S");
+  return s && *s ? std::atoi(s) : 20;
 }
 
 // Expanded constants in double (what the Quadcopter_T ctor computes once).

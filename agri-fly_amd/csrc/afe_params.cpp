@@ -61,6 +61,9 @@ int expand_params(const afe_vehicle_params &in, HostParams &out, const char **wh
   if (!(in.prop_thrust_from_speed_sqr >= 0)) { *why = "prop_thrust_from_speed_sqr must be >= 0"; return AFE_ERR_INVALID_ARG; }
   if (!(in.prop_torque_from_speed_sqr >= 0)) { *why = "prop_torque_from_speed_sqr must be >= 0"; return AFE_ERR_INVALID_ARG; }
   if (!(in.motor_max_speed > in.motor_min_speed)) { *why = "motor_max_speed must exceed motor_min_speed"; return AFE_ERR_INVALID_ARG; }
+  // the lag-free rotor's clamp is one v_med3 between max(motor_min_speed, 0) and motor_max_speed (afe_kernels.hip): that is
+  // Motor.cpp:48-66's max(0, cmd) followed by its clamp only while the lower bound does not exceed the upper one
+  if (!(in.motor_max_speed > 0)) { *why = "motor_max_speed must be positive"; return AFE_ERR_INVALID_ARG; }
   if (!(in.mass > 0)) { *why = "mass must be > 0"; return AFE_ERR_INVALID_ARG; }
   if (!(in.motor_time_const >= 0)) { *why = "motor_time_const must be >= 0"; return AFE_ERR_INVALID_ARG; }
   out.mass = in.mass;

@@ -423,12 +423,14 @@ __device__ __forceinline__ void query_one(const uint4 *__restrict__ sorted, int6
 }
 
 // The workgroup that finishes LAST (a ticket) closes the query: it tells the host how many queries the rings left over
-// (pinned memory, informational) and answers up to AFE_WORLD_TAIL_MAX of them itself by the brute-force definition, one
-// after the other, all 256 threads on each -- the common case: nothing is left over (every bench world) or a handful of
-// isolated vehicles.  More than that is NOT one compute unit's work (n_left x n_all distance evaluations: 10^4 leftovers
-// among 10^6 points would hold the stream for 0.4 s): the count goes to `big_count`, and the launch that follows every
-// query (world_brute_chunks_kernel: 1 024 workgroups that leave at once when the word is zero) shares it over the device.
-#define AFE_WORLD_TAIL_MAX 32u
+// (pinned memory, informational) and answers them itself by the brute-force definition, one after the other, all 256
+// threads on each -- but only while that is little WORK: n_left x n_all distance evaluations within AFE_WORLD_TAIL_WORK
+// (a handful of isolated vehicles in a small world, ~20 us of one compute unit).  Anything more is not one compute
+// unit's work (twenty isolated vehicles among 2^20 points were 1.5 ms per query on one unit, 12 ms at 8 x 2^20; 10^4
+// leftovers among 10^6 points 0.4 s): the count goes to `big_count`, and the launch that follows every query
+// (world_brute_chunks_kernel: 1 024 workgroups that leave at once when the word is zero) shares it over the device.
+// (Round-5 advisor: the gate used to be a COUNT of 32, whatever the world's size.)
+#define AFE_WORLD_TAIL_WORK (1ull << 22)
 __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restrict__ sorted, int64_t n_all, const uint32_t *__restrict__ starts,
                                                           GridDesc g, int64_t first_global, int64_t n_self, float *__restrict__ dist2_out,
                                                           int32_t *__restrict__ index_out, uint32_t *leftover_count,
@@ -444,11 +446,12 @@ __global__ void __launch_bounds__(256) world_query_kernel(const uint4 *__restric
   __syncthreads();
   if (!last_block) return;
   const uint32_t n_left = __hip_atomic_load(leftover_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool in_tail = (unsigned long long)n_left * (unsigned long long)n_all <= AFE_WORLD_TAIL_WORK;     // (nothing left over: in_tail, an empty loop)
   if (threadIdx.x == 0) {
     __hip_atomic_store(host_left, n_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(big_count, n_left > AFE_WORLD_TAIL_MAX ? n_left : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(big_count, in_tail ? 0u : n_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (n_left > AFE_WORLD_TAIL_MAX) return;
+  if (!in_tail) return;
   for (uint32_t k = 0; k < n_left; k++) {
     const int64_t local = __hip_atomic_load(&leftover[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int me = (int)(first_global + local);
@@ -834,8 +837,8 @@ int afe::world_nearest(afe_world *w, void *hip_stream, const float *all_xyz, int
   }
   // 3. queries in cell order; isolated vehicles finish in the brute-force kernel
   uint32_t *left_count = (uint32_t *)(w->lohi + 6);
-  // What the rings leave over is finished by the brute force: up to AFE_WORLD_TAIL_MAX queries inside the query launch by
-  // its last workgroup (the common case: nothing or next to nothing left over), more than that by the launch behind it,
+  // What the rings leave over is finished by the brute force: inside the query launch by its last workgroup while that is
+  // little work (AFE_WORLD_TAIL_WORK distance evaluations: nothing or next to nothing left over in a small world), by the launch behind it otherwise,
   // which shares (query, chunk of the ensemble) items over the whole device and leaves at once when its count is zero.
   // No host-side guess is involved: a world that suddenly leaves 10^5 queries over (a fleet scattered beyond the grid's
   // rings) is answered in milliseconds by that launch, not in seconds by one compute unit.

@@ -99,3 +99,16 @@ def record_parity(test, precision, field, a, b, floor=None):
                   "at_floor": {repr(f): rel_err_vec(a, b, f) for f in PROBE_FLOORS},
                   "max_abs_err": float(np.nanmax(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))}
     return rec[field]["rel_err"]
+
+
+def dev_hooks_env():
+    """Environment for a child process that needs the lab variables of a -DAFE_DEV_HOOKS build (AFE_PLANNER_*, AFE_PERSIST_*,
+    AFE_FAULT): the current one when the loaded library has them, else one that selects agri-fly_amd/lib/dev/ (built by
+    __graft_entry__.build() beside the release library), else None (the caller skips)."""
+    import os
+    if afa.library().afe_has_dev_hooks():
+        return dict(os.environ)
+    dev = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "agri-fly_amd", "lib", "dev", "libagrifly_engine.so")
+    if os.path.exists(dev):
+        return dict(os.environ, AGRIFLY_ENGINE_LIB=dev)
+    return None

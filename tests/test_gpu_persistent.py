@@ -127,8 +127,6 @@ def test_more_steps_than_the_rings_hold_in_one_call_and_in_many():
     a.close(); b.close()
 
 
-@pytest.mark.skipif(not afa.library().afe_has_dev_hooks(), reason="AFE_PERSIST_WAVES_PER_CU is a measurement variable of the -DAFE_DEV_HOOKS build; "
-                    "several chunks per worker are covered at their natural size (2^20 vehicles) in tests/test_gpu_resident_sync.py")
 def test_several_chunks_per_worker_wave():
     """AFE_PERSIST_WAVES_PER_CU=1 leaves 255 worker waves: a 65 536-vehicle ensemble is 1 024 chunks, four or five per
     wave.  Runs in a child process (the variable is read when the grid is first sized)."""
@@ -144,7 +142,11 @@ for k in (1, 2, 30, 1):
 assert_same(a, b)
 print("ok")
 ''' % ROOT
-    env = dict(os.environ, AFE_PERSIST_WAVES_PER_CU="1")
+    from tests.scenarios import dev_hooks_env
+    env = dev_hooks_env()         # AFE_PERSIST_WAVES_PER_CU is a lab variable: the child runs on the -DAFE_DEV_HOOKS build
+    if env is None:
+        pytest.skip("no library with -DAFE_DEV_HOOKS (agri-fly_amd/lib/dev/, built by __graft_entry__.build())")
+    env = dict(env, AFE_PERSIST_WAVES_PER_CU="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 

@@ -120,8 +120,6 @@ def test_a_big_batch_starts_its_longest_planners_first_and_plans_the_same():
     assert np.array_equal(flags, np.concatenate(part_flags, axis=0 if flags.shape[0] == n else 1))
 
 
-@pytest.mark.skipif(not afa.library().afe_has_dev_hooks(), reason="AFE_PLANNER_* are measurement variables of the -DAFE_DEV_HOOKS build; the release "
-                    "library's longest-first scheduling is covered at its natural size by the test above")
 def test_search_in_budgeted_rounds_is_the_uninterrupted_search():
     """The search is interruptible (launch_rappids: a planner works for a budget, writes down the sequential loop's
     variables and leaves its slot; a later launch picks it up).  Big batches use it to start their longest planners
@@ -158,6 +156,10 @@ np.save(sys.argv[1], np.concatenate([np.frombuffer(bytes(out), np.uint8), flags.
 print(np.mean([o.n_pyramids for o in out]), np.mean([o.found for o in out]))
 """ % root
     import tempfile
+    from tests.scenarios import dev_hooks_env
+    base_env = dev_hooks_env()       # AFE_PLANNER_* are lab variables: the children run on the -DAFE_DEV_HOOKS build
+    if base_env is None:
+        pytest.skip("no library with -DAFE_DEV_HOOKS (agri-fly_amd/lib/dev/, built by __graft_entry__.build())")
     with tempfile.TemporaryDirectory() as d:
         res = []
         for name, env in (("whole", {}), ("rounds", {"AFE_PLANNER_ROUNDS_FROM": "0", "AFE_PLANNER_ROUNDS_US": "20,40,80,160,320"}),
@@ -165,7 +167,7 @@ print(np.mean([o.n_pyramids for o in out]), np.mean([o.found for o in out]))
                           ("longest first", {"AFE_PLANNER_LPT_FROM": "0", "AFE_PLANNER_SIZING_US": "30"}),
                           ("longest first, default sizing", {"AFE_PLANNER_LPT_FROM": "0"})):
             path = os.path.join(d, name.replace(" ", "_") + ".npy")
-            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(base_env, **env), capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             res.append(np.load(path))
         pyr, found = [float(x) for x in r.stdout.split()]

@@ -597,6 +597,75 @@ def test_a_world_that_scatters_leaves_thousands_of_queries_over_and_is_still_ans
     MEASUREMENTS["neighbour_query_scattered_world"] = {"vehicles": n, "left_over_by_the_rings": int(info["n_bruteforce"]), "first_query_ms": first_ms, "ms_per_query": ms}
 
 
+def test_a_few_isolated_vehicles_in_a_large_world_do_not_hold_the_stream():
+    """Round-5 advisor: the in-kernel tail of the neighbour query was gated on a COUNT (up to 32 leftovers), so a world of
+    2^20 points with a few dozen permanently isolated vehicles had them brute-forced serially on ONE compute unit at every
+    query -- n_left x n_all distance evaluations, ~1.5 ms (12 ms at 8 x 2^20).  The gate is work now (n_left x n_all <=
+    2^22): this world's 20 leftovers go to the device-wide launch.  Answers are the brute-force definition's; a query
+    costs what the same world without the stragglers costs, plus well under a millisecond."""
+    import torch
+    rng = np.random.default_rng(43)
+    n, n_far = 1 << 20, 20
+    side = 1024 * 4.0
+    pos = np.stack([(np.arange(n) % 1024) * 4.0, (np.arange(n) // 1024) * 4.0, rng.uniform(1, 4, n)]).astype(np.float32)
+    pos[:2] += rng.uniform(-1.0, 1.0, (2, n)).astype(np.float32)
+
+    def per_query_ms(p):
+        world = torch.from_numpy(np.ascontiguousarray(p)).cuda()
+        with afa.Ensemble(n) as e:
+            e.set_type_table([afa.params_from_type(5)])
+            e.set_state(pos=p.astype(np.float64))
+            d2_t = torch.empty(n, dtype=torch.float32, device="cuda")
+            idx_t = torch.empty(n, dtype=torch.int32, device="cuda")
+            for _ in range(3):
+                e.nearest_neighbour(world.data_ptr(), n, d2_t.data_ptr(), idx_t.data_ptr())
+            e.sync()
+            ev0, ev1 = e.event(), e.event()
+            e.record(ev0)
+            for _ in range(10):
+                e.nearest_neighbour(world.data_ptr(), n, d2_t.data_ptr(), idx_t.data_ptr())
+            e.record(ev1)
+            ms = e.elapsed_ms(ev0, ev1) / 10
+            info = e.neighbour_grid_info()
+            return ms, info
+
+    ms_plain, info_plain = per_query_ms(pos)
+    assert info_plain["n_bruteforce"] == 0
+    far = pos.copy()
+    who = np.sort(rng.choice(n, n_far, replace=False))
+    far[0, who] = side + 3000.0 + 500.0 * np.arange(n_far)          # stragglers far outside the lattice, 500 m apart
+    world = torch.from_numpy(np.ascontiguousarray(far)).cuda()
+    with afa.Ensemble(n) as e:
+        e.set_type_table([afa.params_from_type(5)])
+        e.set_state(pos=far.astype(np.float64))
+        d2_t = torch.empty(n, dtype=torch.float32, device="cuda")
+        idx_t = torch.empty(n, dtype=torch.int32, device="cuda")
+        for _ in range(3):
+            e.nearest_neighbour(world.data_ptr(), n, d2_t.data_ptr(), idx_t.data_ptr())
+        e.sync()
+        ev0, ev1 = e.event(), e.event()
+        e.record(ev0)
+        for _ in range(10):
+            e.nearest_neighbour(world.data_ptr(), n, d2_t.data_ptr(), idx_t.data_ptr())
+        e.record(ev1)
+        ms_far = e.elapsed_ms(ev0, ev1) / 10
+        info = e.neighbour_grid_info()
+        assert 1 <= info["n_bruteforce"] <= 64, info               # the stragglers (and nobody else) are left over by the rings
+        q = np.unique(np.concatenate([who, rng.choice(n, 1024, replace=False)])).astype(np.int32)
+        q_t = torch.from_numpy(q).cuda()
+        bd = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+        bi = torch.full((n,), -2, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        e.nearest_neighbour_bruteforce(world.data_ptr(), n, q_t.data_ptr(), q.size, bd.data_ptr(), bi.data_ptr())
+        e.sync()
+        np.testing.assert_array_equal(idx_t.cpu().numpy()[q], bi.cpu().numpy()[q])
+        np.testing.assert_array_equal(d2_t.cpu().numpy()[q], bd.cpu().numpy()[q])
+    assert ms_far < ms_plain + 0.6, (ms_far, ms_plain)             # one compute unit alone would add ~1.5 ms here
+    from tests.scenarios import MEASUREMENTS
+    MEASUREMENTS["neighbour_query_few_isolated_vehicles"] = {"vehicles": n, "isolated": n_far, "left_over_by_the_rings": int(info["n_bruteforce"]),
+                                                             "ms_per_query": ms_far, "ms_per_query_without_them": ms_plain}
+
+
 def test_group_gathers_by_staged_copies_too():
     """round-3 / round-4 advisor: a pair of devices without peer access must not refuse the group, and the copies between
     such a pair must be the runtime's peer copies (hipMemcpyPeerAsync, staged through the host where the devices cannot
