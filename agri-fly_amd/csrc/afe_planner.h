@@ -27,7 +27,8 @@ struct CandSections {
 struct PlannerBatch {
   int64_t n;
   const uint16_t *images;        // [n_images][height][width]
-  uint16_t *images_t;            // [n_images][width][height] scratch, filled by launch_rappids
+  uint16_t *images_t;            // [n_images][width][height_t] scratch, filled by launch_rappids: the transposed images,
+  int height_t;                  //   their columns padded to height_t = height rounded up to 64 pixels (128-byte runs start on 128-byte lines)
   int64_t n_images;
   // Per 64-pixel word of every image (only when width % 64 == 0, else null), filled by launch_rappids together with the
   // transpose: low half = the smallest depth above `ignore` (the vehicle's own radius in counts; 0xffff if none), high

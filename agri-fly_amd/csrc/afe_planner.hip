@@ -886,7 +886,7 @@ __device__ AFE_NI_CORNER bool corner_scan(const uint16_t *__restrict__ img, int 
 
 // DIP.cpp:456-970, executed by one wave (lane = 0..63, everything but the scans is uniform)
 __device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uint16_t *__restrict__ img,
-                                const uint16_t *__restrict__ imgT, const uint32_t *__restrict__ sums, uint64_t *mask, int lane, int x0, int y0,
+                                const uint16_t *__restrict__ imgT, int HT, const uint32_t *__restrict__ sums, uint64_t *mask, int lane, int x0, int y0,
                                 double minimumDepth, PlannerPyramid &out) {
 #pragma clang fp contract(off)
   PL_COUNT(22, 1);
@@ -899,6 +899,7 @@ __device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uin
   // DESIGN.md planner section.)
   x0 = __builtin_amdgcn_readfirstlane(x0);
   y0 = __builtin_amdgcn_readfirstlane(y0);
+  HT = __builtin_amdgcn_readfirstlane(HT);
   {
     const unsigned long long u = (unsigned long long)__double_as_longlong(minimumDepth);
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
@@ -1066,9 +1067,9 @@ __device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uin
           if (d[u] > ignore) laneMin = PL_MIN(laneMin, (int)d[u]);
       }
     }
-    min_line(imgT + rbX * H + rbFrom, 1, rbN, lane, ignore, laneMin);
+    min_line(imgT + rbX * HT + rbFrom, 1, rbN, lane, ignore, laneMin);      // (HT: the transposed image's padded column length)
     min_line(img + tbY * W + tbFrom, 1, tbN, lane, ignore, laneMin);
-    min_line(imgT + lbX * H + lbFrom, 1, lbN, lane, ignore, laneMin);
+    min_line(imgT + lbX * HT + lbFrom, 1, lbN, lane, ignore, laneMin);
     min_line(img + bbY * W + bbFrom, 1, bbN, lane, ignore, laneMin);
   }
   const uint16_t maxDepth = (uint16_t)wave_min_i32(laneMin);
@@ -1085,9 +1086,9 @@ __device__ AFE_NI_INFLATE bool inflate_pyramid(const PlannerConfig &c, const uin
   const int ny = B - T + 1, nx = R - L + 1;
   // right side :617-661 (columns R.. outward, rows T..B); left side :663-698
   if (mask_region_any(mask, WW, lane, R, W - 1, T, B) &&
-      !side_scan<SIDE_RIGHT>(imgT, H, 1, mask, WW, lane, (W - R) * ny, ny, R, T, 1, 0, 0, 1, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
+      !side_scan<SIDE_RIGHT>(imgT, HT, 1, mask, WW, lane, (W - R) * ny, ny, R, T, 1, 0, 0, 1, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
   if (mask_region_any(mask, WW, lane, 0, L, T, B) &&
-      !side_scan<SIDE_LEFT>(imgT, H, 1, mask, WW, lane, (L + 1) * ny, ny, L, T, -1, 0, 0, 1, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
+      !side_scan<SIDE_LEFT>(imgT, HT, 1, mask, WW, lane, (L + 1) * ny, ny, L, T, -1, 0, 0, 1, num, buf, x0, y0, dmin, s)) { PL_COUNT(16, 1); return false; }
   if (s.left + buf > s.right - buf) return false;
   // top side :705-744 (rows T.. outward, columns L..R); bottom side :746-785
   if (mask_region_any(mask, WW, lane, L, R, 0, T) &&
@@ -1227,7 +1228,7 @@ __device__ __forceinline__ double shfl_up1_f64(double v) {
 // IsCollisionFree (DIP.cpp:214-301) on the candidate's sections
 template <bool REGKEYS>
 __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restrict__ img,
-                               const uint16_t *__restrict__ imgT, const uint32_t *__restrict__ sums, uint64_t *mask_lds, int lane, const Poly &p,
+                               const uint16_t *__restrict__ imgT, int HT, const uint32_t *__restrict__ sums, uint64_t *mask_lds, int lane, const Poly &p,
                                const CandSections &first, PlannerPyramid *pyr, PyrKeys &keys, int &nPyr, int maxPyr) {
 #pragma clang fp contract(off)
   Section sec[16];   // pending sections (a std::vector in the reference; 16 like the CPU checker)
@@ -1265,7 +1266,7 @@ __device__ bool collision_free(const PlannerConfig &cfg, const uint16_t *__restr
     if (at < 0) {
       if (nPyr >= maxPyr) return false;                        // _maxNumPyramids, :255-260
       PlannerPyramid fresh;
-      if (!inflate_pyramid(cfg, img, imgT, sums, mask_lds, lane, (int)px, (int)py, ez, fresh)) return false;
+      if (!inflate_pyramid(cfg, img, imgT, HT, sums, mask_lds, lane, (int)px, (int)py, ez, fresh)) return false;
       PL_T0(t_ins);
       int idx = 0;                                             // std::lower_bound + insert, :269-271
       if (REGKEYS) {
@@ -1403,7 +1404,7 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
   extern __shared__ uint64_t mask_lds[];   // one bit per pixel of this planner's image, see build_mask
   const int64_t img_off = (int64_t)(b.image_index ? b.image_index[i] : i) * cfg.width * cfg.height;
   const uint16_t *img = b.images + img_off;
-  const uint16_t *imgT = b.images_t + img_off;
+  const uint16_t *imgT = b.images_t + (int64_t)(b.image_index ? b.image_index[i] : i) * cfg.width * b.height_t;
   const uint32_t *sums = b.sums ? b.sums + (img_off >> 6) : nullptr;      // one dword per 64 pixels
   const double *samples = b.samples + (int64_t)(b.sample_table ? b.sample_table[i] : 0) * b.n_candidates * 4;
   const double *cand_cost = b.cand_cost + i * b.n_candidates;
@@ -1466,7 +1467,7 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
           candidate_poly(k, p);
           PL_T1(t_regen, 21);
           PL_T0(t_cf);
-          const bool cfree = collision_free<REGKEYS>(cfg, img, imgT, sums, mask_lds, lane, p, cand_sections[base + l], pyr, keys, nPyr, b.max_pyramids);
+          const bool cfree = collision_free<REGKEYS>(cfg, img, imgT, b.height_t, sums, mask_lds, lane, p, cand_sections[base + l], pyr, keys, nPyr, b.max_pyramids);
           PL_T1(t_cf, 6);
           if (cfree) {
             result |= 8;
@@ -1538,48 +1539,71 @@ afe_rappids_search_kernel(const PlannerConfig cfg, const PlannerBatch b) {
 #endif
 }
 
-// images [n][H][W] -> images_t [n][W][H] through 64 x 32 LDS tiles, and -- `sums` given (width % 64 == 0) -- the
-// per-word summaries of PlannerBatch::sums on the way: a tile row IS one 64-pixel word of the bit images.
+// images [n][H][W] -> images_t [n][W][H] through 64 x 64 LDS tiles, and -- `sums` given (width % 64 == 0) -- the
+// per-word summaries of PlannerBatch::sums on the way: a tile row IS one 64-pixel word of the bit images.  With one image
+// per planner (config 3: 65 536 images, 10 GB in, 10 GB out) this pass is as long as the search itself, so it moves
+// bytes the wide way: a wave reads a row segment as 32 dwords (two pixels each) and writes a transposed column segment of
+// 64 pixels as 32 dwords -- 128-byte runs on both sides (round 5's 32 x 32 tiles wrote 64-byte runs of single pixels:
+// 2.1 TB/s; round 6: see DESIGN.md).  Even width and height take the dword path, anything else pixel by pixel.
 __global__ void __launch_bounds__(256) afe_prepare_images_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
-                                                                 uint32_t *__restrict__ sums, int W, int H, unsigned ignore) {
-  __shared__ uint16_t tile[32][66];
-  const int64_t off = (int64_t)blockIdx.z * W * H;
+                                                                 uint32_t *__restrict__ sums, int W, int H, int HT, unsigned ignore) {
+  __shared__ uint16_t tile[64][66];
+  const int64_t off = (int64_t)blockIdx.z * W * H, off_t = (int64_t)blockIdx.z * W * HT;
   const int t = threadIdx.x;
-  {
-    const int tx = t & 63, x = blockIdx.x * 64 + tx;
-    for (int r = t >> 6; r < 32; r += 4) {
-      const int y = blockIdx.y * 32 + r;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+  const bool even = ((W | H) & 1) == 0;
+  if (even) {
+    const int c2 = (t & 31) * 2, x = x0 + c2;
+    for (int r = t >> 5; r < 64; r += 8) {
+      const int y = y0 + r;
+      uint32_t two = 0;
+      if (x < W && y < H) two = *reinterpret_cast<const uint32_t *>(src + off + (int64_t)y * W + x);
+      *reinterpret_cast<uint32_t *>(&tile[r][c2]) = two;
+    }
+  } else {
+    const int tx = t & 63, x = x0 + tx;
+    for (int r = t >> 6; r < 64; r += 4) {
+      const int y = y0 + r;
       tile[r][tx] = (x < W && y < H) ? src[off + (int64_t)y * W + x] : (uint16_t)0;
     }
   }
   __syncthreads();
-  {
-    const int ty = t & 31, yo = blockIdx.y * 32 + ty;
+  if (even) {
+    const int r2 = (t & 31) * 2, yo = y0 + r2;
     for (int c = t >> 5; c < 64; c += 8) {
-      const int xo = blockIdx.x * 64 + c;
-      if (xo < W && yo < H) dst[off + (int64_t)xo * H + yo] = tile[ty][c];
+      const int xo = x0 + c;
+      if (xo < W && yo < H)
+        *reinterpret_cast<uint32_t *>(dst + off_t + (int64_t)xo * HT + yo) = (uint32_t)tile[r2][c] | ((uint32_t)tile[r2 + 1][c] << 16);
+    }
+  } else {
+    const int ty = t & 63, yo = y0 + ty;
+    for (int c = t >> 6; c < 64; c += 4) {
+      const int xo = x0 + c;
+      if (xo < W && yo < H) dst[off_t + (int64_t)xo * HT + yo] = tile[ty][c];
     }
   }
   if (sums) {
-    // row r of the tile, eight lanes with eight pixels each
-    const int r = t >> 3, seg = t & 7, y = blockIdx.y * 32 + r;
-    unsigned mn = 0xffffu, mx = 0u;
-    bool ign = false;
+    // rows of the tile, eight lanes with eight pixels each, 32 rows per pass
+    for (int r = t >> 3; r < 64; r += 32) {
+      const int seg = t & 7, y = y0 + r;
+      unsigned mn = 0xffffu, mx = 0u;
+      bool ign = false;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const unsigned d = tile[r][8 * seg + j];
-      if (d > ignore) mn = d < mn ? d : mn; else ign = true;
-      mx = d > mx ? d : mx;
-    }
-    unsigned packed = mn | ((ign ? 0xffffu : mx) << 16);
+      for (int j = 0; j < 8; j++) {
+        const unsigned d = tile[r][8 * seg + j];
+        if (d > ignore) mn = d < mn ? d : mn; else ign = true;
+        mx = d > mx ? d : mx;
+      }
+      unsigned packed = mn | ((ign ? 0xffffu : mx) << 16);
 #pragma unroll
-    for (int m = 1; m <= 4; m <<= 1) {
-      const unsigned o = (unsigned)__shfl_xor((int)packed, m);
-      const unsigned lo = (o & 0xffffu) < (packed & 0xffffu) ? (o & 0xffffu) : (packed & 0xffffu);
-      const unsigned hi = (o >> 16) > (packed >> 16) ? (o >> 16) : (packed >> 16);
-      packed = lo | (hi << 16);
+      for (int m = 1; m <= 4; m <<= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)packed, m);
+        const unsigned lo = (o & 0xffffu) < (packed & 0xffffu) ? (o & 0xffffu) : (packed & 0xffffu);
+        const unsigned hi = (o >> 16) > (packed >> 16) ? (o >> 16) : (packed >> 16);
+        packed = lo | (hi << 16);
+      }
+      if (seg == 0 && y < H) sums[((int64_t)blockIdx.z * H + y) * (W >> 6) + blockIdx.x] = packed;
     }
-    if (seg == 0 && y < H) sums[((int64_t)blockIdx.z * H + y) * (W >> 6) + blockIdx.x] = packed;
   }
 }
 
@@ -1590,9 +1614,9 @@ int launch_rappids(const PlannerConfig &cfg, const PlannerBatch &b, void *stream
   for (int64_t i0 = 0; i0 < b.n_images; i0 += 65535) {
     const int64_t cnt = (b.n_images - i0) < 65535 ? (b.n_images - i0) : 65535;
     const int64_t off = i0 * cfg.width * cfg.height;
-    hipLaunchKernelGGL(afe_prepare_images_kernel, dim3((cfg.width + 63) / 64, (cfg.height + 31) / 32, (unsigned)cnt),
-                       dim3(256), 0, (hipStream_t)stream, b.images + off, b.images_t + off, b.sums ? b.sums + (off >> 6) : nullptr,
-                       cfg.width, cfg.height, ignore);
+    hipLaunchKernelGGL(afe_prepare_images_kernel, dim3((cfg.width + 63) / 64, (cfg.height + 63) / 64, (unsigned)cnt),
+                       dim3(256), 0, (hipStream_t)stream, b.images + off, b.images_t + i0 * cfg.width * b.height_t, b.sums ? b.sums + (off >> 6) : nullptr,
+                       cfg.width, cfg.height, b.height_t, ignore);
   }
   // the bit image, and behind it the list of undecided words of build_mask_sum
   const unsigned mask_bytes = (unsigned)(((cfg.width + 63) >> 6) * cfg.height) * (unsigned)sizeof(uint64_t) + (b.sums ? kSumList * (unsigned)sizeof(uint16_t) : 0u);

@@ -149,7 +149,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   if (cost_vec && !d_c.upload(cost_vec, (size_t)n * 24)) return AFE_ERR_HIP;
   if (sample_table && !d_t.upload(sample_table, (size_t)n * 4)) return AFE_ERR_HIP;
   if (!d_pyr.alloc((size_t)n * cfg->max_pyramids * sizeof(PlannerPyramid)) || !d_out.alloc((size_t)n * sizeof(PlanOutput)) ||
-      !d_imgT.alloc((size_t)n_images * px * 2) || !d_cc.alloc((size_t)n * n_candidates * 8) ||
+      !d_imgT.alloc((size_t)n_images * cfg->width * (size_t)((cfg->height + 63) / 64 * 64) * 2) || !d_cc.alloc((size_t)n * n_candidates * 8) ||
       !d_cb.alloc((size_t)n * n_candidates) || !d_cs.alloc((size_t)n * n_candidates * sizeof(CandSections)))
     return AFE_ERR_HIP;
   if (flags && !d_flags.alloc((size_t)n * n_candidates)) return AFE_ERR_HIP;
@@ -164,6 +164,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   b.n = n;
   b.images = depth_on_device ? depth_images : (const uint16_t *)d_img.p;
   b.images_t = (uint16_t *)d_imgT.p;
+  b.height_t = (cfg->height + 63) / 64 * 64;
   b.sums = whole_words ? (uint32_t *)d_sums.p : nullptr;
   b.pyr_order = cfg->max_pyramids <= 64 ? (uint8_t *)d_order.p : nullptr;
   b.cand_cost = (double *)d_cc.p;
