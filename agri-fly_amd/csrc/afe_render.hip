@@ -332,6 +332,7 @@ struct RenderArgs {
   uint32_t big_first, n_big;
   int groups_x, groups_per_view;   // tiles in groups of kEntryGroup x kEntryGroup for the entry table
   const uint32_t *entry;    // per tile group of this launch: byte offset of the PairNode its walk starts at (afe_tile_entry_kernel); NULL: the root
+  const uint16_t *big_mask; // per tile group: which of the n_big out-of-tree triangles any ray of the group can hit at all (same kernel); NULL: all
   const double *poses;
   uint16_t *out;
   unsigned long long *counters;   // counting build only: see afe_render_depth_stats
@@ -556,7 +557,7 @@ __global__ void __launch_bounds__(256) afe_pixel_ray_table_kernel(double *uv, in
 // of the tile starts at the node where that stops.  In double, with a margin; an axis on which the corners do not
 // agree (or a component is nearly zero) constrains nothing.  Conservative, so the images cannot change; what it saves
 // is the visits of the top levels, whose other child is a part of the scene the tile's 10 m cannot reach.
-__global__ void __launch_bounds__(64) afe_tile_entry_kernel(RenderArgs a, uint32_t *entry) {
+__global__ void __launch_bounds__(64) afe_tile_entry_kernel(RenderArgs a, uint32_t *entry, uint16_t *big_mask) {
 #pragma clang fp contract(off)
   // (one lane per GROUP of kEntryGroup x kEntryGroup tiles: a quarter of the lanes, entries half a level higher)
   const int64_t logical = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -610,6 +611,56 @@ __global__ void __launch_bounds__(64) afe_tile_entry_kernel(RenderArgs a, uint32
     }
   }
   entry[logical] = cur;
+  // The triangles kept out of the tree (a ground plane's two): every tile used to test all of them -- two double-precision
+  // tests where at most one can hit.  A ray's barycentric numerators N_u = tv.(d x e2), N_v = d.(tv x e1) and the
+  // determinant det = e1.(d x e2) are LINEAR in the direction, the direction is linear in the pixel, so over the group's
+  // pixel rectangle each of them -- and N_u + N_v - det -- takes its extremes at the four corner rays.  Where the corners
+  // agree on the determinant's sign and put one of the hit conditions (u >= 0, v >= 0, u + v <= 1, t > 0, t within range)
+  // out of reach for all four, with a margin a million times the rounding of the per-ray test, NO ray of the group hits
+  // the triangle: its bit stays clear and the tiles skip its box and its double-precision test.  Conservative, in double.
+  if (big_mask) {
+    unsigned mask = 0;
+    double dc[4][3];
+    for (int c = 0; c < 4; c++)
+      for (int k = 0; k < 3; k++) dc[c][k] = pose[3 + 3 * k] * us[c & 1] + pose[4 + 3 * k] * vs[c >> 1] + pose[5 + 3 * k];
+    const double t_far = (double)a.max_count * a.depth_scale * 1.001;
+    for (unsigned b = 0; b < a.n_big && b < 16u; b++) {
+      const TriRec &T = a.tris[a.big_first + b];
+      const double tv[3] = {pose[0] - T.v0[0], pose[1] - T.v0[1], pose[2] - T.v0[2]};
+      const double q[3] = {tv[1] * T.e1[2] - tv[2] * T.e1[1], tv[2] * T.e1[0] - tv[0] * T.e1[2], tv[0] * T.e1[1] - tv[1] * T.e1[0]};
+      const double nt = T.e2[0] * q[0] + T.e2[1] * q[1] + T.e2[2] * q[2];
+      double det[4], nu[4], nv[4], mag = 0;
+      for (int c = 0; c < 4; c++) {
+        const double *d = dc[c];
+        const double pv[3] = {d[1] * T.e2[2] - d[2] * T.e2[1], d[2] * T.e2[0] - d[0] * T.e2[2], d[0] * T.e2[1] - d[1] * T.e2[0]};
+        det[c] = T.e1[0] * pv[0] + T.e1[1] * pv[1] + T.e1[2] * pv[2];
+        nu[c] = tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2];
+        nv[c] = d[0] * q[0] + d[1] * q[1] + d[2] * q[2];
+        mag = fmax(mag, fabs(T.e1[0] * pv[0]) + fabs(T.e1[1] * pv[1]) + fabs(T.e1[2] * pv[2]) + fabs(tv[0] * pv[0]) + fabs(tv[1] * pv[1]) +
+                            fabs(tv[2] * pv[2]) + fabs(d[0] * q[0]) + fabs(d[1] * q[1]) + fabs(d[2] * q[2]));
+      }
+      const double eps = 1e-9 * mag + 1e-300;
+      bool keep = true;
+      const bool pos = det[0] > eps && det[1] > eps && det[2] > eps && det[3] > eps;
+      const bool neg = det[0] < -eps && det[1] < -eps && det[2] < -eps && det[3] < -eps;
+      if (pos || neg) {
+        const double sg = pos ? 1.0 : -1.0;
+        double u_max = -1e300, v_max = -1e300, w_min = 1e300, det_max = 0;
+        for (int c = 0; c < 4; c++) {
+          u_max = fmax(u_max, sg * nu[c]);
+          v_max = fmax(v_max, sg * nv[c]);
+          w_min = fmin(w_min, sg * (nu[c] + nv[c] - det[c]));
+          det_max = fmax(det_max, sg * det[c]);
+        }
+        // t = t_num / (sg det): behind the camera when negative, nearest where the determinant is largest
+        const double t_num = sg * nt, eps_t = 1e-9 * (fabs(T.e2[0] * q[0]) + fabs(T.e2[1] * q[1]) + fabs(T.e2[2] * q[2])) + 1e-300;
+        if (u_max < -eps || v_max < -eps || w_min > eps || t_num < -eps_t || (t_num > eps_t && t_num > t_far * det_max * (1.0 + 1e-9)))
+          keep = false;
+      }
+      if (keep) mask |= 1u << b;
+    }
+    big_mask[logical] = (uint16_t)mask;
+  }
 }
 
 template <bool COUNT>
@@ -673,8 +724,15 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
       br.shift[k] = (f32x2){-ray.oi[k] * 0.99999f, -ray.oi[k] * 1.00001f};
     }
     const float *tb = a.tribox + (int64_t)neg * a.n_tri * 8;
-    if (a.n_big) leaf_triangles<COUNT, true>(a, ray, br, tb, a.big_first, a.n_big, __ballot(in_image), cnt);
     const int64_t group = view * a.groups_per_view + (int64_t)((tile / a.tiles_x) / kEntryGroup) * a.groups_x + (tile % a.tiles_x) / kEntryGroup;
+    if (a.n_big) {
+      if (a.big_mask) {      // only the out-of-tree triangles some ray of this tile group can hit (afe_tile_entry_kernel)
+        for (unsigned bm = (unsigned)__builtin_amdgcn_readfirstlane((int)a.big_mask[group]); bm; bm &= bm - 1u)
+          leaf_triangles<COUNT, true>(a, ray, br, tb, a.big_first + (unsigned)(__builtin_ffs((int)bm) - 1), 1u, __ballot(in_image), cnt);
+      } else {
+        leaf_triangles<COUNT, true>(a, ray, br, tb, a.big_first, a.n_big, __ballot(in_image), cnt);
+      }
+    }
     const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.entry ? a.entry[group] : 0u));
     if (start != kNoEntry) walk<COUNT, true>(a, a.pairs + (int64_t)neg * a.n_pairs, tb, ray, br, in_image, neg, cnt, start);
   } else {
@@ -797,7 +855,7 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
     r.uv = uv;
   }
   r.pairs = s->pairs; r.n_pairs = s->n_pairs; r.tris = s->tris; r.tribox = s->tribox; r.n_tri = s->n_tri; r.counters = dev_counters;
-  r.big_first = s->big_first; r.n_big = s->n_big; r.entry = nullptr;
+  r.big_first = s->big_first; r.n_big = s->n_big; r.entry = nullptr; r.big_mask = nullptr;
   r.width = cam->width; r.height = cam->height;
   r.tiles_x = (cam->width + kTileW - 1) / kTileW;
   r.tiles_per_view = r.tiles_x * ((cam->height + kTileH - 1) / kTileH);
@@ -828,10 +886,13 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
     if (!s->plain_walk_only) {     // (the plain walk stays the independent formulation: from the root)
       // the table lives for this launch only, allocated and freed in stream order (several streams may render one scene)
       const int64_t n_groups = nv * r.groups_per_view;
-      if (hipMallocAsync((void **)&entry, (size_t)n_groups * sizeof(uint32_t), stream) != hipSuccess) { rc = AFE_ERR_HIP; break; }
-      r.entry = nullptr;
-      hipLaunchKernelGGL(afe_tile_entry_kernel, dim3((unsigned)((n_groups + 63) / 64)), dim3(64), 0, stream, r, entry);
-      r.entry = entry;
+      // (entries, then -- scenes with out-of-tree triangles -- one 16-bit mask per group behind them)
+      const bool masks = s->n_big > 0 && s->n_big <= 16;
+      if (hipMallocAsync((void **)&entry, (size_t)n_groups * (sizeof(uint32_t) + (masks ? sizeof(uint16_t) : 0)), stream) != hipSuccess) { rc = AFE_ERR_HIP; break; }
+      uint16_t *big_mask = masks ? reinterpret_cast<uint16_t *>(entry + n_groups) : nullptr;
+      r.entry = nullptr; r.big_mask = nullptr;
+      hipLaunchKernelGGL(afe_tile_entry_kernel, dim3((unsigned)((n_groups + 63) / 64)), dim3(64), 0, stream, r, entry, big_mask);
+      r.entry = entry; r.big_mask = big_mask;
     }
     if (dev_counters) hipLaunchKernelGGL(afe_render_depth_kernel<true>, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
     else hipLaunchKernelGGL(afe_render_depth_kernel<false>, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
