@@ -1117,8 +1117,9 @@ def compact_line(full):
     for key in ("config3", "config5"):           # BASELINE configs 3 and 5 at their size, in the metric's unit
         row = full.get(key)
         if row:
+            # (the SQ-counter figures of the two kernels are in `perception` just above; here the frame, in the metric's unit)
             line[key] = _pick(row, ("vehicles", "frame_ms", "physics_ms", "render_ms", "plan_ms", "vsteps_per_s", "rays_per_s", "plans_per_s", "bound_short",
-                                    "valu_issue_frac", "valu_per_ray", "model_valu_per_ray", "floor_valu_per_ray", "valu_per_plan", "counters_stale", "error"))
+                                    "model_valu_per_ray", "floor_valu_per_ray", "counters_stale", "error"))
     if full.get("counters_stale"):
         line["counters_stale"] = [str(x)[:48] for x in full["counters_stale"]][:6]
     sw = full.get("shared_world")
@@ -1134,7 +1135,7 @@ def compact_line(full):
         line["config1_host_in_loop"] = _pick(c1, ("us_per_step", "realtime_factor", "error"))
     line["detail"] = full.get("detail", DETAIL_FILE)
     line = _r(line)
-    for victim in ("config1_host_in_loop", "closed_loop_on_device", "shared_world", "companions", "counter_noise_policy",
+    for victim in ("config1_host_in_loop", "shared_world", "closed_loop_on_device", "companions", "counter_noise_policy",
                    "north_star_shard", "config4_as_stated", "perception", "config5", "config3"):
         if len(json.dumps(line)) <= LINE_LIMIT:
             break

@@ -7,6 +7,8 @@ import copy
 import json
 import os
 
+import pytest
+
 import bench
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,8 +17,8 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def full_record():
-    """a full record as bench.py wrote it on an MI355X this round (committed: profiles/r05_bench_detail_k20.json, 30+ kB)"""
-    return json.load(open(os.path.join(ROOT, "profiles", "r05_bench_detail_k20.json")))
+    """a full record as bench.py wrote it on an MI355X this round (committed: profiles/r06_bench_detail_k20.json, 30+ kB)"""
+    return json.load(open(os.path.join(ROOT, "profiles", "r06_bench_detail_k20.json")))
 
 
 def _walk(x, path=""):
@@ -56,6 +58,16 @@ def test_full_size_record_gives_a_short_line_that_round_trips():
     assert back["detail"] == bench.DETAIL_FILE
     for k in ("sweep", "sweep_note", "disturbance_sweep", "perception_rows"):
         assert k not in back
+    # BASELINE configs 3 and 5 at their size, in the metric's unit (round-5 review item 1), and what bounds them
+    c3, c5 = back["config3"], back["config5"]
+    assert c3["vehicles"] == 65536 and c5["vehicles"] == 262144
+    for row in (c3, c5):
+        assert row["vsteps_per_s"] > 1e7 and row["frame_ms"] == pytest.approx(row["physics_ms"] + row["render_ms"] + row.get("plan_ms", 0.0), rel=1e-4)
+        assert row["render_ms"] > 10 * row["physics_ms"]          # the perception kernels ARE the hot path of these two configs
+    assert c3["plan_ms"] > 0 and 0 < c5["floor_valu_per_ray"] < c5["model_valu_per_ray"]
+    cam, pln = back["perception"]["depth_camera"], back["perception"]["planner"]
+    assert 0.5 < cam["valu_issue_frac"] <= 1.0 and cam["floor_valu_per_ray"] < cam["valu_per_ray"] and cam["counters_from"].startswith("profiles/r06")
+    assert pln["valu_per_plan"] < 640530 / 1.4 and pln["counters_from"].startswith("profiles/r06")      # round 5: 640 530 vector instructions per plan
 
 
 def test_the_line_labels_nothing_above_one_as_an_hbm_fraction():

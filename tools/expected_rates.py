@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "bench_detail.json")))
 assert d["n_gpus"] == 1
 n = d["config"]["vehicles_per_gpu"]
-out = {"from": "bench.py --steps %d --warmup %d on one MI355X (round 5)" % (d["steps"], d["warmup"]), "steps": d["steps"],
+out = {"from": "bench.py --steps %d --warmup %d on one MI355X (round 6)" % (d["steps"], d["warmup"]), "steps": d["steps"],
        "noise": d["config"]["noise"][:40],
        "weak_per_gpu": {str(n): {"vsteps_per_s": d["value"], "ms_per_step": d["ms_per_step"]}},
        "strong_shard": {}}

@@ -43,8 +43,8 @@ cd $ROOT
 NOTE="round 6: release library, rocprofv3 passes of tools/profile_r06.sh"
 for part in $PARTS; do
   case $part in
-    h20)  python3 tools/profile_summary_r03.py r06 "$NOTE (reference noise streams)" 1048576 148 2000 reference_streams > $OUT/summary_r06.log 2>&1 ;;
-    h20c) python3 tools/profile_summary_r03.py r06c "$NOTE (counter noise)" 1048576 144 2000 counter no-traffic-json > $OUT/summary_r06c.log 2>&1 ;;
+    h20)  python3 tools/profile_summary_r03.py r06 "$NOTE (reference noise streams)" 1048576 148 512 reference_streams > $OUT/summary_r06.log 2>&1 ;;
+    h20c) python3 tools/profile_summary_r03.py r06c "$NOTE (counter noise)" 1048576 144 512 counter no-traffic-json > $OUT/summary_r06c.log 2>&1 ;;
     ns)   python3 tools/profile_summary_r04.py r06_ns "$NOTE (reference noise streams)" 131072 148 reference_streams > $OUT/summary_r06_ns.log 2>&1 ;;
     nsc)  python3 tools/profile_summary_r04.py r06c_ns "$NOTE (counter noise)" 131072 144 counter > $OUT/summary_r06c_ns.log 2>&1 ;;
     bc23) python3 tools/profile_summary_r04_bc.py r06_bc23 "$NOTE" 8388608 148 > $OUT/summary_r06_bc23.log 2>&1 ;;
