@@ -76,7 +76,7 @@ int main(int argc, char **argv) {
   int precision = AFE_F32, seeds = AFE_SEED_REFERENCE, digits = 6;
   std::string outPath = "simulation.csv";
   bool useMocapEstimator = true, printSeconds = false;
-  std::string scenePath, trajLogPath;
+  std::string scenePath, trajLogPath, imageLogPath;
   double goalArg[3] = {120.0, 0.0, 3.5};   // main.cpp:241
   double startFlightTime = 5.0;            // :141
   double hoverArg = -1, lineUp = 0;
@@ -96,6 +96,7 @@ int main(int argc, char **argv) {
     else if (k == "--print-seconds") { printSeconds = true; }
     else if (k == "--scene") { scenePath = v; a++; }
     else if (k == "--traj-log") { trajLogPath = v; a++; }
+    else if (k == "--image-log") { imageLogPath = v; a++; }      // development aid: time, pose and a checksum of every depth image of the logged vehicle
     else if (k == "--goal" && a + 3 < argc) { for (int c = 0; c < 3; c++) goalArg[c] = atof(argv[a + 1 + c]); a += 3; }
     else if (k == "--start-flight") { startFlightTime = atof(v); a++; }
     else if (k == "--candidates") { nCandidates = atoi(v); a++; }
@@ -188,6 +189,8 @@ int main(int argc, char **argv) {
   bool requestNewImage = true;                                               // :199
   double const periodBetweenImages = 1 / 30.0;                               // :200-201
   int plannedTrajCount = 0;
+  std::ofstream imageLog;
+  if (!imageLogPath.empty()) { imageLog.open(imageLogPath.c_str()); imageLog << std::setprecision(17); }
   std::ofstream trajLog;
   if (!trajLogPath.empty()) { trajLog.open(trajLogPath.c_str()); trajLog << std::setprecision(17); }
 
@@ -225,6 +228,16 @@ int main(int argc, char **argv) {
       for (int64_t i = 0; i < nVehicles; i++) flight[(size_t)i].imageReady = true;
       for (int c = 0; c < 3; c++) flight[(size_t)logVehicle].imagePose[c] = rp[c];
       for (int c = 0; c < 4; c++) flight[(size_t)logVehicle].imagePose[3 + c] = rq[c];
+      if (imageLog.is_open()) {
+        std::vector<uint16_t> img((size_t)cam.width * cam.height);
+        die(0, afe_device_download(img.data(), (const char *)depthImages + (size_t)logVehicle * img.size() * 2, img.size() * 2), "afe_device_download");
+        uint64_t h = 1469598103934665603ull;      // FNV-1a
+        for (uint16_t px : img) { h ^= px; h *= 1099511628211ull; }
+        imageLog << t.GetSeconds<double>() << "," << h;
+        for (int c = 0; c < 3; c++) imageLog << "," << rp[c];
+        for (int c = 0; c < 4; c++) imageLog << "," << rq[c];
+        imageLog << "\n";
+      }
       requestNewImage = false;
     }
     {   // quad->Run(), Quadcopter_T.cpp:85-91: dt from the integration timer, nothing on the first call

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "afe_planner.h"
+#include "afe_host.h"   // afe_dev_env
 
 using namespace afe;
 
@@ -156,7 +157,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   if (!d_resume.alloc((size_t)n * sizeof(PlannerBatch::Resume))) return AFE_ERR_HIP;
   if (!d_bins.alloc(((size_t)n * PlannerBatch::kBins + 64) * sizeof(int32_t))) return AFE_ERR_HIP;
   // the per-word summaries need rows of whole 64-pixel words (and 512 B of LDS behind the bit image for their list)
-  const bool whole_words = (cfg->width & 63) == 0 && (px >> 6) * 8 + 512 <= 65536;
+  const bool whole_words = (cfg->width & 63) == 0 && (px >> 6) * 8 + 512 <= 65536 && !afe_dev_env("AFE_PLANNER_NO_SUMS");      // (lab variable: the plain sweep everywhere)
   if (whole_words && !d_sums.alloc((size_t)n_images * (px >> 6) * sizeof(uint32_t))) return AFE_ERR_HIP;
   if (cfg->max_pyramids <= 64 && !d_order.alloc((size_t)n * 64)) return AFE_ERR_HIP;
 
@@ -166,7 +167,7 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
   b.images_t = (uint16_t *)d_imgT.p;
   b.height_t = (cfg->height + 63) / 64 * 64;
   b.sums = whole_words ? (uint32_t *)d_sums.p : nullptr;
-  b.pyr_order = cfg->max_pyramids <= 64 ? (uint8_t *)d_order.p : nullptr;
+  b.pyr_order = cfg->max_pyramids <= 64 && !afe_dev_env("AFE_PLANNER_NO_LANE_LIST") ? (uint8_t *)d_order.p : nullptr;      // (lab variable: the pyramid list in HBM)
   b.cand_cost = (double *)d_cc.p;
   b.cand_bits = (uint8_t *)d_cb.p;
   b.cand_sections = (CandSections *)d_cs.p;

@@ -27,9 +27,12 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <list>
+#include <mutex>
 #include <vector>
 
 #include "afe_render.h"
+#include "afe_host.h"   // afe_dev_env
 
 namespace afe {
 
@@ -331,8 +334,10 @@ struct RenderArgs {
   // tree's top levels separate space: records [big_first, big_first + n_big) of tris
   uint32_t big_first, n_big;
   int groups_x, groups_per_view;   // tiles in groups of kEntryGroup x kEntryGroup for the entry table
-  const uint32_t *entry;    // per tile group of this launch: byte offset of the PairNode its walk starts at (afe_tile_entry_kernel); NULL: the root
-  const uint16_t *big_mask; // per tile group: which of the n_big out-of-tree triangles any ray of the group can hit at all (same kernel); NULL: all
+  // per tile group of this launch (afe_tile_entry_kernel), ONE 64-bit word: low half = byte offset of the PairNode the walk
+  // starts at (kNoEntry: nothing in range), bits 32-47 = which of the n_big out-of-tree triangles any ray of the group can
+  // hit at all (all ones when the scene has none to cull).  NULL: from the root, every out-of-tree triangle.
+  const uint64_t *entry;
   const double *poses;
   uint16_t *out;
   unsigned long long *counters;   // counting build only: see afe_render_depth_stats
@@ -557,7 +562,7 @@ __global__ void __launch_bounds__(256) afe_pixel_ray_table_kernel(double *uv, in
 // of the tile starts at the node where that stops.  In double, with a margin; an axis on which the corners do not
 // agree (or a component is nearly zero) constrains nothing.  Conservative, so the images cannot change; what it saves
 // is the visits of the top levels, whose other child is a part of the scene the tile's 10 m cannot reach.
-__global__ void __launch_bounds__(64) afe_tile_entry_kernel(RenderArgs a, uint32_t *entry, uint16_t *big_mask) {
+__global__ void __launch_bounds__(64) afe_tile_entry_kernel(RenderArgs a, uint64_t *entry, int cull_big) {
 #pragma clang fp contract(off)
   // (one lane per GROUP of kEntryGroup x kEntryGroup tiles: a quarter of the lanes, entries half a level higher)
   const int64_t logical = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -610,7 +615,7 @@ __global__ void __launch_bounds__(64) afe_tile_entry_kernel(RenderArgs a, uint32
       break;
     }
   }
-  entry[logical] = cur;
+  unsigned mask = 0xffffu;
   // The triangles kept out of the tree (a ground plane's two): every tile used to test all of them -- two double-precision
   // tests where at most one can hit.  A ray's barycentric numerators N_u = tv.(d x e2), N_v = d.(tv x e1) and the
   // determinant det = e1.(d x e2) are LINEAR in the direction, the direction is linear in the pixel, so over the group's
@@ -618,8 +623,8 @@ __global__ void __launch_bounds__(64) afe_tile_entry_kernel(RenderArgs a, uint32
   // agree on the determinant's sign and put one of the hit conditions (u >= 0, v >= 0, u + v <= 1, t > 0, t within range)
   // out of reach for all four, with a margin a million times the rounding of the per-ray test, NO ray of the group hits
   // the triangle: its bit stays clear and the tiles skip its box and its double-precision test.  Conservative, in double.
-  if (big_mask) {
-    unsigned mask = 0;
+  if (cull_big) {
+    mask = 0;
     double dc[4][3];
     for (int c = 0; c < 4; c++)
       for (int k = 0; k < 3; k++) dc[c][k] = pose[3 + 3 * k] * us[c & 1] + pose[4 + 3 * k] * vs[c >> 1] + pose[5 + 3 * k];
@@ -659,8 +664,11 @@ __global__ void __launch_bounds__(64) afe_tile_entry_kernel(RenderArgs a, uint32
       }
       if (keep) mask |= 1u << b;
     }
-    big_mask[logical] = (uint16_t)mask;
   }
+  // (one store: what the walk starts at and what it tests first travel together -- round 6 first kept the masks in a second
+  // array behind the entries in the same stream-ordered allocation, and under a second process's load one render in two
+  // thousand read masks that were not this launch's: tools/experiments/flight_repro.py)
+  entry[logical] = (uint64_t)cur | ((uint64_t)mask << 32);
 }
 
 template <bool COUNT>
@@ -725,15 +733,11 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
     }
     const float *tb = a.tribox + (int64_t)neg * a.n_tri * 8;
     const int64_t group = view * a.groups_per_view + (int64_t)((tile / a.tiles_x) / kEntryGroup) * a.groups_x + (tile % a.tiles_x) / kEntryGroup;
-    if (a.n_big) {
-      if (a.big_mask) {      // only the out-of-tree triangles some ray of this tile group can hit (afe_tile_entry_kernel)
-        for (unsigned bm = (unsigned)__builtin_amdgcn_readfirstlane((int)a.big_mask[group]); bm; bm &= bm - 1u)
-          leaf_triangles<COUNT, true>(a, ray, br, tb, a.big_first + (unsigned)(__builtin_ffs((int)bm) - 1), 1u, __ballot(in_image), cnt);
-      } else {
-        leaf_triangles<COUNT, true>(a, ray, br, tb, a.big_first, a.n_big, __ballot(in_image), cnt);
-      }
-    }
-    const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.entry ? a.entry[group] : 0u));
+    const uint64_t word = a.entry ? a.entry[group] : (0xffffull << 32);
+    const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
+    // only the out-of-tree triangles some ray of this tile group can hit (afe_tile_entry_kernel)
+    for (unsigned bm = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)(word >> 32)) & ((1u << a.n_big) - 1u); bm; bm &= bm - 1u)
+      leaf_triangles<COUNT, true>(a, ray, br, tb, a.big_first + (unsigned)(__builtin_ffs((int)bm) - 1), 1u, __ballot(in_image), cnt);
     if (start != kNoEntry) walk<COUNT, true>(a, a.pairs + (int64_t)neg * a.n_pairs, tb, ray, br, in_image, neg, cnt, start);
   } else {
     for (int k = 0; k < 3; k++) {
@@ -803,6 +807,15 @@ struct afe_scene {
   // a launch still in flight on some stream may be reading one)
   struct RayTable { int width, height; double cx, cy, focal; double *uv; };
   std::vector<RayTable> ray_tables;
+  // Tile-entry tables (one 64-bit word per tile group of a launch), kept and reused: a launch takes a table no launch in
+  // flight is using -- `done` is recorded behind the render kernel that reads it -- or makes one.  (Round 6: the table used
+  // to come from hipMallocAsync / hipFreeAsync around every launch.  With the entry pass doing more work per group, renders
+  // from the headless loop -- system HIP runtime, another process loading the GPU -- then read tables that were not their
+  // launch's, one image in two thousand: tools/experiments/flight_repro.py.  Not with a synchronous allocation, not with
+  // tables that live as long as the scene.)
+  struct EntryTable { void *p = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool used = false; };
+  std::list<EntryTable> entry_tables;       // (a list: launches hold pointers to their table outside the lock)
+  std::mutex entry_mutex;
 };
 
 namespace {
@@ -855,7 +868,7 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
     r.uv = uv;
   }
   r.pairs = s->pairs; r.n_pairs = s->n_pairs; r.tris = s->tris; r.tribox = s->tribox; r.n_tri = s->n_tri; r.counters = dev_counters;
-  r.big_first = s->big_first; r.n_big = s->n_big; r.entry = nullptr; r.big_mask = nullptr;
+  r.big_first = s->big_first; r.n_big = s->n_big; r.entry = nullptr;
   r.width = cam->width; r.height = cam->height;
   r.tiles_x = (cam->width + kTileW - 1) / kTileW;
   r.tiles_per_view = r.tiles_x * ((cam->height + kTileH - 1) / kTileH);
@@ -882,22 +895,44 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
     r.n_blocks = nv * r.tiles_per_view;
     r.blocks_per_xcd = (r.n_blocks + 7) / 8;
     const int64_t grid = r.blocks_per_xcd * 8;
-    uint32_t *entry = nullptr;
+    uint64_t *entry = nullptr;
+    afe_scene::EntryTable *table = nullptr;
     if (!s->plain_walk_only) {     // (the plain walk stays the independent formulation: from the root)
-      // the table lives for this launch only, allocated and freed in stream order (several streams may render one scene)
+      // a table of the scene's that no launch in flight is reading (several streams may render one scene)
       const int64_t n_groups = nv * r.groups_per_view;
-      // (entries, then -- scenes with out-of-tree triangles -- one 16-bit mask per group behind them)
-      const bool masks = s->n_big > 0 && s->n_big <= 16;
-      if (hipMallocAsync((void **)&entry, (size_t)n_groups * (sizeof(uint32_t) + (masks ? sizeof(uint16_t) : 0)), stream) != hipSuccess) { rc = AFE_ERR_HIP; break; }
-      uint16_t *big_mask = masks ? reinterpret_cast<uint16_t *>(entry + n_groups) : nullptr;
-      r.entry = nullptr; r.big_mask = nullptr;
-      hipLaunchKernelGGL(afe_tile_entry_kernel, dim3((unsigned)((n_groups + 63) / 64)), dim3(64), 0, stream, r, entry, big_mask);
-      r.entry = entry; r.big_mask = big_mask;
+      const int cull_big = (s->n_big > 0 && s->n_big <= 16 && !afe_dev_env("AFE_RENDER_NO_BIG_MASK")) ? 1 : 0;      // (lab variable: every tile tests every out-of-tree triangle)
+      {
+        const size_t need = (size_t)n_groups * sizeof(uint64_t);
+        std::lock_guard<std::mutex> lock(s->entry_mutex);
+        for (afe_scene::EntryTable &t : s->entry_tables)
+          if (t.bytes >= need && (!t.used || hipEventQuery(t.done) == hipSuccess)) { table = &t; break; }
+        if (!table) {
+          afe_scene::EntryTable t;
+          if (hipMalloc(&t.p, need + need / 4) != hipSuccess || hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (t.p) (void)hipFree(t.p);
+            rc = AFE_ERR_HIP;
+            break;
+          }
+          t.bytes = need + need / 4;
+          s->entry_tables.push_back(t);
+          table = &s->entry_tables.back();
+        }
+        table->used = true;
+        (void)hipEventRecord(table->done, stream);      // (taken: re-recorded behind the render kernel below; until then it is at least behind everything queued so far)
+        entry = (uint64_t *)table->p;
+      }
+      r.entry = nullptr;
+      hipLaunchKernelGGL(afe_tile_entry_kernel, dim3((unsigned)((n_groups + 63) / 64)), dim3(64), 0, stream, r, entry, cull_big);
+      r.entry = entry;
     }
     if (dev_counters) hipLaunchKernelGGL(afe_render_depth_kernel<true>, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
     else hipLaunchKernelGGL(afe_render_depth_kernel<false>, dim3((unsigned)grid), dim3(kTileW * kTileH), 0, stream, r);
     rc = hipGetLastError() == hipSuccess ? AFE_OK : AFE_ERR_HIP;
-    if (entry) (void)hipFreeAsync(entry, stream);
+    if (table) {      // free for the next launch once this render kernel has read it
+      std::lock_guard<std::mutex> lock(s->entry_mutex);
+      (void)hipEventRecord(table->done, stream);
+    }
   }
   if (kernel_ms) {
     (void)hipEventRecord(e1, stream);
@@ -1149,6 +1184,7 @@ extern "C" int afe_scene_check_hierarchy(const float *triangles, int64_t n_tri, 
 extern "C" void afe_scene_destroy(afe_scene *s) {
   if (!s) return;
   for (const afe_scene::RayTable &t : s->ray_tables) (void)hipFree(t.uv);
+  for (afe_scene::EntryTable &t : s->entry_tables) { if (t.done) { (void)hipEventSynchronize(t.done); (void)hipEventDestroy(t.done); } if (t.p) (void)hipFree(t.p); }
   if (s->pairs) (void)hipFree(s->pairs);
   if (s->tris) (void)hipFree(s->tris);
   if (s->tribox) (void)hipFree(s->tribox);
