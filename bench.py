@@ -112,6 +112,11 @@ def headline_mode(afa, n):
     (AFE_STEP_PERSISTENT: every step reads the state from memory and writes it back -- SURVEY 8d's accounting) up to 2^20
     vehicles, launches beyond.  (AFE_STEP_AUTO itself would take the resident-state form, which does not read the state
     back between steps authorised ahead: the `resident_state` companion.)"""
+    if os.environ.get("AFE_BENCH_ONE_DEVICE") == "1":
+        # the one-GPU test hook (several ranks on device 0): launches.  Two PROCESSES that each hold a resident grid sized for
+        # the whole device starve each other's late workgroups (one run in ten ended with "persistent step kernel gave up
+        # waiting"); one rank per GPU is the contract, and no number of that hook is meant.
+        return afa.AFE_STEP_LAUNCH
     return afa.AFE_STEP_PERSISTENT if n <= (1 << 20) else afa.AFE_STEP_AUTO
 
 
