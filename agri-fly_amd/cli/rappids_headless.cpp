@@ -26,13 +26,15 @@
 //                    [--seeds reference|decorrelated] [--log-vehicle i] [--digits D] [--out simulation.csv]
 //                    [--estimator mocap|truth] [--print-seconds]
 //                    [--scene mesh.f32 [--goal x y z] [--start-flight T] [--candidates K] [--traj-log file]
-//                     [--hover z] [--line-up dy]]
+//                     [--image-log file] [--hover z] [--line-up dy]]
 // --scene: n x 9 little-endian float32 (v0, v1, v2 per triangle), world frame = the simulation's (z up).
 // --goal: goalWorld (:241; default 120 0 3.5); --start-flight: startFlightTime (:141; default 5 s);
 // --candidates: candidates per plan (default 256); --hover z: fly at height z before and after take-off instead
 // of the reference's 3.5 m / 2 m; --line-up dy: vehicle i starts, hovers and aims dy * i metres further along y.
 // --traj-log: PlannedTrajectory.csv of the logged vehicle, the reference's columns (:534-551) followed by what the
 //   plan was made from (time, winning candidate, planner inputs, the pose its image was rendered at).
+// --image-log: time, an FNV-1a checksum and the pose of every depth image of the logged vehicle (development aid: what
+//   tools/experiments/flight_repro.py compares between runs).
 // --print-seconds: the logged vehicle's true state on stdout after every whole second of Run() calls
 //   ("t=1.000 pos=x y z vel=... q=... f0=..."), the line format SURVEY.md Appendix B quotes for the reference.
 // Defaults are the reference's own: 1 vehicle, dt = 1/500 s, 8 s, 6 significant digits (ofstream default).
