@@ -813,7 +813,9 @@ struct afe_scene {
   // from the headless loop -- system HIP runtime, another process loading the GPU -- then read tables that were not their
   // launch's, one image in two thousand: tools/experiments/flight_repro.py.  Not with a synchronous allocation, not with
   // tables that live as long as the scene.)
-  struct EntryTable { void *p = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool used = false; };
+  // (`taken`: a launch is being queued on it -- nobody else may have it, whatever its event says; `used`: `done` has been
+  //  recorded behind a render kernel that reads it, free again once that event has completed)
+  struct EntryTable { void *p = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool used = false, taken = false; };
   std::list<EntryTable> entry_tables;       // (a list: launches hold pointers to their table outside the lock)
   std::mutex entry_mutex;
 };
@@ -905,7 +907,7 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
         const size_t need = (size_t)n_groups * sizeof(uint64_t);
         std::lock_guard<std::mutex> lock(s->entry_mutex);
         for (afe_scene::EntryTable &t : s->entry_tables)
-          if (t.bytes >= need && (!t.used || hipEventQuery(t.done) == hipSuccess)) { table = &t; break; }
+          if (t.bytes >= need && !t.taken && (!t.used || hipEventQuery(t.done) == hipSuccess)) { table = &t; break; }
         if (!table) {
           afe_scene::EntryTable t;
           if (hipMalloc(&t.p, need + need / 4) != hipSuccess || hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) {
@@ -918,8 +920,7 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
           s->entry_tables.push_back(t);
           table = &s->entry_tables.back();
         }
-        table->used = true;
-        (void)hipEventRecord(table->done, stream);      // (taken: re-recorded behind the render kernel below; until then it is at least behind everything queued so far)
+        table->taken = true;                             // ours until the event behind our render kernel is recorded (below)
         entry = (uint64_t *)table->p;
       }
       r.entry = nullptr;
@@ -932,6 +933,8 @@ int launch_render(afe_scene *s, const afe_camera *cam, int64_t count, const doub
     if (table) {      // free for the next launch once this render kernel has read it
       std::lock_guard<std::mutex> lock(s->entry_mutex);
       (void)hipEventRecord(table->done, stream);
+      table->used = true;
+      table->taken = false;
     }
   }
   if (kernel_ms) {
