@@ -170,10 +170,10 @@ int fail(afe_engine *e, int status, const std::string &msg) {
 
 int check_range(afe_engine *e, int64_t first, int64_t count) {
   if (!e) return AFE_ERR_INVALID_ARG;
-  if (first < 0 || count < 0 || first + count > e->n)
-    return fail(e, AFE_ERR_OUT_OF_RANGE, "vehicle range [" + std::to_string(first) + ", " +
-                                             std::to_string(first + count) + ") outside [0, " +
-                                             std::to_string(e->n) + ")");
+  // (count > n - first, not first + count > n: the sum of two large arguments wraps and would pass)
+  if (first < 0 || count < 0 || first > e->n || count > e->n - first)
+    return fail(e, AFE_ERR_OUT_OF_RANGE, "vehicle range: first " + std::to_string(first) + ", count " +
+                                             std::to_string(count) + " outside [0, " + std::to_string(e->n) + ")");
   return AFE_OK;
 }
 

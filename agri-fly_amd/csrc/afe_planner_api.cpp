@@ -114,10 +114,11 @@ static int plan_impl(int device, const afe_planner_config *cfg, int64_t n, const
                      const double *acc0, const double *grav, const double *cost_vec, const double *samples,
                      int n_tables, const int32_t *sample_table, int n_candidates, afe_plan_output *out,
                      uint8_t *flags, float *kernel_ms) {
-  if (!cfg || n <= 0 || !depth_images || n_images <= 0 || !vel0 || !acc0 || !grav || !samples || n_tables <= 0 ||
+  if (!cfg || n < 0 || !depth_images || n_images <= 0 || !vel0 || !acc0 || !grav || !samples || n_tables <= 0 ||
       n_candidates <= 0 || !out || cfg->max_pyramids <= 0 || cfg->width <= 0 || cfg->height <= 0)
     return AFE_ERR_INVALID_ARG;
   if (!image_index && n_images < n) return AFE_ERR_INVALID_ARG;
+  if (n == 0) return AFE_OK;             // (no planners: an empty request is answered)
   // the search kernel keeps one bit per pixel in LDS (64 KB of dynamic LDS at most) and indexes
   // pixels with 24-bit arithmetic; device-resident images must allow 16-byte loads
   if ((int64_t)((cfg->width + 63) / 64) * cfg->height * 8 > 65536 || (int64_t)cfg->width * cfg->height >= (1 << 24))

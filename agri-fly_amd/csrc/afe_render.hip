@@ -1211,7 +1211,8 @@ extern "C" int afe_scene_info(const afe_scene *s, int64_t *n_tri, int64_t *n_nod
 
 extern "C" int afe_render_depth(afe_scene *s, const afe_camera *cam, int64_t n_views, const double *pos,
                                 const double *att, const double mount[4], uint16_t *depth_out, float *kernel_ms) {
-  if (!s || !camera_ok(cam) || n_views <= 0 || !pos || !att || !depth_out) return AFE_ERR_INVALID_ARG;
+  if (!s || !camera_ok(cam) || n_views < 0 || !pos || !att || !depth_out) return AFE_ERR_INVALID_ARG;
+  if (n_views == 0) return AFE_OK;     // (an empty request is answered, like a getter of no vehicles)
   if (hipSetDevice(s->device) != hipSuccess) return AFE_ERR_HIP;
   const size_t px = (size_t)cam->width * cam->height;
   DevBuf d_pos, d_att, d_pose, d_out;
@@ -1258,12 +1259,13 @@ extern "C" int afe_render_depth_stats(afe_scene *s, const afe_camera *cam, int64
 extern "C" int afe_render_depth_engine(afe_engine *e, afe_scene *s, const afe_camera *cam, int64_t first,
                                        int64_t count, const double mount[4], void *depth_out, int out_is_device,
                                        float *kernel_ms) {
-  if (!e || !s || !camera_ok(cam) || count <= 0 || first < 0 || !depth_out) return AFE_ERR_INVALID_ARG;
+  if (!e || !s || !camera_ok(cam) || count < 0 || first < 0 || !depth_out) return AFE_ERR_INVALID_ARG;
   afe_device_view view;
   view.struct_bytes = sizeof(view);
   int rc = engine_device_view(e, &view);
   if (rc != AFE_OK) return rc;
-  if (first + count > view.n_vehicles) return AFE_ERR_OUT_OF_RANGE;
+  if (first > view.n_vehicles || count > view.n_vehicles - first) return AFE_ERR_OUT_OF_RANGE;   // (no sum: it can wrap)
+  if (count == 0) return AFE_OK;
   hipStream_t stream = nullptr;
   int device = 0;
   engine_stream_device(e, (void **)&stream, &device);

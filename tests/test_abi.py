@@ -98,3 +98,28 @@ def test_product_never_imports_the_oracle():
                     text = open(os.path.join(dirpath, f)).read()
                     m = bad.search(text)
                     assert not m, "%s references the oracle: %r" % (os.path.join(dirpath, f), m.group(0))
+
+
+def test_every_entry_point_survives_null_and_zero_arguments(afa):
+    """The boundary's error behaviour: called with NULL for every pointer / handle and 0 for every number, each of the
+    header's functions RETURNS -- an AFE_ERR_* where it takes a handle or has to write somewhere -- instead of
+    dereferencing.  In a child process, so that a crash is this test's failure and not the run's end.  (With live handles
+    and bad data arguments: tests/test_gpu_abi_abuse.py.)"""
+    code = r'''
+import ctypes as C, importlib, sys
+sys.path.insert(0, %r)
+afa = importlib.import_module("agri-fly_amd")
+L = afa.library()
+def zero(t):
+    if t is C.c_void_p or (hasattr(t, "_type_") and not isinstance(t._type_, str)): return None
+    return t(0)
+ok_with_nothing = {"afe_abi_version", "afe_has_dev_hooks", "afe_planner_release_scratch", "afe_device_free", "afe_type_from_id"}
+for name in sorted(afa.ABI_FUNCTIONS):
+    fn = getattr(L, name)
+    rc = fn(*[zero(t) for t in fn.argtypes])
+    if fn.restype is C.c_int and name not in ok_with_nothing:
+        assert rc != 0, name + " accepted NULL / 0 for everything"
+print("survived", len(afa.ABI_FUNCTIONS))
+''' % ROOT
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "survived" in out.stdout, (out.returncode, out.stdout[-500:], out.stderr[-1500:])
