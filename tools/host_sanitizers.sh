@@ -8,6 +8,7 @@
 #
 #   make -C agri-fly_amd/csrc asan                                        (here, 1 min; the .so travels to the box with the tree)
 #   gpurun --timeout 1800 -- 'bash tools/host_sanitizers.sh'             -> gpurun_out/host_sanitizers/{summary.txt, asan.*}
+#   TESTS=tests/test_gpu_abi_abuse.py SOAK="12000 1500" bash tools/host_sanitizers.sh <dir>    one file, and the hand-shake soak
 set -u
 cd "$(dirname "$0")/.."
 LIB=$PWD/agri-fly_amd/lib/asan/libagrifly_engine.so
@@ -40,6 +41,11 @@ print("probe ok", float(np.abs(s["pos"]).max()))
   echo "== python -m pytest ${TESTS:-tests} -m gpu"
   # shellcheck disable=SC2086
   timeout 3000 python -m pytest ${TESTS:-tests} -m gpu -q -p no:cacheprovider 2>&1 | tail -15
+  if [ -n "${SOAK:-}" ]; then     # SOAK="<first seed> <seeds>": tools/handshake_soak.py on the sanitized library as well
+    echo "== python tools/handshake_soak.py $SOAK"
+    # shellcheck disable=SC2086
+    timeout 3000 python tools/handshake_soak.py $SOAK 2>&1 | grep -v ": ok (" | tail -12
+  fi
   echo "== sanitizer reports: $(ls "$OUT" | grep -c '^asan\.')"
   for f in "$OUT"/asan.*; do [ -f "$f" ] && { echo "--- $f"; head -40 "$f"; }; done
 } > "$OUT/summary.txt" 2>&1
