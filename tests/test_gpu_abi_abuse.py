@@ -174,6 +174,41 @@ answered(plan(n=0), "plan of 0 planners")
 again = afa.plans_as_array(afa.rappids_plan(cfg, img, z, z, z - [[0], [0], [9.81]], samples)[0])
 assert good.tobytes() == again.tobytes()
 
+# ---- groups of shards on this one device, engines, events
+g = C.c_void_p()
+dev0 = (C.c_int * 2)(0, 0)
+refused(L.afe_group_create(C.byref(g), 1000, afa.AFE_F32, None, 2), "group without devices")
+refused(L.afe_group_create(C.byref(g), 1000, afa.AFE_F32, dev0, 0), "group of 0 shards")
+refused(L.afe_group_create(C.byref(g), 1000, afa.AFE_F32, dev0, -2), "group of -2 shards")
+refused(L.afe_group_create(C.byref(g), 0, afa.AFE_F32, dev0, 2), "group of 0 vehicles")
+refused(L.afe_group_create(C.byref(g), -5, afa.AFE_F32, dev0, 2), "group of -5 vehicles")
+refused(L.afe_group_create(C.byref(g), 1000, 7, dev0, 2), "group of an unknown precision")
+refused(L.afe_group_create(None, 1000, afa.AFE_F32, dev0, 2), "group handle to NULL")
+bad_dev = (C.c_int * 2)(0, 99)
+refused(L.afe_group_create(C.byref(g), 1000, afa.AFE_F32, bad_dev, 2), "group with device 99")
+answered(L.afe_group_create(C.byref(g), 1000, afa.AFE_F32, dev0, 2), "group of two shards on device 0")
+sh = C.c_void_p(); f0 = C.c_int64(); c0 = C.c_int64()
+refused(L.afe_group_shard(g, 2, C.byref(sh), C.byref(f0), C.byref(c0)), "shard 2 of 2")
+refused(L.afe_group_shard(g, -1, C.byref(sh), C.byref(f0), C.byref(c0)), "shard -1")
+answered(L.afe_group_shard(g, 1, C.byref(sh), C.byref(f0), C.byref(c0)), "shard 1 of 2")
+assert f0.value + c0.value == 1000
+refused(L.afe_group_step(g, 1000, -1), "group step of -1")
+answered(L.afe_group_gather_positions(g, None), "group gather without the optional pointer table")
+answered(L.afe_group_destroy(g), "group destroy")
+h2 = C.c_void_p()
+refused(L.afe_create(C.byref(h2), 0, afa.AFE_F32, 0, 0), "engine of 0 vehicles")
+refused(L.afe_create(C.byref(h2), -1, afa.AFE_F32, 0, 0), "engine of -1 vehicles")
+refused(L.afe_create(C.byref(h2), 1000, 9, 0, 0), "engine of an unknown precision")
+refused(L.afe_create(C.byref(h2), 1000, afa.AFE_F32, 99, 0), "engine on device 99")
+refused(L.afe_create(C.byref(h2), 1000, afa.AFE_F32, 0, -1), "engine with a negative global index")
+refused(L.afe_create(None, 1000, afa.AFE_F32, 0, 0), "engine handle to NULL")
+refused(L.afe_create(C.byref(h2), 2 ** 40, afa.AFE_F32, 0, 0), "engine of 2^40 vehicles")
+ev = C.c_void_p()
+answered(L.afe_event_create(C.byref(ev)), "event")
+refused(L.afe_event_elapsed_ms(ev, ev, None), "elapsed to NULL")
+refused(L.afe_event_record(None, ev), "record without an engine")
+answered(L.afe_event_destroy(ev), "event destroy")
+
 # ---- UWB, scratch
 u = C.c_void_p()
 answered(L.afe_uwb_create(C.byref(u)), "uwb create")
