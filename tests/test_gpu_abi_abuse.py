@@ -94,6 +94,20 @@ for persistent in (False, True):
     refused(L.afe_save_checkpoint(h, blob.ctypes.data, sz.value - 1), "save into a short buffer")
     refused(L.afe_load_checkpoint(h, blob.ctypes.data, sz.value), "load of zeros")
     refused(L.afe_load_checkpoint(h, None, sz.value), "load from NULL")
+    # a real checkpoint with damaged header bytes or a cut-off tail: refused or (a flipped time stamp, say) taken -- never a
+    # crash, never a read past the buffer (the sanitized build watches) -- and the undamaged one puts everything back
+    answered(L.afe_save_checkpoint(h, blob.ctypes.data, sz.value), "save")
+    good_blob = blob.copy()
+    frng = np.random.default_rng(77)
+    for trial in range(300):
+        hurt = good_blob.copy()
+        for at in frng.integers(0, 256, frng.integers(1, 5)):
+            hurt[at] ^= np.uint8(1 << frng.integers(0, 8))
+        L.afe_load_checkpoint(h, hurt.ctypes.data, sz.value)
+        calls[0] += 1
+    for cut in (0, 1, 16, 255, sz.value // 2, sz.value - 1):
+        refused(L.afe_load_checkpoint(h, good_blob.ctypes.data, cut), "checkpoint cut to %%d bytes" %% cut)
+    answered(L.afe_load_checkpoint(h, good_blob.ctypes.data, sz.value), "load of the undamaged checkpoint")
     # ---- shared-world queries
     idx = np.zeros(8, np.int64); d2 = np.zeros(8, np.float32)
     refused(L.afe_nearest_neighbour(h, None, 8, idx.ctypes.data, d2.ctypes.data), "nearest neighbour, NULL positions")
