@@ -725,7 +725,13 @@ __global__ __launch_bounds__(kTileW *kTileH) void afe_render_depth_kernel(Render
   ordered = ordered && !a.plain_walk_only;
   WalkCounters cnt;
   BoxRay br;
-  if (ordered) {
+  // A camera at a non-finite position (a vehicle that has diverged) shows nothing, by the contract's own arithmetic: tv = o - v0
+  // is not finite, so neither is any t, and no t that is not finite becomes a hit.  Without this its NaN passes every box test
+  // (max / min drop a NaN operand) and each of its tiles walks the WHOLE tree: one such view cost 1 150 ordinary ones
+  // (tools/experiments/nan_pose_probe.py).  A non-finite attitude needs no care: the entry pass already finds nothing to walk.
+  const bool somewhere = __builtin_isfinite(ray.o[0]) && __builtin_isfinite(ray.o[1]) && __builtin_isfinite(ray.o[2]);
+  if (!somewhere) {
+  } else if (ordered) {
     for (int k = 0; k < 3; k++) {
       const float ai = fabsf(ray.inv[k]);      // mirrored axis: -inv, and (-o)(-inv) = o * inv
       br.scale[k] = (f32x2){ai * 0.99999f, ai * 1.00001f};

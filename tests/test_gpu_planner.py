@@ -354,3 +354,35 @@ def test_wide_campaign_every_mismatch_is_an_ulp_of_libm():
     assert stats["unexplained"] == 0
     assert stats["hard_mismatches"] <= 0.002 * stats["plans"]
     assert stats["pyramid_count_differences"] <= 0.03 * stats["plans"]
+
+
+def test_planners_of_diverged_vehicles_answer_like_the_oracle_and_disturb_nobody(ora):
+    """A vehicle whose state has gone NaN / inf still gets a plan call with everybody's.  Engine and oracle must agree on
+    it candidate by candidate (nothing passes a comparison with a NaN: no trajectory is found, no pyramid grown), the search
+    must end, and its neighbours' plans are those of a batch without it."""
+    rng = np.random.default_rng(31)
+    n, m = 24, 128
+    images = np.stack([afa.scenarios.synthetic_depth_image(seed=300 + k, n_trunks=5) for k in range(3)])
+    ocfg = ora.planner_config(320, 240, 10.0 / 256.0, 160.0, 0.116, 0.174, 0.5)
+    ocfg.max_pyramids = 64
+    idx = rng.integers(0, 3, n).astype(np.int32)
+    vel0 = np.stack([rng.normal(0, 0.5, n), rng.normal(0, 0.3, n), rng.uniform(0, 2.5, n)])
+    acc0 = rng.normal(0, 0.5, (3, n))
+    grav = np.tile(np.array([[0.0], [9.81], [0.0]]), (1, n))
+    samples = ora.planner_samples(4, 320, 240, m)
+    clean, clean_flags, _ = afa.rappids_plan(_cfg(ocfg), images, vel0, acc0, grav, samples, image_index=idx, want_flags=True)
+    clean = afa.plans_as_array(clean).copy()
+    vel0[0, 1] = np.nan
+    vel0[:, 4] = np.inf
+    acc0[2, 7] = -np.inf
+    acc0[:, 9] = np.nan
+    grav[:, 12] = np.nan
+    vel0[:, 15] = 1e300
+    gone = [1, 4, 7, 9, 12, 15]
+    refs = [ora.planner_run(ocfg, images[idx[i]], vel0[:, i], acc0[:, i], grav[:, i], samples) for i in range(n)]
+    out, flags, _ = afa.rappids_plan(_cfg(ocfg), images, vel0, acc0, grav, samples, image_index=idx, want_flags=True)
+    _compare(out, flags, refs)
+    got = afa.plans_as_array(out)
+    keep = ~np.isin(np.arange(n), gone)
+    assert got[keep].tobytes() == clean[keep].tobytes() and np.array_equal(flags[keep], clean_flags[keep])
+    assert not got["found"][gone].any()

@@ -235,3 +235,38 @@ def test_ordered_and_plain_walk_give_the_same_images_on_thousands_of_views():
                 np.testing.assert_array_equal(got[0], want)
     scene.set_walk(False)
     scene.close()
+
+
+def test_a_camera_at_a_non_finite_position_sees_nothing_and_holds_nobody_up(ora):
+    """A vehicle that has diverged (NaN / inf position) still gets its image rendered with everybody's.  By the checker's own
+    arithmetic such a camera hits nothing -- and it must not cost more than a view that does: the NaN passes every box test
+    (max / min drop a NaN operand), and before round 6's guard each of its tiles walked the whole tree, 1 150 views' worth of
+    time for one view (tools/experiments/nan_pose_probe.py)."""
+    tris = scen.orchard_mesh(rows=12, cols=12, seed=2)
+    scene = afa.Scene(tris)
+    cam = afa.camera_default(160, 120)
+    mount = afa.camera_default_mount()
+    rng = np.random.default_rng(9)
+    n = 128
+    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    pos = np.stack([rng.uniform(lo[0] + 2, hi[0] - 2, n), rng.uniform(lo[1] + 2, hi[1] - 2, n), rng.uniform(0.5, 3.0, n)])
+    att = scen.random_attitudes(rng, n, max_tilt_deg=20.0)
+    ref, _ = scene.render(cam, pos, att, mount)
+    base = min(scene.render(cam, pos, att, mount)[1] for _ in range(5))
+    ocam = ora.render_camera(160, 120)
+    for value, where in ((np.nan, 0), (np.inf, 2), (-np.inf, 1)):
+        p = pos.copy()
+        p[where, 5] = value
+        p[where, 77] = value
+        for walk in (0, 1):
+            scene.set_walk(walk)
+            img, _ = scene.render(cam, p, att, mount)
+            ms = min(scene.render(cam, p, att, mount)[1] for _ in range(5))
+            keep = ~np.isin(np.arange(n), (5, 77))
+            assert np.array_equal(img[keep], ref[keep])
+            assert (img[5] == 255).all() and (img[77] == 255).all()
+            if walk == 0:
+                assert ms < 2.0 * base + 0.2, (value, ms, base)
+        scene.set_walk(0)
+        assert np.array_equal(ora.render_depth(ocam, tris[:2000], p[:, 5], att[:, 5], mount), np.full((120, 160), 255, np.uint16))
+    scene.close()
